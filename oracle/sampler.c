@@ -1,0 +1,368 @@
+/* oracle/sampler.c -- TEST INFRASTRUCTURE ONLY.  See sampler.h. */
+#include "sampler.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- S/RNG.scala:6-26 ------------------------------------------------------------------ */
+static double rng_uniform(jrandom *r) { return jrandom_next_double(r); }
+static double rng_normal(jrandom *r) { return jrandom_next_gaussian(r); }
+static int rng_int(jrandom *r, int until) { /* RNG.int: min((u*until).toInt, until-1) */
+  int v = (int)(rng_uniform(r) * until);
+  return v < until - 1 ? v : until - 1;
+}
+
+/* ---- S/Stats.scala:19-58 RingBuffer ------------------------------------------------------ */
+typedef struct { int full, i, size; double *buf; } ringbuf;
+static void ring_init(ringbuf *rb, int size) { rb->full = 0; rb->i = 0; rb->size = size; rb->buf = calloc(size, sizeof(double)); }
+static void ring_add(ringbuf *rb, double v) { /* :24-30 pre-increment, slot 0 written last */
+  rb->i += 1;
+  if (rb->i == rb->size) rb->full = 1;
+  rb->i = rb->i % rb->size;
+  rb->buf[rb->i] = v;
+}
+static double ring_sample(ringbuf *rb, jrandom *r) { /* :40-45 */
+  if (rb->full) return rb->buf[rng_int(r, rb->size)];
+  return rb->buf[rng_int(r, rb->i + 1)];
+}
+
+/* ---- S/LeapFrog.scala ------------------------------------------------------------------ */
+struct orc_leapfrog {
+  orc_density_fn f; void *ctx; jrandom *rng; int math_mode;
+  int n;          /* nVars */
+  double *pqBuf;  /* [2n+1]  :118-129 layout p | q | potential */
+  double *buf;    /* [n] */
+  double *out;    /* [n+1] density outputs */
+  double prevH;
+  int64_t gradientEvaluations; /* Stats.gradientEvaluations :199 */
+  int64_t leapfrogSteps;       /* not in the reference: number of newQs calls */
+  int64_t iterations; int64_t accepted; double sumAccept;
+  int density_error;
+};
+
+orc_leapfrog *orc_lf_new(orc_density_fn f, void *ctx, int nvars, jrandom *rng, int math_mode) {
+  orc_leapfrog *lf = calloc(1, sizeof(*lf));
+  lf->f = f; lf->ctx = ctx; lf->rng = rng; lf->n = nvars; lf->math_mode = math_mode;
+  lf->pqBuf = calloc(2 * nvars + 1, sizeof(double));
+  lf->buf = calloc(nvars, sizeof(double));
+  lf->out = calloc(nvars + 1, sizeof(double));
+  return lf;
+}
+void orc_lf_free(orc_leapfrog *lf) { if (lf) { free(lf->pqBuf); free(lf->buf); free(lf->out); free(lf); } }
+
+static void lf_copy(const orc_leapfrog *lf, const double *src, double *dst) { memcpy(dst, src, sizeof(double) * (2 * lf->n + 1)); }
+
+/* :194-200 */
+static void copyQsAndUpdateDensity(orc_leapfrog *lf) {
+  memcpy(lf->buf, lf->pqBuf + lf->n, sizeof(double) * lf->n);
+  if (lf->f(lf->ctx, lf->buf, lf->out)) lf->density_error = 1;
+  lf->gradientEvaluations += 1;
+}
+/* :202-216 (Identity and Diagonal) */
+static void velocity(const orc_leapfrog *lf, const double *in, double *out, const double *mass) {
+  if (!mass) memcpy(out, in, sizeof(double) * lf->n);
+  else for (int i = 0; i < lf->n; i++) out[i] = in[i] * mass[i];
+}
+/* :218-227 */
+static double dot(const double *x, const double *y, int n) {
+  double k = 0.0;
+  for (int i = 0; i < n; i++) k += (x[i] * y[i]);
+  return k;
+}
+/* :131-136 */
+static double energy(orc_leapfrog *lf, const double *params, const double *mass) {
+  double potential = params[2 * lf->n];
+  velocity(lf, params, lf->buf, mass);
+  double kinetic = dot(lf->buf, params, lf->n) / 2.0;
+  return potential + kinetic;
+}
+/* :138-142 */
+static double logAcceptanceProb(const orc_leapfrog *lf, double deltaH) {
+  if (isnan(deltaH)) return jm_log(lf->math_mode, 0.0);
+  return (-deltaH) < 0.0 ? (-deltaH) : 0.0; /* (-deltaH).min(0.0) */
+}
+/* :144-151 */
+static void newQs(orc_leapfrog *lf, double stepSize, const double *mass) {
+  velocity(lf, lf->pqBuf, lf->buf, mass);
+  for (int i = 0; i < lf->n; i++) lf->pqBuf[i + lf->n] += (stepSize * lf->buf[i]);
+  lf->leapfrogSteps += 1;
+}
+/* :165-173 */
+static void fullPs(orc_leapfrog *lf, double stepSize) {
+  copyQsAndUpdateDensity(lf);
+  for (int i = 0; i < lf->n; i++) lf->pqBuf[i] += stepSize * lf->out[i + 1];
+}
+/* :153-163 */
+static void initialHalfThenFullStep(orc_leapfrog *lf, double stepSize, const double *mass) {
+  fullPs(lf, stepSize / 2.0);
+  newQs(lf, stepSize, mass);
+  copyQsAndUpdateDensity(lf);
+  lf->pqBuf[2 * lf->n] = lf->out[0] * -1;
+}
+/* :175-184 */
+static void twoFullSteps(orc_leapfrog *lf, double stepSize, const double *mass) {
+  fullPs(lf, stepSize);
+  newQs(lf, stepSize, mass);
+  copyQsAndUpdateDensity(lf);
+  lf->pqBuf[2 * lf->n] = lf->out[0] * -1;
+}
+/* :186-188 */
+static void finalHalfStep(orc_leapfrog *lf, double stepSize) { fullPs(lf, stepSize / 2.0); }
+
+/* :229-251 */
+static void initializePs(orc_leapfrog *lf, double *params, const double *mass) {
+  for (int i = 0; i < lf->n; i++) lf->buf[i] = rng_normal(lf->rng);
+  if (!mass) memcpy(params, lf->buf, sizeof(double) * lf->n);
+  else for (int i = 0; i < lf->n; i++) params[i] = lf->buf[i] / sqrt(mass[i]); /* stdDevs S/MassMatrix.scala:10-12 */
+}
+
+/* :14-22 */
+double orc_lf_try_stepping(orc_leapfrog *lf, const double *params, double stepSize, const double *mass) {
+  lf_copy(lf, params, lf->pqBuf);
+  initialHalfThenFullStep(lf, stepSize, mass);
+  finalHalfStep(lf, stepSize);
+  double deltaH = energy(lf, lf->pqBuf, mass) - energy(lf, params, mass);
+  return logAcceptanceProb(lf, deltaH);
+}
+/* :24-33 */
+void orc_lf_take_steps(orc_leapfrog *lf, int l, double stepSize, const double *mass) {
+  initialHalfThenFullStep(lf, stepSize, mass);
+  int i = 1;
+  while (i < l) { twoFullSteps(lf, stepSize, mass); i += 1; }
+  finalHalfStep(lf, stepSize);
+}
+/* :35-47 */
+int orc_lf_is_uturn(orc_leapfrog *lf, const double *params) {
+  double out = 0.0;
+  for (int i = 0; i < lf->n; i++) out += (lf->pqBuf[i + lf->n] - params[i + lf->n]) * lf->pqBuf[i];
+  if (isnan(out)) return 1;
+  return out < 0;
+}
+/* :52-59 */
+void orc_lf_start_iteration(orc_leapfrog *lf, double *params, const double *mass) {
+  lf->prevH = energy(lf, params, mass);
+  initializePs(lf, params, mass);
+  lf_copy(lf, params, lf->pqBuf);
+}
+/* :61-82 */
+double orc_lf_finish_iteration(orc_leapfrog *lf, double *params, const double *mass) {
+  double startH = energy(lf, params, mass);
+  double endH = energy(lf, lf->pqBuf, mass);
+  double deltaH = endH - startH;
+  double a = logAcceptanceProb(lf, deltaH);
+  if (a > jm_log(lf->math_mode, rng_uniform(lf->rng))) { lf_copy(lf, lf->pqBuf, params); lf->accepted += 1; }
+  lf->iterations += 1;
+  lf->sumAccept += jm_exp(lf->math_mode, a);
+  return a;
+}
+/* :102-116 */
+void orc_lf_initialize(orc_leapfrog *lf, const double *mass, double *params) {
+  int n = lf->n;
+  memset(lf->pqBuf, 0, sizeof(double) * (2 * n + 1));
+  for (int i = n; i < 2 * n; i++) lf->pqBuf[i] = rng_normal(lf->rng);
+  copyQsAndUpdateDensity(lf);
+  lf->pqBuf[2 * n] = lf->out[0] * -1;
+  lf_copy(lf, lf->pqBuf, params);
+  initializePs(lf, params, mass);
+}
+static void lf_snapshot(const orc_leapfrog *lf, double *out) { lf_copy(lf, lf->pqBuf, out); }  /* :84-85 */
+static void lf_restore(orc_leapfrog *lf, const double *in) { lf_copy(lf, in, lf->pqBuf); }     /* :87-88 */
+
+/* ---- S/DualAvg.scala --------------------------------------------------------------------- */
+typedef struct { /* final class DualAvg :43-78 */
+  double delta, logStepSize, logStepSizeBar, avgError, shrinkageTarget;
+  int iteration; int math_mode;
+} dualavg;
+static dualavg dualavg_new(double delta, double stepSize, int mode) { /* :80-89 */
+  dualavg d; d.delta = delta; d.logStepSize = jm_log(mode, stepSize); d.logStepSizeBar = 0.0; d.avgError = 0.0;
+  d.iteration = 0; d.shrinkageTarget = jm_log(mode, 10 * stepSize); d.math_mode = mode; return d;
+}
+static void dualavg_update(dualavg *d, double logAcceptanceProb) { /* :58-77 */
+  const double stepSizeUpdateDenom = 0.05; const int acceptanceProbUpdateDenom = 10;
+  double newAcceptanceProb = jm_exp(d->math_mode, logAcceptanceProb);
+  d->iteration = d->iteration + 1;
+  double avgErrorMultiplier = 1.0 / ((double)d->iteration + acceptanceProbUpdateDenom);
+  double stepSizeMultiplier = jm_pow_neg075(d->math_mode, (double)d->iteration); /* Math.pow(it, -decayRate) */
+  d->avgError = ((1.0 - avgErrorMultiplier) * d->avgError + (avgErrorMultiplier * (d->delta - newAcceptanceProb)));
+  d->logStepSize = (d->shrinkageTarget - (d->avgError * jm_sqrt((double)d->iteration) / stepSizeUpdateDenom));
+  d->logStepSizeBar = (stepSizeMultiplier * d->logStepSize + (1.0 - stepSizeMultiplier) * d->logStepSizeBar);
+}
+/* :27-41 */
+static double findReasonableStepSize(orc_leapfrog *lf, const double *params, const double *mass) {
+  int mode = lf->math_mode;
+  double stepSize = 1.0;
+  double logAcceptanceProb = orc_lf_try_stepping(lf, params, stepSize, mass);
+  double exponent = (logAcceptanceProb > jm_log(mode, 0.5)) ? 1.0 : -1.0;
+  double doubleOrHalf = exponent > 0 ? 2.0 : 0.5; /* Math.pow(2, +-1) is exact */
+  while (stepSize != 0.0 && (exponent * logAcceptanceProb > -exponent * jm_log(mode, 2))) {
+    stepSize *= doubleOrHalf;
+    logAcceptanceProb = orc_lf_try_stepping(lf, params, stepSize, mass);
+  }
+  return stepSize;
+}
+
+/* ---- S/MassMatrixEstimator.scala:52-113 VarianceEstimator -------------------------------- */
+typedef struct { int samples, size; double *mean, *raw, *oldDiff, *newDiff; } varest;
+static void varest_init(varest *v, int size) {
+  v->samples = 0; v->size = size;
+  v->mean = calloc(size, sizeof(double)); v->raw = calloc(size, sizeof(double));
+  v->oldDiff = calloc(size, sizeof(double)); v->newDiff = calloc(size, sizeof(double));
+}
+static void varest_free(varest *v) { free(v->mean); free(v->raw); free(v->oldDiff); free(v->newDiff); }
+static void varest_reset(varest *v) { /* :60-67 -- does NOT reset samples */
+  for (int i = 0; i < v->size; i++) { v->mean[i] = 0.0; v->raw[i] = 0.0; }
+}
+static void varest_update(varest *v, const double *sample) { /* :69-84 */
+  v->samples += 1;
+  for (int i = 0; i < v->size; i++) v->oldDiff[i] = sample[i] - v->mean[i];
+  for (int i = 0; i < v->size; i++) v->mean[i] += (v->oldDiff[i] / (double)v->samples);
+  for (int i = 0; i < v->size; i++) v->newDiff[i] = sample[i] - v->mean[i];
+  for (int j = 0; j < v->size; j++) v->raw[j] += v->oldDiff[j] * v->newDiff[j];
+}
+static void varest_variance(const varest *v, double *elements) { /* :93-101 */
+  for (int i = 0; i < v->size; i++) elements[i] = v->raw[i] / (double)v->samples;
+}
+
+/* ---- S/MassMatrix.scala:126-173 WindowedMassMatrixTuner (Diagonal) ------------------------ */
+typedef struct {
+  int kind; int windowSize; double windowExpansion; int skipFirst, skipLast;
+  int i, j, totalIterations; varest est;
+} masstuner;
+/* returns 1 and writes `mass` when a new matrix is produced (Some(m)) */
+static int masstuner_update(masstuner *t, const double *sample, double *mass) { /* :147-164 */
+  if (t->kind != ORC_MASS_DIAG_WINDOWED) return 0;
+  t->j += 1;
+  if (t->j < t->skipFirst || (t->totalIterations - t->j) < t->skipLast) return 0;
+  t->i += 1;
+  varest_update(&t->est, sample);
+  if (t->i == t->windowSize) {
+    t->i = 0;
+    t->windowSize = (int)(t->windowSize * t->windowExpansion);
+    varest_variance(&t->est, mass);
+    varest_reset(&t->est);
+    return 1;
+  }
+  return 0;
+}
+
+/* ---- S/HMC.scala, S/EHMC.scala ----------------------------------------------------------- */
+typedef struct { const orc_config *cfg; ringbuf steps; double *snap; } samplerst;
+
+static void ehmc_countSteps(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) { /* S/EHMC.scala:32-50 */
+  int l = 0;
+  while (!orc_lf_is_uturn(lf, params) && l < s->cfg->max_steps) {
+    l += 1;
+    orc_lf_take_steps(lf, 1, stepSize, mass);
+    if (l == s->cfg->min_steps) lf_snapshot(lf, s->snap);
+  }
+  if (l < s->cfg->min_steps) orc_lf_take_steps(lf, s->cfg->min_steps - l, stepSize, mass);
+  else lf_restore(lf, s->snap);
+  ring_add(&s->steps, (double)l);
+}
+static double sampler_warmup(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  orc_lf_start_iteration(lf, params, mass);
+  if (s->cfg->sampler == ORC_HMC) { /* S/HMC.scala:6-13 */
+    orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass);
+  } else { /* S/EHMC.scala:15-30 */
+    int shouldCount = !s->steps.full || rng_uniform(lf->rng) < s->cfg->p_count;
+    if (shouldCount) ehmc_countSteps(s, params, lf, stepSize, mass);
+    else { int n = (int)ring_sample(&s->steps, lf->rng); orc_lf_take_steps(lf, n, stepSize, mass); }
+  }
+  return orc_lf_finish_iteration(lf, params, mass);
+}
+static void sampler_run(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  orc_lf_start_iteration(lf, params, mass);
+  if (s->cfg->sampler == ORC_HMC) orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass); /* S/HMC.scala:15-23 */
+  else { int n = (int)ring_sample(&s->steps, lf->rng); orc_lf_take_steps(lf, n, stepSize, mass); } /* S/EHMC.scala:52-61 */
+  (void)orc_lf_finish_iteration(lf, params, mass);
+}
+
+/* ---- S/Driver.scala:7-119 ------------------------------------------------------------------ */
+int orc_sample_chain(const orc_config *cfg, orc_density_fn f, void *ctx, int n, int64_t seed,
+                     double *draws, double *mass_out, orc_stats *stats) {
+  jrandom rng; jrandom_init(&rng, seed); /* ScalaRNG(seed) */
+  orc_leapfrog *lf = orc_lf_new(f, ctx, n, &rng, cfg->math_mode);
+  double *params = calloc(2 * n + 1, sizeof(double));
+  double *massbuf = calloc(n, sizeof(double));
+  const double *mass = NULL; /* IdentityMassMatrix */
+  samplerst s; s.cfg = cfg; s.snap = calloc(2 * n + 1, sizeof(double));
+  ring_init(&s.steps, cfg->sampler == ORC_EHMC ? cfg->buf_size : 1);
+
+  orc_lf_initialize(lf, NULL, params); /* :22 lf.initialize(IdentityMassMatrix) */
+
+  /* warmup :49-90 */
+  /* sampler.initialize: HMC no-op, EHMC allocates snapshot buffer */
+  dualavg da; double stepSize;
+  if (cfg->step_tuner == ORC_STEP_DUALAVG) { /* DualAvgTuner.initialize S/DualAvg.scala:6-10 (always Identity) */
+    stepSize = findReasonableStepSize(lf, params, NULL);
+    da = dualavg_new(cfg->delta, stepSize, cfg->math_mode);
+  } else { stepSize = cfg->static_step; memset(&da, 0, sizeof(da)); }
+  masstuner mt; memset(&mt, 0, sizeof(mt));
+  mt.kind = cfg->mass_tuner;
+  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED) { /* S/MassMatrix.scala:139-143 */
+    mt.windowSize = cfg->init_window; mt.windowExpansion = cfg->expansion; mt.skipFirst = cfg->skip_first; mt.skipLast = cfg->skip_last;
+    mt.totalIterations = cfg->warmup; varest_init(&mt.est, n);
+  } else if (cfg->mass_tuner == ORC_MASS_STATIC_DIAG) { memcpy(massbuf, cfg->static_mass, sizeof(double) * n); mass = massbuf; }
+
+  double *sample = calloc(n, sizeof(double));
+  for (int i = 0; i < cfg->warmup; i++) {
+    double logAcceptProb = sampler_warmup(&s, params, lf, stepSize, mass);
+    if (cfg->step_tuner == ORC_STEP_DUALAVG) { dualavg_update(&da, logAcceptProb); stepSize = jm_exp(cfg->math_mode, da.logStepSize); }
+    memcpy(sample, params + n, sizeof(double) * n); /* lf.variables */
+    if (masstuner_update(&mt, sample, massbuf)) {
+      mass = massbuf; /* DiagonalMassMatrix(variance) -- require(!elements.contains(0.0)) not enforced here */
+      if (cfg->step_tuner == ORC_STEP_DUALAVG) { /* DualAvgTuner.reset S/DualAvg.scala:17-21 */
+        double ss = jm_exp(cfg->math_mode, da.logStepSizeBar);
+        da = dualavg_new(cfg->delta, ss, cfg->math_mode);
+        stepSize = ss;
+      }
+    }
+  }
+  if (stats) { stats->warmup_leapfrog_steps = lf->leapfrogSteps; stats->warmup_gradient_evaluations = lf->gradientEvaluations; }
+  /* lf.resetStats() :31 */
+  lf->gradientEvaluations = 0; lf->leapfrogSteps = 0; lf->iterations = 0; lf->accepted = 0; lf->sumAccept = 0;
+  /* stepSizeTuner.stepSize :37 */
+  double finalStep = cfg->step_tuner == ORC_STEP_DUALAVG ? jm_exp(cfg->math_mode, da.logStepSizeBar) : cfg->static_step;
+  for (int i = 0; i < cfg->iterations; i++) { /* collectSamples :92-119 */
+    sampler_run(&s, params, lf, finalStep, mass);
+    memcpy(draws + (size_t)i * n, params + n, sizeof(double) * n);
+  }
+  for (int i = 0; i < n; i++) mass_out[i] = mass ? mass[i] : 1.0;
+  if (stats) {
+    stats->gradient_evaluations = lf->gradientEvaluations; stats->leapfrog_steps = lf->leapfrogSteps;
+    stats->accepted = lf->accepted; stats->mean_accept_prob = lf->iterations ? lf->sumAccept / lf->iterations : 0.0;
+    stats->step_size = finalStep; stats->density_error = lf->density_error;
+  }
+  int rc = lf->density_error;
+  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED) varest_free(&mt.est);
+  free(sample); free(s.snap); free(s.steps.buf); free(params); free(massbuf); orc_lf_free(lf);
+  return rc;
+}
+
+/* ---- rainier-core/.../core/Trace.scala:52-120 -------------------------------------------- */
+static double variogram(const double *trace, int n, int lag) { /* :111-119 */
+  double sum = 0.0;
+  for (int i = lag; i < n; i++) { double d = trace[i] - trace[i - lag]; sum += d * d; /* Math.pow(x,2) == x*x exactly */ }
+  return sum / (double)(n - lag);
+}
+void orc_diagnostics(const double *traces, int mi, int ni, double *rhat, double *ess) {
+  double m = mi, n = ni;
+  double *means = malloc(sizeof(double) * mi);
+  for (int c = 0; c < mi; c++) { double s = 0.0; for (int i = 0; i < ni; i++) s += traces[(size_t)c * ni + i]; means[c] = s / n; }
+  double meanMean = 0.0; for (int c = 0; c < mi; c++) meanMean += means[c]; meanMean /= m;
+  double bs = 0.0; for (int c = 0; c < mi; c++) { double d = means[c] - meanMean; bs += d * d; }
+  double b = (n / (m - 1)) * bs;
+  double ws = 0.0;
+  for (int c = 0; c < mi; c++) { double s = 0.0; for (int i = 0; i < ni; i++) { double d = traces[(size_t)c * ni + i] - means[c]; s += d * d; } ws += s / (n - 1); }
+  double w = ws / m;
+  double v = (n - 1) / n * w + b / n;
+  *rhat = sqrt(v / w);
+  double acc = 0.0; int lag = 1; /* autocorrelation :91-109 */
+  for (;;) {
+    double vt = 0.0; for (int c = 0; c < mi; c++) vt += variogram(traces + (size_t)c * ni, ni, lag); vt /= m;
+    double pt = 1.0 - (vt / (2.0 * v));
+    if (pt > 0.0 && lag < 100) { acc += pt; lag += 1; } else break;
+  }
+  *ess = n * m / (1 + (2 * acc));
+  free(means);
+}

@@ -1,0 +1,158 @@
+"""RIR programs + synthetic data for the BASELINE.json configs.
+
+Each builder returns a `ModelSpec(name, rir, columns, nrows, n_params, meta)`; `columns` is the
+flattened list (target order, then column order) of float64 numpy arrays the C ABI expects.
+
+Parameterisations follow the reference's own arithmetic: location-scale families are
+non-centred (`Normal(mu, s).latent = z*s + mu`, rainier-core/.../core/Continuous.scala:28-67),
+positive supports are log-transformed (core/Support.scala:78-84) and the priors are the standard
+densities of Continuous.scala:63-77.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+
+from .frontend import Graph
+
+HALF_LOG_2PI = 0.5 * math.log(2 * math.pi)  # Normal.logDensity, core/Continuous.scala:63-67
+
+
+@dataclass
+class ModelSpec:
+    name: str
+    rir: bytes
+    columns: List[np.ndarray]
+    nrows: List[int]           # per target (0 for data-free targets)
+    n_params: int
+    meta: Dict = field(default_factory=dict)
+
+    @property
+    def rows_streamed(self) -> int:
+        return int(sum(self.nrows))
+
+    @property
+    def bytes_per_row(self) -> int:
+        # algorithmic bytes per row-chain eval = 8*(K+1): base columns only
+        return 8 * len(self.columns)
+
+
+def std_normal_logpdf(z):
+    return (z * z) / -2.0 - HALF_LOG_2PI
+
+
+def funnel(dim: int = 10) -> ModelSpec:
+    """cfg 1 -- Neal's funnel in Rainier's parameter space (README.md:44):
+    y = Normal(0,3).latent = 3 z0, x_i = Normal(0, exp(y/2)).latent = z_i exp(3 z0 / 2).
+    Non-centring makes the *sampled* density an isotropic standard normal; the funnel shape only
+    appears after predict().  Targets: "prior" + the constant-zero Model.track likelihood
+    (core/Model.scala:67)."""
+    g = Graph(dim, [0, 0])
+    prior = g.sum([std_normal_logpdf(g.param(i)) for i in range(dim)])
+    rir = g.compile([prior, g.const(0.0)])
+    return ModelSpec("funnel%d" % dim, rir, [], [0, 0], dim, {"kind": "funnel"})
+
+
+def linreg_data(n: int, k: int = 3, seed: int = 20260925):
+    """Synthetic cfg-2 data: X~N(0,1), y = 0.5 + X.(1,-2,0.5) + 0.7 N(0,1)."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((k, n))
+    beta = np.array([1.0, -2.0, 0.5] + [0.25] * max(0, k - 3))[:k]
+    y = 0.5 + beta @ X + 0.7 * rng.standard_normal(n)
+    return [np.ascontiguousarray(y)] + [np.ascontiguousarray(X[j]) for j in range(k)]
+
+
+def linreg(n: int = 1_000_000, k: int = 3, seed: int = 20260925, columns=None) -> ModelSpec:
+    """cfg 2 -- README linear regression (README.md:19-32), UN-INLINED.
+    theta = (s, a, b_0..b_{k-1}); sigma = exp(s) (Exponential(1).latent: prior s - e^s),
+    a, b ~ N(0,1).  Row term: Normal(mu, sigma).logDensity(y) =
+    -((y-mu)^2) e^{-2s}/2 - s - 0.5 log 2pi."""
+    g = Graph(2 + k, [0, 1 + k])
+    s, a = g.param(0), g.param(1)
+    b = [g.param(2 + j) for j in range(k)]
+    prior = (s - s.exp()) + std_normal_logpdf(a)
+    for bj in b:
+        prior = prior + std_normal_logpdf(bj)
+    y = g.col(1, 0)
+    x = [g.col(1, 1 + j) for j in range(k)]
+    mu = a
+    for bj, xj in zip(b, x):
+        mu = mu + bj * xj
+    r = y - mu
+    inv_var = (s * -2.0).exp()
+    row = (r * r) * inv_var / -2.0 - s - HALF_LOG_2PI
+    rir = g.compile([prior, row])
+    cols = linreg_data(n, k, seed) if columns is None else columns
+    return ModelSpec("linreg_%dx%d" % (k, n), rir, cols, [0, n], 2 + k,
+                     {"kind": "linreg", "k": k, "flops_per_row": 4 * k + 4})
+
+
+EIGHT_SCHOOLS_Y = (28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0)       # bench/stan/EightSchools.scala:22
+EIGHT_SCHOOLS_SIGMA = (15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0)  # bench/stan/EightSchools.scala:23
+
+
+def eight_schools() -> ModelSpec:
+    """cfg 3 -- bench/stan/EightSchools.scala:9-20.
+    theta = (m, c, z_1..z_8): mu = 5m, tau = |5c| (Cauchy(0,5).latent.abs), theta_i = z_i tau + mu.
+    Targets: prior, Model.empty's zero likelihood, then 8 single-observation Normal likelihoods
+    (each its own data-free target; a 1-element observation never becomes a Column)."""
+    n = 10
+    g = Graph(n, [0] * 10)
+    m, c = g.param(0), g.param(1)
+    z = [g.param(2 + i) for i in range(8)]
+    cauchy = ((c * c + 1.0) * math.pi).log() * -1.0  # Cauchy.logDensity core/Continuous.scala:72-77
+    prior = std_normal_logpdf(m) + cauchy
+    for zi in z:
+        prior = prior + std_normal_logpdf(zi)
+    mu = m * 5.0
+    tau = (c * 5.0).abs()
+    liks = []
+    for zi, y, sg in zip(z, EIGHT_SCHOOLS_Y, EIGHT_SCHOOLS_SIGMA):
+        theta = zi * tau + mu
+        u = (theta * -1.0 + y) / sg
+        liks.append(std_normal_logpdf(u) - math.log(sg))
+    rir = g.compile([prior, g.const(0.0)] + liks)
+    return ModelSpec("eight_schools", rir, [], [0] * 10, n, {"kind": "eight_schools"})
+
+
+def logistic_data(n: int, k: int = 50, seed: int = 4):
+    """cfg-4 data: X~N(0,1)/sqrt(k), beta~N(0,1), y~Bernoulli(sigmoid(X beta))."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((k, n)) / math.sqrt(k)
+    beta = rng.standard_normal(k)
+    p = 1.0 / (1.0 + np.exp(-(beta @ X)))
+    y = (rng.random(n) < p).astype(np.float64)
+    return [np.ascontiguousarray(y)] + [np.ascontiguousarray(X[j]) for j in range(k)]
+
+
+def logistic(n: int = 10_000_000, k: int = 50, seed: int = 4, columns=None) -> ModelSpec:
+    """cfg 4 -- logistic GLM.  theta = (a, b_0..b_{k-1}) ~ N(0,1).
+    Bernoulli(p).logDensity(v) = Real.eq(v, 0, log(1-p), log p) (core/Discrete.scala:50-51),
+    p = 1/(1+exp(-eta)) written naively like the reference (compute/Real.scala:42)."""
+    g = Graph(1 + k, [0, 1 + k])
+    a = g.param(0)
+    b = [g.param(1 + j) for j in range(k)]
+    prior = std_normal_logpdf(a)
+    for bj in b:
+        prior = prior + std_normal_logpdf(bj)
+    y = g.col(1, 0)
+    eta = a
+    for j, bj in enumerate(b):
+        eta = eta + bj * g.col(1, 1 + j)
+    p = 1.0 / ((eta * -1.0).exp() + 1.0)
+    row = g.eq(y, 0.0, (1.0 - p).log(), p.log())
+    rir = g.compile([prior, row])
+    cols = logistic_data(n, k, seed) if columns is None else columns
+    return ModelSpec("logistic_%dx%d" % (k, n), rir, cols, [0, n], 1 + k,
+                     {"kind": "logistic", "k": k, "flops_per_row": 4 * k + 10})
+
+
+def normal_1d() -> ModelSpec:
+    """The fake density of rainier-test/.../sampler/LeapFrogTest.scala:5-13: density -x^2/2, gradient -x."""
+    g = Graph(1, [0])
+    x = g.param(0)
+    rir = g.compile([(x * x) / -2.0])
+    return ModelSpec("normal1d", rir, [], [0], 1, {"kind": "normal1d"})

@@ -1,0 +1,197 @@
+"""Pins for the CPU oracle (oracle/): known answers, the reference's own LeapFrogTest, gradients."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from rainier_amd import models
+from tests import oracle_lib as O
+
+
+def test_java_util_random_known_answers(oracle):
+    # published JDK values (java.util.Random Javadoc algorithm); SURVEY.md §8(c)
+    assert O.JavaRandom(42).next_int() == -1170105035
+    assert O.JavaRandom(0).next_double() == 0.730967787376657
+    assert O.JavaRandom(0).next_gaussian() == 0.8025330637390305
+    assert O.JavaRandom(42).next_gaussian() == 1.1419053154730547
+    r = O.JavaRandom(123)  # ScalaRNG(123L), the seed of LeapFrogTest.scala:16
+    got = [r.next_gaussian() for _ in range(3)]
+    assert got == [-1.4380493091409068, 0.6341950751776804, 0.22606201283216426]
+
+
+def test_gaussian_cache_survives_uniform(oracle):
+    # nextGaussian caches its 2nd value; an intervening nextDouble must not drop it
+    a = O.JavaRandom(7); g1 = a.next_gaussian(); u = a.next_double(); g2 = a.next_gaussian()
+    b = O.JavaRandom(7); h1 = b.next_gaussian(); h2 = b.next_gaussian()
+    assert g1 == h1 and g2 == h2 and 0.0 <= u < 1.0
+
+
+def test_fdlibm_log_exp_within_one_ulp(oracle):
+    rng = np.random.default_rng(0)
+    xs = np.exp(rng.uniform(-700, 700, 20000))
+    for x in xs[:5000]:
+        a, b = oracle.jm_strict_log(x), math.log(x)
+        assert abs(a - b) <= abs(np.spacing(b))
+    for y in rng.uniform(-700, 700, 5000):
+        a, b = oracle.jm_strict_exp(y), math.exp(y)
+        assert abs(a - b) <= abs(np.spacing(b))
+    assert oracle.jm_strict_log(0.0) == -math.inf and math.isnan(oracle.jm_strict_log(-1.0))
+    assert oracle.jm_strict_exp(-math.inf) == 0.0 and oracle.jm_strict_exp(1.0) == 2.7182818284590455
+    for t in (1.0, 2.0, 17.0, 1000.0):
+        assert abs(oracle.jm_pow_neg075(O.JM_DET, t) - t ** -0.75) <= 2 * np.spacing(t ** -0.75)
+
+
+def _leapfrog_test_run(oracle, rng, mass):
+    """rainier-test/.../sampler/LeapFrogTest.scala:18-36 `run`, over the RIR normal_1d model."""
+    spec = models.normal_1d()
+    d = O.OracleDensity(spec)
+    lf = oracle.orc_lf_new(d.fn_ptr, d.handle, 1, C.byref(rng), O.JM_LIBM)
+    params = np.zeros(3)
+    m = None if mass is None else np.array(mass, dtype=np.float64)
+    mp = None if m is None else O._dp(m)
+    oracle.orc_lf_initialize(lf, mp, O._dp(params))
+    out = []
+    for _ in range(1000):
+        oracle.orc_lf_start_iteration(lf, O._dp(params), mp)
+        oracle.orc_lf_take_steps(lf, 1, 1.0, mp)
+        oracle.orc_lf_finish_iteration(lf, O._dp(params), mp)
+        out.append(params[1])
+    oracle.orc_lf_free(lf)
+    return np.array(out)
+
+
+def test_reference_leapfrogtest(oracle):
+    # LeapFrogTest.scala:15-78.  `implicit val rng = new ScalaRNG(123L)` is ONE class-level stream:
+    # the identity-mass test runs first and the diagonal-mass test continues the same stream.
+    # thresholds: |mean| < 0.2, |var(about 0) - 1| < 0.2 (identity) / 0.3 (DiagonalMassMatrix(Array(0.1)))
+    rng = O.JRandom(); oracle.jrandom_init(C.byref(rng), 123)
+    for mass, eps_var in [(None, 0.2), ([0.1], 0.3)]:
+        xs = _leapfrog_test_run(oracle, rng, mass)
+        mean = xs.sum() / xs.size
+        var = ((xs - 0.0) ** 2).sum() / (xs.size - 1)
+        assert abs(mean) < 0.2, (mass, mean)
+        assert abs(var - 1.0) < eps_var, (mass, var)
+
+
+@pytest.mark.parametrize("builder", [
+    lambda: models.funnel(10), lambda: models.eight_schools(),
+    lambda: models.linreg(n=257, k=3), lambda: models.logistic(n=101, k=5)])
+def test_gradient_matches_central_difference(oracle, builder):
+    # compute/RealTest.scala:39-52: symbolic gradient == central difference, dx = 1e-5, rel 1e-3
+    spec = builder()
+    d = O.OracleDensity(spec)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        q = rng.normal(size=spec.n_params) * 0.5
+        out = d.update(q)
+        for i in range(spec.n_params):
+            dq = np.zeros_like(q); dq[i] = 1e-5
+            fd = (d.update(q + dq)[0] - d.update(q - dq)[0]) / 2e-5
+            assert fd == pytest.approx(out[1 + i], rel=1e-3, abs=1e-6)
+
+
+def test_eight_schools_closed_form(oracle):
+    # independent closed form of SURVEY §3.4.3 on the reference's data (EightSchools.scala:22-23)
+    spec = models.eight_schools()
+    d = O.OracleDensity(spec)
+    q = np.array([0.3, -0.7, 0.1, 0.2, -0.3, 0.4, -0.5, 0.6, -0.7, 0.8])
+    m, c, z = q[0], q[1], q[2:]
+    ys = np.array(models.EIGHT_SCHOOLS_Y); sg = np.array(models.EIGHT_SCHOOLS_SIGMA)
+    theta = z * abs(5 * c) + 5 * m
+    lp = (-0.5 * m * m - models.HALF_LOG_2PI) - math.log(math.pi * (1 + c * c)) + np.sum(-0.5 * z * z - models.HALF_LOG_2PI)
+    lp += np.sum(-0.5 * ((ys - theta) / sg) ** 2 - np.log(sg) - models.HALF_LOG_2PI)
+    out = d.update(q)
+    assert out[0] == pytest.approx(lp, rel=1e-13)
+    resid = (ys - theta) / sg ** 2
+    assert out[1] == pytest.approx(-m + 5 * resid.sum(), rel=1e-12)
+    assert out[2] == pytest.approx(-2 * c / (1 + c * c) + np.sum(resid * z) * 5 * np.sign(c), rel=1e-12)
+    np.testing.assert_allclose(out[3:], -z + resid * abs(5 * c), rtol=1e-12)
+
+
+def test_linreg_closed_form_and_ld(oracle):
+    spec = models.linreg(n=5000, k=3, seed=3)
+    d = O.OracleDensity(spec)
+    q = np.array([-0.2, 0.4, 0.9, -1.8, 0.45])
+    y, X = spec.columns[0], np.stack(spec.columns[1:])
+    s, a, b = q[0], q[1], q[2:]
+    r = y - a - b @ X
+    iv = math.exp(-2 * s)
+    lp = (s - math.exp(s)) + np.sum(-0.5 * q[1:] ** 2 - models.HALF_LOG_2PI) + np.sum(-0.5 * r * r * iv - s - models.HALF_LOG_2PI)
+    g = np.concatenate([[1 - math.exp(s) + np.sum(r * r * iv - 1)], [-a + iv * r.sum()], -b + iv * (X @ r)])
+    out = d.update(q)
+    tol = 1e-12 * d.abs_sums(q)
+    assert abs(out[0] - lp) <= tol[0]
+    assert np.all(np.abs(out[1:] - g) <= tol[1:] + 1e-12)
+    assert np.all(np.abs(d.update_ld(q) - out) <= tol)
+
+
+def test_lookup_out_of_range_is_an_error(oracle):
+    from rainier_amd.frontend import Graph
+    g = Graph(1, [0])
+    x = g.param(0)
+    e = g.lookup(x, [g.const(1.0), x * 2.0], low=0)
+    spec = models.ModelSpec("lk", g.compile([e]), [], [0], 1)
+    d = O.OracleDensity(spec)
+    assert d.update(np.array([1.5]))[0] == 3.0      # D2I truncation: 1.5 -> 1
+    assert d.update(np.array([0.99]))[0] == 1.0
+    with pytest.raises(RuntimeError):
+        d.update(np.array([2.0]))                    # generated NPE in the reference (MethodGenerator.scala:164-167)
+    with pytest.raises(RuntimeError):
+        d.update(np.array([-1.0]))
+
+
+def test_compare_and_pow_semantics(oracle):
+    from rainier_amd.frontend import Graph
+    g = Graph(2, [0])
+    a, b = g.param(0), g.param(1)
+    spec = models.ModelSpec("cp", g.compile([a.compare(b) + (a ** b) * 0.0 + 0.0], gradients=[[g.const(0.0)] * 2]), [], [0], 2)
+    d = O.OracleDensity(spec)
+    assert d.update(np.array([2.0, 1.0]))[0] == 1.0
+    assert d.update(np.array([1.0, 1.0]))[0] == 0.0
+    assert d.update(np.array([0.5, 1.0]))[0] == -1.0
+    g2 = Graph(2, [0]); a, b = g2.param(0), g2.param(1)
+    spec2 = models.ModelSpec("c2", g2.compile([a.compare(b)], gradients=[[g2.const(0.0)] * 2]), [], [0], 2)
+    d2 = O.OracleDensity(spec2)
+    assert d2.update(np.array([math.nan, 1.0]))[0] == -1.0   # DCMPL: NaN -> -1
+
+
+def test_trace_diagnostics_matches_numpy(oracle):
+    rng = np.random.default_rng(5)
+    m, n = 4, 500
+    x = np.zeros((m, n))
+    for c in range(m):
+        for i in range(1, n):
+            x[c, i] = 0.7 * x[c, i - 1] + rng.normal()
+    rhat, ess = O.diagnostics(x)
+    means = x.mean(axis=1); b = n / (m - 1) * ((means - means.mean()) ** 2).sum()
+    w = (((x - means[:, None]) ** 2).sum(axis=1) / (n - 1)).mean()
+    v = (n - 1) / n * w + b / n
+    acc, lag = 0.0, 1
+    while True:
+        vt = np.mean([((x[c, lag:] - x[c, :-lag]) ** 2).sum() / (n - lag) for c in range(m)])
+        pt = 1 - vt / (2 * v)
+        if pt > 0 and lag < 100:
+            acc += pt; lag += 1
+        else:
+            break
+    assert rhat == pytest.approx(math.sqrt(v / w), rel=1e-12)
+    assert ess == pytest.approx(n * m / (1 + 2 * acc), rel=1e-10)
+    assert 100 < ess < 1000
+
+
+def test_driver_runs_and_recovers_posterior(oracle):
+    # funnel in parameter space is N(0, I): posterior mean ~0, var ~1 (statistical, 4-sigma bounds)
+    spec = models.funnel(10)
+    cfg = O.make_config(sampler=O.HMC, n_steps=5, iterations=4000, warmup=1000)
+    draws, mass, st = O.sample_model(spec, cfg, 123)
+    assert st.leapfrog_steps == 4000 * 5
+    assert st.gradient_evaluations == 4000 * 11          # reference evaluates 2L+1 per trajectory
+    assert np.all(np.abs(draws.mean(axis=0)) < 0.15)
+    assert np.all(np.abs(draws.var(axis=0) - 1.0) < 0.25)
+    assert 0.6 < st.mean_accept_prob < 0.95
+    # EHMC + windowed diagonal mass adaptation (DefaultConfig, S/Sampler.scala:17-27)
+    cfg = O.make_config(sampler=O.EHMC, max_steps=1024, iterations=2000, warmup=1000, mass_tuner=O.MASS_DIAG_WINDOWED)
+    draws, mass, st = O.sample_model(models.eight_schools(), cfg, 7)
+    assert np.all(np.isfinite(draws)) and np.all(mass > 0) and not np.allclose(mass, 1.0)
+    assert abs(draws[:, 2:].mean()) < 0.3
