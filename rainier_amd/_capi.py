@@ -1,0 +1,132 @@
+"""ctypes binding of include/rainier_hip.h (the C-ABI drop-in boundary).
+
+The shared library is built in-tree (rainier_amd/librainier_hip.so) by `make -C rainier_amd/csrc`
+(see __graft_entry__.build).  There is no CPU fallback: without the library, or without a HIP
+device, every compute entry point fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librainier_hip.so")
+
+RH_OK, RH_E_INVALID, RH_E_COMPILE, RH_E_DEVICE, RH_E_LOOKUP, RH_E_UNSUPPORTED = range(6)
+MATH_FAST, MATH_STRICT = 0, 1
+SAMPLER_HMC, SAMPLER_EHMC = 0, 1
+STEP_DUALAVG, STEP_STATIC = 0, 1
+MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG = 0, 1, 2
+
+# every symbol include/rainier_hip.h declares (checked by tests/test_capi_cpu.py)
+EXPORTS = [
+    "rh_model_create", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
+    "rh_density_eval", "rh_config_default", "rh_sample", "rh_sampler_create", "rh_sampler_destroy",
+    "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
+    "rh_sampler_timing", "rh_diagnostics", "rh_abi_version", "rh_device_count",
+]
+
+
+class CompileOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("math_mode", C.c_int32),
+                ("fp_contract", C.c_int32), ("rows_unroll", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("iterations", C.c_int32), ("warmup", C.c_int32), ("sampler", C.c_int32),
+        ("hmc_steps", C.c_int32), ("ehmc_max_steps", C.c_int32), ("ehmc_min_steps", C.c_int32),
+        ("ehmc_buf_size", C.c_int32), ("ehmc_p_count", C.c_double), ("step_tuner", C.c_int32),
+        ("mass_tuner", C.c_int32), ("dualavg_delta", C.c_double), ("static_step", C.c_double),
+        ("mass_init_window", C.c_int32), ("mass_skip_first", C.c_int32), ("mass_skip_last", C.c_int32),
+        ("reserved0", C.c_int32), ("mass_expansion", C.c_double), ("static_mass", C.POINTER(C.c_double)),
+        ("reserved", C.c_int64 * 4),
+    ]
+
+
+class ChainStats(C.Structure):
+    _fields_ = [("leapfrog_steps", C.c_int64), ("warmup_leapfrog_steps", C.c_int64),
+                ("gradient_evaluations", C.c_int64), ("accepted", C.c_int64), ("mean_accept_prob", C.c_double),
+                ("step_size", C.c_double), ("error", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int64), ("density_evals", C.c_int64),
+                ("row_chain_evals", C.c_int64), ("dominant_kernel", C.c_char * 64)]
+
+
+class RainierHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rainier_hip status %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load librainier_hip.so; raises if the native library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RainierHipError(RH_E_DEVICE, "native library missing: %s (run __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    L.rh_model_create.restype = C.c_int
+    L.rh_model_create.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.POINTER(CompileOpts), C.POINTER(vp)]
+    L.rh_model_destroy.argtypes = [vp]
+    L.rh_model_nvars.argtypes = [vp]
+    L.rh_model_hip_source.restype = C.c_char_p; L.rh_model_hip_source.argtypes = [vp]
+    L.rh_last_error.restype = C.c_char_p; L.rh_last_error.argtypes = [vp]
+    L.rh_density_eval.argtypes = [vp, dp, C.c_int32, dp, dp]
+    L.rh_config_default.argtypes = [C.POINTER(Config)]
+    L.rh_sample.argtypes = [vp, C.POINTER(Config), C.POINTER(C.c_int64), C.c_int32, dp, dp, C.POINTER(ChainStats)]
+    L.rh_sampler_create.argtypes = [vp, C.POINTER(Config), C.POINTER(C.c_int64), C.c_int32, C.POINTER(vp)]
+    L.rh_sampler_destroy.argtypes = [vp]
+    L.rh_sampler_warmup.argtypes = [vp]
+    L.rh_sampler_run.argtypes = [vp, C.c_int32]
+    L.rh_sampler_draws.argtypes = [vp, C.c_int32, C.c_int32, dp]
+    L.rh_sampler_draws_device.argtypes = [vp, C.POINTER(vp)]
+    L.rh_sampler_stats.argtypes = [vp, C.POINTER(ChainStats), dp]
+    L.rh_sampler_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.rh_diagnostics.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
+    L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.rh_free.argtypes = [vp]
+    L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]
+    _lib = L
+    return L
+
+
+def check(rc, model=None):
+    if rc != RH_OK:
+        msg = lib().rh_last_error(model)
+        raise RainierHipError(rc, msg.decode(errors="replace") if msg else "")
+
+
+def dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0):
+    o = CompileOpts()
+    o.struct_size = C.sizeof(CompileOpts)
+    o.device, o.math_mode, o.fp_contract, o.rows_unroll = device, math_mode, int(fp_contract), rows_unroll
+    return o
+
+
+def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950"):
+    """RIR -> HIP source -> gfx950 code object, without a device.  Returns (source, code_size)."""
+    L = lib()
+    src = C.c_char_p()
+    size = C.c_size_t(0)
+    buf = C.create_string_buffer(rir, len(rir))
+    o = opts if opts is not None else compile_opts()
+    rc = L.rh_lower_only(buf, len(rir), C.byref(o), arch.encode(), C.byref(src), C.byref(size))
+    text = src.value.decode() if src.value else ""
+    if src:
+        L.rh_free(src)
+    check(rc)
+    return text, size.value

@@ -1,0 +1,545 @@
+// rh_engine.hip.h -- hand-written gfx950 device library, part 2.
+//
+// Comes after the per-model generated code, which defines for every target t a
+//   template<> struct rh_target<t> { NCOLS, COL0, NINV, HAS_ROWS, invariants(th, inv, err), row(th, inv, c, acc, err) }
+// (the lowering of the reference's per-output bytecode methods, ir/CompiledFunction.scala:42-120).
+//
+//   * rh_density        : DataFunction.apply (ir/DataFunction.scala:32-84) for ONE chain on ONE wavefront:
+//                         lanes stride the observation rows (coalesced 512 B per column per load), per-lane
+//                         fp64 accumulators for all n+1 outputs, fixed-order wave butterfly at the end.
+//   * rh_chain          : the device-resident state of one chain: LeapFrog's params/pqBuf (LeapFrog.scala:118-129),
+//                         DualAvg (DualAvg.scala:43-78), VarianceEstimator + windowed tuner
+//                         (MassMatrixEstimator.scala:52-113, MassMatrix.scala:126-173), EHMC ring buffer
+//                         (Stats.scala:19-58) and the java.util.Random stream.
+//   * rh_advance        : Driver.sample (Driver.scala:7-119) + HMCSampler/EHMCSampler as a resumable automaton
+//                         that yields whenever it needs the gradient at pqBuf.q.  Each leapfrog step costs ONE
+//                         gradient evaluation (the reference spends two, LeapFrog.scala:158-188, at identical
+//                         inputs); the (p, q) sequence is the same.
+//   * kernels           : rh_chain_kernel (whole Driver loop, one chain per wavefront), rh_density_kernel
+//                         (seam 2, batched DensityFunction), rh_selftest_kernel.
+#pragma clang fp contract(off)
+
+template <int T> struct rh_target;
+
+// ---- DataFunction.apply for one chain ------------------------------------------------------------
+#ifndef RH_ROWS_UNROLL
+#define RH_ROWS_UNROLL 4
+#endif
+
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+template <int T>
+RH_DEV void rh_accumulate_target(const double (&th)[RH_NVARS], const rh_model_data &d, const int lane,
+                                 double (&tot)[RH_NOUT], int &err) {
+  typedef rh_target<T> TG;
+  double inv[TG::NINV > 0 ? TG::NINV : 1];
+  TG::invariants(th, inv, err);
+  if constexpr (!TG::HAS_ROWS) {
+    // data-free target: evaluated once, outputs(o) += f_o(theta)   (DataFunction.scala:73-83)
+    TG::row(th, inv, nullptr, tot, err);
+  } else {
+    constexpr int NC = TG::NCOLS;
+    constexpr int U = RH_ROWS_UNROLL;
+    const long long n = d.nrows[T];
+    const double *cp[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
+    double acc[RH_NOUT];
+#pragma unroll
+    for (int o = 0; o < RH_NOUT; o++) acc[o] = 0.0;
+    long long k = lane;
+    for (; k + 64LL * (U - 1) < n; k += 64LL * U) {
+      double c[U][NC];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + 64LL * u];
+#pragma unroll
+      for (int u = 0; u < U; u++) TG::row(th, inv, c[u], acc, err);
+    }
+    for (; k < n; k += 64) {
+      double c[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) c[j] = cp[j][k];
+      TG::row(th, inv, c, acc, err);
+    }
+#pragma unroll
+    for (int o = 0; o < RH_NOUT; o++) tot[o] += rh_wave_sum(acc[o]);
+  }
+}
+template <int T>
+RH_DEV void rh_accumulate_all(const double (&th)[RH_NVARS], const rh_model_data &d, const int lane,
+                              double (&tot)[RH_NOUT], int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    rh_accumulate_target<T>(th, d, lane, tot, err);
+    rh_accumulate_all<T + 1>(th, d, lane, tot, err);
+  }
+}
+#pragma clang fp contract(off)
+
+// q (lane-distributed) -> logp (wave-uniform), grad (lane-distributed)
+RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, double &logp, wvec &grad, int &err) {
+  double th[RH_NVARS];
+#pragma unroll
+  for (int i = 0; i < RH_NVARS; i++) th[i] = rh_readlane(q.s[i >> 6], i & 63); // theta in SGPR pairs
+  double tot[RH_NOUT];
+#pragma unroll
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  rh_accumulate_all<0>(th, d, lane, tot, err);
+  logp = tot[0];
+  wv_zero(grad);
+#pragma unroll
+  for (int i = 0; i < RH_NVARS; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
+}
+
+// ---- chain state ----------------------------------------------------------------------------------
+#define RH_STATE_VECS(X) \
+  X(Pp) X(Pq) X(Pg) X(Bp) X(Bq) X(Bg) X(Sp) X(Sq) X(Sg) X(M) X(SD) X(ve_mean) X(ve_raw) X(pend_g)
+#define RH_STATE_F64(X) \
+  X(PU) X(BU) X(SU) X(eps) X(da_logEps) X(da_logEpsBar) X(da_avgErr) X(da_mu) X(exponent) X(pend_logp) \
+  X(rng_nn) X(sum_accept)
+#define RH_STATE_INT(X) \
+  X(rng_have) X(pc) X(ret) X(it) X(ts_l) X(ts_i) X(cnt_l) X(find_first) X(sampling_started) X(need_eval) \
+  X(mass_identity) X(ve_samples) X(win_size) X(win_i) X(win_j) X(da_iter) X(ring_i) X(ring_full) X(n_accept) \
+  X(n_samp_iters) X(err)
+#define RH_STATE_I64(X) X(rng_seed) X(n_leapfrog) X(n_warm_leapfrog) X(n_grad)
+
+struct rh_chain {
+#define X(n) wvec n;
+  RH_STATE_VECS(X)
+#undef X
+#define X(n) double n;
+  RH_STATE_F64(X)
+#undef X
+#define X(n) int n;
+  RH_STATE_INT(X)
+#undef X
+#define X(n) rh_i64 n;
+  RH_STATE_I64(X)
+#undef X
+  double ring[RH_RING_SLOTS]; // EHMC step counts, entry i in lane i%64 of slot i/64
+};
+
+#define RH_CNT(n) +1
+#define RH_STATE_WORDS \
+  ((0 RH_STATE_VECS(RH_CNT)) * RH_SLOTS + (0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + \
+   (0 RH_STATE_I64(RH_CNT)) + RH_RING_SLOTS)
+
+// state image: word w of chain c, lane l at st[(c * RH_STATE_WORDS + w) * 64 + l]   (coalesced)
+RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
+  int w = 0;
+#define X(n) \
+  for (int k = 0; k < RH_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.n.s[k]);
+  RH_STATE_VECS(X)
+#undef X
+#define X(n) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.n);
+  RH_STATE_F64(X)
+#undef X
+#define X(n) st[(w++) * 64 + lane] = (rh_u64)(rh_i64)c.n;
+  RH_STATE_INT(X)
+#undef X
+#define X(n) st[(w++) * 64 + lane] = (rh_u64)c.n;
+  RH_STATE_I64(X)
+#undef X
+  for (int k = 0; k < RH_RING_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ring[k]);
+}
+RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
+  int w = 0;
+#define X(n) \
+  for (int k = 0; k < RH_SLOTS; k++) c.n.s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  RH_STATE_VECS(X)
+#undef X
+#define X(n) c.n = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  RH_STATE_F64(X)
+#undef X
+#define X(n) c.n = rh_uniform_i((int)(rh_i64)st[(w++) * 64 + lane]);
+  RH_STATE_INT(X)
+#undef X
+#define X(n) c.n = (rh_i64)st[(w++) * 64 + lane];
+  RH_STATE_I64(X)
+#undef X
+  for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+}
+
+// ---- automaton states ------------------------------------------------------------------------------
+enum {
+  RH_S_INIT = 0, RH_S_INIT2, RH_S_TRY_BEGIN, RH_S_TRY_END, RH_S_WARM_SETUP, RH_S_ITER_TOP, RH_S_COUNT_LOOP,
+  RH_S_COUNT_AFTER, RH_S_COUNT_DONE, RH_S_TS_BEGIN, RH_S_TS_MID, RH_S_FINISH, RH_S_DONE
+};
+
+RH_DEV rh_rng rh_rng_of(const rh_chain &c) { rh_rng r; r.seed = (rh_u64)c.rng_seed; r.have = c.rng_have; r.nn = c.rng_nn; return r; }
+RH_DEV void rh_rng_put(rh_chain &c, const rh_rng &r) { c.rng_seed = (rh_i64)r.seed; c.rng_have = (int)r.have; c.rng_nn = r.nn; }
+
+// n gaussians in ascending coordinate order (LeapFrog.scala:105-110, 231-236)
+RH_DEV void rh_fill_normal(rh_chain &c, wvec &v, const int lane) {
+  rh_rng r = rh_rng_of(c);
+  wv_zero(v);
+  for (int i = 0; i < RH_NVARS; i++) {
+    const double g = rh_rng_normal(r);
+    wv_set(v, i, g, lane);
+  }
+  rh_rng_put(c, r);
+}
+// velocity (LeapFrog.scala:202-216): Identity -> p, Diagonal -> p * elements
+RH_DEV void rh_velocity(const rh_chain &c, const wvec &p, wvec &out, const bool identity) {
+  if (identity) out = p; else wv_mul(out, p, c.M);
+}
+// energy (LeapFrog.scala:131-136)
+RH_DEV double rh_energy(const rh_chain &c, const wvec &p, const double U, const bool identity) {
+  wvec v, pr;
+  rh_velocity(c, p, v, identity);
+  wv_mul(pr, v, p);
+  const double kinetic = wv_sum_seq(pr) / 2.0;
+  return U + kinetic;
+}
+RH_DEV double rh_log_accept(const double deltaH) { // LeapFrog.scala:138-142
+  if (deltaH != deltaH) return -RH_INF;
+  return (-deltaH) < 0.0 ? (-deltaH) : 0.0;
+}
+RH_DEV void rh_new_qs(rh_chain &c, const bool identity) { // LeapFrog.scala:144-151
+  wvec v;
+  rh_velocity(c, c.Bp, v, identity);
+  wv_axpy(c.Bq, c.eps, v);
+  if (c.sampling_started) c.n_leapfrog += 1; else c.n_warm_leapfrog += 1;
+}
+RH_DEV void rh_copy_P_to_B(rh_chain &c) { c.Bp = c.Pp; c.Bq = c.Pq; c.Bg = c.Pg; c.BU = c.PU; }
+RH_DEV void rh_copy_B_to_P(rh_chain &c) { c.Pp = c.Bp; c.Pq = c.Bq; c.Pg = c.Bg; c.PU = c.BU; }
+// initializePs (LeapFrog.scala:229-251)
+RH_DEV void rh_initialize_ps(rh_chain &c, const bool identity, const int lane) {
+  wvec buf;
+  rh_fill_normal(c, buf, lane);
+  if (identity) c.Pp = buf;
+  else {
+#pragma unroll
+    for (int k = 0; k < RH_SLOTS; k++) c.Pp.s[k] = (k * 64 + lane < RH_NVARS) ? buf.s[k] / c.SD.s[k] : 0.0;
+  }
+}
+RH_DEV void rh_dualavg_new(rh_chain &c, const double stepSize) { // DualAvg.scala:80-89
+  c.da_logEps = rh_strict_log(stepSize);
+  c.da_logEpsBar = 0.0;
+  c.da_avgErr = 0.0;
+  c.da_iter = 0;
+  c.da_mu = rh_strict_log(10 * stepSize);
+}
+RH_DEV void rh_dualavg_update(rh_chain &c, const double delta, const double logAcceptanceProb) { // DualAvg.scala:58-77
+  const double newAcceptanceProb = rh_strict_exp(logAcceptanceProb);
+  c.da_iter = c.da_iter + 1;
+  const double it = (double)c.da_iter;
+  const double avgErrorMultiplier = 1.0 / (it + 10);
+  const double stepSizeMultiplier = rh_pow_neg075(it);
+  c.da_avgErr = ((1.0 - avgErrorMultiplier) * c.da_avgErr + (avgErrorMultiplier * (delta - newAcceptanceProb)));
+  c.da_logEps = (c.da_mu - (c.da_avgErr * rh_strict_sqrt(it) / 0.05));
+  c.da_logEpsBar = (stepSizeMultiplier * c.da_logEps + (1.0 - stepSizeMultiplier) * c.da_logEpsBar);
+}
+// WindowedMassMatrixTuner.update + VarianceEstimator (MassMatrix.scala:147-164, MassMatrixEstimator.scala:60-101)
+RH_DEV bool rh_mass_update(rh_chain &c, const rh_cfg_dev &cfg, const int lane) {
+  if (cfg.mass_tuner != 1 /*RH_MASS_DIAG_WINDOWED*/) return false;
+  c.win_j += 1;
+  if (c.win_j < cfg.mass_skip_first || (cfg.warmup - c.win_j) < cfg.mass_skip_last) return false;
+  c.win_i += 1;
+  c.ve_samples += 1;
+  const double ns = (double)c.ve_samples;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) {
+    const double oldDiff = c.Pq.s[k] - c.ve_mean.s[k];
+    c.ve_mean.s[k] += (oldDiff / ns);
+    const double newDiff = c.Pq.s[k] - c.ve_mean.s[k];
+    c.ve_raw.s[k] += oldDiff * newDiff;
+  }
+  if (c.win_i == c.win_size) {
+    c.win_i = 0;
+    c.win_size = (int)(c.win_size * cfg.mass_expansion);
+#pragma unroll
+    for (int k = 0; k < RH_SLOTS; k++) {
+      const bool live = (k * 64 + lane < RH_NVARS);
+      c.M.s[k] = live ? c.ve_raw.s[k] / ns : 1.0;         // variance = raw / samples (population form)
+      c.SD.s[k] = live ? rh_strict_sqrt(c.M.s[k]) : 1.0;  // DiagonalMassMatrix.stdDevs
+      c.ve_mean.s[k] = 0.0;                               // reset() zeroes mean and raw, NOT samples
+      c.ve_raw.s[k] = 0.0;
+    }
+    c.mass_identity = 0;
+    return true;
+  }
+  return false;
+}
+RH_DEV void rh_ring_add(rh_chain &c, const int size, const double v, const int lane) { // Stats.scala:24-30
+  c.ring_i += 1;
+  if (c.ring_i == size) c.ring_full = 1;
+  c.ring_i = c.ring_i % size;
+#pragma unroll
+  for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = (k * 64 + lane == c.ring_i) ? v : c.ring[k];
+}
+RH_DEV double rh_ring_sample(rh_chain &c, const int size) { // Stats.scala:40-45
+  rh_rng r = rh_rng_of(c);
+  const int idx = rh_uniform_i(c.ring_full ? rh_rng_int(r, size) : rh_rng_int(r, c.ring_i + 1));
+  rh_rng_put(c, r);
+  double out = 0.0;
+#pragma unroll
+  for (int k = 0; k < RH_RING_SLOTS; k++)
+    if ((idx >> 6) == k) out = rh_readlane(c.ring[k], idx & 63);
+  return out;
+}
+RH_DEV bool rh_is_uturn(const rh_chain &c) { // LeapFrog.scala:35-47
+  wvec dq, pr;
+  wv_sub(dq, c.Bq, c.Pq);
+  wv_mul(pr, dq, c.Bp);
+  const double out = wv_sum_seq(pr);
+  if (out != out) return true;
+  return out < 0;
+}
+
+// Consumes the pending gradient (c.pend_logp / c.pend_g, evaluated at c.Bq) if the automaton was waiting for
+// one, and runs until it needs the next gradient (RH_ADV_NEED_GRAD), reaches iteration `it_stop`
+// (RH_ADV_PAUSED) or finishes (RH_ADV_DONE).  All control flow is wave-uniform.
+RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, const rh_i64 seed,
+                      const double *static_mass, double *draws, const int lane) {
+  for (;;) {
+    switch (c.pc) {
+    case RH_S_INIT: { // LeapFrog.initialize (LeapFrog.scala:102-116), first half
+      rh_rng r; rh_rng_init(r, seed); rh_rng_put(c, r);
+      wv_zero(c.Bp); wv_zero(c.Bg); c.BU = 0.0;
+      rh_fill_normal(c, c.Bq, lane);
+      wv_fill(c.M, 1.0, lane); wv_fill(c.SD, 1.0, lane); c.mass_identity = 1;
+      c.pc = RH_S_INIT2; c.n_grad += 1;
+      return RH_ADV_NEED_GRAD;
+    }
+    case RH_S_INIT2: {
+      c.BU = c.pend_logp * -1; c.Bg = c.pend_g;
+      rh_copy_B_to_P(c);
+      rh_initialize_ps(c, true, lane);
+      // sampler.initialize: nothing to do (EHMC's snapshot buffer is part of the state)
+      if (cfg.step_tuner == 0 /*DualAvgTuner.initialize: findReasonableStepSize with IdentityMassMatrix*/) {
+        c.eps = 1.0; c.find_first = 1; c.pc = RH_S_TRY_BEGIN;
+      } else { c.eps = cfg.static_step; c.pc = RH_S_WARM_SETUP; }
+      break;
+    }
+    case RH_S_TRY_BEGIN: { // LeapFrog.tryStepping (LeapFrog.scala:14-22) up to the gradient at the new q
+      rh_copy_P_to_B(c);
+      wv_axpy(c.Bp, c.eps / 2.0, c.Bg);
+      rh_new_qs(c, true);
+      c.pc = RH_S_TRY_END; c.n_grad += 1;
+      return RH_ADV_NEED_GRAD;
+    }
+    case RH_S_TRY_END: { // DualAvg.scala:27-41
+      c.BU = c.pend_logp * -1; c.Bg = c.pend_g;
+      wv_axpy(c.Bp, c.eps / 2.0, c.Bg);
+      const double a = rh_log_accept(rh_energy(c, c.Bp, c.BU, true) - rh_energy(c, c.Pp, c.PU, true));
+      if (c.find_first) { c.exponent = (a > rh_strict_log(0.5)) ? 1.0 : -1.0; c.find_first = 0; }
+      if (c.eps != 0.0 && (c.exponent * a > -c.exponent * rh_strict_log(2.0))) {
+        c.eps *= (c.exponent > 0.0 ? 2.0 : 0.5);
+        c.pc = RH_S_TRY_BEGIN;
+      } else {
+        rh_dualavg_new(c, c.eps);
+        c.pc = RH_S_WARM_SETUP;
+      }
+      break;
+    }
+    case RH_S_WARM_SETUP: { // massMatrixTuner.initialize (MassMatrix.scala:139-143, Sampler.scala:47-50)
+      if (cfg.mass_tuner == 2 /*StaticMassMatrix(DiagonalMassMatrix)*/) {
+#pragma unroll
+        for (int k = 0; k < RH_SLOTS; k++) {
+          const int i = k * 64 + lane;
+          c.M.s[k] = i < RH_NVARS ? static_mass[i] : 1.0;
+          c.SD.s[k] = rh_strict_sqrt(c.M.s[k]);
+        }
+        c.mass_identity = 0;
+      }
+      c.win_size = cfg.mass_init_window; c.win_i = 0; c.win_j = 0; c.ve_samples = 0;
+      wv_zero(c.ve_mean); wv_zero(c.ve_raw);
+      c.it = 0; c.pc = RH_S_ITER_TOP;
+      break;
+    }
+    case RH_S_ITER_TOP: { // Driver.warmup / collectSamples loop heads (Driver.scala:67, 104)
+      if (c.it >= cfg.warmup && !c.sampling_started) { // lf.resetStats(); stepSize = stepSizeTuner.stepSize
+        if (cfg.step_tuner == 0) c.eps = rh_strict_exp(c.da_logEpsBar);
+        c.sampling_started = 1; c.n_grad = 0;
+      }
+      if (c.it >= cfg.warmup + cfg.iterations) { c.pc = RH_S_DONE; return RH_ADV_DONE; }
+      if (c.it >= it_stop) return RH_ADV_PAUSED;
+      // startIteration (LeapFrog.scala:52-59): fresh momenta, pqBuf := params
+      rh_initialize_ps(c, c.mass_identity != 0, lane);
+      rh_copy_P_to_B(c);
+      if (cfg.sampler == 0) { // HMCSampler (HMC.scala:6-23)
+        c.ts_l = cfg.hmc_steps; c.ret = RH_S_FINISH; c.pc = RH_S_TS_BEGIN;
+      } else {                // EHMCSampler (EHMC.scala:15-30, 52-61)
+        bool count = false;
+        if (c.it < cfg.warmup) {
+          if (!c.ring_full) count = true;
+          else { rh_rng r = rh_rng_of(c); const double u = rh_rng_uniform(r); rh_rng_put(c, r); count = u < cfg.ehmc_p_count; }
+        }
+        if (count) { c.cnt_l = 0; c.pc = RH_S_COUNT_LOOP; }
+        else { c.ts_l = rh_uniform_i((int)rh_ring_sample(c, cfg.ehmc_buf_size)); c.ret = RH_S_FINISH; c.pc = RH_S_TS_BEGIN; }
+      }
+      break;
+    }
+    case RH_S_COUNT_LOOP: { // EHMC.countSteps (EHMC.scala:32-50)
+      if (!rh_is_uturn(c) && c.cnt_l < cfg.ehmc_max_steps) {
+        c.cnt_l += 1; c.ts_l = 1; c.ret = RH_S_COUNT_AFTER; c.pc = RH_S_TS_BEGIN;
+      } else if (c.cnt_l < cfg.ehmc_min_steps) {
+        c.ts_l = cfg.ehmc_min_steps - c.cnt_l; c.ret = RH_S_COUNT_DONE; c.pc = RH_S_TS_BEGIN;
+      } else {
+        c.Bp = c.Sp; c.Bq = c.Sq; c.Bg = c.Sg; c.BU = c.SU; // lf.restore(buf)
+        c.pc = RH_S_COUNT_DONE;
+      }
+      break;
+    }
+    case RH_S_COUNT_AFTER: {
+      if (c.cnt_l == cfg.ehmc_min_steps) { c.Sp = c.Bp; c.Sq = c.Bq; c.Sg = c.Bg; c.SU = c.BU; } // lf.snapshot(buf)
+      c.pc = RH_S_COUNT_LOOP;
+      break;
+    }
+    case RH_S_COUNT_DONE: {
+      rh_ring_add(c, cfg.ehmc_buf_size, (double)c.cnt_l, lane);
+      c.pc = RH_S_FINISH;
+      break;
+    }
+    case RH_S_TS_BEGIN: { // takeSteps: initialHalfThenFullStep (LeapFrog.scala:24-33, 153-163)
+      wv_axpy(c.Bp, c.eps / 2.0, c.Bg);
+      rh_new_qs(c, c.mass_identity != 0);
+      c.ts_i = 1; c.pc = RH_S_TS_MID; c.n_grad += 1;
+      return RH_ADV_NEED_GRAD;
+    }
+    case RH_S_TS_MID: {
+      c.BU = c.pend_logp * -1; c.Bg = c.pend_g;
+      if (c.ts_i < c.ts_l) { // twoFullSteps (LeapFrog.scala:175-184): ONE p += eps * grad, then q
+        wv_axpy(c.Bp, c.eps, c.Bg);
+        rh_new_qs(c, c.mass_identity != 0);
+        c.ts_i += 1; c.n_grad += 1;
+        return RH_ADV_NEED_GRAD;
+      }
+      wv_axpy(c.Bp, c.eps / 2.0, c.Bg); // finalHalfStep
+      c.pc = c.ret;
+      break;
+    }
+    case RH_S_FINISH: { // finishIteration (LeapFrog.scala:61-82) + the Driver's per-iteration bookkeeping
+      const bool ident = c.mass_identity != 0;
+      const double startH = rh_energy(c, c.Pp, c.PU, ident);
+      const double endH = rh_energy(c, c.Bp, c.BU, ident);
+      const double a = rh_log_accept(endH - startH);
+      rh_rng r = rh_rng_of(c);
+      const double u = rh_rng_uniform(r);
+      rh_rng_put(c, r);
+      const bool accept = a > rh_strict_log(u);
+      if (accept) rh_copy_B_to_P(c);
+      if (c.it < cfg.warmup) { // Driver.warmup (Driver.scala:68-80)
+        if (cfg.step_tuner == 0) { rh_dualavg_update(c, cfg.dualavg_delta, a); c.eps = rh_strict_exp(c.da_logEps); }
+        if (rh_mass_update(c, cfg, lane)) {
+          if (cfg.step_tuner == 0) { // stepSizeTuner.reset() (DualAvg.scala:17-21)
+            const double ss = rh_strict_exp(c.da_logEpsBar);
+            rh_dualavg_new(c, ss);
+            c.eps = ss;
+          }
+        }
+      } else { // Driver.collectSamples (Driver.scala:104-108)
+        c.n_accept += accept ? 1 : 0;
+        c.sum_accept += rh_strict_exp(a);
+        c.n_samp_iters += 1;
+        double *out = draws + (size_t)(c.it - cfg.warmup) * RH_NVARS;
+#pragma unroll
+        for (int k = 0; k < RH_SLOTS; k++)
+          if (k * 64 + lane < RH_NVARS) out[k * 64 + lane] = c.Pq.s[k];
+      }
+      c.it += 1;
+      c.pc = RH_S_ITER_TOP;
+      break;
+    }
+    default:
+      return RH_ADV_DONE;
+    }
+  }
+}
+
+RH_DEV void rh_stats_write(const rh_chain &c, rh_chain_stats_dev *out, const int status, const int lane) {
+  if (lane == 0) {
+    out->leapfrog_steps = c.n_leapfrog; out->warmup_leapfrog_steps = c.n_warm_leapfrog;
+    out->gradient_evaluations = c.n_grad; out->accepted = c.n_accept;
+    out->sum_accept_prob = c.sum_accept; out->step_size = c.eps;
+    out->sampling_iterations = c.n_samp_iters; out->error = c.err; out->status = status;
+  }
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------
+// One chain per wavefront (64-thread workgroup), the whole Driver loop on the device.  `fresh` starts the
+// chains from their seeds; otherwise the state image is resumed.  The launch ends for a chain when it reaches
+// iteration it_stop, finishes, or has spent max_ticks gradient evaluations (host relaunches until all paused).
+extern "C" __global__ void __launch_bounds__(64)
+rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__ state,
+                const rh_i64 *__restrict__ seeds, const double *__restrict__ static_mass,
+                double *__restrict__ draws, rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running,
+                const int chains, const int it_stop, const int max_ticks, const int fresh) {
+  const int chain = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (chain >= chains) return;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_WORDS * 64;
+  rh_chain c;
+  if (fresh) {
+    rh_u64 *z = st;
+    for (int w = 0; w < RH_STATE_WORDS; w++) z[w * 64 + lane] = 0;
+  }
+  rh_chain_load(c, st, lane);
+  double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
+  const rh_i64 seed = seeds[chain];
+  int ticks = 0, status;
+  if (c.need_eval) {
+    int err = 0;
+    rh_density(c.Bq, d, lane, c.pend_logp, c.pend_g, err);
+    c.err |= err; c.need_eval = 0; ticks = 1;
+  }
+  for (;;) {
+    status = rh_advance(c, cfg, it_stop, seed, static_mass, my_draws, lane);
+    if (status != RH_ADV_NEED_GRAD) break;
+    if (ticks >= max_ticks) { c.need_eval = 1; break; }
+    int err = 0;
+    rh_density(c.Bq, d, lane, c.pend_logp, c.pend_g, err);
+    c.err |= err;
+    ticks += 1;
+  }
+  rh_chain_store(c, st, lane);
+  rh_stats_write(c, stats + chain, status, lane);
+  if (status == RH_ADV_NEED_GRAD && lane == 0) atomicAdd(n_running, 1);
+}
+
+// Seam 2: batched DensityFunction.  q [chains][nvars] -> logp [chains], grad [chains][nvars]; one wavefront per chain.
+extern "C" __global__ void __launch_bounds__(64)
+rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,
+                  double *__restrict__ grad, int *__restrict__ err_out, const int chains) {
+  const int chain = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (chain >= chains) return;
+  wvec qv, gv;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
+  double lp; int err = 0;
+  rh_density(qv, d, lane, lp, gv, err);
+  if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++)
+    if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
+}
+
+// Device self-test of the bit-exact pieces: mode 0 = n gaussians of ScalaRNG(seed), 1 = n uniforms,
+// 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75
+extern "C" __global__ void __launch_bounds__(64)
+rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__ in, double *__restrict__ out, const int n) {
+  const int lane = threadIdx.x;
+  if (mode <= 1) {
+    rh_rng r; rh_rng_init(r, seed);
+    for (int i = 0; i < n; i++) {
+      const double v = mode == 0 ? rh_rng_normal(r) : rh_rng_uniform(r);
+      if (lane == (i & 63)) out[i] = v;
+    }
+  } else {
+    for (int i = lane + blockIdx.x * 64; i < n; i += 64 * gridDim.x) {
+      double v;
+      if (mode == 2) v = rh_strict_log(in[i]);
+      else if (mode == 3) v = rh_strict_exp(in[i]);
+      else if (mode == 4) v = rh_strict_sqrt(in[i]);
+      else if (mode == 5) v = in[2 * i] / in[2 * i + 1];
+      else v = rh_pow_neg075(in[i]);
+      out[i] = v;
+    }
+  }
+}
+
+extern "C" __device__ __attribute__((used)) const int rh_state_words = RH_STATE_WORDS;

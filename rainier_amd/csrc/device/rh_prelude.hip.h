@@ -1,0 +1,230 @@
+// rh_prelude.hip.h -- hand-written gfx950 device library, part 1 (wave64, one chain per wavefront).
+//
+//   * strict fp64 helpers: fdlibm log/exp (java.lang.StrictMath), Java pow/compare/d2i semantics
+//   * device java.util.Random (bit-exact LCG + polar nextGaussian)  -- replaces sampler/RNG.scala:20-26
+//   * wvec: a length-RH_NVARS vector distributed over the 64 lanes of the chain's wavefront
+//
+// Everything here is compiled with FP contraction OFF: the JVM never fuses a*b+c, and the sampler
+// arithmetic (LeapFrog.scala:144-173 `x(i) += s * y(i)`) must round the product before the add.
+#pragma clang fp contract(off)
+
+typedef unsigned long long rh_u64;
+typedef long long rh_i64;
+#define RH_DEV __device__ __forceinline__
+#define RH_INF (__builtin_huge_val())
+#define RH_NAN (__builtin_nan(""))
+
+RH_DEV int rh_hi(double x) { return __double2hiint(x); }
+RH_DEV unsigned rh_lo(double x) { return (unsigned)__double2loint(x); }
+RH_DEV double rh_with_hi(double x, int h) { return __hiloint2double(h, __double2loint(x)); }
+
+// ---- fdlibm 5.3 e_log.c (== java.lang.StrictMath.log) --------------------------------------------
+RH_DEV double rh_strict_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
+               Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+               Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+  int hx = rh_hi(x);
+  unsigned lx = rh_lo(x);
+  int k = 0;
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | lx) == 0) return -RH_INF;
+    if (hx < 0) return RH_NAN;
+    k -= 54; x *= two54; hx = rh_hi(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  int i = (hx + 0x95f64) & 0x100000;
+  x = rh_with_hi(x, hx | (i ^ 0x3ff00000));
+  k += (i >> 20);
+  double f = x - 1.0;
+  double dk = (double)k;
+  if ((0x000fffff & (2 + hx)) < 3) {
+    if (f == 0.0) { if (k == 0) return 0.0; return dk * ln2_hi + dk * ln2_lo; }
+    double R = f * f * (0.5 - 0.33333333333333333 * f);
+    if (k == 0) return f - R;
+    return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  double s = f / (2.0 + f);
+  double z = s * s;
+  i = hx - 0x6147a;
+  double w = z * z;
+  int j = 0x6b851 - hx;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  double R = t2 + t1;
+  if (i > 0) {
+    double hfsq = 0.5 * f * f;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  if (k == 0) return f - s * (f - R);
+  return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// ---- fdlibm 5.3 e_exp.c (== java.lang.StrictMath.exp) --------------------------------------------
+RH_DEV double rh_strict_exp(double x) {
+  const double huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302,
+               o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+               ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+               P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  double hi = 0.0, lo = 0.0;
+  int k = 0;
+  unsigned hx = (unsigned)rh_hi(x);
+  const int xsb = (int)((hx >> 31) & 1);
+  hx &= 0x7fffffff;
+  if (hx >= 0x40862E42) {
+    if (hx >= 0x7ff00000) {
+      if (((hx & 0xfffff) | rh_lo(x)) != 0) return x + x;
+      return (xsb == 0) ? x : 0.0;
+    }
+    if (x > o_threshold) return huge * huge;
+    if (x < u_threshold) return twom1000 * twom1000;
+  }
+  if (hx > 0x3fd62e42) {
+    if (hx < 0x3FF0A2B2) {
+      hi = x - (xsb ? -ln2HI : ln2HI); lo = xsb ? -ln2LO : ln2LO; k = 1 - xsb - xsb;
+    } else {
+      k = (int)(invln2 * x + (xsb ? -0.5 : 0.5));
+      const double t = (double)k;
+      hi = x - t * ln2HI;
+      lo = t * ln2LO;
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000) {
+    return 1.0 + x;
+  }
+  const double t = x * x;
+  const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k >= -1021) return rh_with_hi(y, rh_hi(y) + (k << 20));
+  y = rh_with_hi(y, rh_hi(y) + ((k + 1000) << 20));
+  return y * twom1000;
+}
+
+RH_DEV double rh_strict_sqrt(double x) { return __builtin_sqrt(x); } // IEEE correctly rounded (checked by tests)
+// Math.pow(t, -0.75) for the dual-averaging decay, t a positive integer: sqrt-composed, bit-reproducible
+RH_DEV double rh_pow_neg075(double t) { const double r = rh_strict_sqrt(t); return 1.0 / (r * rh_strict_sqrt(r)); }
+
+// ---- JVM op semantics used by generated model code (ir/MethodGenerator.scala:56-94,134-167) -------
+RH_DEV double rh_compare(double l, double r) { return l > r ? 1.0 : (l == r ? 0.0 : -1.0); } // DCMPL; I2D
+RH_DEV int rh_d2i(double x) { // D2I: NaN -> 0, saturating
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (-2147483647 - 1);
+  return (int)x;
+}
+RH_DEV double rh_java_pow(double x, double y) { // java.lang.Math.pow = C99 pow + two Java-specific NaN cases
+  if (y == 0.0) return 1.0;
+  if (y != y) return RH_NAN;
+  if (__builtin_isinf(y) && __builtin_fabs(x) == 1.0) return RH_NAN;
+  return pow(x, y);
+}
+
+// ---- java.util.Random, one stream per chain, replicated in every lane (wave-uniform) -------------
+struct rh_rng {
+  rh_u64 seed;
+  rh_i64 have; // haveNextNextGaussian
+  double nn;   // nextNextGaussian
+};
+RH_DEV void rh_rng_init(rh_rng &r, rh_i64 seed) {
+  r.seed = ((rh_u64)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1);
+  r.have = 0; r.nn = 0.0;
+}
+RH_DEV int rh_rng_next(rh_rng &r, int bits) {
+  r.seed = (r.seed * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+  return (int)(r.seed >> (48 - bits));
+}
+RH_DEV double rh_rng_uniform(rh_rng &r) { // nextDouble  == RNG.standardUniform
+  const rh_i64 a = (rh_i64)rh_rng_next(r, 26);
+  const rh_i64 b = (rh_i64)rh_rng_next(r, 27);
+  return (double)((a << 27) + b) * 0x1.0p-53;
+}
+RH_DEV double rh_rng_normal(rh_rng &r) { // nextGaussian == RNG.standardNormal
+  if (r.have) { r.have = 0; return r.nn; }
+  double v1, v2, s;
+  do {
+    v1 = 2 * rh_rng_uniform(r) - 1;
+    v2 = 2 * rh_rng_uniform(r) - 1;
+    s = v1 * v1 + v2 * v2;
+  } while (s >= 1 || s == 0);
+  const double multiplier = rh_strict_sqrt(-2 * rh_strict_log(s) / s);
+  r.nn = v2 * multiplier;
+  r.have = 1;
+  return v1 * multiplier;
+}
+RH_DEV int rh_rng_int(rh_rng &r, int until) { // RNG.int (sampler/RNG.scala:9-10)
+  const int v = (int)(rh_rng_uniform(r) * until);
+  return v < until - 1 ? v : until - 1;
+}
+
+// ---- wave64 primitives ---------------------------------------------------------------------------
+RH_DEV double rh_readlane(double v, int lane) { // wave-uniform broadcast of one lane's value (SGPR pair)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+RH_DEV double rh_uniform(double v) { return rh_readlane(v, 0); }
+RH_DEV int rh_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// fixed-order butterfly: every lane ends with the bitwise-identical sum (run-to-run reproducible)
+RH_DEV double rh_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// length-RH_NVARS vector, element i in lane (i % 64), slot (i / 64); unused lanes hold 0
+struct wvec { double s[RH_SLOTS]; };
+RH_DEV void wv_zero(wvec &v) {
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) v.s[k] = 0.0;
+}
+RH_DEV void wv_fill(wvec &v, double x, int lane) {
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) v.s[k] = (k * 64 + lane < RH_NVARS) ? x : 0.0;
+}
+// y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
+RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) {
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) y.s[k] += a * x.s[k];
+}
+RH_DEV void wv_mul(wvec &out, const wvec &x, const wvec &y) {
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] * y.s[k];
+}
+RH_DEV void wv_sub(wvec &out, const wvec &x, const wvec &y) {
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] - y.s[k];
+}
+RH_DEV void wv_set(wvec &v, int i, double x, int lane) { // i wave-uniform
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) v.s[k] = (k * 64 + lane == i) ? x : v.s[k];
+}
+RH_DEV double wv_get(const wvec &v, int i) { // i wave-uniform; returns wave-uniform value
+  double out = 0.0;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++)
+    if ((i >> 6) == k) out = rh_readlane(v.s[k], i & 63);
+  return out;
+}
+// sum_{i<n} x(i), strictly left to right like the reference's while loops (LeapFrog.scala:218-227)
+RH_DEV double wv_sum_seq(const wvec &x) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) {
+    const int m = (RH_NVARS - k * 64) < 64 ? (RH_NVARS - k * 64) : 64;
+    if (RH_NVARS <= 64) {
+#pragma unroll
+      for (int l = 0; l < m; l++) acc += rh_readlane(x.s[k], l);
+    } else {
+      for (int l = 0; l < m; l++) acc += rh_readlane(x.s[k], l);
+    }
+  }
+  return acc;
+}

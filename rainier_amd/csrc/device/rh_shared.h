@@ -1,0 +1,40 @@
+// rh_shared.h -- POD types shared verbatim by the host engine (C++) and the device code (hiprtc).
+// Plain C; no includes (it is also prepended to the runtime-compiled source).
+#ifndef RH_SHARED_H
+#define RH_SHARED_H
+
+#define RH_MAX_TARGETS 64
+#define RH_MAX_COLS 128
+#define RH_RING_SLOTS 4  /* EHMC step-count ring buffer: <= 256 entries, lane-distributed */
+
+/* return codes of the per-chain automaton */
+#define RH_ADV_NEED_GRAD 0
+#define RH_ADV_PAUSED 1
+#define RH_ADV_DONE 2
+
+/* device copy of rh_config (include/rainier_hip.h); static mass is uploaded separately */
+typedef struct rh_cfg_dev {
+  int iterations, warmup;
+  int sampler, hmc_steps;
+  int ehmc_max_steps, ehmc_min_steps, ehmc_buf_size, step_tuner;
+  double ehmc_p_count;
+  double dualavg_delta, static_step;
+  int mass_tuner, mass_init_window, mass_skip_first, mass_skip_last;
+  double mass_expansion;
+} rh_cfg_dev;
+
+/* observation columns resident in HBM: flattened target-major, then column */
+typedef struct rh_model_data {
+  const double *cols[RH_MAX_COLS];
+  long long nrows[RH_MAX_TARGETS];
+} rh_model_data;
+
+/* per-chain result record written by the kernels (mirrors rh_chain_stats) */
+typedef struct rh_chain_stats_dev {
+  long long leapfrog_steps, warmup_leapfrog_steps, gradient_evaluations, accepted;
+  double sum_accept_prob, step_size;
+  long long sampling_iterations;
+  int error, status; /* status: last RH_ADV_* */
+} rh_chain_stats_dev;
+
+#endif

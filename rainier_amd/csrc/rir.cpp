@@ -1,0 +1,104 @@
+// rir.cpp -- RIR reader/validator (format: include/rainier_hip_rir.h).
+#include "rir.hpp"
+
+#include <cstring>
+
+#include "../../include/rainier_hip_rir.h"
+#include "device/rh_shared.h"
+
+namespace rh {
+namespace {
+struct Reader {
+  const uint8_t *p;
+  size_t n, pos = 0;
+  bool bad = false;
+  uint32_t u32() {
+    if (pos + 4 > n) { bad = true; return 0; }
+    uint32_t v; std::memcpy(&v, p + pos, 4); pos += 4; return v;
+  }
+  double f64() {
+    if (pos + 8 > n) { bad = true; return 0; }
+    double v; std::memcpy(&v, p + pos, 8); pos += 8; return v;
+  }
+};
+}  // namespace
+
+bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
+  if (!buf || len < 24 || (len & 3)) { err = "RIR: blob too short or not 4-byte sized"; return false; }
+  Reader r{static_cast<const uint8_t *>(buf), len};
+  if (r.u32() != RH_RIR_MAGIC) { err = "RIR: bad magic"; return false; }
+  if (r.u32() != RH_RIR_VERSION) { err = "RIR: unsupported version"; return false; }
+  P.n_params = r.u32();
+  const uint32_t n_targets = r.u32(), n_nodes = r.u32();
+  (void)r.u32();
+  if (P.n_params == 0 || n_targets == 0 || n_targets > RH_MAX_TARGETS) { err = "RIR: bad header (params/targets)"; return false; }
+  if ((size_t)n_nodes * 8 > len) { err = "RIR: node count exceeds blob"; return false; }
+  P.targets.resize(n_targets);
+  uint32_t in = P.n_params, col = 0;
+  for (auto &t : P.targets) {
+    t.n_cols = r.u32(); (void)r.u32();
+    t.input_start = in; t.col0 = col;
+    in += t.n_cols; col += t.n_cols;
+    t.outputs.resize(P.n_params + 1);
+    for (auto &o : t.outputs) { o = r.u32(); if (o >= n_nodes) { err = "RIR: output node id out of range"; return false; } }
+    if (r.bad) { err = "RIR: truncated target table"; return false; }
+  }
+  if (col > RH_MAX_COLS) { err = "RIR: too many data columns"; return false; }
+  P.n_inputs = in; P.n_cols_total = col;
+  P.nodes.resize(n_nodes);
+  for (uint32_t i = 0; i < n_nodes; i++) {
+    Node &nd = P.nodes[i];
+    nd.op = r.u32();
+    uint8_t dep = 0;
+    auto use = [&](uint32_t x) -> bool {
+      if (x >= i) { err = "RIR: node " + std::to_string(i) + " references a later node"; return false; }
+      const uint8_t d = P.nodes[x].dep;
+      if (d) { if (dep && dep != d) { err = "RIR: node " + std::to_string(i) + " mixes columns of two targets"; return false; } dep = d; }
+      return true;
+    };
+    switch (nd.op) {
+      case RH_RIR_CONST:
+        nd.cval = r.f64();
+        if (nd.cval != nd.cval) { err = "RIR: NaN constant"; return false; }
+        break;
+      case RH_RIR_INPUT:
+        nd.input = r.u32();
+        if (nd.input >= P.n_inputs) { err = "RIR: input index out of range"; return false; }
+        if (nd.input >= P.n_params)
+          for (uint32_t t = 0; t < n_targets; t++)
+            if (nd.input >= P.targets[t].input_start && nd.input < P.targets[t].input_start + P.targets[t].n_cols) dep = (uint8_t)(t + 1);
+        break;
+      case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_POW: case RH_RIR_COMPARE:
+      case RH_RIR_SEQ:
+        nd.a = r.u32(); nd.b = r.u32();
+        if (!use(nd.a) || !use(nd.b)) return false;
+        break;
+      case RH_RIR_EXP: case RH_RIR_LOG: case RH_RIR_ABS: case RH_RIR_NOOP: case RH_RIR_SIN: case RH_RIR_COS:
+      case RH_RIR_TAN: case RH_RIR_ASIN: case RH_RIR_ACOS: case RH_RIR_ATAN:
+        nd.a = r.u32();
+        if (!use(nd.a)) return false;
+        break;
+      case RH_RIR_LOOKUP: {
+        nd.a = r.u32(); nd.low = (int32_t)r.u32();
+        const uint32_t cnt = r.u32();
+        if (cnt == 0 || (size_t)cnt * 4 > len) { err = "RIR: bad lookup table size"; return false; }
+        if (!use(nd.a)) return false;
+        nd.table.resize(cnt);
+        for (auto &e : nd.table) { e = r.u32(); if (!use(e)) return false; }
+        break;
+      }
+      default: err = "RIR: unknown opcode " + std::to_string(nd.op); return false;
+    }
+    if (r.bad) { err = "RIR: truncated node table"; return false; }
+    nd.dep = dep;
+  }
+  if (r.pos != r.n) { err = "RIR: trailing bytes"; return false; }
+  // a target's outputs may only reach its own columns
+  for (uint32_t t = 0; t < n_targets; t++)
+    for (uint32_t o : P.targets[t].outputs) {
+      const uint8_t d = P.nodes[o].dep;
+      if (d && d != t + 1) { err = "RIR: target " + std::to_string(t) + " reads a column of another target"; return false; }
+    }
+  return true;
+}
+}  // namespace rh

@@ -1,0 +1,44 @@
+// rir.hpp -- in-memory form of an RIR program (include/rainier_hip_rir.h) and the IR -> HIP emitter.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rh {
+
+struct Node {
+  uint32_t op = 0, a = 0, b = 0;
+  double cval = 0.0;
+  uint32_t input = 0;
+  int32_t low = 0;
+  std::vector<uint32_t> table;
+  uint8_t dep = 0;  // 0: parameters only; t+1: reads a column of target t
+};
+
+struct Target {
+  uint32_t n_cols = 0;
+  uint32_t input_start = 0;  // first DataFunction input slot of this target's columns
+  uint32_t col0 = 0;         // index of its first column in the flattened column list
+  std::vector<uint32_t> outputs;  // [n_params + 1]
+};
+
+struct Program {
+  uint32_t n_params = 0, n_inputs = 0, n_cols_total = 0;
+  std::vector<Target> targets;
+  std::vector<Node> nodes;
+};
+
+// Parses and validates a blob; returns false and sets err on malformed input.
+bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
+
+struct EmitOptions {
+  bool strict_math = false;  // EXP/LOG -> fdlibm
+  bool fp_contract = false;  // allow FMA contraction in model code
+  int rows_unroll = 4;
+};
+
+// Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).
+// The replacement for the reference's ASM generators (ir/ExprMethodGenerator.scala, ir/OutputClassGenerator.scala).
+bool emit_hip(const Program &p, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err);
+
+}  // namespace rh

@@ -1,0 +1,98 @@
+"""CPU-side checks of the C-ABI library: it loads, exports what include/rainier_hip.h declares, lowers every
+model to a gfx950 code object, rejects malformed input -- and refuses to compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rainier_amd import _capi, models
+from tests import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as G
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rainier_amd", "csrc")])
+    return _capi.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "rainier_hip.h")).read()
+    declared = set(re.findall(r"\b(rh_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rh_abi_version() == 1
+
+
+def test_struct_layouts_match_header(lib):
+    c = _capi.Config()
+    lib.rh_config_default(C.byref(c))
+    assert c.struct_size == C.sizeof(_capi.Config)
+    # DefaultConfig (sampler/Sampler.scala:17-27)
+    assert (c.iterations, c.warmup, c.sampler, c.ehmc_max_steps, c.ehmc_min_steps, c.ehmc_buf_size) == (1000, 1000, 1, 1024, 1, 100)
+    assert (c.ehmc_p_count, c.dualavg_delta, c.step_tuner, c.mass_tuner) == (0.1, 0.8, 0, 1)
+    assert (c.mass_init_window, c.mass_expansion, c.mass_skip_first, c.mass_skip_last) == (50, 1.5, 50, 50)
+
+
+@pytest.mark.parametrize("builder", [models.normal_1d, models.funnel, models.eight_schools,
+                                     lambda: models.linreg(n=8), lambda: models.logistic(n=8, k=5)])
+def test_lowering_cross_compiles_for_gfx950(lib, builder):
+    spec = builder()
+    for mode in (_capi.MATH_FAST, _capi.MATH_STRICT):
+        src, size = _capi.lower_only(spec.rir, _capi.compile_opts(math_mode=mode))
+        assert size > 1000
+        assert "#define RH_NVARS %d" % spec.n_params in src
+        assert src.count("template <> struct rh_target<") == len(spec.nrows)
+        for kernel in ("rh_chain_kernel", "rh_density_kernel", "rh_selftest_kernel"):
+            assert kernel in src
+
+
+def test_invariants_are_hoisted_out_of_the_row_loop(lib):
+    src, _ = _capi.lower_only(models.linreg(n=8).rir)
+    tgt = src[src.index("template <> struct rh_target<1>"):]
+    inv, row = tgt[:tgt.index("static RH_DEV void row")], tgt[tgt.index("static RH_DEV void row"):tgt.index("};")]
+    assert "RH_EXP" in inv and "RH_EXP" not in row          # exp(-2s) evaluated once per gradient, not per row
+    assert "c[0]" in row and "c[3]" in row
+
+
+def test_malformed_rir_is_rejected(lib):
+    good = models.funnel().rir
+    for bad, what in [(b"", "short"), (good[:-4], "truncated"), (b"XXXX" + good[4:], "magic"), (good + b"\0\0\0\0", "trailing")]:
+        with pytest.raises(_capi.RainierHipError) as e:
+            _capi.lower_only(bad)
+        assert e.value.code == _capi.RH_E_INVALID, what
+    # forward reference
+    import struct
+    blob = struct.pack("<6I", 0x31524952, 1, 1, 1, 1, 0) + struct.pack("<4I", 0, 0, 0, 0) + struct.pack("<3I", 2, 0, 5)
+    with pytest.raises(_capi.RainierHipError):
+        _capi.lower_only(blob)
+
+
+def test_no_cpu_fallback(lib):
+    import rainier_amd as R
+    if lib.rh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(models.funnel())
+    assert e.value.code == _capi.RH_E_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_diagnostics_match_oracle(lib):
+    import rainier_amd as R
+    rng = np.random.default_rng(2)
+    m, n, k = 5, 300, 3
+    x = np.zeros((m, n, k))
+    for i in range(1, n):
+        x[:, i, :] = np.array([0.9, 0.5, 0.0]) * x[:, i - 1, :] + rng.normal(size=(m, k))
+    got = R.diagnostics(x)
+    for p in range(k):
+        rhat, ess = O.diagnostics(x[:, :, p])
+        assert got[p][0] == pytest.approx(rhat, rel=1e-13) and got[p][1] == pytest.approx(ess, rel=1e-12)
+    with pytest.raises(ValueError):
+        R.diagnostics(x[:1])

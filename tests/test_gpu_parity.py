@@ -1,0 +1,249 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: RNG streams bit-exact; sampler arithmetic bit-exact given identical density values
+(data-free models in RH_MATH_STRICT mode are therefore bit-exact end to end); log-density / gradient of streamed
+models within tol * sum_rows |term| with tol = 1e-12 (N <= 1e4) / 1e-11 (N = 1e6..1e7), because the GPU sums
+rows lane-strided + butterfly while the reference sums them sequentially (ir/DataFunction.scala:64-71).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rainier_amd as R
+from rainier_amd import _capi, models
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def funnel_strict():
+    return R.Model(models.funnel(10), device=0, math_mode=_capi.MATH_STRICT)
+
+
+# ---- bit-exact building blocks -----------------------------------------------------------------------
+def test_strict_math_is_bit_exact(funnel_strict, oracle):
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0, 2, 20000), [0.0, 1.0, 0.5, 2.0, 1e-310, np.inf]])
+    got = funnel_strict.selftest(2, x=xs)
+    want = np.array([oracle.jm_strict_log(float(x)) for x in xs])
+    assert np.array_equal(got, want)
+    ys = np.concatenate([rng.uniform(-745, 710, 20000), rng.uniform(-1, 1, 20000), [0.0, -0.0, 709.9, -745.2, 1e-9, -np.inf, np.inf]])
+    got = funnel_strict.selftest(3, x=ys)
+    want = np.array([oracle.jm_strict_exp(float(y)) for y in ys])
+    assert np.array_equal(got, want)
+    got = funnel_strict.selftest(4, x=xs)
+    assert np.array_equal(got, np.sqrt(xs))                      # IEEE correctly rounded sqrt
+    ab = np.stack([rng.normal(size=30000) * np.exp(rng.uniform(-50, 50, 30000)), rng.normal(size=30000) * np.exp(rng.uniform(-50, 50, 30000))], axis=1)
+    got = funnel_strict.selftest(5, x=ab.ravel())
+    assert np.array_equal(got, ab[:, 0] / ab[:, 1])              # IEEE correctly rounded division
+    ts = np.arange(1, 3000, dtype=np.float64)
+    got = funnel_strict.selftest(6, x=ts)
+    assert np.array_equal(got, np.array([oracle.jm_pow_neg075(O.JM_DET, float(t)) for t in ts]))
+
+
+@pytest.mark.parametrize("seed", [0, 42, 123, -7, 1528673302081, 2**40 + 12345])
+def test_java_util_random_streams_bit_exact(funnel_strict, seed):
+    n = 4001  # odd: exercises the cached second gaussian
+    r = O.JavaRandom(seed)
+    want = np.array([r.next_gaussian() for _ in range(n)])
+    assert np.array_equal(funnel_strict.selftest(0, seed=seed, n=n), want)
+    r = O.JavaRandom(seed)
+    want = np.array([r.next_double() for _ in range(n)])
+    assert np.array_equal(funnel_strict.selftest(1, seed=seed, n=n), want)
+    if seed == 0:
+        assert funnel_strict.selftest(0, seed=0, n=1)[0] == 0.8025330637390305   # published JDK value
+
+
+# ---- DensityFunction (seam 2) ---------------------------------------------------------------------------
+def _check_density(spec, model, qs, tol, math_mode=O.JM_LIBM, exact=False):
+    d = O.OracleDensity(spec, math_mode)
+    lp, g = model.density_batch(qs)
+    for c, q in enumerate(qs):
+        ref = d.update(q)
+        got = np.concatenate([[lp[c]], g[c]])
+        if exact:
+            assert np.array_equal(got, ref), (spec.name, c, got - ref)
+        else:
+            bound = tol * d.abs_sums(q) + 1e-300
+            assert np.all(np.abs(got - ref) <= bound), (spec.name, c, np.abs(got - ref) / bound)
+
+
+@pytest.mark.parametrize("builder", [models.normal_1d, models.funnel, models.eight_schools])
+def test_data_free_density_bit_exact_in_strict_mode(builder):
+    spec = builder()
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    qs = np.random.default_rng(3).normal(size=(64, spec.n_params)) * 1.5
+    _check_density(spec, m, qs, 0, O.JM_DET, exact=True)
+    m2 = R.Model(spec, device=0, math_mode=_capi.MATH_FAST)
+    _check_density(spec, m2, qs, 4e-16)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 256, 257, 1000, 4099])
+def test_linreg_density_ragged_row_counts(n):
+    spec = models.linreg(n=n, k=3, seed=n + 1)
+    m = R.Model(spec, device=0)
+    qs = np.random.default_rng(n).normal(size=(5, 5)) * 0.7
+    _check_density(spec, m, qs, 1e-12)
+
+
+def test_linreg_density_fma_contraction_within_tolerance():
+    spec = models.linreg(n=10000, k=3)
+    qs = np.random.default_rng(1).normal(size=(8, 5)) * 0.5
+    _check_density(spec, R.Model(spec, device=0, fp_contract=True), qs, 1e-12)
+    _check_density(spec, R.Model(spec, device=0, rows_unroll=8), qs, 1e-12)
+
+
+def test_logistic_density_lookup_and_compare():
+    spec = models.logistic(n=3000, k=50)
+    m = R.Model(spec, device=0)
+    qs = np.random.default_rng(2).normal(size=(4, 51)) * 0.3
+    _check_density(spec, m, qs, 1e-12)
+
+
+def test_density_trait_chains_1(funnel_strict):
+    df = funnel_strict.density()                      # trait DensityFunction, chains = 1
+    q = np.linspace(-1, 1, 10)
+    df.update(q)
+    assert df.nVars == 10
+    assert df.density == pytest.approx(np.sum(-0.5 * q * q - models.HALF_LOG_2PI), rel=1e-15)
+    assert [df.gradient(i) for i in range(10)] == list(-q)
+
+
+def test_nan_logp_is_data_and_lookup_error_is_reported():
+    from rainier_amd.frontend import Graph
+    g = Graph(1, [0]); x = g.param(0)
+    spec = models.ModelSpec("lg", g.compile([x.log()]), [], [0], 1)
+    lp, gr = R.Model(spec, device=0).density_batch(np.array([[-1.0], [0.0], [2.0]]))
+    assert np.isnan(lp[0]) and lp[1] == -np.inf and lp[2] == pytest.approx(np.log(2.0))
+    g = Graph(1, [0]); x = g.param(0)
+    spec = models.ModelSpec("lk", g.compile([g.lookup(x, [g.const(1.0), x * 2.0], low=0)]), [], [0], 1)
+    m = R.Model(spec, device=0)
+    assert m.density_batch(np.array([[1.5]]))[0][0] == 3.0
+    with pytest.raises(R.RainierHipError) as e:
+        m.density_batch(np.array([[1.5], [7.0]]))
+    assert e.value.code == _capi.RH_E_LOOKUP
+
+
+# ---- whole chains (seam 3) ---------------------------------------------------------------------------------
+def _oracle_cfg(config, math_mode):
+    s, st, mt = config.sampler(), config.stepSizeTuner(), config.massMatrixTuner()
+    kw = dict(iterations=config.iterations, warmup=config.warmupIterations, math_mode=math_mode)
+    if isinstance(s, R.HMCSampler): kw.update(sampler=O.HMC, n_steps=s.nSteps)
+    else: kw.update(sampler=O.EHMC, max_steps=s.maxSteps, min_steps=s.minSteps, buf_size=s.bufSize, p_count=s.pCount)
+    if isinstance(st, R.DualAvgTuner): kw.update(step_tuner=O.STEP_DUALAVG, delta=st.delta)
+    else: kw.update(step_tuner=O.STEP_STATIC, static_step=st.stepSize)
+    if isinstance(mt, R.IdentityMassMatrixTuner): kw.update(mass_tuner=O.MASS_IDENTITY)
+    elif isinstance(mt, R.DiagonalMassMatrixTuner):
+        kw.update(mass_tuner=O.MASS_DIAG_WINDOWED, init_window=mt.initialWindowSize, expansion=mt.windowExpansion,
+                  skip_first=mt.skipFirst, skip_last=mt.skipLast)
+    else: kw.update(mass_tuner=O.MASS_STATIC_DIAG, static_mass=np.array(mt.mass.elements, dtype=np.float64))
+    return O.make_config(**kw)
+
+
+def _assert_chains_bit_exact(spec, config, seeds):
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    tr = m.sample(config, seeds=seeds)
+    ocfg = _oracle_cfg(config, O.JM_DET)
+    for c, seed in enumerate(seeds):
+        want, mass, st = O.sample_model(spec, ocfg, seed)
+        assert np.array_equal(tr.chains[c], want), (spec.name, seed, np.argwhere(tr.chains[c] != want)[:3])
+        assert np.array_equal(tr.mass[c], mass)
+        assert tr.stats[c].leapfrogSteps == st.leapfrog_steps
+        assert tr.stats[c].warmupLeapfrogSteps == st.warmup_leapfrog_steps
+        assert tr.stats[c].accepted == st.accepted
+        assert tr.stats[c].stepSize == st.step_size
+        assert tr.stats[c].meanAcceptProb == pytest.approx(st.mean_accept_prob, rel=1e-12)
+    return tr
+
+
+def test_reference_leapfrogtest_on_gpu():
+    # rainier-test/.../sampler/LeapFrogTest.scala:38-78 on the device, identity-mass case (fresh ScalaRNG(123))
+    spec = models.normal_1d()
+    cfg = R.make_config(1000, 0, R.HMCSampler(1), R.StaticStepSize(1.0), R.IdentityMassMatrixTuner())
+    tr = _assert_chains_bit_exact(spec, cfg, [123])
+    xs = tr.chains[0][:, 0]
+    assert abs(xs.sum() / xs.size) < 0.2 and abs((xs ** 2).sum() / (xs.size - 1) - 1.0) < 0.2
+    cfg = R.make_config(1000, 0, R.HMCSampler(1), R.StaticStepSize(1.0), R.StaticMassMatrix(R.DiagonalMassMatrix([0.1])))
+    tr = _assert_chains_bit_exact(spec, cfg, [123, 124])
+    for c in range(2):
+        xs = tr.chains[c][:, 0]
+        assert abs(xs.sum() / xs.size) < 0.25 and abs((xs ** 2).sum() / (xs.size - 1) - 1.0) < 0.3
+
+
+def test_cfg1_funnel_hmc_l5_bit_exact():
+    # BASELINE config 1 shape (README.md:44): HMC L=5, DualAvg(0.8), 1 chain, seed 123 -- shortened iterations
+    cfg = R.HMC(300, 500, 5)
+    cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
+    _assert_chains_bit_exact(models.funnel(10), cfg, [123, 7, 99991])
+
+
+def test_default_config_ehmc_diag_mass_bit_exact():
+    # DefaultConfig: EHMCSampler(1024) + DualAvgTuner(0.8) + DiagonalMassMatrixTuner(50,1.5,50,50)
+    cfg = R.make_config(200, 400)
+    _assert_chains_bit_exact(models.eight_schools(), cfg, [2000, 2001, 2002])
+    _assert_chains_bit_exact(models.funnel(10), cfg, [5])
+
+
+def test_ehmc_variants_bit_exact():
+    cfg = R.make_config(150, 300, R.EHMCSampler(64, 3, 10, 0.3), R.DualAvgTuner(0.65), R.DiagonalMassMatrixTuner(20, 2.0, 10, 30))
+    _assert_chains_bit_exact(models.eight_schools(), cfg, [11, 12])
+    cfg = R.EHMC(200, 100, 2, 7)
+    cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
+    _assert_chains_bit_exact(models.funnel(3), cfg, [1])
+
+
+def test_many_chains_match_single_chain_runs():
+    # parity protocol of SURVEY fact 5: chain c == reference run with nChains = 1 and ScalaRNG(seed_c)
+    spec = models.eight_schools()
+    cfg = R.make_config(60, 120)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    seeds = list(range(2000, 2000 + 300))
+    tr = m.sample(cfg, seeds=seeds)
+    ocfg = _oracle_cfg(cfg, O.JM_DET)
+    for c in (0, 1, 63, 64, 150, 299):
+        want, _, _ = O.sample_model(spec, ocfg, seeds[c])
+        assert np.array_equal(tr.chains[c], want)
+    assert np.all(np.isfinite(tr.chains))
+
+
+def test_split_warmup_run_equals_one_shot():
+    spec = models.funnel(10)
+    cfg = R.HMC(100, 90, 5)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    whole = m.sample(cfg, seeds=[1, 2, 3]).chains
+    s = R.Sampler(m, cfg, [1, 2, 3])
+    s.warmup(); s.run(30); s.run(1); s.run(59)
+    assert np.array_equal(s.draws(), whole)
+    assert np.array_equal(s.draws(30, 31), whole[:, 30:61])
+    t = s.timing()
+    assert t["kernel_ms"] > 0 and t["launches"] >= 4
+    s.close()
+
+
+def test_linreg_chain_tracks_oracle():
+    # streamed model: trajectories agree to rounding for the first iterations, then statistically
+    spec = models.linreg(n=2000, k=3)
+    cfg = R.make_config(40, 60, R.HMCSampler(8), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    tr = m.sample(cfg, seeds=[1000, 1001])
+    ocfg = _oracle_cfg(cfg, O.JM_DET)
+    for c, seed in enumerate((1000, 1001)):
+        want, _, st = O.sample_model(spec, ocfg, seed)
+        assert tr.stats[c].leapfrogSteps == st.leapfrog_steps == 40 * 8
+        np.testing.assert_allclose(tr.chains[c][:5], want[:5], rtol=1e-7, atol=1e-9)
+    cfg = R.make_config(400, 300, R.HMCSampler(8), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    tr = R.Model(spec, device=0).sample(cfg, seeds=range(1000, 1008))
+    post = tr.chains.reshape(-1, 5).mean(axis=0)
+    assert np.allclose(post[1:], [0.5, 1.0, -2.0, 0.5], atol=0.08) and abs(post[0] - np.log(0.7)) < 0.08
+    assert all(r < 1.05 for r, _ in tr.diagnostics())
+
+
+def test_invalid_configs_are_rejected(funnel_strict):
+    with pytest.raises(ValueError):
+        R.DiagonalMassMatrix([1.0, 0.0])
+    cfg = R.make_config(10, 10, R.EHMCSampler(16, 1, 1000, 0.1))
+    with pytest.raises(R.RainierHipError) as e:
+        funnel_strict.sample(cfg, seeds=[1])
+    assert e.value.code == _capi.RH_E_INVALID
