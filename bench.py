@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on the BASELINE.json config (see the contract in the task statement).
+
+  metric : leapfrog steps/sec summed over all chains (one step = one (p,q) update = one distinct gradient
+           evaluation), plus ESS/sec (Trace.diagnostics formula, min over parameters)
+  config : cfg 2 -- README linear regression, 3 covariates x 1e6 rows (un-inlined, streamed), static HMC L=32,
+           1024 chains per GPU, DualAvgTuner(0.8), identity mass, chain seeds 1000 + global chain id.
+  step   : one HMC iteration of every chain = 32 leapfrog steps x chains x 1e6 rows.
+  --warmup W : W sampler warm-up iterations (step-size search + dual averaging), untimed.
+  N > 1  : one process per GPU (torch.distributed / RCCL); chains sharded by global id (weak scaling: 1024 per GPU),
+           data replicated, no collective on the data path; ONE all-gather of the draws over xGMI at the end,
+           inside the timed region.
+
+Synthetic data (numpy default_rng(20260925)); inputs resident in HBM before the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6    # MI355X public FP64 vector peak (not in the local guide)
+
+
+def cpu_baseline(spec, L, seconds_budget=20.0):
+    """The oracle (oracle/: C restatement of the reference JVM path, kind = "port") timed on this box's host
+    cores on a bounded sample of the same workload: one chain per thread, each running whole HMC iterations
+    (L=32) over the full data set with the reference's own 2L+1 gradient evaluations per trajectory."""
+    from tests import oracle_lib as O
+    d0 = O.OracleDensity(spec)
+    q = np.zeros(spec.n_params)
+    t = time.perf_counter(); d0.update(q); per_grad = time.perf_counter() - t
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    iters = max(1, int(seconds_budget / (per_grad * (2 * L + 2))))
+    cfg = O.make_config(sampler=O.HMC, n_steps=L, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
+                        static_step=1e-3, math_mode=O.JM_LIBM)
+    steps = [0] * cores
+
+    def work(i):
+        d = O.OracleDensity(spec)
+        _, _, st, _ = O.sample_chain(d.fn_ptr, d.handle, spec.n_params, cfg, 1000 + i)
+        steps[i] = st.leapfrog_steps
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t = time.perf_counter()
+    [x.start() for x in th]; [x.join() for x in th]
+    dt = time.perf_counter() - t
+    total = float(sum(steps))
+    return {"value": total / dt, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d HMC iterations (L=%d, %d rows), RIR interpreter, reference's 2L+1 gradient "
+                      "evaluations per trajectory, %.1f s" % (cores, iters, L, spec.rows_streamed, dt),
+            "row_chain_evals_per_s": total * spec.rows_streamed / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--chains-per-gpu", type=int, default=1024)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--leapfrog", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="no FMA contraction in model code (JVM semantics)")
+    ap.add_argument("--rows-unroll", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import rainier_amd as R
+    from rainier_amd import models
+
+    K, W, L = a.steps, a.warmup, a.leapfrog
+    spec = models.linreg(n=a.rows, k=3)
+    model = R.Model(spec, device=local_rank, fp_contract=not a.strict, rows_unroll=a.rows_unroll)
+    cpg = a.chains_per_gpu
+    seeds = [1000 + rank * cpg + c for c in range(cpg)]
+    cfg = R.make_config(K, W, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    s = R.Sampler(model, cfg, seeds)
+    s.warmup()                      # W untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
+    s.timing(reset=True)
+
+    gathered = None
+    if dist is not None:
+        import torch
+        hip = C.CDLL("libamdhip64.so")
+        local = torch.empty((cpg, K, spec.n_params), dtype=torch.float64, device="cuda")
+        gathered = torch.empty((world * cpg, K, spec.n_params), dtype=torch.float64, device="cuda")
+        dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.run(K)                        # synchronises the engine stream
+    if dist is not None:
+        hip.hipMemcpy(C.c_void_p(local.data_ptr()), C.c_void_p(s.draws_device_ptr()), C.c_size_t(local.numel() * 8), 3)
+        dist.all_gather_into_tensor(gathered, local)   # the ONE collective: draws over xGMI (RCCL)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    tim = s.timing()
+    stats, _ = s.stats()
+    steps_local = sum(st.leapfrogSteps for st in stats)
+    assert steps_local == K * L * cpg, (steps_local, K, L, cpg)
+    total_steps = steps_local * world
+    draws = gathered.cpu().numpy() if gathered is not None else s.draws()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    rows = spec.rows_streamed
+    value = total_steps / dt
+    rce = value * rows
+    ess_min = None
+    if K >= 4 and draws.shape[0] >= 2:
+        ess_min = min(e for _, e in R.diagnostics(draws))
+    # dominant kernel, this rank: HIP events recorded on the engine's stream around each launch
+    k_s = tim["kernel_ms"] / 1e3
+    algo_bytes = tim["row_chain_evals"] * spec.bytes_per_row          # 8*(K+1) = 32 B per row-chain eval
+    achieved = algo_bytes / k_s / 1e9
+    flops = tim["row_chain_evals"] * spec.meta["flops_per_row"]       # 4K+4 = 16 flop per row-chain eval
+    out = {
+        "metric": "leapfrog steps/sec (all chains)", "value": value, "unit": "leapfrog steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cfg2: linear regression 3 covariates x %d rows (un-inlined, streamed), static HMC L=%d, "
+                               "%d chains/GPU, DualAvgTuner(0.8), identity mass" % (rows, L, cpg),
+                   "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict,
+                   "engine": "chain-per-wavefront persistent kernel"},
+        "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,
+        "ess_per_s": (ess_min / dt) if ess_min is not None else None,
+        "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in stats])),
+        "roofline": {"bound": "hbm", "kernel": tim["dominant_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "launches": tim["launches"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
+                     "algorithmic_bytes_per_launch": algo_bytes / max(1, tim["launches"]),
+                     "fp64_valu": {"achieved": flops / k_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": flops / k_s / 1e12 / FP64_PEAK_TFLOPS}},
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec, L)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
