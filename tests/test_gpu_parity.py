@@ -222,16 +222,19 @@ def test_split_warmup_run_equals_one_shot():
 
 
 def test_linreg_chain_tracks_oracle():
-    # streamed model: trajectories agree to rounding for the first iterations, then statistically
+    # streamed model: the row sum is ordered differently (lane-strided + butterfly vs sequential), so trajectories
+    # agree to rounding while the dynamics are tame (static small step, no adaptation) and only statistically
+    # after a chaotic warm-up ("exact match not claimed beyond a few steps").
     spec = models.linreg(n=2000, k=3)
-    cfg = R.make_config(40, 60, R.HMCSampler(8), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    cfg = R.make_config(6, 0, R.HMCSampler(8), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner())
     m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
     tr = m.sample(cfg, seeds=[1000, 1001])
     ocfg = _oracle_cfg(cfg, O.JM_DET)
     for c, seed in enumerate((1000, 1001)):
         want, _, st = O.sample_model(spec, ocfg, seed)
-        assert tr.stats[c].leapfrogSteps == st.leapfrog_steps == 40 * 8
-        np.testing.assert_allclose(tr.chains[c][:5], want[:5], rtol=1e-7, atol=1e-9)
+        assert tr.stats[c].leapfrogSteps == st.leapfrog_steps == 6 * 8
+        assert tr.stats[c].accepted == st.accepted
+        np.testing.assert_allclose(tr.chains[c], want, rtol=1e-9, atol=1e-11)
     cfg = R.make_config(400, 300, R.HMCSampler(8), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
     tr = R.Model(spec, device=0).sample(cfg, seeds=range(1000, 1008))
     post = tr.chains.reshape(-1, 5).mean(axis=0)
