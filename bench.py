@@ -90,7 +90,8 @@ def main():
     spec = models.linreg(n=a.rows, k=3)
     model = R.Model(spec, device=local_rank, fp_contract=not a.strict, rows_unroll=a.rows_unroll)
     cpg = a.chains_per_gpu
-    seeds = [1000 + rank * cpg + c for c in range(cpg)]
+    from rainier_amd import distributed as D
+    seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
     cfg = R.make_config(K, W, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
     s = R.Sampler(model, cfg, seeds)
     s.warmup()                      # W untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
@@ -101,13 +102,12 @@ def main():
         import torch
         hip = C.CDLL("libamdhip64.so")
         local = torch.empty((cpg, K, spec.n_params), dtype=torch.float64, device="cuda")
-        gathered = torch.empty((world * cpg, K, spec.n_params), dtype=torch.float64, device="cuda")
         dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     s.run(K)                        # synchronises the engine stream
     if dist is not None:
         hip.hipMemcpy(C.c_void_p(local.data_ptr()), C.c_void_p(s.draws_device_ptr()), C.c_size_t(local.numel() * 8), 3)
-        dist.all_gather_into_tensor(gathered, local)   # the ONE collective: draws over xGMI (RCCL)
+        gathered = D.gather_draws(local, world)        # the ONE collective: draws over xGMI (RCCL all-gather)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
