@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="no FMA contraction in model code (JVM semantics)")
     ap.add_argument("--rows-unroll", type=int, default=0)
+    ap.add_argument("--engine", choices=["auto", "chain", "tick"], default="auto")
+    ap.add_argument("--grad-chains", type=int, default=0)
+    ap.add_argument("--grad-unroll", type=int, default=0)
+    ap.add_argument("--grad-splits", type=int, default=0)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,11 +92,14 @@ def main():
 
     K, W, L = a.steps, a.warmup, a.leapfrog
     spec = models.linreg(n=a.rows, k=3)
-    model = R.Model(spec, device=local_rank, fp_contract=not a.strict, rows_unroll=a.rows_unroll)
+    model = R.Model(spec, device=local_rank, fp_contract=not a.strict, rows_unroll=a.rows_unroll,
+                    grad_chains=a.grad_chains, grad_unroll=a.grad_unroll)
     cpg = a.chains_per_gpu
     from rainier_amd import distributed as D
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
-    cfg = R.make_config(K, W, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    engine = {"auto": 0, "chain": 1, "tick": 2}[a.engine]
+    cfg = R.make_config(K, W, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=engine,
+                        gradSplits=a.grad_splits)
     s = R.Sampler(model, cfg, seeds)
     s.warmup()                      # W untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
     s.timing(reset=True)
@@ -144,13 +151,14 @@ def main():
         "config": {"workload": "cfg2: linear regression 3 covariates x %d rows (un-inlined, streamed), static HMC L=%d, "
                                "%d chains/GPU, DualAvgTuner(0.8), identity mass" % (rows, L, cpg),
                    "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict,
-                   "engine": "chain-per-wavefront persistent kernel"},
+                   "engine": tim["dominant_kernel"], "grad_chains": a.grad_chains, "grad_unroll": a.grad_unroll,
+                   "grad_splits": a.grad_splits},
         "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,
         "ess_per_s": (ess_min / dt) if ess_min is not None else None,
         "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in stats])),
         "roofline": {"bound": "hbm", "kernel": tim["dominant_kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "launches": tim["launches"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
+                     "launches": tim["launches"], "all_kernels_ms": tim["total_ms"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, tim["launches"]),
                      "fp64_valu": {"achieved": flops / k_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": flops / k_s / 1e12 / FP64_PEAK_TFLOPS}},

@@ -19,6 +19,7 @@ MATH_FAST, MATH_STRICT = 0, 1
 SAMPLER_HMC, SAMPLER_EHMC = 0, 1
 STEP_DUALAVG, STEP_STATIC = 0, 1
 MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG = 0, 1, 2
+ENGINE_AUTO, ENGINE_CHAIN, ENGINE_TICK = 0, 1, 2
 
 # every symbol include/rainier_hip.h declares (checked by tests/test_capi_cpu.py)
 EXPORTS = [
@@ -31,7 +32,8 @@ EXPORTS = [
 
 class CompileOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("math_mode", C.c_int32),
-                ("fp_contract", C.c_int32), ("rows_unroll", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("fp_contract", C.c_int32), ("rows_unroll", C.c_int32), ("grad_chains", C.c_int32),
+                ("grad_unroll", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -42,7 +44,7 @@ class Config(C.Structure):
         ("mass_tuner", C.c_int32), ("dualavg_delta", C.c_double), ("static_step", C.c_double),
         ("mass_init_window", C.c_int32), ("mass_skip_first", C.c_int32), ("mass_skip_last", C.c_int32),
         ("reserved0", C.c_int32), ("mass_expansion", C.c_double), ("static_mass", C.POINTER(C.c_double)),
-        ("reserved", C.c_int64 * 4),
+        ("engine", C.c_int32), ("grad_splits", C.c_int32), ("reserved", C.c_int64 * 3),
     ]
 
 
@@ -53,7 +55,7 @@ class ChainStats(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_int64), ("density_evals", C.c_int64),
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("launches", C.c_int64), ("density_evals", C.c_int64),
                 ("row_chain_evals", C.c_int64), ("dominant_kernel", C.c_char * 64)]
 
 
@@ -110,10 +112,11 @@ def dptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0):
+def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0, grad_chains=0, grad_unroll=0):
     o = CompileOpts()
     o.struct_size = C.sizeof(CompileOpts)
     o.device, o.math_mode, o.fp_contract, o.rows_unroll = device, math_mode, int(fp_contract), rows_unroll
+    o.grad_chains, o.grad_unroll = grad_chains, grad_unroll
     return o
 
 

@@ -500,6 +500,170 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
   if (status == RH_ADV_NEED_GRAD && lane == 0) atomicAdd(n_running, 1);
 }
 
+// ---- engine 2: tick engine for data-heavy models ---------------------------------------------------------
+// One "tick" = every chain that is waiting for a gradient gets one.  rh_grad_kernel streams the observation rows
+// ONCE per group of RH_GRAD_K chains (row values in VGPRs, the K parameter vectors in SGPRs, K x (n+1) per-lane
+// accumulators) for one contiguous row split, and writes per-split partial sums; rh_tick_kernel combines the
+// partials in fixed split order (plus the data-free targets, in target order), feeds the result to the chain's
+// automaton and publishes the next q.  The sampler automaton is the same rh_advance as in rh_chain_kernel.
+#if RH_NROWTARGETS > 0
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+template <int T>
+RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_model_data &d, const int lane,
+                            const int split, const int nsplit, const int chain0, const int chains,
+                            double *__restrict__ partial, int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (TG::HAS_ROWS) {
+      constexpr int NC = TG::NCOLS, U = RH_GRAD_U, K = RH_GRAD_K;
+      double inv[K][TG::NINV > 0 ? TG::NINV : 1];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) TG::invariants(th[kk], inv[kk], err);
+      const long long n = d.nrows[T];
+      const long long chunk = 64LL * U;
+      const long long per = (((n + chunk - 1) / chunk) + nsplit - 1) / nsplit; // chunks per split
+      long long r0 = (long long)split * per * chunk, r1 = r0 + per * chunk;
+      if (r0 > n) r0 = n;
+      if (r1 > n) r1 = n;
+      const double *cp[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
+      double acc[K][RH_NOUT];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++)
+#pragma unroll
+        for (int o = 0; o < RH_NOUT; o++) acc[kk][o] = 0.0;
+      long long k = r0 + lane;
+      for (; k + 64LL * (U - 1) < r1; k += chunk) {
+        double c[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + 64LL * u];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c[u], acc[kk], err);
+      }
+      for (; k < r1; k += 64) {
+        double c[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) c[j] = cp[j][k];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c, acc[kk], err);
+      }
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) {
+        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NOUT;
+#pragma unroll
+        for (int o = 0; o < RH_NOUT; o++) {
+          const double v = rh_wave_sum(acc[kk][o]);
+          if (lane == 0 && chain0 + kk < chains) out[o] = v;
+        }
+      }
+    }
+    rh_grad_targets<T + 1>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+  }
+}
+#pragma clang fp contract(off)
+
+// grid: 1-D, ngroups * nsplit single-wave workgroups.  XCD-aware mapping: workgroup b lands on XCD b % 8, so XCD x
+// takes the row splits {x, x+8, ...} of EVERY chain group: each XCD's private L2 then serves only 1/8 of the rows.
+extern "C" __global__ void __launch_bounds__(64)
+rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+               double *__restrict__ partial, int *__restrict__ err_out, const int chains, const int nsplit,
+               const int xcd_aware) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  int group, split;
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    group = idx / spx;
+  } else { split = b % nsplit; group = b / nsplit; }
+  const int chain0 = group * RH_GRAD_K;
+  if (chain0 >= chains) return;
+  bool any = false;
+  double th[RH_GRAD_K][RH_NVARS];
+#pragma unroll
+  for (int kk = 0; kk < RH_GRAD_K; kk++) {
+    const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
+    any = any || (active[c] != 0);
+#pragma unroll
+    for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i]; // wave-uniform address -> s_load
+  }
+  if (!any) return;
+  int err = 0;
+  rh_grad_targets<0>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+  if (err && lane == 0) atomicOr(err_out, 1);
+}
+
+// partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
+template <int T>
+RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const int nsplit,
+                               const int chain, const int chains, double (&tot)[RH_NOUT], int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (!TG::HAS_ROWS) {
+      double inv[1];
+      TG::row(th, inv, nullptr, tot, err);
+    } else {
+      for (int s = 0; s < nsplit; s++) {
+        const double *p = partial + (((size_t)TG::ROWT * nsplit + s) * chains + chain) * RH_NOUT;
+#pragma unroll
+        for (int o = 0; o < RH_NOUT; o++) tot[o] += p[o];
+      }
+    }
+    rh_combine_targets<T + 1>(th, partial, nsplit, chain, chains, tot, err);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+rh_tick_kernel(const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *__restrict__ seeds,
+               const double *__restrict__ static_mass, double *__restrict__ draws,
+               rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running, double *__restrict__ qbuf,
+               int *__restrict__ active, const double *__restrict__ partial, const int *__restrict__ grad_err,
+               const int chains, const int nsplit, const int it_stop, const int fresh) {
+  const int chain = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (chain >= chains) return;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_WORDS * 64;
+  rh_chain c;
+  if (fresh)
+    for (int w = 0; w < RH_STATE_WORDS; w++) st[w * 64 + lane] = 0;
+  rh_chain_load(c, st, lane);
+  if (c.need_eval) { // the gradient requested at the previous tick is in `partial`
+    double th[RH_NVARS];
+#pragma unroll
+    for (int i = 0; i < RH_NVARS; i++) th[i] = rh_readlane(c.Bq.s[i >> 6], i & 63);
+    double tot[RH_NOUT];
+#pragma unroll
+    for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+    int err = grad_err[0];
+    rh_combine_targets<0>(th, partial, nsplit, chain, chains, tot, err);
+    c.pend_logp = tot[0];
+    wv_zero(c.pend_g);
+#pragma unroll
+    for (int i = 0; i < RH_NVARS; i++) c.pend_g.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : c.pend_g.s[i >> 6];
+    c.err |= err; c.need_eval = 0;
+  }
+  double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
+  const int status = rh_advance(c, cfg, it_stop, seeds[chain], static_mass, my_draws, lane);
+  if (status == RH_ADV_NEED_GRAD) {
+    c.need_eval = 1;
+#pragma unroll
+    for (int k = 0; k < RH_SLOTS; k++)
+      if (k * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + k * 64 + lane] = c.Bq.s[k];
+  }
+  if (lane == 0) active[chain] = (status == RH_ADV_NEED_GRAD) ? 1 : 0;
+  rh_chain_store(c, st, lane);
+  rh_stats_write(c, stats + chain, status, lane);
+  if (status == RH_ADV_NEED_GRAD && lane == 0) atomicAdd(n_running, 1);
+}
+#endif  // RH_NROWTARGETS > 0
+
 // Seam 2: batched DensityFunction.  q [chains][nvars] -> logp [chains], grad [chains][nvars]; one wavefront per chain.
 extern "C" __global__ void __launch_bounds__(64)
 rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,

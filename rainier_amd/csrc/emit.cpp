@@ -115,6 +115,9 @@ struct TargetEmitter {
     os << "template <> struct rh_target<" << t << "> {\n";
     os << "  static constexpr int NCOLS = " << T.n_cols << ", COL0 = " << T.col0 << ", NINV = " << inv_slot.size() << ";\n";
     os << "  static constexpr bool HAS_ROWS = " << (rows ? "true" : "false") << ";\n";
+    int rowt = -1;
+    if (rows) { rowt = 0; for (uint32_t u = 0; u < t; u++) if (P.targets[u].n_cols) rowt++; }
+    os << "  static constexpr int ROWT = " << rowt << ";\n";
     os << "  static RH_DEV void invariants(const double (&th)[RH_NVARS], double *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
     if (rows) {
       for (size_t n = 0; n < P.nodes.size(); n++)
@@ -147,6 +150,10 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (P.n_params + 1) << "\n#define RH_SLOTS "
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";
+  int nrowt = 0;
+  for (auto &T : P.targets) if (T.n_cols) nrowt++;
+  d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_GRAD_K " << (o.grad_chains > 0 ? o.grad_chains : 4)
+    << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();

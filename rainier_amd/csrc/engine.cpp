@@ -115,7 +115,8 @@ struct rh_model {
   int device = 0;
   bool loaded = false;
   hipModule_t module = nullptr;
-  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr;
+  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr;
+  int n_row_targets = 0, grad_k = 4;
   int state_words = 0;
   rh_model_data data{};
   std::vector<void *> dev_cols;
@@ -132,8 +133,13 @@ struct rh_sampler {
   int it_done = 0;  // sampling iterations completed
   bool started = false, warmed = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  double kernel_ms = 0;
+  double kernel_ms = 0, total_ms = 0;
   int64_t launches = 0;
+  // tick engine
+  bool tick_engine = false;
+  int nsplit = 0, xcd_aware = 1;
+  void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
+  std::vector<hipEvent_t> ev;
   std::vector<rh_chain_stats_dev> last_stats;
   int64_t grads_at_reset = 0;
 };
@@ -167,6 +173,13 @@ void load_module(rh_model *m) {
   HIPCHK(hipModuleGetFunction(&m->k_chain, m->module, "rh_chain_kernel"));
   HIPCHK(hipModuleGetFunction(&m->k_density, m->module, "rh_density_kernel"));
   HIPCHK(hipModuleGetFunction(&m->k_selftest, m->module, "rh_selftest_kernel"));
+  m->n_row_targets = 0;
+  for (auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets++;
+  if (m->n_row_targets > 0) {  // the tick engine only exists for models that stream rows
+    HIPCHK(hipModuleGetFunction(&m->k_grad, m->module, "rh_grad_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
+  }
+  m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
   HIPCHK(hipMemcpy(&m->state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
@@ -201,6 +214,9 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
       m->eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
       m->eopt.fp_contract = opts->fp_contract != 0;
       if (opts->rows_unroll > 0) m->eopt.rows_unroll = opts->rows_unroll;
+      if (opts->grad_chains < 0 || opts->grad_chains > 16 || opts->grad_unroll < 0 || opts->grad_unroll > 16)
+        throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
+      m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;
       dev = opts->device;
     }
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
@@ -275,6 +291,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
       m.eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
       m.eopt.fp_contract = opts->fp_contract != 0;
       if (opts->rows_unroll > 0) m.eopt.rows_unroll = opts->rows_unroll;
+      m.eopt.grad_chains = opts->grad_chains; m.eopt.grad_unroll = opts->grad_unroll;
     }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
@@ -390,6 +407,31 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     HIPCHK(hipEventCreate(&s->e0));
     HIPCHK(hipEventCreate(&s->e1));
     s->last_stats.resize(chains);
+    if (cfg->engine < RH_ENGINE_AUTO || cfg->engine > RH_ENGINE_TICK) throw Fail{RH_E_INVALID, "unknown engine"};
+    if (cfg->engine == RH_ENGINE_TICK && m->n_row_targets == 0) throw Fail{RH_E_INVALID, "the tick engine needs a model that streams rows"};
+    s->tick_engine = cfg->engine == RH_ENGINE_TICK || (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && m->rows_total >= 65536);
+    if (s->tick_engine) {
+      const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+      int64_t max_rows = 1;
+      for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
+      int nsplit = cfg->grad_splits;
+      if (nsplit <= 0) {  // ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD mapping applies
+        nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
+        nsplit = ((nsplit + 7) / 8) * 8;
+        const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);   // keep >= 2048 rows per split
+        nsplit = (int)std::min<int64_t>(nsplit, cap);
+      }
+      if (nsplit > 65536) throw Fail{RH_E_INVALID, "grad_splits too large"};
+      s->nsplit = nsplit;
+      if (const char *e = std::getenv("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
+      HIPCHK(hipMalloc(&s->d_qbuf, sizeof(double) * n * chains));
+      HIPCHK(hipMalloc(&s->d_active, sizeof(int) * chains));
+      HIPCHK(hipMalloc(&s->d_partial, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * (n + 1)));
+      HIPCHK(hipMalloc(&s->d_graderr, sizeof(int)));
+      HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
+      HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
+      HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
+    }
   });
   if (rc != RH_OK) { rh_sampler_destroy(s); return rc; }
   *out = s;
@@ -399,16 +441,73 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
 extern "C" void rh_sampler_destroy(rh_sampler *s) {
   if (!s) return;
   if (s->m) hipSetDevice(s->m->device);
-  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running})
+  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr})
     if (p) hipFree(p);
+  for (hipEvent_t e : s->ev) hipEventDestroy(e);
   if (s->e0) hipEventDestroy(s->e0);
   if (s->e1) hipEventDestroy(s->e1);
   delete s;
 }
 
 namespace {
+// tick engine: [tick] then repeat { [grad] [tick] } until no chain asks for a gradient any more.
+void advance_to_ticks(rh_sampler *s, int it_stop) {
+  rh_model *m = s->m;
+  HIPCHK(hipSetDevice(m->device));
+  int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
+  const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+  auto tick = [&](int fresh) {
+    HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
+    void *args[] = {&s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+                    &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+    launch(m->k_tick, (unsigned)chains, 64, m->stream, args);
+  };
+  auto grad = [&]() {
+    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &xcd};
+    launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
+  };
+  // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
+  int remaining_hint = 32;
+  if (s->cfg.sampler == RH_SAMPLER_HMC && s->warmed) {
+    const int iters = it_stop - (s->cfg.warmup + s->it_done);
+    remaining_hint = std::max(1, iters * std::max(1, s->cfg.hmc_steps));
+  }
+  HIPCHK(hipEventRecord(s->e0, m->stream));
+  tick(s->started ? 0 : 1);
+  s->started = true;
+  HIPCHK(hipEventRecord(s->e1, m->stream));
+  for (;;) {
+    int running = 0;
+    HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->e0, s->e1));
+    s->total_ms += ms;
+    if (running == 0) break;
+    const int B = std::min(remaining_hint, 256);
+    while ((int)s->ev.size() < 2 * B) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev.push_back(e); }
+    HIPCHK(hipEventRecord(s->e0, m->stream));
+    for (int i = 0; i < B; i++) {
+      HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
+      grad();
+      HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
+      tick(0);
+    }
+    HIPCHK(hipEventRecord(s->e1, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < B; i++) {
+      float g = 0;
+      HIPCHK(hipEventElapsedTime(&g, s->ev[2 * i], s->ev[2 * i + 1]));
+      s->kernel_ms += g;
+    }
+    s->launches += B;
+    remaining_hint = std::max(32, remaining_hint - B);
+  }
+}
+
 // drive every chain to global iteration index it_stop (warmup iterations count first)
 void advance_to(rh_sampler *s, int it_stop) {
+  if (s->tick_engine) { advance_to_ticks(s, it_stop); return; }
   rh_model *m = s->m;
   HIPCHK(hipSetDevice(m->device));
   // bound one launch to roughly seconds of device time: a tick streams rows_total rows per chain
@@ -428,6 +527,7 @@ void advance_to(rh_sampler *s, int it_stop) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s->e0, s->e1));
     s->kernel_ms += ms;
+    s->total_ms += ms;
     s->launches += 1;
     s->started = true;
     if (running == 0) break;
@@ -493,12 +593,12 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
     if (mass_diag) {
       // M is the 10th vector of the state image (RH_STATE_VECS order in rh_engine.hip.h): Pp Pq Pg Bp Bq Bg Sp Sq Sg M
       const int n = (int)s->m->prog.n_params, slots = (n + 63) / 64, W = s->m->state_words;
-      std::vector<uint64_t> img((size_t)slots * 64);
-      for (int c = 0; c < s->chains; c++) {
-        const char *base = (const char *)s->d_state + ((size_t)c * W + (size_t)9 * slots) * 64 * sizeof(uint64_t);
-        HIPCHK(hipMemcpy(img.data(), base, img.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; i++) std::memcpy(&mass_diag[(size_t)c * n + i], &img[i], sizeof(double));
-      }
+      const size_t width = (size_t)slots * 64 * sizeof(uint64_t);
+      std::vector<uint64_t> img((size_t)slots * 64 * s->chains);
+      const char *base = (const char *)s->d_state + (size_t)9 * slots * 64 * sizeof(uint64_t);
+      HIPCHK(hipMemcpy2D(img.data(), width, base, (size_t)W * 64 * sizeof(uint64_t), width, (size_t)s->chains, hipMemcpyDeviceToHost));
+      for (int c = 0; c < s->chains; c++)
+        for (int i = 0; i < n; i++) std::memcpy(&mass_diag[(size_t)c * n + i], &img[(size_t)c * slots * 64 + i], sizeof(double));
     }
   });
   if (rc == RH_OK && any_lookup) { s->m->err = g_err = "Lookup index out of range during sampling"; return RH_E_LOOKUP; }
@@ -512,11 +612,11 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     int64_t grads = 0;
     for (auto &d : s->last_stats) grads += d.gradient_evaluations;
     std::memset(out, 0, sizeof(*out));
-    out->kernel_ms = s->kernel_ms; out->launches = s->launches;
+    out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, "rh_chain_kernel");
-    if (reset) { s->kernel_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? "rh_grad_kernel" : "rh_chain_kernel");
+    if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }
 

@@ -35,6 +35,8 @@ struct EmitOptions {
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
   int rows_unroll = 4;
+  int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
+  int grad_unroll = 0;  // row-loop unroll of the batched gradient kernel (0 = default)
 };
 
 // Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).

@@ -80,6 +80,8 @@ class SamplerConfig:
     iterations = 1000
     warmupIterations = 1000
     statsWindow = 100
+    engine = _capi.ENGINE_AUTO   # engine extension: device mapping (rh_engine_kind); not part of the reference trait
+    gradSplits = 0
 
     def stepSizeTuner(self): return DualAvgTuner(0.8)
     def massMatrixTuner(self): return DiagonalMassMatrixTuner(50, 1.5, 50, 50)
@@ -89,9 +91,11 @@ class SamplerConfig:
 DefaultConfig = SamplerConfig
 
 
-def make_config(iterations=1000, warmupIterations=1000, sampler=None, stepSizeTuner=None, massMatrixTuner=None):
+def make_config(iterations=1000, warmupIterations=1000, sampler=None, stepSizeTuner=None, massMatrixTuner=None,
+                engine=_capi.ENGINE_AUTO, gradSplits=0):
     cfg = SamplerConfig()
     cfg.iterations, cfg.warmupIterations = iterations, warmupIterations
+    cfg.engine, cfg.gradSplits = engine, gradSplits
     if sampler is not None: cfg.sampler = lambda: sampler
     if stepSizeTuner is not None: cfg.stepSizeTuner = lambda: stepSizeTuner
     if massMatrixTuner is not None: cfg.massMatrixTuner = lambda: massMatrixTuner
@@ -110,6 +114,7 @@ def to_c_config(config: SamplerConfig, nvars: int):
     c = _capi.Config()
     _capi.lib().rh_config_default(C.byref(c))
     c.iterations, c.warmup = int(config.iterations), int(config.warmupIterations)
+    c.engine, c.grad_splits = int(getattr(config, 'engine', 0)), int(getattr(config, 'gradSplits', 0))
     s, st, mt = config.sampler(), config.stepSizeTuner(), config.massMatrixTuner()
     keep = None
     if isinstance(s, HMCSampler):
@@ -225,7 +230,7 @@ class Sampler:
     def timing(self, reset: bool = False):
         t = _capi.Timing()
         _capi.check(_capi.lib().rh_sampler_timing(self._h, C.byref(t), int(reset)), self.model._h)
-        return {"kernel_ms": t.kernel_ms, "launches": t.launches, "density_evals": t.density_evals,
+        return {"kernel_ms": t.kernel_ms, "total_ms": t.total_ms, "launches": t.launches, "density_evals": t.density_evals,
                 "row_chain_evals": t.row_chain_evals, "dominant_kernel": t.dominant_kernel.decode()}
 
     def close(self):
@@ -241,14 +246,14 @@ class Model:
     """A compiled model: Compiler.compileTargets' replacement (compute/Compiler.scala:14-30) + Model.sample."""
 
     def __init__(self, spec, device: int = -1, math_mode: int = _capi.MATH_FAST, fp_contract: bool = False,
-                 rows_unroll: int = 0):
+                 rows_unroll: int = 0, grad_chains: int = 0, grad_unroll: int = 0):
         L = _capi.lib()
         self.spec = spec
         self.nVars = spec.n_params
         self._cols = [np.ascontiguousarray(c, dtype=np.float64) for c in spec.columns]
         colarr = (C.POINTER(C.c_double) * max(1, len(self._cols)))(*[_capi.dptr(c) for c in self._cols])
         nrows = (C.c_int64 * len(spec.nrows))(*spec.nrows)
-        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll)
+        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll, grad_chains, grad_unroll)
         blob = C.create_string_buffer(spec.rir, len(spec.rir))
         self._h = C.c_void_p()
         _capi.check(L.rh_model_create(blob, len(spec.rir), colarr, nrows, C.byref(opts), C.byref(self._h)))

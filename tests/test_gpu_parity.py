@@ -249,3 +249,90 @@ def test_invalid_configs_are_rejected(funnel_strict):
     with pytest.raises(R.RainierHipError) as e:
         funnel_strict.sample(cfg, seeds=[1])
     assert e.value.code == _capi.RH_E_INVALID
+
+
+# ---- tick engine (batched multi-chain gradient kernel + per-chain automaton kernel) -------------------------
+def _tame(iters, engine, splits=0):
+    return R.make_config(iters, 0, R.HMCSampler(4), R.StaticStepSize(2e-3), R.IdentityMassMatrixTuner(),
+                         engine=engine, gradSplits=splits)
+
+
+@pytest.mark.parametrize("n,chains,splits", [(1, 1, 1), (63, 3, 1), (64, 4, 3), (65, 5, 8), (1000, 9, 8), (4099, 2, 16),
+                                             (70001, 6, 0), (300000, 17, 0)])
+def test_tick_engine_matches_chain_engine_and_oracle(n, chains, splits):
+    spec = models.linreg(n=n, k=3, seed=n)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    seeds = [500 + c for c in range(chains)]
+    a = m.sample(_tame(5, _capi.ENGINE_CHAIN), seeds=seeds)
+    b = m.sample(_tame(5, _capi.ENGINE_TICK, splits), seeds=seeds)
+    np.testing.assert_allclose(b.chains, a.chains, rtol=1e-9, atol=1e-11)
+    for c in range(chains):
+        assert b.stats[c].leapfrogSteps == a.stats[c].leapfrogSteps == 20 and b.stats[c].accepted == a.stats[c].accepted
+    if n <= 5000:
+        want, _, st = O.sample_model(spec, _oracle_cfg(_tame(5, 0), O.JM_DET), seeds[-1])
+        np.testing.assert_allclose(b.chains[-1], want, rtol=1e-9, atol=1e-11)
+
+
+def test_tick_engine_grad_kernel_variants():
+    spec = models.linreg(n=20000, k=3)
+    base = R.Model(spec, device=0).sample(_tame(4, _capi.ENGINE_CHAIN), seeds=range(10))
+    for gk, gu in [(1, 1), (2, 4), (4, 2), (8, 1), (3, 3)]:
+        m = R.Model(spec, device=0, grad_chains=gk, grad_unroll=gu, fp_contract=(gk == 8))
+        got = m.sample(_tame(4, _capi.ENGINE_TICK), seeds=range(10))
+        np.testing.assert_allclose(got.chains, base.chains, rtol=1e-8, atol=1e-10)
+
+
+def test_tick_engine_full_driver_statistics():
+    # whole Driver on the tick engine: step-size search, dual averaging, windowed mass adaptation, EHMC
+    spec = models.linreg(n=3000, k=3)
+    cfg = R.make_config(300, 300, engine=_capi.ENGINE_TICK)
+    tr = R.Model(spec, device=0).sample(cfg, seeds=range(40, 48))
+    post = tr.chains.reshape(-1, 5).mean(axis=0)
+    assert np.allclose(post[1:], [0.5, 1.0, -2.0, 0.5], atol=0.08) and abs(post[0] - np.log(0.7)) < 0.08
+    assert all(r < 1.05 for r, _ in tr.diagnostics())
+    assert not np.allclose(tr.mass, 1.0)
+    # split launches resume correctly on the tick engine too
+    m = R.Model(spec, device=0)
+    cfg = R.make_config(12, 20, R.HMCSampler(3), engine=_capi.ENGINE_TICK)
+    whole = m.sample(cfg, seeds=[1, 2, 3, 4, 5]).chains
+    s = R.Sampler(m, cfg, [1, 2, 3, 4, 5]); s.warmup(); s.run(5); s.run(7)
+    assert np.array_equal(s.draws(), whole)
+    t = s.timing()
+    assert t["dominant_kernel"] == "rh_grad_kernel" and 0 < t["kernel_ms"] <= t["total_ms"]
+    s.close()
+    with pytest.raises(R.RainierHipError):
+        R.Model(models.funnel(), device=0).sample(R.make_config(5, 5, engine=_capi.ENGINE_TICK), seeds=[1])
+
+
+def test_cfg2_full_size_properties():
+    # BASELINE cfg 2 at full size (1e6 rows): closed form + size-independent properties
+    spec = models.linreg(n=1_000_000, k=3)
+    m = R.Model(spec, device=0)
+    rng = np.random.default_rng(9)
+    qs = rng.normal(size=(3, 5)) * 0.3 + np.array([-0.35, 0.5, 1.0, -2.0, 0.5])
+    lp, g = m.density_batch(qs)
+    y, X = spec.columns[0], np.stack(spec.columns[1:])
+    for c, q in enumerate(qs):
+        s_, a, b = q[0], q[1], q[2:]
+        r = y - a - b @ X
+        iv = np.exp(-2 * s_)
+        terms_lp = -0.5 * r * r * iv - s_ - models.HALF_LOG_2PI
+        ref_lp = (s_ - np.exp(s_)) + np.sum(-0.5 * q[1:] ** 2 - models.HALF_LOG_2PI) + np.sum(terms_lp)
+        assert abs(lp[c] - ref_lp) <= 1e-11 * np.abs(terms_lp).sum()
+        gs = 1 - np.exp(s_) + np.sum(r * r * iv - 1)
+        assert abs(g[c, 0] - gs) <= 1e-11 * np.sum(np.abs(r * r * iv - 1))
+        assert abs(g[c, 1] - (-a + iv * r.sum())) <= 1e-11 * iv * np.abs(r).sum()
+        for k in range(3):
+            assert abs(g[c, 2 + k] - (-b[k] + iv * (X[k] @ r))) <= 1e-11 * iv * np.abs(X[k] * r).sum()
+    # additivity over a row partition: density(all rows) - prior == sum of halves - 2*prior (within tolerance)
+    h1 = models.linreg(n=500_000, columns=[c[:500_000] for c in spec.columns])
+    h2 = models.linreg(n=500_000, columns=[c[500_000:] for c in spec.columns])
+    prior = models.linreg(n=0, columns=[c[:0] for c in spec.columns])
+    l1, g1 = R.Model(h1, device=0).density_batch(qs); l2, g2 = R.Model(h2, device=0).density_batch(qs)
+    l0, g0 = R.Model(prior, device=0).density_batch(qs)
+    np.testing.assert_allclose(lp, l1 + l2 - l0, rtol=1e-12)
+    np.testing.assert_allclose(g, g1 + g2 - g0, rtol=1e-9, atol=1e-6)
+    # both engines agree at full size (tame dynamics)
+    a = m.sample(_tame(2, _capi.ENGINE_CHAIN), seeds=range(6))
+    b = m.sample(_tame(2, _capi.ENGINE_TICK), seeds=range(6))
+    np.testing.assert_allclose(b.chains, a.chains, rtol=1e-8, atol=1e-10)
