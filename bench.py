@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--leapfrog", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strict", action="store_true", help="no FMA contraction in model code (JVM semantics)")
+    ap.add_argument("--strict", action="store_true",
+                    help="JVM-faithful model arithmetic: no FMA contraction, outputs accumulated per row un-factored")
+    ap.add_argument("--no-factor", action="store_true", help="keep FMA contraction but do not factor outputs")
     ap.add_argument("--rows-unroll", type=int, default=0)
     ap.add_argument("--engine", choices=["auto", "chain", "tick"], default="auto")
     ap.add_argument("--grad-chains", type=int, default=0)
@@ -93,7 +95,8 @@ def main():
     K, W, L = a.steps, a.warmup, a.leapfrog
     spec = models.linreg(n=a.rows, k=3)
     model = R.Model(spec, device=local_rank, fp_contract=not a.strict, rows_unroll=a.rows_unroll,
-                    grad_chains=a.grad_chains, grad_unroll=a.grad_unroll)
+                    grad_chains=a.grad_chains, grad_unroll=a.grad_unroll,
+                    factor_outputs=not (a.strict or a.no_factor))
     cpg = a.chains_per_gpu
     from rainier_amd import distributed as D
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
@@ -150,7 +153,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg2: linear regression 3 covariates x %d rows (un-inlined, streamed), static HMC L=%d, "
                                "%d chains/GPU, DualAvgTuner(0.8), identity mass" % (rows, L, cpg),
-                   "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict,
+                   "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict, "factor_outputs": not (a.strict or a.no_factor),
                    "engine": tim["dominant_kernel"], "grad_chains": a.grad_chains, "grad_unroll": a.grad_unroll,
                    "grad_splits": a.grad_splits},
         "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,

@@ -33,7 +33,7 @@ EXPORTS = [
 class CompileOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("math_mode", C.c_int32),
                 ("fp_contract", C.c_int32), ("rows_unroll", C.c_int32), ("grad_chains", C.c_int32),
-                ("grad_unroll", C.c_int32), ("reserved", C.c_int32)]
+                ("grad_unroll", C.c_int32), ("factor_outputs", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -112,11 +112,12 @@ def dptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0, grad_chains=0, grad_unroll=0):
+def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0, grad_chains=0, grad_unroll=0,
+                 factor_outputs=False):
     o = CompileOpts()
     o.struct_size = C.sizeof(CompileOpts)
     o.device, o.math_mode, o.fp_contract, o.rows_unroll = device, math_mode, int(fp_contract), rows_unroll
-    o.grad_chains, o.grad_unroll = grad_chains, grad_unroll
+    o.grad_chains, o.grad_unroll, o.factor_outputs = grad_chains, grad_unroll, int(factor_outputs)
     return o
 
 

@@ -45,9 +45,10 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NVARS], const rh_model_da
     const double *cp[NC];
 #pragma unroll
     for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
-    double acc[RH_NOUT];
+    constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+    double acc[NA];
 #pragma unroll
-    for (int o = 0; o < RH_NOUT; o++) acc[o] = 0.0;
+    for (int o = 0; o < NA; o++) acc[o] = 0.0;
     long long k = lane;
     for (; k + 64LL * (U - 1) < n; k += 64LL * U) {
       double c[U][NC];
@@ -64,8 +65,10 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NVARS], const rh_model_da
       for (int j = 0; j < NC; j++) c[j] = cp[j][k];
       TG::row(th, inv, c, acc, err);
     }
+    double S[NA];
 #pragma unroll
-    for (int o = 0; o < RH_NOUT; o++) tot[o] += rh_wave_sum(acc[o]);
+    for (int o = 0; o < NA; o++) S[o] = rh_wave_sum(acc[o]);
+    TG::finish(th, inv, S, (double)n, tot);
   }
 }
 template <int T>
@@ -530,11 +533,12 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_mo
       const double *cp[NC];
 #pragma unroll
       for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
-      double acc[K][RH_NOUT];
+      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+      double acc[K][NA];
 #pragma unroll
       for (int kk = 0; kk < K; kk++)
 #pragma unroll
-        for (int o = 0; o < RH_NOUT; o++) acc[kk][o] = 0.0;
+        for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
       long long k = r0 + lane;
       for (; k + 64LL * (U - 1) < r1; k += chunk) {
         double c[U][NC];
@@ -556,9 +560,9 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_mo
       }
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
-        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NOUT;
+        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
 #pragma unroll
-        for (int o = 0; o < RH_NOUT; o++) {
+        for (int o = 0; o < NA; o++) {
           const double v = rh_wave_sum(acc[kk][o]);
           if (lane == 0 && chain0 + kk < chains) out[o] = v;
         }
@@ -602,26 +606,33 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
-RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const int nsplit,
-                               const int chain, const int chains, double (&tot)[RH_NOUT], int &err) {
+RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const long long *nrows,
+                               const int nsplit, const int chain, const int chains, double (&tot)[RH_NOUT], int &err) {
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (!TG::HAS_ROWS) {
       double inv[1];
       TG::row(th, inv, nullptr, tot, err);
     } else {
-      for (int s = 0; s < nsplit; s++) {
-        const double *p = partial + (((size_t)TG::ROWT * nsplit + s) * chains + chain) * RH_NOUT;
+      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+      double S[NA];
 #pragma unroll
-        for (int o = 0; o < RH_NOUT; o++) tot[o] += p[o];
+      for (int o = 0; o < NA; o++) S[o] = 0.0;
+      for (int s = 0; s < nsplit; s++) { // fixed split order
+        const double *p = partial + (((size_t)TG::ROWT * nsplit + s) * chains + chain) * RH_NACC_MAX;
+#pragma unroll
+        for (int o = 0; o < NA; o++) S[o] += p[o];
       }
+      double inv[TG::NINV > 0 ? TG::NINV : 1];
+      TG::invariants(th, inv, err);
+      TG::finish(th, inv, S, (double)nrows[T], tot);
     }
-    rh_combine_targets<T + 1>(th, partial, nsplit, chain, chains, tot, err);
+    rh_combine_targets<T + 1>(th, partial, nrows, nsplit, chain, chains, tot, err);
   }
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-rh_tick_kernel(const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *__restrict__ seeds,
+rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *__restrict__ seeds,
                const double *__restrict__ static_mass, double *__restrict__ draws,
                rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running, double *__restrict__ qbuf,
                int *__restrict__ active, const double *__restrict__ partial, const int *__restrict__ grad_err,
@@ -642,7 +653,7 @@ rh_tick_kernel(const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *_
 #pragma unroll
     for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
     int err = grad_err[0];
-    rh_combine_targets<0>(th, partial, nsplit, chain, chains, tot, err);
+    rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, tot, err);
     c.pend_logp = tot[0];
     wv_zero(c.pend_g);
 #pragma unroll

@@ -1,19 +1,35 @@
-// emit.cpp -- IR -> HIP lowering.  One straight-line fp64 function pair per target:
-//   invariants(th, inv) : the sub-DAG that depends on parameters only (hoisted out of the row loop; the
-//                         reference re-evaluates it for every row inside its generated methods)
-//   row(th, inv, c, acc): the per-row sub-DAG; acc[o] += output_o, o = 0..n   (DataFunction.scala:64-71)
-// The whole DAG is evaluated once per row -- the reference's "outputs must be evaluated in index order so
-// that a VarDef precedes its VarRefs" constraint disappears in a fused kernel.
+// emit.cpp -- IR -> HIP lowering.  Per target three straight-line fp64 functions:
+//   invariants(th, inv, err)          : the sub-DAG that depends on parameters only (hoisted out of the row loop;
+//                                       the reference re-evaluates it for every row inside its generated methods)
+//   row(th, inv, c, acc, err)         : the per-row sub-DAG; acc[j] += basis term j
+//   finish(th, inv, S, nrows, tot)    : tot[o] += (row-summed) output o, from the reduced basis sums S
+// The whole DAG is evaluated once per row -- the reference's "outputs must be evaluated in index order so that a
+// VarDef precedes its VarRefs" constraint disappears in a fused kernel.
+//
+// Default (JVM-faithful) mode: the basis terms ARE the outputs (acc[o] += output_o per row, as
+// ir/DataFunction.scala:64-71 does), finish() just adds the sums.
+// factor_outputs mode: every output is peeled into  alpha * t + beta  with alpha, beta parameter-only and t a
+// row-dependent basis term (through +,-,*,/ by invariants and products of single-term forms).  The row loop then
+// accumulates the distinct basis terms only and finish() applies  alpha * sum(t) + nrows * beta  once per gradient.
+// For the README regression this turns 6 outputs x ~20 fp64 ops per row into 5 basis sums (r*r, r, r*x_k) x 9 ops.
+// Rows are still streamed for every evaluation (no data-only sums are hoisted: every basis term involves the
+// parameters or is consumed as a product with one that does); only rounding changes, so it is a fast-mode option.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <map>
 #include <sstream>
+#include <tuple>
 
 #include "../../include/rainier_hip_rir.h"
 #include "rir.hpp"
 
 namespace rh {
 namespace {
+
+constexpr uint32_t ZERO = 0xFFFFFFFFu;  // the invariant constant 0 (no node)
+constexpr uint32_t ONE = 0xFFFFFFFEu;   // the invariant constant 1 (no node)
+constexpr uint32_t NONE = 0xFFFFFFFDu;  // no basis term
 
 std::string lit(double v) {
   if (std::isinf(v)) return v > 0 ? "RH_INF" : "(-RH_INF)";
@@ -23,41 +39,182 @@ std::string lit(double v) {
   return v < 0 || std::signbit(v) ? "(" + s + ")" : s;
 }
 
+bool is_binary(uint32_t op) { return (op >= RH_RIR_ADD && op <= RH_RIR_COMPARE) || op == RH_RIR_SEQ; }
+
+struct Lin {  // alpha * term + beta
+  uint32_t term = NONE, alpha = ONE, beta = ZERO;
+};
+
 struct TargetEmitter {
-  const Program &P;
+  Program P;  // private copy: factoring appends synthesized nodes
   uint32_t t;
-  std::vector<char> reach;
-  std::map<uint32_t, int> inv_slot;  // non-trivial invariant node -> index in inv[]
-  TargetEmitter(const Program &p, uint32_t ti) : P(p), t(ti), reach(p.nodes.size(), 0) {
-    for (uint32_t o : P.targets[t].outputs) reach[o] = 1;
-    for (size_t n = P.nodes.size(); n-- > 0;) {
-      if (!reach[n]) continue;
-      const Node &nd = P.nodes[n];
-      switch (nd.op) {
-        case RH_RIR_CONST: case RH_RIR_INPUT: break;
-        case RH_RIR_LOOKUP: reach[nd.a] = 1; for (uint32_t e : nd.table) reach[e] = 1; break;
-        case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_POW: case RH_RIR_COMPARE:
-        case RH_RIR_SEQ: reach[nd.a] = 1; reach[nd.b] = 1; break;
-        default: reach[nd.a] = 1;
+  bool factor;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;  // hash-consing of synthesized nodes
+  std::map<uint32_t, Lin> memo;
+  std::vector<uint32_t> basis;            // basis term node ids, accumulator order
+  std::vector<Lin> outs;                  // per output: (basis index in .term, alpha, beta)
+  std::map<uint32_t, int> inv_slot;       // non-trivial invariant node -> index in inv[]
+  std::vector<char> reach_row, reach_inv;
+
+  TargetEmitter(const Program &p, uint32_t ti, bool f) : P(p), t(ti), factor(f) {
+    for (uint32_t i = 0; i < P.nodes.size(); i++)  // let synthesized nodes reuse identical existing ones
+      if (P.nodes[i].op >= RH_RIR_ADD && P.nodes[i].op <= RH_RIR_DIV) cons.emplace(std::make_tuple(P.nodes[i].op, P.nodes[i].a, P.nodes[i].b), i);
+  }
+
+  bool has_rows() const { return P.targets[t].n_cols > 0; }
+  bool trivial(uint32_t id) const { return P.nodes[id].op == RH_RIR_CONST || P.nodes[id].op == RH_RIR_INPUT; }
+  bool is_const(uint32_t id, double v) const { return id < P.nodes.size() && P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == v; }
+
+  uint32_t mk_const(double v) {
+    for (uint32_t i = 0; i < P.nodes.size(); i++)
+      if (P.nodes[i].op == RH_RIR_CONST && P.nodes[i].cval == v && std::signbit(P.nodes[i].cval) == std::signbit(v)) return i;
+    Node n; n.op = RH_RIR_CONST; n.cval = v; n.dep = 0;
+    P.nodes.push_back(n);
+    return (uint32_t)P.nodes.size() - 1;
+  }
+  uint32_t mk(uint32_t op, uint32_t a, uint32_t b, uint8_t dep) {
+    auto key = std::make_tuple(op, a, b);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.b = b; n.dep = dep;
+    P.nodes.push_back(n);
+    return cons[key] = (uint32_t)P.nodes.size() - 1;
+  }
+  // invariant arithmetic on {ZERO, ONE, node}
+  uint32_t iadd(uint32_t a, uint32_t b) { if (a == ZERO) return b; if (b == ZERO) return a; return mk(RH_RIR_ADD, real(a), real(b), 0); }
+  uint32_t isub(uint32_t a, uint32_t b) { if (b == ZERO) return a; return mk(RH_RIR_SUB, a == ZERO ? mk_const(0.0) : real(a), real(b), 0); }
+  uint32_t imul(uint32_t a, uint32_t b) { if (a == ZERO || b == ZERO) return ZERO; if (a == ONE) return b; if (b == ONE) return a; return mk(RH_RIR_MUL, a, b, 0); }
+  uint32_t idiv(uint32_t a, uint32_t b) { if (a == ZERO) return ZERO; if (b == ONE) return a; return mk(RH_RIR_DIV, real(a), b, 0); }
+  uint32_t real(uint32_t a) { return a == ONE ? mk_const(1.0) : (a == ZERO ? mk_const(0.0) : a); }
+
+  Lin opaque(uint32_t id) { Lin l; l.term = id; return l; }
+  Lin lin(uint32_t id) {
+    auto it = memo.find(id);
+    if (it != memo.end()) return it->second;
+    Lin r = lin_impl(id);
+    memo[id] = r;
+    return r;
+  }
+  Lin lin_impl(uint32_t id) {
+    const Node nd = P.nodes[id];
+    if (nd.dep == 0) {
+      Lin l; l.term = NONE; l.alpha = ZERO; l.beta = id;
+      if (nd.op == RH_RIR_CONST && nd.cval == 0.0) l.beta = ZERO;
+      if (nd.op == RH_RIR_CONST && nd.cval == 1.0) l.beta = ONE;
+      return l;
+    }
+    switch (nd.op) {
+      case RH_RIR_NOOP: return lin(nd.a);
+      case RH_RIR_SEQ: return lin(nd.b);
+      case RH_RIR_ADD: case RH_RIR_SUB: {
+        const Lin a = lin(nd.a), b = lin(nd.b);
+        const bool sub = nd.op == RH_RIR_SUB;
+        Lin r;
+        if (a.term != NONE && b.term != NONE) {
+          if (a.term != b.term) return opaque(id);
+          r.term = a.term; r.alpha = sub ? isub(a.alpha, b.alpha) : iadd(a.alpha, b.alpha);
+        } else if (a.term != NONE) { r.term = a.term; r.alpha = a.alpha; }
+        else { r.term = b.term; r.alpha = sub ? isub(ZERO, b.alpha) : b.alpha; }
+        r.beta = sub ? isub(a.beta, b.beta) : iadd(a.beta, b.beta);
+        return r;
       }
+      case RH_RIR_MUL: {
+        const Lin a = lin(nd.a), b = lin(nd.b);
+        if (a.term == NONE) { Lin r; r.term = b.term; r.alpha = imul(b.alpha, a.beta); r.beta = imul(b.beta, a.beta); return r; }
+        if (b.term == NONE) { Lin r; r.term = a.term; r.alpha = imul(a.alpha, b.beta); r.beta = imul(a.beta, b.beta); return r; }
+        if (a.beta == ZERO && b.beta == ZERO) {
+          Lin r;
+          const uint32_t lo = std::min(a.term, b.term), hi = std::max(a.term, b.term);
+          r.term = (a.alpha == ONE && b.alpha == ONE) ? id : mk(RH_RIR_MUL, lo, hi, (uint8_t)(t + 1));
+          r.alpha = imul(a.alpha, b.alpha);
+          return r;
+        }
+        return opaque(id);
+      }
+      case RH_RIR_DIV: {
+        const Lin a = lin(nd.a), b = lin(nd.b);
+        if (b.term == NONE && a.term != NONE) { Lin r; r.term = a.term; r.alpha = idiv(a.alpha, b.beta); r.beta = idiv(a.beta, b.beta); return r; }
+        return opaque(id);
+      }
+      default: return opaque(id);
     }
   }
-  bool trivial(uint32_t id) const { return P.nodes[id].op == RH_RIR_CONST || P.nodes[id].op == RH_RIR_INPUT; }
-  bool has_rows() const { return P.targets[t].n_cols > 0; }
-  // how an operand is spelled inside row() (in_row) or invariants()
-  std::string ref(uint32_t id, bool in_row) const {
+
+  void operands(const Node &nd, std::vector<uint32_t> &out) const {
+    out.clear();
+    switch (nd.op) {
+      case RH_RIR_CONST: case RH_RIR_INPUT: break;
+      case RH_RIR_LOOKUP: out.push_back(nd.a); for (uint32_t e : nd.table) out.push_back(e); break;
+      default: out.push_back(nd.a); if (is_binary(nd.op)) out.push_back(nd.b);
+    }
+  }
+  void sweep(std::vector<char> &reach) const {
+    std::vector<uint32_t> ops;
+    for (size_t n = P.nodes.size(); n-- > 0;) {
+      if (!reach[n]) continue;
+      operands(P.nodes[n], ops);
+      for (uint32_t o : ops) reach[o] = 1;
+    }
+  }
+
+  // synthesized nodes are appended after their operands, so ascending id stays a topological order
+  void plan() {
+    const Target &T = P.targets[t];
+    outs.resize(T.outputs.size());
+    std::map<uint32_t, int> bidx;
+    auto basis_of = [&](uint32_t term) { auto it = bidx.find(term); if (it != bidx.end()) return it->second; int i = (int)basis.size(); basis.push_back(term); bidx[term] = i; return i; };
+    for (size_t o = 0; o < T.outputs.size(); o++) {
+      const uint32_t id = T.outputs[o];
+      Lin l;
+      if (!has_rows()) { l.term = NONE; l.alpha = ZERO; l.beta = id; }
+      else if (factor) l = lin(id);
+      else if (is_const(id, 0.0) && !std::signbit(P.nodes[id].cval)) { l.term = NONE; l.alpha = ZERO; l.beta = ZERO; }  // += +0.0 is the identity
+      else l = opaque(id);  // JVM-faithful: accumulate the output itself (also when it is parameter-only)
+      if (l.term != NONE) l.term = (uint32_t)basis_of(l.term);
+      outs[o] = l;
+    }
+    reach_row.assign(P.nodes.size(), 0);
+    reach_inv.assign(P.nodes.size(), 0);
+    if (has_rows()) {
+      for (uint32_t b : basis) reach_row[b] = 1;
+      sweep(reach_row);
+      // invariants needed: parameter-only operands of row nodes, plus every alpha / beta
+      std::vector<uint32_t> ops;
+      auto want = [&](uint32_t x) {
+        if (x >= NONE) return;
+        if (P.nodes[x].dep == 0 && !trivial(x) && !inv_slot.count(x)) { int s = (int)inv_slot.size(); inv_slot[x] = s; }
+      };
+      for (size_t n = 0; n < P.nodes.size(); n++) {
+        if (!reach_row[n]) continue;
+        if (P.nodes[n].dep == 0) { if (std::find(basis.begin(), basis.end(), (uint32_t)n) != basis.end()) want((uint32_t)n); continue; }
+        operands(P.nodes[n], ops);
+        for (uint32_t o : ops) want(o);
+      }
+      for (const Lin &l : outs) { want(l.alpha); want(l.beta); }
+      for (auto &kv : inv_slot) reach_inv[kv.first] = 1;
+      sweep(reach_inv);
+    } else {
+      for (uint32_t o : T.outputs) reach_row[o] = 1;
+      sweep(reach_row);
+    }
+  }
+
+  // how an operand is spelled: ctx 0 = invariants(), 1 = row(), 2 = finish()
+  std::string ref(uint32_t id, int ctx) const {
+    if (id == ONE) return "0x1p+0";
+    if (id == ZERO) return "0x0p+0";
     const Node &nd = P.nodes[id];
     if (nd.op == RH_RIR_CONST) return lit(nd.cval);
     if (nd.op == RH_RIR_INPUT) {
       if (nd.input < P.n_params) return "th[" + std::to_string(nd.input) + "]";
       return "c[" + std::to_string(nd.input - P.targets[t].input_start) + "]";
     }
-    if (in_row && has_rows() && nd.dep == 0) return "inv[" + std::to_string(inv_slot.at(id)) + "]";
+    if (ctx != 0 && has_rows() && nd.dep == 0) return "inv[" + std::to_string(inv_slot.at(id)) + "]";
     return "n" + std::to_string(id);
   }
-  bool emit_node(std::ostringstream &os, uint32_t id, bool in_row, std::string &err) const {
+  bool emit_node(std::ostringstream &os, uint32_t id, int ctx, std::string &err) const {
     const Node &nd = P.nodes[id];
-    auto R = [&](uint32_t x) { return ref(x, in_row); };
+    auto R = [&](uint32_t x) { return ref(x, ctx); };
     const std::string lhs = "    const double n" + std::to_string(id) + " = ";
     switch (nd.op) {
       case RH_RIR_ADD: os << lhs << R(nd.a) << " + " << R(nd.b) << ";\n"; break;
@@ -91,54 +248,64 @@ struct TargetEmitter {
     }
     return true;
   }
+
+  int nacc() const { return has_rows() ? (int)basis.size() : 0; }
+
   bool emit(std::ostringstream &os, std::string &err) {
     const Target &T = P.targets[t];
     const bool rows = has_rows();
-    // invariant frontier: non-trivial parameter-only nodes that row nodes (or outputs) read
-    if (rows) {
-      auto want = [&](uint32_t x) {
-        if (P.nodes[x].dep == 0 && !trivial(x) && !inv_slot.count(x)) { int s = (int)inv_slot.size(); inv_slot[x] = s; }
-      };
-      for (size_t n = 0; n < P.nodes.size(); n++) {
-        if (!reach[n] || P.nodes[n].dep == 0) continue;
-        const Node &nd = P.nodes[n];
-        switch (nd.op) {
-          case RH_RIR_INPUT: break;
-          case RH_RIR_LOOKUP: want(nd.a); for (uint32_t e : nd.table) want(e); break;
-          case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_POW: case RH_RIR_COMPARE:
-          case RH_RIR_SEQ: want(nd.a); want(nd.b); break;
-          default: want(nd.a);
-        }
-      }
-      for (uint32_t o : T.outputs) want(o);
-    }
-    os << "template <> struct rh_target<" << t << "> {\n";
-    os << "  static constexpr int NCOLS = " << T.n_cols << ", COL0 = " << T.col0 << ", NINV = " << inv_slot.size() << ";\n";
-    os << "  static constexpr bool HAS_ROWS = " << (rows ? "true" : "false") << ";\n";
     int rowt = -1;
     if (rows) { rowt = 0; for (uint32_t u = 0; u < t; u++) if (P.targets[u].n_cols) rowt++; }
-    os << "  static constexpr int ROWT = " << rowt << ";\n";
+    os << "template <> struct rh_target<" << t << "> {\n";
+    os << "  static constexpr int NCOLS = " << T.n_cols << ", COL0 = " << T.col0 << ", NINV = " << inv_slot.size()
+       << ", NACC = " << nacc() << ", ROWT = " << rowt << ";\n";
+    os << "  static constexpr bool HAS_ROWS = " << (rows ? "true" : "false") << ";\n";
+    // ---- invariants
     os << "  static RH_DEV void invariants(const double (&th)[RH_NVARS], double *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
     if (rows) {
       for (size_t n = 0; n < P.nodes.size(); n++)
-        if (reach[n] && P.nodes[n].dep == 0 && !trivial((uint32_t)n))
-          if (!emit_node(os, (uint32_t)n, false, err)) return false;
+        if (reach_inv[n] && P.nodes[n].dep == 0 && !trivial((uint32_t)n))
+          if (!emit_node(os, (uint32_t)n, 0, err)) return false;
       for (auto &kv : inv_slot) os << "    inv[" << kv.second << "] = n" << kv.first << ";\n";
     }
     os << "  }\n";
-    os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
-          "    (void)th; (void)inv; (void)c; (void)err;\n";
-    for (size_t n = 0; n < P.nodes.size(); n++) {
-      if (!reach[n] || trivial((uint32_t)n)) continue;
-      if (rows && P.nodes[n].dep == 0) continue;  // hoisted
-      if (!emit_node(os, (uint32_t)n, true, err)) return false;
+    // ---- row
+    if (rows) {
+      os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double *acc, int &err) {\n"
+            "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n";
+      for (size_t n = 0; n < P.nodes.size(); n++) {
+        if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
+        if (!emit_node(os, (uint32_t)n, 1, err)) return false;
+      }
+      for (size_t j = 0; j < basis.size(); j++) os << "    acc[" << j << "] += " << ref(basis[j], 1) << ";\n";
+      os << "  }\n";
+      // ---- finish: tot[o] += alpha * S[j] + nrows * beta
+      os << "  static RH_DEV void finish(const double (&th)[RH_NVARS], const double *inv, const double *S, const double nrows, double (&tot)[RH_NOUT]) {\n"
+            "    (void)th; (void)inv; (void)S; (void)nrows;\n";
+      for (size_t o = 0; o < outs.size(); o++) {
+        const Lin &l = outs[o];
+        std::string e;
+        if (l.term != NONE && l.alpha != ZERO) e = l.alpha == ONE ? "S[" + std::to_string(l.term) + "]" : ref(l.alpha, 2) + " * S[" + std::to_string(l.term) + "]";
+        if (l.beta != ZERO) e += (e.empty() ? "" : " + ") + ("nrows * " + ref(l.beta, 2));
+        if (!e.empty()) os << "    tot[" << o << "] += " << e << ";\n";
+      }
+      os << "  }\n";
+    } else {
+      // data-free target: evaluated once, outputs(o) += f_o(theta)  (DataFunction.scala:73-83)
+      os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
+            "    (void)th; (void)inv; (void)c; (void)err;\n";
+      for (size_t n = 0; n < P.nodes.size(); n++) {
+        if (!reach_row[n] || trivial((uint32_t)n)) continue;
+        if (!emit_node(os, (uint32_t)n, 1, err)) return false;
+      }
+      for (size_t o = 0; o < T.outputs.size(); o++) {
+        const Node &on = P.nodes[T.outputs[o]];
+        if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
+        os << "    acc[" << o << "] += " << ref(T.outputs[o], 1) << ";\n";
+      }
+      os << "  }\n";
     }
-    for (size_t o = 0; o < T.outputs.size(); o++) {
-      const Node &on = P.nodes[T.outputs[o]];
-      if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
-      os << "    acc[" << o << "] += " << ref(T.outputs[o], true) << ";\n";
-    }
-    os << "  }\n};\n";
+    os << "};\n";
     return true;
   }
 };
@@ -146,26 +313,28 @@ struct TargetEmitter {
 }  // namespace
 
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err) {
+  std::ostringstream os;
+  os << "template <int T> struct rh_target;\n";
+  if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
+  int nacc_max = 1, nrowt = 0;
+  for (uint32_t t = 0; t < P.targets.size(); t++) {
+    TargetEmitter te(P, t, o.factor_outputs);
+    te.plan();
+    if (!te.emit(os, err)) return false;
+    nacc_max = std::max(nacc_max, te.nacc());
+    if (P.targets[t].n_cols) nrowt++;
+  }
+  os << "#pragma clang fp contract(off)\n";
+  targets = os.str();
   std::ostringstream d;
   d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (P.n_params + 1) << "\n#define RH_SLOTS "
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";
-  int nrowt = 0;
-  for (auto &T : P.targets) if (T.n_cols) nrowt++;
-  d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_GRAD_K " << (o.grad_chains > 0 ? o.grad_chains : 4)
-    << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2) << "\n";
+  d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
+    << (o.grad_chains > 0 ? o.grad_chains : 4) << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();
-  std::ostringstream os;
-  os << "template <int T> struct rh_target;\n";
-  if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
-  for (uint32_t t = 0; t < P.targets.size(); t++) {
-    TargetEmitter te(P, t);
-    if (!te.emit(os, err)) return false;
-  }
-  os << "#pragma clang fp contract(off)\n";
-  targets = os.str();
   return true;
 }
 }  // namespace rh

@@ -116,7 +116,7 @@ struct rh_model {
   bool loaded = false;
   hipModule_t module = nullptr;
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr;
-  int n_row_targets = 0, grad_k = 4;
+  int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   int state_words = 0;
   rh_model_data data{};
   std::vector<void *> dev_cols;
@@ -149,6 +149,7 @@ namespace {
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
+  { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
@@ -217,6 +218,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
       if (opts->grad_chains < 0 || opts->grad_chains > 16 || opts->grad_unroll < 0 || opts->grad_unroll > 16)
         throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
       m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;
+      m->eopt.factor_outputs = opts->factor_outputs != 0;
       dev = opts->device;
     }
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
@@ -292,6 +294,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
       m.eopt.fp_contract = opts->fp_contract != 0;
       if (opts->rows_unroll > 0) m.eopt.rows_unroll = opts->rows_unroll;
       m.eopt.grad_chains = opts->grad_chains; m.eopt.grad_unroll = opts->grad_unroll;
+      m.eopt.factor_outputs = opts->factor_outputs != 0;
     }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
@@ -426,7 +429,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       if (const char *e = std::getenv("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
       HIPCHK(hipMalloc(&s->d_qbuf, sizeof(double) * n * chains));
       HIPCHK(hipMalloc(&s->d_active, sizeof(int) * chains));
-      HIPCHK(hipMalloc(&s->d_partial, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * (n + 1)));
+      HIPCHK(hipMalloc(&s->d_partial, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
       HIPCHK(hipMalloc(&s->d_graderr, sizeof(int)));
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
@@ -458,7 +461,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   auto tick = [&](int fresh) {
     HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
-    void *args[] = {&s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+    void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
                     &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
     launch(m->k_tick, (unsigned)chains, 64, m->stream, args);
   };

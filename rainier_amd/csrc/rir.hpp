@@ -35,6 +35,7 @@ struct EmitOptions {
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
   int rows_unroll = 4;
+  bool factor_outputs = false;  // peel invariant affine wrappers off the accumulated outputs (fast mode)
   int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
   int grad_unroll = 0;  // row-loop unroll of the batched gradient kernel (0 = default)
 };

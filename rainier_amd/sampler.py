@@ -246,14 +246,14 @@ class Model:
     """A compiled model: Compiler.compileTargets' replacement (compute/Compiler.scala:14-30) + Model.sample."""
 
     def __init__(self, spec, device: int = -1, math_mode: int = _capi.MATH_FAST, fp_contract: bool = False,
-                 rows_unroll: int = 0, grad_chains: int = 0, grad_unroll: int = 0):
+                 rows_unroll: int = 0, grad_chains: int = 0, grad_unroll: int = 0, factor_outputs: bool = False):
         L = _capi.lib()
         self.spec = spec
         self.nVars = spec.n_params
         self._cols = [np.ascontiguousarray(c, dtype=np.float64) for c in spec.columns]
         colarr = (C.POINTER(C.c_double) * max(1, len(self._cols)))(*[_capi.dptr(c) for c in self._cols])
         nrows = (C.c_int64 * len(spec.nrows))(*spec.nrows)
-        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll, grad_chains, grad_unroll)
+        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll, grad_chains, grad_unroll, factor_outputs)
         blob = C.create_string_buffer(spec.rir, len(spec.rir))
         self._h = C.c_void_p()
         _capi.check(L.rh_model_create(blob, len(spec.rir), colarr, nrows, C.byref(opts), C.byref(self._h)))

@@ -95,6 +95,24 @@ def test_linreg_density_fma_contraction_within_tolerance():
     _check_density(spec, R.Model(spec, device=0, rows_unroll=8), qs, 1e-12)
 
 
+def test_output_factoring_within_tolerance():
+    # factor_outputs: alpha*sum(t) + nrows*beta instead of sum(alpha*t + beta) -- rounding changes only
+    qs = np.random.default_rng(4).normal(size=(6, 5)) * 0.5
+    for n in (1, 100, 10000):
+        spec = models.linreg(n=n, k=3)
+        m = R.Model(spec, device=0, factor_outputs=True, fp_contract=True)
+        assert "static constexpr int NCOLS = 4, COL0 = 0, NINV = 4, NACC = 5" in m.hip_source
+        _check_density(spec, m, qs, 1e-12)
+    spec = models.logistic(n=3000, k=50)
+    _check_density(spec, R.Model(spec, device=0, factor_outputs=True), np.random.default_rng(5).normal(size=(3, 51)) * 0.3, 1e-12)
+    # both engines, factored: same chains as the un-factored build to rounding
+    spec = models.linreg(n=20000, k=3)
+    base = R.Model(spec, device=0).sample(_tame(4, _capi.ENGINE_CHAIN), seeds=range(6))
+    mf = R.Model(spec, device=0, factor_outputs=True, fp_contract=True, grad_chains=8)
+    for eng in (_capi.ENGINE_CHAIN, _capi.ENGINE_TICK):
+        np.testing.assert_allclose(mf.sample(_tame(4, eng), seeds=range(6)).chains, base.chains, rtol=1e-8, atol=1e-10)
+
+
 def test_logistic_density_lookup_and_compare():
     spec = models.logistic(n=3000, k=50)
     m = R.Model(spec, device=0)
