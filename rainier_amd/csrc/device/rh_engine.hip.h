@@ -125,27 +125,33 @@ struct rh_chain {
 };
 
 #define RH_CNT(n) +1
-#define RH_STATE_WORDS \
-  ((0 RH_STATE_VECS(RH_CNT)) * RH_SLOTS + (0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + \
-   (0 RH_STATE_I64(RH_CNT)) + RH_RING_SLOTS)
+#define RH_STATE_NVEC (0 RH_STATE_VECS(RH_CNT))
+#define RH_STATE_NSCALAR ((0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + (0 RH_STATE_I64(RH_CNT)))
+// u64 words of one chain's state image: lane-distributed vectors and the ring buffer take 64 words per slot,
+// wave-uniform scalars are stored once (lane 0 writes, every lane reads the same address -> scalar loads).
+#define RH_STATE_U64 ((RH_STATE_NVEC * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
 
-// state image: word w of chain c, lane l at st[(c * RH_STATE_WORDS + w) * 64 + l]   (coalesced)
+// image of chain c starts at st = state + c * RH_STATE_U64: [vector slot w][lane] ..., [ring slot][lane] ..., scalars
 RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
   int w = 0;
 #define X(n) \
   for (int k = 0; k < RH_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.n.s[k]);
   RH_STATE_VECS(X)
 #undef X
-#define X(n) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.n);
-  RH_STATE_F64(X)
-#undef X
-#define X(n) st[(w++) * 64 + lane] = (rh_u64)(rh_i64)c.n;
-  RH_STATE_INT(X)
-#undef X
-#define X(n) st[(w++) * 64 + lane] = (rh_u64)c.n;
-  RH_STATE_I64(X)
-#undef X
   for (int k = 0; k < RH_RING_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ring[k]);
+  if (lane == 0) {
+    rh_u64 *sc = st + (size_t)w * 64;
+    int j = 0;
+#define X(n) sc[j++] = (rh_u64)__double_as_longlong(c.n);
+    RH_STATE_F64(X)
+#undef X
+#define X(n) sc[j++] = (rh_u64)(rh_i64)c.n;
+    RH_STATE_INT(X)
+#undef X
+#define X(n) sc[j++] = (rh_u64)c.n;
+    RH_STATE_I64(X)
+#undef X
+  }
 }
 RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
   int w = 0;
@@ -153,16 +159,21 @@ RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
   for (int k = 0; k < RH_SLOTS; k++) c.n.s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
   RH_STATE_VECS(X)
 #undef X
-#define X(n) c.n = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  const rh_u64 *sc = st + (size_t)w * 64;
+  int j = 0;
+#define X(n) c.n = __longlong_as_double((rh_i64)sc[j++]);
   RH_STATE_F64(X)
 #undef X
-#define X(n) c.n = rh_uniform_i((int)(rh_i64)st[(w++) * 64 + lane]);
+#define X(n) c.n = rh_uniform_i((int)(rh_i64)sc[j++]);
   RH_STATE_INT(X)
 #undef X
-#define X(n) c.n = (rh_i64)st[(w++) * 64 + lane];
+#define X(n) c.n = (rh_i64)sc[j++];
   RH_STATE_I64(X)
 #undef X
-  for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+}
+RH_DEV void rh_chain_zero(rh_u64 *st, const int lane) {
+  for (int w = lane; w < RH_STATE_U64; w += 64) st[w] = 0;
 }
 
 // ---- automaton states ------------------------------------------------------------------------------
@@ -474,12 +485,9 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
   const int chain = blockIdx.x;
   const int lane = threadIdx.x;
   if (chain >= chains) return;
-  rh_u64 *st = state + (size_t)chain * RH_STATE_WORDS * 64;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   rh_chain c;
-  if (fresh) {
-    rh_u64 *z = st;
-    for (int w = 0; w < RH_STATE_WORDS; w++) z[w * 64 + lane] = 0;
-  }
+  if (fresh) rh_chain_zero(st, lane);
   rh_chain_load(c, st, lane);
   double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
   const rh_i64 seed = seeds[chain];
@@ -540,6 +548,37 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_mo
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
       long long k = r0 + lane;
+#if RH_GRAD_PIPELINE
+      // software pipeline: the loads of tile i+1 are in flight while tile i is consumed
+      if (k + 64LL * (U - 1) < r1) {
+        double cn[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int j = 0; j < NC; j++) cn[u][j] = cp[j][k + 64LL * u];
+        for (;;) {
+          double c[U][NC];
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) c[u][j] = cn[u][j];
+          const long long kn = k + chunk;
+          const bool more = kn + 64LL * (U - 1) < r1;
+          if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+              for (int j = 0; j < NC; j++) cn[u][j] = cp[j][kn + 64LL * u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c[u], acc[kk], err);
+          k = kn;
+          if (!more) break;
+        }
+      }
+#else
       for (; k + 64LL * (U - 1) < r1; k += chunk) {
         double c[U][NC];
 #pragma unroll
@@ -551,6 +590,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_mo
 #pragma unroll
           for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c[u], acc[kk], err);
       }
+#endif
       for (; k < r1; k += 64) {
         double c[NC];
 #pragma unroll
@@ -640,10 +680,9 @@ rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__
   const int chain = blockIdx.x;
   const int lane = threadIdx.x;
   if (chain >= chains) return;
-  rh_u64 *st = state + (size_t)chain * RH_STATE_WORDS * 64;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   rh_chain c;
-  if (fresh)
-    for (int w = 0; w < RH_STATE_WORDS; w++) st[w * 64 + lane] = 0;
+  if (fresh) rh_chain_zero(st, lane);
   rh_chain_load(c, st, lane);
   if (c.need_eval) { // the gradient requested at the previous tick is in `partial`
     double th[RH_NVARS];
@@ -717,4 +756,4 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
   }
 }
 
-extern "C" __device__ __attribute__((used)) const int rh_state_words = RH_STATE_WORDS;
+extern "C" __device__ __attribute__((used)) const int rh_state_words = RH_STATE_U64; // u64 words per chain image

@@ -148,6 +148,7 @@ namespace {
 
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
+  if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
   { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
@@ -394,7 +395,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     d.mass_skip_first = cfg->mass_skip_first; d.mass_skip_last = cfg->mass_skip_last; d.mass_expansion = cfg->mass_expansion;
     HIPCHK(hipSetDevice(m->device));
     const int n = (int)m->prog.n_params;
-    const size_t state_bytes = (size_t)chains * m->state_words * 64 * sizeof(uint64_t);
+    const size_t state_bytes = (size_t)chains * m->state_words * sizeof(uint64_t);
     HIPCHK(hipMalloc(&s->d_state, state_bytes));
     HIPCHK(hipMalloc(&s->d_seeds, sizeof(int64_t) * chains));
     HIPCHK(hipMalloc(&s->d_mass, sizeof(double) * n));
@@ -599,7 +600,7 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
       const size_t width = (size_t)slots * 64 * sizeof(uint64_t);
       std::vector<uint64_t> img((size_t)slots * 64 * s->chains);
       const char *base = (const char *)s->d_state + (size_t)9 * slots * 64 * sizeof(uint64_t);
-      HIPCHK(hipMemcpy2D(img.data(), width, base, (size_t)W * 64 * sizeof(uint64_t), width, (size_t)s->chains, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy2D(img.data(), width, base, (size_t)W * sizeof(uint64_t), width, (size_t)s->chains, hipMemcpyDeviceToHost));
       for (int c = 0; c < s->chains; c++)
         for (int i = 0; i < n; i++) std::memcpy(&mass_diag[(size_t)c * n + i], &img[(size_t)c * slots * 64 + i], sizeof(double));
     }

@@ -37,7 +37,8 @@ struct EmitOptions {
   int rows_unroll = 4;
   bool factor_outputs = false;  // peel invariant affine wrappers off the accumulated outputs (fast mode)
   int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
-  int grad_unroll = 0;  // row-loop unroll of the batched gradient kernel (0 = default)
+  int grad_unroll = 0;
+  bool grad_pipeline = false;  // software-pipelined row loop in the batched gradient kernel  // row-loop unroll of the batched gradient kernel (0 = default)
 };
 
 // Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).
