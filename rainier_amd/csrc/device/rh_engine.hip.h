@@ -617,10 +617,11 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_mo
 // takes the row splits {x, x+8, ...} of EVERY chain group: each XCD's private L2 then serves only 1/8 of the rows.
 extern "C" __global__ void __launch_bounds__(64)
 rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
-               double *__restrict__ partial, int *__restrict__ err_out, const int chains, const int nsplit,
-               const int xcd_aware) {
+               double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+               const int chains, const int nsplit, const int xcd_aware) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
+  if (b == 0 && lane == 0) *n_running = 0; // re-armed for the tick kernel that follows in stream order
   int group, split;
   if (xcd_aware && (nsplit % 8) == 0) {
     const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
@@ -647,7 +648,8 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
 RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const long long *nrows,
-                               const int nsplit, const int chain, const int chains, double (&tot)[RH_NOUT], int &err) {
+                               const int nsplit, const int chain, const int chains, const int lane,
+                               double (&tot)[RH_NOUT], int &err) {
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (!TG::HAS_ROWS) {
@@ -655,19 +657,23 @@ RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__res
       TG::row(th, inv, nullptr, tot, err);
     } else {
       constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+      // lane l sums the splits l, l+64, ... (ascending), then the fixed-order butterfly: deterministic, and the
+      // nsplit loads are issued in parallel instead of as one dependent chain
       double S[NA];
 #pragma unroll
       for (int o = 0; o < NA; o++) S[o] = 0.0;
-      for (int s = 0; s < nsplit; s++) { // fixed split order
+      for (int s = lane; s < nsplit; s += 64) {
         const double *p = partial + (((size_t)TG::ROWT * nsplit + s) * chains + chain) * RH_NACC_MAX;
 #pragma unroll
         for (int o = 0; o < NA; o++) S[o] += p[o];
       }
+#pragma unroll
+      for (int o = 0; o < NA; o++) S[o] = rh_wave_sum(S[o]);
       double inv[TG::NINV > 0 ? TG::NINV : 1];
       TG::invariants(th, inv, err);
       TG::finish(th, inv, S, (double)nrows[T], tot);
     }
-    rh_combine_targets<T + 1>(th, partial, nrows, nsplit, chain, chains, tot, err);
+    rh_combine_targets<T + 1>(th, partial, nrows, nsplit, chain, chains, lane, tot, err);
   }
 }
 
@@ -692,7 +698,7 @@ rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__
 #pragma unroll
     for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
     int err = grad_err[0];
-    rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, tot, err);
+    rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
     c.pend_logp = tot[0];
     wv_zero(c.pend_g);
 #pragma unroll

@@ -149,6 +149,13 @@ namespace {
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
   if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
+  {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
+    int ncols_max = 1;
+    for (auto &T : m->prog.targets) ncols_max = std::max<int>(ncols_max, (int)T.n_cols);
+    const int nacc_guess = (int)m->prog.n_params + 1;
+    if (m->eopt.grad_chains <= 0) m->eopt.grad_chains = std::max(1, std::min(8, 48 / nacc_guess));
+    if (m->eopt.grad_unroll <= 0) m->eopt.grad_unroll = std::max(1, std::min(4, 16 / ncols_max));
+  }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
   { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
@@ -460,14 +467,14 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   HIPCHK(hipSetDevice(m->device));
   int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
-  auto tick = [&](int fresh) {
-    HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
+  auto tick = [&](int fresh, bool reset_counter) {
+    if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
                     &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
     launch(m->k_tick, (unsigned)chains, 64, m->stream, args);
   };
   auto grad = [&]() {
-    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &xcd};
+    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
     launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
   };
   // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
@@ -477,7 +484,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     remaining_hint = std::max(1, iters * std::max(1, s->cfg.hmc_steps));
   }
   HIPCHK(hipEventRecord(s->e0, m->stream));
-  tick(s->started ? 0 : 1);
+  tick(s->started ? 0 : 1, true);
   s->started = true;
   HIPCHK(hipEventRecord(s->e1, m->stream));
   for (;;) {
@@ -495,7 +502,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
       HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
       grad();
       HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
-      tick(0);
+      tick(0, false);
     }
     HIPCHK(hipEventRecord(s->e1, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
