@@ -354,3 +354,18 @@ def test_cfg2_full_size_properties():
     a = m.sample(_tame(2, _capi.ENGINE_CHAIN), seeds=range(6))
     b = m.sample(_tame(2, _capi.ENGINE_TICK), seeds=range(6))
     np.testing.assert_allclose(b.chains, a.chains, rtol=1e-8, atol=1e-10)
+
+
+# ---- the reference's own end-to-end known answer, on the GPU ---------------------------------------------------
+@pytest.mark.parametrize("engine", [_capi.ENGINE_CHAIN, _capi.ENGINE_TICK])
+def test_gpu_reproduces_reference_sbc_goldset(engine):
+    # SBCTest / SBCUniformNormal (rainier-test/.../core/SBCTest.scala:7-21, SBCModel.scala:46-60), relative 1e-10
+    from tests import test_reference_goldset as G
+    spec, rstate, _ = G.sbc_uniform_normal_spec()
+    gold = np.array(G.GOLD["goldset"])
+    cfg = R.make_config(len(gold), G.GOLD["warmup"], R.HMCSampler(1), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(),
+                        engine=engine)
+    seed = rstate.seed ^ 0x5DEECE66D          # continue the stream that synthesize() consumed from
+    tr = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(cfg, seeds=[seed])
+    got = G.predict(tr.chains[0])
+    assert np.abs((got - gold) / gold).max() < 1e-10
