@@ -166,6 +166,15 @@ def main():
                      "fp64_valu": {"achieved": flops / k_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": flops / k_s / 1e12 / FP64_PEAK_TFLOPS}},
     }
+    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this
+    # is the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this
+    # same command (profiles/r1_b_tick_engine/), reported as collected (KB -> bytes; the gfx950 x2 FETCH_SIZE
+    # correction is calibrated for 16 B/lane loads and these are 8 B/lane, so the read side is 1-2x this figure)
+    prof = os.path.join(ROOT, "profiles", "r1_b_tick_engine", "pmc_grad_kernel.json")
+    if tim["dominant_kernel"] == "rh_grad_kernel" and os.path.exists(prof) and rows == 1_000_000 and cpg == 1024:
+        pc = json.load(open(prof))["counters"]
+        out["roofline"]["traffic"] = (pc["FETCH_SIZE"]["mean_per_launch"] + pc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+        out["roofline"]["traffic_source"] = "profiles/r1_b_tick_engine/pmc_grad_kernel.json (separate rocprofv3 --pmc passes)"
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, L)
     print(json.dumps(out))
