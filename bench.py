@@ -60,6 +60,31 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
             "row_chain_evals_per_s": total * spec.rows_streamed / dt}
 
 
+def side_workload(a, R, models, rank, local_rank, world):
+    """cfg1 (funnel, HMC L=5) / cfg3 (eight schools, DefaultConfig: EHMC(1024) + DualAvg + windowed diagonal mass):
+    data-free models on the chain-per-wavefront engine.  Single-process timing only."""
+    spec = models.funnel(10) if a.workload == "cfg1" else models.eight_schools()
+    model = R.Model(spec, device=local_rank)
+    cpg = a.chains_per_gpu
+    cfg = R.HMC(a.warmup, a.steps, 5) if a.workload == "cfg1" else R.make_config(a.steps, a.warmup)
+    if a.workload == "cfg1":
+        cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
+    s = R.Sampler(model, cfg, [2000 + rank * cpg + c for c in range(cpg)])
+    t0 = time.perf_counter(); s.warmup(); tw = time.perf_counter() - t0
+    t0 = time.perf_counter(); s.run(a.steps); dt = time.perf_counter() - t0
+    stats, _ = s.stats()
+    steps = sum(st.leapfrogSteps for st in stats); wsteps = sum(st.warmupLeapfrogSteps for st in stats)
+    draws = s.draws()
+    ess = min(e for _, e in R.diagnostics(draws)) if a.steps >= 4 and cpg >= 2 else None
+    print(json.dumps({"metric": "leapfrog steps/sec (all chains)", "value": steps / dt, "unit": "leapfrog steps/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": a.workload + ": " + spec.name, "chains": cpg},
+                      "warmup_leapfrog_steps_per_s": wsteps / tw, "ess_per_s": ess / dt if ess else None,
+                      "mean_leapfrog_per_iteration": steps / (a.steps * cpg),
+                      "roofline": None, "note": "data-free model: latency-bound, no HBM/MFMA roofline applies"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +94,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--leapfrog", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3"], default="cfg2",
+                    help="cfg2 is the BASELINE metric's configuration (default); cfg1 / cfg3 are data-free parity "
+                         "configurations that can be timed for reference (no roofline: <= 100 doubles per chain)")
     ap.add_argument("--strict", action="store_true",
                     help="JVM-faithful model arithmetic: no FMA contraction, outputs accumulated per row un-factored")
     ap.add_argument("--no-factor", action="store_true", help="keep FMA contraction but do not factor outputs")
@@ -91,6 +119,8 @@ def main():
 
     import rainier_amd as R
     from rainier_amd import models
+    if a.workload != "cfg2":
+        return side_workload(a, R, models, rank, local_rank, world)
 
     K, W, L = a.steps, a.warmup, a.leapfrog
     spec = models.linreg(n=a.rows, k=3)
