@@ -111,7 +111,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: exercise the RCCL path
+        os.environ["NCCL_DEBUG"] = "WARN"   # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
