@@ -645,6 +645,126 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 
+// ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
+// With many columns (cfg 4: 51) the K x NACC accumulators leave room for only one or two chains per wavefront, so
+// every chain would re-read every row from L2.  Here a workgroup of W wavefronts (= W different chain groups) walks
+// the same row split: each 64-row tile is loaded from global memory ONCE per workgroup (wave w fetches columns
+// w, w+W, ...; coalesced 512 B per column), parked in LDS [column][row] and consumed by all W waves with
+// conflict-free ds_read_b64 (lane = row).  Global loads for tile t+1 are issued before tile t is consumed
+// (issue-early / write-late), one barrier per tile, two LDS buffers.
+#ifndef RH_GRAD_W
+#define RH_GRAD_W 8
+#endif
+#define RH_LDS_TRP 64 /* rows per tile; lane = row */
+
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+template <int T>
+RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_model_data &d, const int lane,
+                                const int wave, const int split, const int nsplit, const int chain0, const int chains,
+                                const bool compute, double *__restrict__ partial, double *lds, int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (TG::HAS_ROWS) {
+      constexpr int NC = TG::NCOLS, K = RH_GRAD_K, W = RH_GRAD_W;
+      constexpr int MYC = (NC + W - 1) / W; // columns this wave stages
+      double inv[K][TG::NINV > 0 ? TG::NINV : 1];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) TG::invariants(th[kk], inv[kk], err);
+      const long long n = d.nrows[T];
+      const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit; // tiles per split
+      long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
+      if (r0 > n) r0 = n;
+      if (r1 > n) r1 = n;
+      const long long ntiles = (r1 - r0 + 63) / 64;
+      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+      double acc[K][NA];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++)
+#pragma unroll
+        for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
+      double stage[MYC];
+      auto fetch = [&](long long tile) { // global -> registers (rows past the end are clamped, masked at use)
+        long long row = r0 + tile * 64 + lane;
+        if (row >= n) row = n - 1;
+#pragma unroll
+        for (int m = 0; m < MYC; m++) {
+          const int j = wave + m * W;
+          stage[m] = (j < NC && n > 0) ? d.cols[TG::COL0 + j][row] : 0.0;
+        }
+      };
+      auto park = [&](int buf) { // registers -> LDS
+#pragma unroll
+        for (int m = 0; m < MYC; m++) {
+          const int j = wave + m * W;
+          if (j < NC) lds[(buf * NC + j) * RH_LDS_TRP + lane] = stage[m];
+        }
+      };
+      if (ntiles > 0) { fetch(0); park(0); }
+      __syncthreads();
+      for (long long t = 0; t < ntiles; t++) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntiles) fetch(t + 1);
+        if (compute && r0 + t * 64 + lane < r1) {
+          double c[NC];
+#pragma unroll
+          for (int j = 0; j < NC; j++) c[j] = lds[(buf * NC + j) * RH_LDS_TRP + lane];
+#pragma unroll
+          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c, acc[kk], err);
+        }
+        if (t + 1 < ntiles) park(buf ^ 1);
+        __syncthreads();
+      }
+      if (compute) {
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+          double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
+#pragma unroll
+          for (int o = 0; o < NA; o++) {
+            const double v = rh_wave_sum(acc[kk][o]);
+            if (lane == 0 && chain0 + kk < chains) out[o] = v;
+          }
+        }
+      }
+    }
+    rh_grad_lds_targets<T + 1>(th, d, lane, wave, split, nsplit, chain0, chains, compute, partial, lds, err);
+  }
+}
+#pragma clang fp contract(off)
+
+// grid: ceil(ngroups / W) * nsplit workgroups of W wavefronts; dynamic LDS = 2 * max(NCOLS) * 64 doubles
+extern "C" __global__ void __launch_bounds__(64 * RH_GRAD_W)
+rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+                   double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                   const int chains, const int nsplit, const int xcd_aware) {
+  extern __shared__ __attribute__((aligned(16))) double rh_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) *n_running = 0;
+  int bgroup, split;
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    bgroup = idx / spx;
+  } else { split = b % nsplit; bgroup = b / nsplit; }
+  const int group = __builtin_amdgcn_readfirstlane(bgroup * RH_GRAD_W + wave);
+  const int chain0 = group * RH_GRAD_K;
+  bool any = false;
+  double th[RH_GRAD_K][RH_NVARS];
+#pragma unroll
+  for (int kk = 0; kk < RH_GRAD_K; kk++) {
+    int c = chain0 + kk;
+    if (c >= chains) c = chains - 1;
+    any = any || (chain0 + kk < chains && active[c] != 0);
+#pragma unroll
+    for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
+  }
+  int err = 0;
+  rh_grad_lds_targets<0>(th, d, lane, wave, split, nsplit, chain0, chains, any, partial, rh_lds, err);
+  if (err && lane == 0) atomicOr(err_out, 1);
+}
+
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
 RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const long long *nrows,

@@ -332,7 +332,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << (o.grad_chains > 0 ? o.grad_chains : 4) << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
-    << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n";
+    << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();

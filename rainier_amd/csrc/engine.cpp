@@ -115,7 +115,9 @@ struct rh_model {
   int device = 0;
   bool loaded = false;
   hipModule_t module = nullptr;
-  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr;
+  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
+  int grad_w = 8, ncols_max = 0;
+  bool use_lds_grad = false;
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   int state_words = 0;
   rh_model_data data{};
@@ -187,7 +189,14 @@ void load_module(rh_model *m) {
   if (m->n_row_targets > 0) {  // the tick engine only exists for models that stream rows
     HIPCHK(hipModuleGetFunction(&m->k_grad, m->module, "rh_grad_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_grad_lds, m->module, "rh_grad_lds_kernel"));
   }
+  m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
+  m->ncols_max = 0;
+  for (auto &T : m->prog.targets) m->ncols_max = std::max<int>(m->ncols_max, (int)T.n_cols);
+  // wide models: stage row tiles through LDS and share them between the wavefronts of a workgroup
+  m->use_lds_grad = m->ncols_max >= 8;
+  if (const char *e = std::getenv("RH_GRAD_LDS")) m->use_lds_grad = std::atoi(e) != 0;
   m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
@@ -428,6 +437,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       int nsplit = cfg->grad_splits;
       if (nsplit <= 0) {  // ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD mapping applies
         nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
+        if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
         nsplit = ((nsplit + 7) / 8) * 8;
         const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);   // keep >= 2048 rows per split
         nsplit = (int)std::min<int64_t>(nsplit, cap);
@@ -475,7 +485,12 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   };
   auto grad = [&]() {
     void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
-    launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
+    if (m->use_lds_grad) {
+      const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
+      const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
+      HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
+    } else
+      launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
   };
   // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
   int remaining_hint = 32;
@@ -626,7 +641,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? "rh_grad_kernel" : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

@@ -300,6 +300,21 @@ def test_tick_engine_grad_kernel_variants():
         np.testing.assert_allclose(got.chains, base.chains, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,chains,k", [(1, 1, 9), (63, 3, 9), (129, 17, 12), (5000, 20, 50), (70001, 9, 8)])
+def test_tick_engine_lds_staged_wide_models(n, chains, k):
+    # >= 8 columns: rh_grad_lds_kernel (row tiles staged through LDS, shared by the wavefronts of a workgroup)
+    spec = models.logistic(n=n, k=k, seed=n)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    seeds = [900 + c for c in range(chains)]
+    cfg = lambda e: R.make_config(3, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=e)
+    a = m.sample(cfg(_capi.ENGINE_CHAIN), seeds=seeds)
+    b = m.sample(cfg(_capi.ENGINE_TICK), seeds=seeds)
+    np.testing.assert_allclose(b.chains, a.chains, rtol=1e-9, atol=1e-11)
+    if n <= 5000:
+        want, _, st = O.sample_model(spec, _oracle_cfg(cfg(0), O.JM_DET), seeds[0])
+        np.testing.assert_allclose(b.chains[0], want, rtol=1e-9, atol=1e-11)
+
+
 def test_tick_engine_full_driver_statistics():
     # whole Driver on the tick engine: step-size search, dual averaging, windowed mass adaptation, EHMC
     spec = models.linreg(n=3000, k=3)

@@ -1,0 +1,14 @@
+import sys, time, json
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rainier_amd as R
+from rainier_amd import models, _capi
+n = int(sys.argv[1]); chains = int(sys.argv[2]); eng = int(sys.argv[3])
+t = time.time(); spec = models.logistic(n=n, k=50); print('data', time.time() - t, flush=True)
+t = time.time(); m = R.Model(spec, device=0, factor_outputs=True, fp_contract=True); print('model', time.time() - t, flush=True)
+cfg = R.make_config(2, 0, R.HMCSampler(4), R.StaticStepSize(1e-4), R.IdentityMassMatrixTuner(), engine=eng)
+s = R.Sampler(m, cfg, list(range(chains)))
+s.warmup(); s.timing(reset=True)
+t = time.time(); s.run(2); dt = time.time() - t
+tim = s.timing()
+print(json.dumps({"n": n, "chains": chains, "engine": eng, "s_per_tick": dt / 8, "row_chain_evals_per_s": n * chains * 8 / dt, "kernel_ms": tim["kernel_ms"], "launches": tim["launches"]}))
