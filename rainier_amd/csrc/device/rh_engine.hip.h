@@ -765,6 +765,163 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 
+// ---- dense GLM targets on the fp64 matrix cores ---------------------------------------------------------------
+// rh_glm<T> (generated) describes a target whose row term is f(eta, other columns) with eta = X.theta a dense linear
+// predictor over P >= 8 columns.  Both contractions run on v_mfma_f64_16x16x4_f64 with 16 chains per wavefront:
+//     forward   eta[16 rows x 16 chains] = sum_ks  X[16 rows x 4 preds] . B[4 preds x 16 chains]
+//     backward  G[16 preds x 16 chains] += X^T[16 preds x 4 rows] . w[4 rows x 16 chains]
+// The f64 C/D layout (col = lane & 15, row = (lane >> 4) + 4 * reg) makes D register s of the forward product exactly
+// the B operand of backward k-step s, so w never moves between lanes.  Only the scalar part elem(eta) -> (w, others)
+// runs on the VALU.  Row tiles (64 rows x all columns) are staged through LDS once per workgroup of RH_GLM_W waves
+// (= 16 * RH_GLM_W chains) with a padded column stride of 66 doubles (backward reads conflict-free, forward 2-way).
+// The G accumulators cost 4 VGPR pairs per 16 predictors for 16 chains -- the VALU path needs P+1 pairs per chain.
+#ifdef RH_GLM_TARGET
+#ifndef RH_GLM_W
+#define RH_GLM_W 4
+#endif
+#define RH_GLM_TRP 66
+typedef double rh_v4d __attribute__((ext_vector_type(4)));
+
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W)
+rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+                   double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                   const int chains, const int nsplit, const int xcd_aware) {
+  typedef rh_glm<RH_GLM_TARGET> GL;
+  typedef rh_target<RH_GLM_TARGET> TG;
+  constexpr int P = GL::P, NC = GL::NCOLS, W = RH_GLM_W;
+  constexpr int PT = (P + 3) / 4;    // forward k-steps (4 predictors each)
+  constexpr int CT = (P + 15) / 16;  // backward predictor tiles
+  constexpr int MYC = (NC + W - 1) / W;
+  extern __shared__ __attribute__((aligned(16))) double rh_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) *n_running = 0;
+  int bgroup, split;
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    bgroup = idx / spx;
+  } else { split = b % nsplit; bgroup = b / nsplit; }
+  const int chain0 = (bgroup * W + wave) * 16;
+  const int mychain = chain0 + li;
+  const int cl = mychain < chains ? mychain : chains - 1;
+  const bool compute = __any((mychain < chains) && (active[cl] != 0));
+  // forward B operands: lane (li, lg) holds theta[chain li][pred 4 ks + lg]
+  double Bf[PT];
+  int acol[PT];
+#pragma unroll
+  for (int ks = 0; ks < PT; ks++) {
+    const int pred = 4 * ks + lg;
+    Bf[ks] = (pred < P) ? q[(size_t)cl * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
+    acol[ks] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2;
+  }
+  int bcol[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) {
+    const int pred = 16 * ct + li;
+    bcol[ct] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2;
+  }
+  double thu[GL::NTHU > 0 ? GL::NTHU : 1];
+#pragma unroll
+  for (int k = 0; k < GL::NTHU; k++) thu[k] = q[(size_t)cl * RH_NVARS + GL::thu_param[k]];
+  rh_v4d G[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) G[ct] = (rh_v4d){0.0, 0.0, 0.0, 0.0};
+  double oth[GL::NOTHER > 0 ? GL::NOTHER : 1];
+#pragma unroll
+  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
+  int err = 0;
+
+  const long long n = d.nrows[RH_GLM_TARGET];
+  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
+  long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
+  if (r0 > n) r0 = n;
+  if (r1 > n) r1 = n;
+  const long long ntiles = (r1 - r0 + 63) / 64;
+  double stage[MYC];
+  auto fetch = [&](long long tile) {
+    long long row = r0 + tile * 64 + lane;
+    if (row >= n) row = n - 1;
+#pragma unroll
+    for (int m = 0; m < MYC; m++) {
+      const int j = wave + m * W;
+      stage[m] = (j < NC && n > 0) ? d.cols[TG::COL0 + j][row] : 0.0;
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int m = 0; m < MYC; m++) {
+      const int j = wave + m * W;
+      if (j < NC) rh_lds[(buf * NC + j) * RH_GLM_TRP + lane] = stage[m];
+    }
+  };
+  if (ntiles > 0) { fetch(0); park(0); }
+  __syncthreads();
+  for (long long t = 0; t < ntiles; t++) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntiles) fetch(t + 1);
+    if (compute) {
+      const double *tile = rh_lds + (size_t)buf * NC * RH_GLM_TRP;
+#pragma unroll 1
+      for (int sub = 0; sub < 4; sub++) {
+        const int row0s = sub * 16;
+        rh_v4d D = (rh_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < PT; ks++) {
+          const double a = acol[ks] >= 0 ? tile[acol[ks] * RH_GLM_TRP + row0s + li] : (acol[ks] == -1 ? 1.0 : 0.0);
+          D = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bf[ks], D, 0, 0, 0);
+        }
+        rh_v4d Wv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int rrow = row0s + lg + 4 * r;
+          const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
+          double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+          GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+          Wv[r] = valid ? w : 0.0;
+#pragma unroll
+          for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+          for (int sstep = 0; sstep < 4; sstep++) {
+            const int rr = row0s + 4 * sstep + lg;
+            const double a = bcol[ct] >= 0 ? tile[bcol[ct] * RH_GLM_TRP + rr] : (bcol[ct] == -1 ? 1.0 : 0.0);
+            G[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Wv[sstep], G[ct], 0, 0, 0);
+          }
+      }
+    }
+    if (t + 1 < ntiles) park(buf ^ 1);
+    __syncthreads();
+  }
+  if (compute) {
+    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cl) * RH_NACC_MAX;
+    // G[ct][r] at lane (li, lg) = sum_rows x[pred 16 ct + lg + 4 r] * w  for chain li
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int pred = 16 * ct + lg + 4 * r;
+        if (pred < P && mychain < chains) out[GL::pred_acc[pred < P ? pred : 0]] = G[ct][r];
+      }
+#pragma unroll
+    for (int k = 0; k < GL::NOTHER; k++) {
+      double v = oth[k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && mychain < chains) out[GL::other_acc[k]] = v;
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
+}
+#pragma clang fp contract(off)
+#endif  // RH_GLM_TARGET
+
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
 RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const long long *nrows,

@@ -249,6 +249,186 @@ struct TargetEmitter {
     return true;
   }
 
+
+  // ---- GLM pattern: a dense linear predictor feeding a scalar nonlinearity -------------------------------------
+  // eta = theta_p0 + sum_k theta_pk * x_k (>= 8 terms) and, after output factoring, basis terms {w * x_k for every
+  // predictor column, w itself for the bare intercept, plus a few "other" terms}.  Then eta = X.B and the gradient
+  // sums X^T.w are genuine dense contractions: rh_grad_glm_kernel runs them on the fp64 matrix cores
+  // (v_mfma_f64_16x16x4_f64, 16 chains per wavefront) and only the scalar part elem(eta, ...) -> (w, others) stays on
+  // the VALU.  This is the only place MFMA is used.
+  struct Glm {
+    bool ok = false;
+    uint32_t L = 0, w = 0;
+    std::vector<int> pred_param, pred_col, pred_acc;  // pred_col = -1: the constant 1 column (bare intercept)
+    std::vector<std::pair<uint32_t, int>> others;     // (node, accumulator index)
+    std::vector<uint32_t> thu;                        // parameters the scalar part reads (compact order)
+    std::vector<uint32_t> elem_nodes;                 // row nodes of the scalar part, ascending
+    std::vector<uint32_t> inv_nodes;                  // invariant nodes of the scalar part, ascending
+  } glm;
+
+  bool lincomb(uint32_t id, std::vector<std::pair<int, int>> &out) const {
+    const Node &nd = P.nodes[id];
+    auto is_param = [&](uint32_t x) { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input < P.n_params; };
+    auto is_col = [&](uint32_t x) { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input >= P.n_params; };
+    if (is_param(id)) { out.push_back({(int)nd.input, -1}); return true; }
+    if (nd.op == RH_RIR_MUL) {
+      if (is_param(nd.a) && is_col(nd.b)) { out.push_back({(int)P.nodes[nd.a].input, (int)(P.nodes[nd.b].input - P.targets[t].input_start)}); return true; }
+      if (is_param(nd.b) && is_col(nd.a)) { out.push_back({(int)P.nodes[nd.b].input, (int)(P.nodes[nd.a].input - P.targets[t].input_start)}); return true; }
+      return false;
+    }
+    if (nd.op == RH_RIR_ADD) return lincomb(nd.a, out) && lincomb(nd.b, out);
+    return false;
+  }
+
+  void detect_glm() {
+    if (!has_rows() || !factor || basis.empty()) return;
+    // the widest linear predictor among the row nodes
+    size_t best = 0;
+    for (size_t n = 0; n < P.nodes.size(); n++) {
+      if (!reach_row[n] || P.nodes[n].dep == 0 || P.nodes[n].op != RH_RIR_ADD) continue;
+      std::vector<std::pair<int, int>> terms;
+      if (lincomb((uint32_t)n, terms) && terms.size() >= 8 && terms.size() > best) { best = terms.size(); glm.L = (uint32_t)n; }
+    }
+    if (!best) return;
+    std::vector<std::pair<int, int>> terms;
+    lincomb(glm.L, terms);
+    std::map<int, int> col_pred;
+    int bare = -1;
+    for (auto &pc : terms) {
+      if (pc.second < 0) { if (bare >= 0) return; bare = (int)glm.pred_param.size(); }
+      else if (col_pred.count(pc.second)) return;
+      else col_pred[pc.second] = (int)glm.pred_param.size();
+      glm.pred_param.push_back(pc.first); glm.pred_col.push_back(pc.second); glm.pred_acc.push_back(-1);
+    }
+    auto col_of = [&](uint32_t x) -> int {
+      const Node &nd = P.nodes[x];
+      return (nd.op == RH_RIR_INPUT && nd.input >= P.n_params) ? (int)(nd.input - P.targets[t].input_start) : -1;
+    };
+    // classify the basis terms
+    bool have_w = false;
+    std::vector<int> other_idx;
+    for (size_t j = 0; j < basis.size(); j++) {
+      const Node &nd = P.nodes[basis[j]];
+      bool matched = false;
+      if (nd.op == RH_RIR_MUL) {
+        for (int sw = 0; sw < 2 && !matched; sw++) {
+          const uint32_t x = sw ? nd.b : nd.a, y = sw ? nd.a : nd.b;
+          const int c = col_of(y);
+          if (c >= 0 && col_pred.count(c) && col_of(x) < 0 && P.nodes[x].dep != 0) {
+            if (have_w && glm.w != x) continue;
+            glm.w = x; have_w = true; glm.pred_acc[col_pred[c]] = (int)j; matched = true;
+          }
+        }
+      }
+      if (!matched) other_idx.push_back((int)j);
+    }
+    if (!have_w) return;
+    for (int j : other_idx) {
+      if (basis[j] == glm.w && bare >= 0 && glm.pred_acc[bare] < 0) glm.pred_acc[bare] = j;
+      else glm.others.push_back({basis[j], j});
+    }
+    for (int a : glm.pred_acc) if (a < 0) return;
+    if (glm.others.size() > 8) return;
+    // the scalar part: everything reachable from {w, others} with L as a leaf; it must not look inside L
+    std::vector<char> in_L(P.nodes.size(), 0), need(P.nodes.size(), 0);
+    in_L[glm.L] = 1;
+    { std::vector<uint32_t> ops;
+      for (size_t n = P.nodes.size(); n-- > 0;) { if (!in_L[n]) continue; operands(P.nodes[n], ops); for (uint32_t o : ops) if (P.nodes[o].op != RH_RIR_INPUT && P.nodes[o].op != RH_RIR_CONST) in_L[o] = 1; } }
+    need[glm.w] = 1;
+    for (auto &o : glm.others) need[o.first] = 1;
+    { std::vector<uint32_t> ops;
+      for (size_t n = P.nodes.size(); n-- > 0;) {
+        if (!need[n] || n == glm.L) continue;
+        operands(P.nodes[n], ops);
+        for (uint32_t o : ops) need[o] = 1;
+      } }
+    std::map<uint32_t, int> thu_idx;
+    for (size_t n = 0; n < P.nodes.size(); n++) {
+      if (!need[n]) continue;
+      if (in_L[n] && n != glm.L) return;  // a partial sum of eta is used elsewhere
+      const Node &nd = P.nodes[n];
+      if (nd.op == RH_RIR_INPUT && nd.input < P.n_params) { if (!thu_idx.count(nd.input)) { thu_idx[nd.input] = (int)glm.thu.size(); glm.thu.push_back(nd.input); } continue; }
+      if (trivial((uint32_t)n) || n == glm.L) continue;
+      if (nd.dep == 0) glm.inv_nodes.push_back((uint32_t)n); else glm.elem_nodes.push_back((uint32_t)n);
+    }
+    if (glm.thu.size() > 8) return;
+    glm.ok = true;
+  }
+
+  std::string glm_ref(uint32_t id) const {
+    if (id == glm.L) return "eta";
+    const Node &nd = P.nodes[id];
+    if (nd.op == RH_RIR_CONST) return lit(nd.cval);
+    if (nd.op == RH_RIR_INPUT) {
+      if (nd.input < P.n_params) {
+        for (size_t k = 0; k < glm.thu.size(); k++) if (glm.thu[k] == nd.input) return "thu[" + std::to_string(k) + "]";
+        return "0x0p+0";
+      }
+      return "RH_GLM_COL(" + std::to_string(nd.input - P.targets[t].input_start) + ")";
+    }
+    return "n" + std::to_string(id);
+  }
+  bool emit_glm(std::ostringstream &os, std::string &err) const {
+    const size_t Pn = glm.pred_param.size();
+    os << "template <> struct rh_glm<" << t << "> {\n  static constexpr int P = " << Pn << ", NOTHER = " << glm.others.size()
+       << ", NTHU = " << glm.thu.size() << ", NCOLS = " << P.targets[t].n_cols << ";\n";
+    auto arr = [&](const char *name, const std::vector<int> &v) {
+      os << "  static constexpr int " << name << "[" << (v.empty() ? 1 : v.size()) << "] = {";
+      for (size_t i = 0; i < v.size(); i++) os << (i ? "," : "") << v[i];
+      if (v.empty()) os << "0";
+      os << "};\n";
+    };
+    arr("pred_param", glm.pred_param); arr("pred_col", glm.pred_col); arr("pred_acc", glm.pred_acc);
+    std::vector<int> oacc, thu;
+    for (auto &o : glm.others) oacc.push_back(o.second);
+    for (uint32_t x : glm.thu) thu.push_back((int)x);
+    arr("other_acc", oacc); arr("thu_param", thu);
+    // the scalar part; RH_GLM_COL(j) reads column j of the current row from the LDS tile
+    os << "  template <class ColFn>\n  static RH_DEV void elem(const double *thu, const double eta, ColFn RH_GLM_COL, double &w, double *other, int &err) {\n"
+          "    (void)thu; (void)eta; (void)other; (void)err;\n";
+    // emit_node spells operands through ref(); the GLM scalar part needs its own spelling
+    for (uint32_t n : glm.inv_nodes) if (!emit_glm_node(os, n, err)) return false;
+    for (uint32_t n : glm.elem_nodes) if (!emit_glm_node(os, n, err)) return false;
+    os << "    w = " << glm_ref(glm.w) << ";\n";
+    for (size_t k = 0; k < glm.others.size(); k++) os << "    other[" << k << "] = " << glm_ref(glm.others[k].first) << ";\n";
+    os << "  }\n};\n";
+    return true;
+  }
+  bool emit_glm_node(std::ostringstream &os, uint32_t id, std::string &err) const {
+    const Node &nd = P.nodes[id];
+    auto R = [&](uint32_t x) { return glm_ref(x); };
+    const std::string lhs = "    const double n" + std::to_string(id) + " = ";
+    switch (nd.op) {
+      case RH_RIR_ADD: os << lhs << R(nd.a) << " + " << R(nd.b) << ";\n"; break;
+      case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
+      case RH_RIR_MUL: os << lhs << R(nd.a) << " * " << R(nd.b) << ";\n"; break;
+      case RH_RIR_DIV: os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break;
+      case RH_RIR_POW: os << lhs << "rh_java_pow(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
+      case RH_RIR_COMPARE: os << lhs << "rh_compare(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
+      case RH_RIR_EXP: os << lhs << "RH_EXP(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_LOG: os << lhs << "RH_LOG(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_ABS: os << lhs << "__builtin_fabs(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_NOOP: os << lhs << R(nd.a) << ";\n"; break;
+      case RH_RIR_SIN: os << lhs << "sin(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_COS: os << lhs << "cos(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_TAN: os << lhs << "tan(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_ASIN: os << lhs << "asin(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_ACOS: os << lhs << "acos(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_ATAN: os << lhs << "atan(" << R(nd.a) << ");\n"; break;
+      case RH_RIR_SEQ: os << lhs << R(nd.b) << ";\n"; break;
+      case RH_RIR_LOOKUP: {
+        if (nd.table.size() > 64) { err = "Lookup tables with more than 64 entries are not supported yet"; return false; }
+        const std::string k = "k" + std::to_string(id);
+        os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n" << lhs;
+        for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
+        os << R(nd.table.back()) << ";\n    if ((unsigned)" << k << " >= " << nd.table.size() << "u) err = 1;\n";
+        break;
+      }
+      default: err = "emit: unexpected opcode"; return false;
+    }
+    return true;
+  }
+
   int nacc() const { return has_rows() ? (int)basis.size() : 0; }
 
   bool emit(std::ostringstream &os, std::string &err) {
@@ -314,13 +494,17 @@ struct TargetEmitter {
 
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err) {
   std::ostringstream os;
-  os << "template <int T> struct rh_target;\n";
+  os << "template <int T> struct rh_target;\ntemplate <int T> struct rh_glm;\n";
   if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
-  int nacc_max = 1, nrowt = 0;
+  int nacc_max = 1, nrowt = 0, glm_target = -1;
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
     te.plan();
     if (!te.emit(os, err)) return false;
+    if (glm_target < 0 && o.glm_mfma) {
+      te.detect_glm();
+      if (te.glm.ok) { if (!te.emit_glm(os, err)) return false; glm_target = (int)t; }
+    }
     nacc_max = std::max(nacc_max, te.nacc());
     if (P.targets[t].n_cols) nrowt++;
   }
@@ -333,6 +517,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << (o.grad_chains > 0 ? o.grad_chains : 4) << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
     << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
+  if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();

@@ -118,6 +118,9 @@ struct rh_model {
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
   int grad_w = 8, ncols_max = 0;
   bool use_lds_grad = false;
+  hipFunction_t k_grad_glm = nullptr;
+  bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
+  int glm_w = 4;
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   int state_words = 0;
   rh_model_data data{};
@@ -160,6 +163,7 @@ void assemble_source(rh_model *m) {
   }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
   { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
+  m->has_glm = defines.find("#define RH_GLM_TARGET ") != std::string::npos;
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
@@ -195,8 +199,10 @@ void load_module(rh_model *m) {
   m->ncols_max = 0;
   for (auto &T : m->prog.targets) m->ncols_max = std::max<int>(m->ncols_max, (int)T.n_cols);
   // wide models: stage row tiles through LDS and share them between the wavefronts of a workgroup
-  m->use_lds_grad = m->ncols_max >= 8;
+  m->use_lds_grad = false;  // opt-in: measured slower than the register kernel on cfg 4 (VALU/occupancy-bound, not L2-bound)
   if (const char *e = std::getenv("RH_GRAD_LDS")) m->use_lds_grad = std::atoi(e) != 0;
+  if (m->has_glm && m->n_row_targets == 1) HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, "rh_grad_glm_kernel"));
+  if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
@@ -438,6 +444,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       if (nsplit <= 0) {  // ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD mapping applies
         nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
         if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
+        if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
         nsplit = ((nsplit + 7) / 8) * 8;
         const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);   // keep >= 2048 rows per split
         nsplit = (int)std::min<int64_t>(nsplit, cap);
@@ -485,7 +492,12 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   };
   auto grad = [&]() {
     void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
-    if (m->use_lds_grad) {
+    if (m->k_grad_glm) {
+      const int ctiles = (chains + 15) / 16;
+      const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
+      const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
+      HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
+    } else if (m->use_lds_grad) {
       const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
       const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
       HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
@@ -641,7 +653,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->k_grad_glm ? "rh_grad_glm_kernel" : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

@@ -38,6 +38,7 @@ struct EmitOptions {
   bool factor_outputs = false;  // peel invariant affine wrappers off the accumulated outputs (fast mode)
   int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
   int grad_unroll = 0;
+  bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool grad_pipeline = false;  // software-pipelined row loop in the batched gradient kernel  // row-loop unroll of the batched gradient kernel (0 = default)
 };

@@ -301,8 +301,9 @@ def test_tick_engine_grad_kernel_variants():
 
 
 @pytest.mark.parametrize("n,chains,k", [(1, 1, 9), (63, 3, 9), (129, 17, 12), (5000, 20, 50), (70001, 9, 8)])
-def test_tick_engine_lds_staged_wide_models(n, chains, k):
-    # >= 8 columns: rh_grad_lds_kernel (row tiles staged through LDS, shared by the wavefronts of a workgroup)
+def test_tick_engine_lds_staged_wide_models(n, chains, k, monkeypatch):
+    # opt-in rh_grad_lds_kernel (row tiles staged through LDS, shared by the wavefronts of a workgroup)
+    monkeypatch.setenv("RH_GRAD_LDS", "1")
     spec = models.logistic(n=n, k=k, seed=n)
     m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
     seeds = [900 + c for c in range(chains)]
@@ -313,6 +314,36 @@ def test_tick_engine_lds_staged_wide_models(n, chains, k):
     if n <= 5000:
         want, _, st = O.sample_model(spec, _oracle_cfg(cfg(0), O.JM_DET), seeds[0])
         np.testing.assert_allclose(b.chains[0], want, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,chains,k", [(1, 1, 8), (15, 3, 9), (64, 16, 12), (65, 17, 16), (1000, 33, 50), (5000, 40, 50),
+                                        (70001, 70, 31), (200000, 256, 50)])
+def test_glm_mfma_kernel_matches_valu_path_and_oracle(n, chains, k):
+    # dense linear predictor -> rh_grad_glm_kernel (v_mfma_f64_16x16x4_f64, 16 chains per wavefront)
+    spec = models.logistic(n=n, k=k, seed=n + 7)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT, factor_outputs=True)
+    assert "#define RH_GLM_TARGET 1" in m.hip_source and "rh_grad_glm_kernel" in m.hip_source
+    seeds = [700 + c for c in range(chains)]
+    cfg = lambda e: R.make_config(3, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=e)
+    s = R.Sampler(m, cfg(_capi.ENGINE_TICK), seeds); s.warmup(); s.run(3)
+    assert s.timing()["dominant_kernel"] == "rh_grad_glm_kernel"
+    b = s.draws(); s.close()
+    a = m.sample(cfg(_capi.ENGINE_CHAIN), seeds=seeds).chains
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-11)
+    if n <= 5000:
+        want, _, st = O.sample_model(spec, _oracle_cfg(cfg(0), O.JM_DET), seeds[-1])
+        np.testing.assert_allclose(b[-1], want, rtol=1e-9, atol=1e-11)
+
+
+def test_glm_mfma_full_driver_statistics():
+    # adaptation + EHMC on the MFMA path recover the generating coefficients
+    spec = models.logistic(n=20000, k=8, seed=3)
+    m = R.Model(spec, device=0, factor_outputs=True, fp_contract=True)
+    tr = m.sample(R.make_config(150, 200, engine=_capi.ENGINE_TICK), seeds=range(32))
+    rng = np.random.default_rng(3); rng.standard_normal((8, 20000)); beta = rng.standard_normal(8)
+    post = tr.chains.reshape(-1, 9).mean(axis=0)
+    assert np.all(np.abs(post[1:] - beta) < 0.25) and abs(post[0]) < 0.1
+    assert all(r < 1.1 for r, _ in tr.diagnostics())
 
 
 def test_tick_engine_full_driver_statistics():

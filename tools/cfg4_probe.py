@@ -11,4 +11,4 @@ s = R.Sampler(m, cfg, list(range(chains)))
 s.warmup(); s.timing(reset=True)
 t = time.time(); s.run(2); dt = time.time() - t
 tim = s.timing()
-print(json.dumps({"n": n, "chains": chains, "engine": eng, "s_per_tick": dt / 8, "row_chain_evals_per_s": n * chains * 8 / dt, "kernel_ms": tim["kernel_ms"], "launches": tim["launches"]}))
+print(json.dumps({"n": n, "chains": chains, "engine": eng, "s_per_tick": dt / 8, "row_chain_evals_per_s": n * chains * 8 / dt, "kernel_ms": tim["kernel_ms"], "launches": tim["launches"], "kernel": tim["dominant_kernel"]}))
