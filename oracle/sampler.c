@@ -245,6 +245,99 @@ static int masstuner_update(masstuner *t, const double *sample, double *mass) { 
   return 0;
 }
 
+
+/* ---- NUTS (EXTENSION: the reference has no NUTS; parity against the reference is unpinned) ----
+ * Specification = iterative multinomial NUTS: Phan, Pradhan, Jankowiak, "Composable Effects for Flexible and Accelerated
+ * Probabilistic Programming in NumPyro" (2019), Appendix A (the algorithm NumPyro/BlackJAX ship): trajectory doubling
+ * with a uniformly random direction, leaves generated one leapfrog step at a time, uniform progressive sampling inside a
+ * subtree, biased progressive sampling between the old tree and the new subtree, U-turn checks of every aligned
+ * power-of-two sub-trajectory through O(depth) momentum checkpoints, divergence when H - H0 > 1000.
+ * Draws per iteration from the chain's java.util.Random stream: n gaussians (momenta), then per doubling 1 uniform
+ * (direction), 1 uniform per leaf (subtree sampling) and 1 uniform for the merge.  It plugs in as a `Sampler`
+ * (S/Sampler.scala:52-62): warmup/run return log(mean leaf acceptance) to the step-size tuner.
+ * This C text and rh_engine.hip.h's NUTS states are two statements of the same algorithm, compared bit for bit. */
+#define ORC_NUTS_MAXD 12
+static double logaddexp_det(int mode, double a, double b) {
+  double m = a > b ? a : b;
+  if (m == -INFINITY) return -INFINITY;
+  return m + jm_log(mode, jm_exp(mode, a - m) + jm_exp(mode, b - m));
+}
+/* _is_turning: v = M^-1 r; r_sum' = r_sum - (r_left + r_right)/2; turning iff v_left.r_sum' <= 0 or v_right.r_sum' <= 0 */
+static int nuts_is_turning(int n, const double *mass, const double *rl, const double *rr, const double *rsum) {
+  double dl = 0.0, dr = 0.0;
+  for (int i = 0; i < n; i++) {
+    double adj = rsum[i] - (rl[i] + rr[i]) / 2.0;
+    double vl = mass ? rl[i] * mass[i] : rl[i], vr = mass ? rr[i] * mass[i] : rr[i];
+    dl += vl * adj; dr += vr * adj;
+  }
+  return !(dl > 0.0) || !(dr > 0.0); /* NaN counts as turning */
+}
+static double nuts_iteration(const orc_config *cfg, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  const int n = lf->n, mode = cfg->math_mode, sz = 2 * n + 1;
+  orc_lf_start_iteration(lf, params, mass); /* fresh momenta; pqBuf := params */
+  const double H0 = energy(lf, params, mass);
+  double *L = malloc(sizeof(double) * sz), *R = malloc(sizeof(double) * sz), *prop = malloc(sizeof(double) * sz);
+  double *subprop = malloc(sizeof(double) * sz), *rsum = calloc(n, sizeof(double)), *srsum = calloc(n, sizeof(double));
+  double *ckr = calloc((size_t)ORC_NUTS_MAXD * n, sizeof(double)), *ckrs = calloc((size_t)ORC_NUTS_MAXD * n, sizeof(double));
+  memcpy(L, params, sizeof(double) * sz); memcpy(R, params, sizeof(double) * sz); memcpy(prop, params, sizeof(double) * sz);
+  memcpy(rsum, params, sizeof(double) * n);
+  double tree_logw = 0.0, sum_accept = 0.0; long nleaf_total = 0;
+  int depth = 0, stop = 0;
+  while (depth < cfg->nuts_max_depth && !stop) {
+    const int going_right = rng_uniform(lf->rng) > 0.5;
+    const double eps = going_right ? stepSize : -stepSize;
+    lf_restore(lf, going_right ? R : L);
+    double sub_logw = -INFINITY; int sub_turning = 0, sub_div = 0;
+    for (int i = 0; i < n; i++) srsum[i] = 0.0;
+    const long nleaf = 1L << depth;
+    for (long leaf = 0; leaf < nleaf && !sub_turning && !sub_div; leaf++) {
+      orc_lf_take_steps(lf, 1, eps, mass); /* one leapfrog step in the chosen direction */
+      double delta = energy(lf, lf->pqBuf, mass) - H0;
+      if (isnan(delta)) delta = INFINITY;
+      const double leaf_logw = -delta;
+      if (delta > 1000.0) sub_div = 1;
+      sum_accept += delta <= 0.0 ? 1.0 : jm_exp(mode, -delta); nleaf_total++;
+      const double new_logw = logaddexp_det(mode, sub_logw, leaf_logw);
+      const double u = rng_uniform(lf->rng);
+      if (leaf == 0 || u < jm_exp(mode, leaf_logw - new_logw)) lf_snapshot(lf, subprop);
+      sub_logw = new_logw;
+      for (int i = 0; i < n; i++) srsum[i] += lf->pqBuf[i];
+      /* checkpoints (NumPyro _leaf_idx_to_ckpt_idxs) */
+      int idx_max = 0; for (long x = leaf >> 1; x > 0; x >>= 1) idx_max += (int)(x & 1);
+      int nsub = 0; for (long x = leaf; (x & 1) != 0; x >>= 1) nsub++;
+      const int idx_min = idx_max - nsub + 1;
+      if ((leaf & 1) == 0) {
+        memcpy(ckr + (size_t)idx_max * n, lf->pqBuf, sizeof(double) * n);
+        memcpy(ckrs + (size_t)idx_max * n, srsum, sizeof(double) * n);
+      } else {
+        for (int k = idx_max; k >= idx_min && !sub_turning; k--) {
+          double *sub = lf->buf; /* subtree r_sum = r_sum - r_sum_ckpt + r_ckpt */
+          for (int i = 0; i < n; i++) sub[i] = srsum[i] - ckrs[(size_t)k * n + i] + ckr[(size_t)k * n + i];
+          double *tmp = malloc(sizeof(double) * n); memcpy(tmp, sub, sizeof(double) * n);
+          sub_turning = nuts_is_turning(n, mass, ckr + (size_t)k * n, lf->pqBuf, tmp);
+          free(tmp);
+        }
+      }
+    }
+    if (sub_turning || sub_div) { stop = 1; break; }
+    /* merge: biased progressive sampling, then the U-turn check of the doubled tree */
+    const double u = rng_uniform(lf->rng);
+    if (u < jm_exp(mode, sub_logw - tree_logw)) memcpy(prop, subprop, sizeof(double) * sz);
+    tree_logw = logaddexp_det(mode, tree_logw, sub_logw);
+    for (int i = 0; i < n; i++) rsum[i] += srsum[i];
+    lf_snapshot(lf, going_right ? R : L);
+    depth++;
+    if (nuts_is_turning(n, mass, L, R, rsum)) stop = 1;
+  }
+  /* the draw: position, potential (and its gradient) of the selected point; momentum is irrelevant from here on */
+  memcpy(params + n, prop + n, sizeof(double) * (n + 1));
+  lf->iterations += 1; lf->accepted += 1;
+  const double mean_acc = nleaf_total ? sum_accept / (double)nleaf_total : 0.0;
+  lf->sumAccept += mean_acc;
+  free(L); free(R); free(prop); free(subprop); free(rsum); free(srsum); free(ckr); free(ckrs);
+  return jm_log(mode, mean_acc);
+}
+
 /* ---- S/HMC.scala, S/EHMC.scala ----------------------------------------------------------- */
 typedef struct { const orc_config *cfg; ringbuf steps; double *snap; } samplerst;
 
@@ -260,6 +353,7 @@ static void ehmc_countSteps(samplerst *s, double *params, orc_leapfrog *lf, doub
   ring_add(&s->steps, (double)l);
 }
 static double sampler_warmup(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  if (s->cfg->sampler == ORC_NUTS) return nuts_iteration(s->cfg, params, lf, stepSize, mass);
   orc_lf_start_iteration(lf, params, mass);
   if (s->cfg->sampler == ORC_HMC) { /* S/HMC.scala:6-13 */
     orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass);
@@ -271,6 +365,7 @@ static double sampler_warmup(samplerst *s, double *params, orc_leapfrog *lf, dou
   return orc_lf_finish_iteration(lf, params, mass);
 }
 static void sampler_run(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  if (s->cfg->sampler == ORC_NUTS) { (void)nuts_iteration(s->cfg, params, lf, stepSize, mass); return; }
   orc_lf_start_iteration(lf, params, mass);
   if (s->cfg->sampler == ORC_HMC) orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass); /* S/HMC.scala:15-23 */
   else { int n = (int)ring_sample(&s->steps, lf->rng); orc_lf_take_steps(lf, n, stepSize, mass); } /* S/EHMC.scala:52-61 */

@@ -12,7 +12,7 @@
 /* S/DensityFunction.scala:3-8 folded into one call: out[0] = density, out[1+i] = gradient(i) */
 typedef int (*orc_density_fn)(void *ctx, const double *q, double *out);
 
-enum { ORC_HMC = 0, ORC_EHMC = 1 };
+enum { ORC_HMC = 0, ORC_EHMC = 1, ORC_NUTS = 2 };
 enum { ORC_STEP_DUALAVG = 0, ORC_STEP_STATIC = 1 };
 enum { ORC_MASS_IDENTITY = 0, ORC_MASS_DIAG_WINDOWED = 1, ORC_MASS_STATIC_DIAG = 2 };
 
@@ -26,6 +26,7 @@ typedef struct {
   int mass_tuner;      /* IdentityMassMatrixTuner | DiagonalMassMatrixTuner(50,1.5,50,50) | StaticMassMatrix(Diagonal) */
   int init_window; double expansion; int skip_first, skip_last;
   const double *static_mass; /* [nvars] DiagonalMassMatrix.elements */
+  int nuts_max_depth;        /* ORC_NUTS (extension; NOT in the reference -- see sampler.c) */
   int iterations, warmup;    /* SamplerConfig   S/Sampler.scala:3-11 */
   int math_mode;             /* JM_LIBM | JM_DET (oracle/jmath.h) */
 } orc_config;

@@ -6,6 +6,6 @@
   models.py        the BASELINE.json configurations as RIR + synthetic data
 """
 from .sampler import (DefaultConfig, DensityFunction, DiagonalMassMatrix, DiagonalMassMatrixTuner,  # noqa: F401
-                      DualAvgTuner, EHMC, EHMCSampler, HMC, HMCSampler, IdentityMassMatrixTuner, Model,
+                      DualAvgTuner, EHMC, EHMCSampler, HMC, HMCSampler, IdentityMassMatrixTuner, Model, NUTSSampler,
                       RainierHipError, Sampler, SamplerConfig, StaticMassMatrix, StaticStepSize, Trace,
                       diagnostics, make_config)

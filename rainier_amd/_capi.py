@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "librainier_hip.so")
 
 RH_OK, RH_E_INVALID, RH_E_COMPILE, RH_E_DEVICE, RH_E_LOOKUP, RH_E_UNSUPPORTED = range(6)
 MATH_FAST, MATH_STRICT = 0, 1
-SAMPLER_HMC, SAMPLER_EHMC = 0, 1
+SAMPLER_HMC, SAMPLER_EHMC, SAMPLER_NUTS = 0, 1, 2
 STEP_DUALAVG, STEP_STATIC = 0, 1
 MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG = 0, 1, 2
 ENGINE_AUTO, ENGINE_CHAIN, ENGINE_TICK = 0, 1, 2
@@ -33,7 +33,7 @@ EXPORTS = [
 class CompileOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("math_mode", C.c_int32),
                 ("fp_contract", C.c_int32), ("rows_unroll", C.c_int32), ("grad_chains", C.c_int32),
-                ("grad_unroll", C.c_int32), ("factor_outputs", C.c_int32)]
+                ("grad_unroll", C.c_int32), ("factor_outputs", C.c_int32), ("with_nuts", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -43,7 +43,7 @@ class Config(C.Structure):
         ("ehmc_buf_size", C.c_int32), ("ehmc_p_count", C.c_double), ("step_tuner", C.c_int32),
         ("mass_tuner", C.c_int32), ("dualavg_delta", C.c_double), ("static_step", C.c_double),
         ("mass_init_window", C.c_int32), ("mass_skip_first", C.c_int32), ("mass_skip_last", C.c_int32),
-        ("reserved0", C.c_int32), ("mass_expansion", C.c_double), ("static_mass", C.POINTER(C.c_double)),
+        ("nuts_max_depth", C.c_int32), ("mass_expansion", C.c_double), ("static_mass", C.POINTER(C.c_double)),
         ("engine", C.c_int32), ("grad_splits", C.c_int32), ("reserved", C.c_int64 * 3),
     ]
 
@@ -113,11 +113,12 @@ def dptr(a: np.ndarray):
 
 
 def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=0, grad_chains=0, grad_unroll=0,
-                 factor_outputs=False):
+                 factor_outputs=False, with_nuts=False):
     o = CompileOpts()
     o.struct_size = C.sizeof(CompileOpts)
     o.device, o.math_mode, o.fp_contract, o.rows_unroll = device, math_mode, int(fp_contract), rows_unroll
     o.grad_chains, o.grad_unroll, o.factor_outputs = grad_chains, grad_unroll, int(factor_outputs)
+    o.with_nuts = int(with_nuts)
     return o
 
 

@@ -97,15 +97,27 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
 }
 
 // ---- chain state ----------------------------------------------------------------------------------
+#ifndef RH_WITH_NUTS
+#define RH_WITH_NUTS 0
+#endif
+#if RH_WITH_NUTS
+#define RH_STATE_VECS_NUTS(X) X(NLq) X(NLp) X(NLg) X(NRq) X(NRp) X(NRg) X(Nrsum)
+#define RH_STATE_F64_NUTS(X) X(nH0) X(n_tree_logw) X(n_sub_logw) X(n_sum_acc)
+#define RH_STATE_INT_NUTS(X) X(n_depth) X(n_leaf) X(n_right) X(n_leaf_total)
+#else
+#define RH_STATE_VECS_NUTS(X)
+#define RH_STATE_F64_NUTS(X)
+#define RH_STATE_INT_NUTS(X)
+#endif
 #define RH_STATE_VECS(X) \
-  X(Pp) X(Pq) X(Pg) X(Bp) X(Bq) X(Bg) X(Sp) X(Sq) X(Sg) X(M) X(SD) X(ve_mean) X(ve_raw) X(pend_g)
+  X(Pp) X(Pq) X(Pg) X(Bp) X(Bq) X(Bg) X(Sp) X(Sq) X(Sg) X(M) X(SD) X(ve_mean) X(ve_raw) X(pend_g) RH_STATE_VECS_NUTS(X)
 #define RH_STATE_F64(X) \
   X(PU) X(BU) X(SU) X(eps) X(da_logEps) X(da_logEpsBar) X(da_avgErr) X(da_mu) X(exponent) X(pend_logp) \
-  X(rng_nn) X(sum_accept)
+  X(rng_nn) X(sum_accept) RH_STATE_F64_NUTS(X)
 #define RH_STATE_INT(X) \
   X(rng_have) X(pc) X(ret) X(it) X(ts_l) X(ts_i) X(cnt_l) X(find_first) X(sampling_started) X(need_eval) \
   X(mass_identity) X(ve_samples) X(win_size) X(win_i) X(win_j) X(da_iter) X(ring_i) X(ring_full) X(n_accept) \
-  X(n_samp_iters) X(err)
+  X(n_samp_iters) X(err) RH_STATE_INT_NUTS(X)
 #define RH_STATE_I64(X) X(rng_seed) X(n_leapfrog) X(n_warm_leapfrog) X(n_grad)
 
 struct rh_chain {
@@ -122,14 +134,22 @@ struct rh_chain {
   RH_STATE_I64(X)
 #undef X
   double ring[RH_RING_SLOTS]; // EHMC step counts, entry i in lane i%64 of slot i/64
+#if RH_WITH_NUTS
+  wvec ckr[RH_NUTS_MAXD], ckrs[RH_NUTS_MAXD]; // NUTS momentum / momentum-sum checkpoints
+#endif
 };
+#if RH_WITH_NUTS
+#define RH_STATE_NCK (2 * RH_NUTS_MAXD)
+#else
+#define RH_STATE_NCK 0
+#endif
 
 #define RH_CNT(n) +1
 #define RH_STATE_NVEC (0 RH_STATE_VECS(RH_CNT))
 #define RH_STATE_NSCALAR ((0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + (0 RH_STATE_I64(RH_CNT)))
 // u64 words of one chain's state image: lane-distributed vectors and the ring buffer take 64 words per slot,
 // wave-uniform scalars are stored once (lane 0 writes, every lane reads the same address -> scalar loads).
-#define RH_STATE_U64 ((RH_STATE_NVEC * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
+#define RH_STATE_U64 (((RH_STATE_NVEC + RH_STATE_NCK) * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
 
 // image of chain c starts at st = state + c * RH_STATE_U64: [vector slot w][lane] ..., [ring slot][lane] ..., scalars
 RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
@@ -139,6 +159,13 @@ RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
   RH_STATE_VECS(X)
 #undef X
   for (int k = 0; k < RH_RING_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ring[k]);
+#if RH_WITH_NUTS
+  for (int j = 0; j < RH_NUTS_MAXD; j++)
+    for (int k = 0; k < RH_SLOTS; k++) {
+      st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ckr[j].s[k]);
+      st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ckrs[j].s[k]);
+    }
+#endif
   if (lane == 0) {
     rh_u64 *sc = st + (size_t)w * 64;
     int j = 0;
@@ -160,6 +187,13 @@ RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
   RH_STATE_VECS(X)
 #undef X
   for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+#if RH_WITH_NUTS
+  for (int j = 0; j < RH_NUTS_MAXD; j++)
+    for (int k = 0; k < RH_SLOTS; k++) {
+      c.ckr[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+      c.ckrs[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+    }
+#endif
   const rh_u64 *sc = st + (size_t)w * 64;
   int j = 0;
 #define X(n) c.n = __longlong_as_double((rh_i64)sc[j++]);
@@ -179,7 +213,8 @@ RH_DEV void rh_chain_zero(rh_u64 *st, const int lane) {
 // ---- automaton states ------------------------------------------------------------------------------
 enum {
   RH_S_INIT = 0, RH_S_INIT2, RH_S_TRY_BEGIN, RH_S_TRY_END, RH_S_WARM_SETUP, RH_S_ITER_TOP, RH_S_COUNT_LOOP,
-  RH_S_COUNT_AFTER, RH_S_COUNT_DONE, RH_S_TS_BEGIN, RH_S_TS_MID, RH_S_FINISH, RH_S_DONE
+  RH_S_COUNT_AFTER, RH_S_COUNT_DONE, RH_S_TS_BEGIN, RH_S_TS_MID, RH_S_FINISH, RH_S_DONE,
+  RH_S_NUTS_TOP, RH_S_NUTS_DOUBLE, RH_S_NUTS_LEAF, RH_S_NUTS_LEAF2, RH_S_NUTS_DONE
 };
 
 RH_DEV rh_rng rh_rng_of(const rh_chain &c) { rh_rng r; r.seed = (rh_u64)c.rng_seed; r.have = c.rng_have; r.nn = c.rng_nn; return r; }
@@ -210,6 +245,12 @@ RH_DEV double rh_energy(const rh_chain &c, const wvec &p, const double U, const 
 RH_DEV double rh_log_accept(const double deltaH) { // LeapFrog.scala:138-142
   if (deltaH != deltaH) return -RH_INF;
   return (-deltaH) < 0.0 ? (-deltaH) : 0.0;
+}
+RH_DEV void rh_new_qs_e(rh_chain &c, const double e, const bool identity) { // LeapFrog.scala:144-151, signed step
+  wvec v;
+  rh_velocity(c, c.Bp, v, identity);
+  wv_axpy(c.Bq, e, v);
+  if (c.sampling_started) c.n_leapfrog += 1; else c.n_warm_leapfrog += 1;
 }
 RH_DEV void rh_new_qs(rh_chain &c, const bool identity) { // LeapFrog.scala:144-151
   wvec v;
@@ -303,6 +344,50 @@ RH_DEV bool rh_is_uturn(const rh_chain &c) { // LeapFrog.scala:35-47
   return out < 0;
 }
 
+// Driver.warmup / collectSamples bookkeeping after one sampler iteration (Driver.scala:68-80, 104-108)
+RH_DEV void rh_iteration_done(rh_chain &c, const rh_cfg_dev &cfg, const double a, const bool accept, const double acc_prob,
+                              double *draws, const int lane) {
+  if (c.it < cfg.warmup) {
+    if (cfg.step_tuner == 0) { rh_dualavg_update(c, cfg.dualavg_delta, a); c.eps = rh_strict_exp(c.da_logEps); }
+    if (rh_mass_update(c, cfg, lane)) {
+      if (cfg.step_tuner == 0) { // stepSizeTuner.reset() (DualAvg.scala:17-21)
+        const double ss = rh_strict_exp(c.da_logEpsBar);
+        rh_dualavg_new(c, ss);
+        c.eps = ss;
+      }
+    }
+  } else {
+    c.n_accept += accept ? 1 : 0;
+    c.sum_accept += acc_prob;
+    c.n_samp_iters += 1;
+    double *out = draws + (size_t)(c.it - cfg.warmup) * RH_NVARS;
+#pragma unroll
+    for (int k = 0; k < RH_SLOTS; k++)
+      if (k * 64 + lane < RH_NVARS) out[k * 64 + lane] = c.Pq.s[k];
+  }
+  c.it += 1;
+  c.pc = RH_S_ITER_TOP;
+}
+#if RH_WITH_NUTS
+RH_DEV double rh_logaddexp(const double a, const double b) {
+  const double m = a > b ? a : b;
+  if (m == -RH_INF) return -RH_INF;
+  return m + rh_strict_log(rh_strict_exp(a - m) + rh_strict_exp(b - m));
+}
+// v = M^-1 r; r_sum' = r_sum - (r_left + r_right)/2; turning iff v_left . r_sum' <= 0 or v_right . r_sum' <= 0 (NaN: turning)
+RH_DEV bool rh_nuts_is_turning(const rh_chain &c, const wvec &rl, const wvec &rr, const wvec &rsum, const bool identity) {
+  wvec adj, vl, vr, pl, pr;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) adj.s[k] = rsum.s[k] - (rl.s[k] + rr.s[k]) / 2.0;
+  rh_velocity(c, rl, vl, identity);
+  rh_velocity(c, rr, vr, identity);
+  wv_mul(pl, vl, adj);
+  wv_mul(pr, vr, adj);
+  const double dl = wv_sum_seq(pl), dr = wv_sum_seq(pr);
+  return !(dl > 0.0) || !(dr > 0.0);
+}
+#endif
+
 // Consumes the pending gradient (c.pend_logp / c.pend_g, evaluated at c.Bq) if the automaton was waiting for
 // one, and runs until it needs the next gradient (RH_ADV_NEED_GRAD), reaches iteration `it_stop`
 // (RH_ADV_PAUSED) or finishes (RH_ADV_DONE).  All control flow is wave-uniform.
@@ -376,6 +461,8 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
       rh_copy_P_to_B(c);
       if (cfg.sampler == 0) { // HMCSampler (HMC.scala:6-23)
         c.ts_l = cfg.hmc_steps; c.ret = RH_S_FINISH; c.pc = RH_S_TS_BEGIN;
+      } else if (cfg.sampler == 2) { // NUTS (extension)
+        c.pc = RH_S_NUTS_TOP;
       } else {                // EHMCSampler (EHMC.scala:15-30, 52-61)
         bool count = false;
         if (c.it < cfg.warmup) {
@@ -436,28 +523,98 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
       rh_rng_put(c, r);
       const bool accept = a > rh_strict_log(u);
       if (accept) rh_copy_B_to_P(c);
-      if (c.it < cfg.warmup) { // Driver.warmup (Driver.scala:68-80)
-        if (cfg.step_tuner == 0) { rh_dualavg_update(c, cfg.dualavg_delta, a); c.eps = rh_strict_exp(c.da_logEps); }
-        if (rh_mass_update(c, cfg, lane)) {
-          if (cfg.step_tuner == 0) { // stepSizeTuner.reset() (DualAvg.scala:17-21)
-            const double ss = rh_strict_exp(c.da_logEpsBar);
-            rh_dualavg_new(c, ss);
-            c.eps = ss;
-          }
-        }
-      } else { // Driver.collectSamples (Driver.scala:104-108)
-        c.n_accept += accept ? 1 : 0;
-        c.sum_accept += rh_strict_exp(a);
-        c.n_samp_iters += 1;
-        double *out = draws + (size_t)(c.it - cfg.warmup) * RH_NVARS;
-#pragma unroll
-        for (int k = 0; k < RH_SLOTS; k++)
-          if (k * 64 + lane < RH_NVARS) out[k * 64 + lane] = c.Pq.s[k];
-      }
-      c.it += 1;
-      c.pc = RH_S_ITER_TOP;
+      rh_iteration_done(c, cfg, a, accept, rh_strict_exp(a), draws, lane);
       break;
     }
+#if RH_WITH_NUTS
+    // ---- NUTS (extension; not in the reference).  Same algorithm statement as oracle/sampler.c nuts_iteration:
+    // iterative multinomial NUTS (Phan, Pradhan, Jankowiak 2019, App. A).
+    case RH_S_NUTS_TOP: {
+      c.nH0 = rh_energy(c, c.Pp, c.PU, c.mass_identity != 0);
+      c.NLq = c.Pq; c.NLp = c.Pp; c.NLg = c.Pg; c.NRq = c.Pq; c.NRp = c.Pp; c.NRg = c.Pg;
+      c.Nrsum = c.Pp;
+      c.n_tree_logw = 0.0; c.n_sum_acc = 0.0; c.n_leaf_total = 0; c.n_depth = 0;
+      c.pc = RH_S_NUTS_DOUBLE;
+      break;
+    }
+    case RH_S_NUTS_DOUBLE: {
+      if (c.n_depth >= cfg.nuts_max_depth) { c.pc = RH_S_NUTS_DONE; break; }
+      rh_rng r = rh_rng_of(c); const double u = rh_rng_uniform(r); rh_rng_put(c, r);
+      c.n_right = rh_uniform_i(u > 0.5 ? 1 : 0);
+      if (c.n_right) { c.Bq = c.NRq; c.Bp = c.NRp; c.Bg = c.NRg; } else { c.Bq = c.NLq; c.Bp = c.NLp; c.Bg = c.NLg; }
+      c.n_sub_logw = -RH_INF; wv_zero(c.Sp); c.n_leaf = 0;
+      c.pc = RH_S_NUTS_LEAF;
+      break;
+    }
+    case RH_S_NUTS_LEAF: { // one leapfrog step in the chosen direction: takeSteps(1, +-eps)
+      const double e = c.n_right ? c.eps : -c.eps;
+      wv_axpy(c.Bp, e / 2.0, c.Bg);
+      rh_new_qs_e(c, e, c.mass_identity != 0);
+      c.pc = RH_S_NUTS_LEAF2; c.n_grad += 1;
+      return RH_ADV_NEED_GRAD;
+    }
+    case RH_S_NUTS_LEAF2: {
+      const bool ident = c.mass_identity != 0;
+      const double e = c.n_right ? c.eps : -c.eps;
+      c.BU = c.pend_logp * -1; c.Bg = c.pend_g;
+      wv_axpy(c.Bp, e / 2.0, c.Bg);
+      double delta = rh_energy(c, c.Bp, c.BU, ident) - c.nH0;
+      if (delta != delta) delta = RH_INF;
+      const double leaf_logw = -delta;
+      const bool sub_div = delta > 1000.0;
+      c.n_sum_acc += (delta <= 0.0) ? 1.0 : rh_strict_exp(-delta);
+      c.n_leaf_total += 1;
+      const double new_logw = rh_logaddexp(c.n_sub_logw, leaf_logw);
+      rh_rng r = rh_rng_of(c); const double u = rh_rng_uniform(r); rh_rng_put(c, r);
+      if (c.n_leaf == 0 || u < rh_strict_exp(leaf_logw - new_logw)) { c.Sq = c.Bq; c.Sg = c.Bg; c.SU = c.BU; }
+      c.n_sub_logw = new_logw;
+#pragma unroll
+      for (int k = 0; k < RH_SLOTS; k++) c.Sp.s[k] += c.Bp.s[k]; // subtree momentum sum lives in Sp
+      // checkpoints (NumPyro _leaf_idx_to_ckpt_idxs)
+      int idx_max = 0;
+      for (int x = c.n_leaf >> 1; x > 0; x >>= 1) idx_max += (x & 1);
+      int nsub = 0;
+      for (int x = c.n_leaf; (x & 1) != 0; x >>= 1) nsub++;
+      const int idx_min = idx_max - nsub + 1;
+      bool sub_turning = false;
+      if ((c.n_leaf & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < RH_NUTS_MAXD; j++)
+          if (j == idx_max) { c.ckr[j] = c.Bp; c.ckrs[j] = c.Sp; }
+      } else {
+        for (int k = idx_max; k >= idx_min && !sub_turning; k--) {
+          wvec rk, rsk;
+          wv_zero(rk); wv_zero(rsk);
+#pragma unroll
+          for (int j = 0; j < RH_NUTS_MAXD; j++)
+            if (j == k) { rk = c.ckr[j]; rsk = c.ckrs[j]; }
+          wvec sub;
+#pragma unroll
+          for (int s2 = 0; s2 < RH_SLOTS; s2++) sub.s[s2] = c.Sp.s[s2] - rsk.s[s2] + rk.s[s2];
+          sub_turning = rh_nuts_is_turning(c, rk, c.Bp, sub, ident);
+        }
+      }
+      c.n_leaf += 1;
+      if (sub_turning || sub_div) { c.pc = RH_S_NUTS_DONE; break; }
+      if (c.n_leaf < (1 << c.n_depth)) { c.pc = RH_S_NUTS_LEAF; break; }
+      { // merge the finished subtree: biased progressive sampling, then the U-turn check of the doubled tree
+        rh_rng r2 = rh_rng_of(c); const double u2 = rh_rng_uniform(r2); rh_rng_put(c, r2);
+        if (u2 < rh_strict_exp(c.n_sub_logw - c.n_tree_logw)) { c.Pq = c.Sq; c.Pg = c.Sg; c.PU = c.SU; }
+        c.n_tree_logw = rh_logaddexp(c.n_tree_logw, c.n_sub_logw);
+#pragma unroll
+        for (int k = 0; k < RH_SLOTS; k++) c.Nrsum.s[k] += c.Sp.s[k];
+        if (c.n_right) { c.NRq = c.Bq; c.NRp = c.Bp; c.NRg = c.Bg; } else { c.NLq = c.Bq; c.NLp = c.Bp; c.NLg = c.Bg; }
+        c.n_depth += 1;
+        c.pc = rh_nuts_is_turning(c, c.NLp, c.NRp, c.Nrsum, ident) ? RH_S_NUTS_DONE : RH_S_NUTS_DOUBLE;
+      }
+      break;
+    }
+    case RH_S_NUTS_DONE: {
+      const double mean_acc = c.n_leaf_total ? c.n_sum_acc / (double)c.n_leaf_total : 0.0;
+      rh_iteration_done(c, cfg, rh_strict_log(mean_acc), true, mean_acc, draws, lane);
+      break;
+    }
+#endif
     default:
       return RH_ADV_DONE;
     }

@@ -6,6 +6,7 @@
 #define RH_MAX_TARGETS 64
 #define RH_MAX_COLS 128
 #define RH_RING_SLOTS 4  /* EHMC step-count ring buffer: <= 256 entries, lane-distributed */
+#define RH_NUTS_MAXD 12  /* NUTS: deepest tree (2^12 leaves); momentum checkpoints per chain */
 
 /* return codes of the per-chain automaton */
 #define RH_ADV_NEED_GRAD 0
@@ -21,6 +22,7 @@ typedef struct rh_cfg_dev {
   double dualavg_delta, static_step;
   int mass_tuner, mass_init_window, mass_skip_first, mass_skip_last;
   double mass_expansion;
+  int nuts_max_depth, reserved;
 } rh_cfg_dev;
 
 /* observation columns resident in HBM: flattened target-major, then column */

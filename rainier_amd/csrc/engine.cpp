@@ -107,7 +107,16 @@ std::vector<char> compile_hip(const std::string &src, const std::string &arch, s
 }
 }  // namespace
 
+struct KSet {  // the per-chain sampler kernels of one compiled variant (with / without NUTS support)
+  hipModule_t module = nullptr;
+  hipFunction_t k_chain = nullptr, k_tick = nullptr;
+  int state_words = 0;
+  bool loaded = false;
+};
+
 struct rh_model {
+  KSet nuts;  // variant compiled with RH_WITH_NUTS (larger chain state); built on first use
+  bool want_nuts = false;
   rh::Program prog;
   rh::EmitOptions eopt;
   std::string source, err, arch;
@@ -131,6 +140,8 @@ struct rh_model {
 };
 
 struct rh_sampler {
+  hipFunction_t k_chain = nullptr, k_tick = nullptr;
+  int state_words = 0;
   rh_model *m = nullptr;
   rh_cfg_dev cfg{};
   int chains = 0;
@@ -168,6 +179,22 @@ void assemble_source(rh_model *m) {
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
 }
+
+std::vector<char> build_source(const std::string &arch, const std::string &source) {
+  int hv = 0;
+  hiprtcVersion(&hv, &hv);
+  const uint64_t h = fnv1a(arch + "|" + std::to_string(hv) + "|" + source);
+  char name[64];
+  std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+  const std::string path = cache_dir() + name;
+  std::vector<char> code;
+  if (!std::getenv("RH_NO_KERNEL_CACHE") && read_file(path, code)) return code;
+  std::string log;
+  code = compile_hip(source, arch, log);
+  if (!std::getenv("RH_NO_KERNEL_CACHE")) write_file(path, code);
+  return code;
+}
+const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
 void build_code(rh_model *m) {
   int hv = 0;
@@ -211,6 +238,20 @@ void load_module(rh_model *m) {
   m->loaded = true;
 }
 
+// the NUTS variant: same translation unit with RH_WITH_NUTS, only its per-chain kernels are used
+void load_nuts_variant(rh_model *m) {
+  if (m->nuts.loaded) return;
+  HIPCHK(hipSetDevice(m->device));
+  const std::vector<char> code = build_source(m->arch, std::string(kNutsDefine) + m->source);
+  HIPCHK(hipModuleLoadData(&m->nuts.module, code.data()));
+  HIPCHK(hipModuleGetFunction(&m->nuts.k_chain, m->nuts.module, "rh_chain_kernel"));
+  if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&m->nuts.k_tick, m->nuts.module, "rh_tick_kernel"));
+  hipDeviceptr_t p; size_t sz;
+  HIPCHK(hipModuleGetGlobal(&p, &sz, m->nuts.module, "rh_state_words"));
+  HIPCHK(hipMemcpy(&m->nuts.state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  m->nuts.loaded = true;
+}
+
 int guard(rh_model *m, const std::function<void()> &fn) {
   try { fn(); return RH_OK; }
   catch (const Fail &f) { g_err = f.msg; if (m) m->err = f.msg; return f.code; }
@@ -242,6 +283,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
         throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
       m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;
       m->eopt.factor_outputs = opts->factor_outputs != 0;
+      m->want_nuts = opts->with_nuts != 0;
       dev = opts->device;
     }
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
@@ -264,6 +306,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     if (colon != std::string::npos) m->arch = m->arch.substr(0, colon);
     build_code(m);
     load_module(m);
+    if (m->want_nuts) load_nuts_variant(m);
     // observation columns -> HBM (the engine copies; the caller keeps ownership)
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
       const auto &T = m->prog.targets[t];
@@ -291,6 +334,7 @@ extern "C" void rh_model_destroy(rh_model *m) {
     for (void *d : m->dev_cols) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     if (m->module) hipModuleUnload(m->module);
+    if (m->nuts.module) hipModuleUnload(m->nuts.module);
   }
   delete m;
 }
@@ -324,6 +368,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
     build_code(&m);
     if (code_size) *code_size = m.code.size();
+    if (opts && opts->with_nuts) (void)build_source(m.arch, std::string(kNutsDefine) + m.source);
   });
   return rc;
 }
@@ -400,7 +445,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     if (!cfg || cfg->struct_size != (int32_t)sizeof(rh_config)) throw Fail{RH_E_INVALID, "rh_config.struct_size mismatch"};
     if (!seeds || chains <= 0) throw Fail{RH_E_INVALID, "seeds/chains invalid"};
     if (cfg->iterations < 0 || cfg->warmup < 0) throw Fail{RH_E_INVALID, "negative iteration count"};
-    if (cfg->sampler != RH_SAMPLER_HMC && cfg->sampler != RH_SAMPLER_EHMC) throw Fail{RH_E_INVALID, "unknown sampler"};
+    if (cfg->sampler != RH_SAMPLER_HMC && cfg->sampler != RH_SAMPLER_EHMC && cfg->sampler != RH_SAMPLER_NUTS) throw Fail{RH_E_INVALID, "unknown sampler"};
+    if (cfg->sampler == RH_SAMPLER_NUTS && (cfg->nuts_max_depth < 1 || cfg->nuts_max_depth > RH_NUTS_MAXD)) throw Fail{RH_E_INVALID, "nuts_max_depth must be in [1, 12]"};
     if (cfg->sampler == RH_SAMPLER_EHMC && (cfg->ehmc_buf_size < 1 || cfg->ehmc_buf_size > 64 * RH_RING_SLOTS))
       throw Fail{RH_E_INVALID, "ehmc_buf_size must be in [1, 256]"};
     if (cfg->mass_tuner == RH_MASS_STATIC_DIAG) {
@@ -409,15 +455,21 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
         if (cfg->static_mass[i] == 0.0) throw Fail{RH_E_INVALID, "requirement failed: mass matrix element is 0.0"};
     }
     s->m = m; s->chains = chains;
+    HIPCHK(hipSetDevice(m->device));
+    if (cfg->sampler == RH_SAMPLER_NUTS) {
+      load_nuts_variant(m);
+      s->k_chain = m->nuts.k_chain; s->k_tick = m->nuts.k_tick; s->state_words = m->nuts.state_words;
+    } else { s->k_chain = m->k_chain; s->k_tick = m->k_tick; s->state_words = m->state_words; }
     rh_cfg_dev &d = s->cfg;
     d.iterations = cfg->iterations; d.warmup = cfg->warmup; d.sampler = cfg->sampler; d.hmc_steps = cfg->hmc_steps;
     d.ehmc_max_steps = cfg->ehmc_max_steps; d.ehmc_min_steps = cfg->ehmc_min_steps; d.ehmc_buf_size = cfg->ehmc_buf_size;
     d.step_tuner = cfg->step_tuner; d.ehmc_p_count = cfg->ehmc_p_count; d.dualavg_delta = cfg->dualavg_delta;
     d.static_step = cfg->static_step; d.mass_tuner = cfg->mass_tuner; d.mass_init_window = cfg->mass_init_window;
     d.mass_skip_first = cfg->mass_skip_first; d.mass_skip_last = cfg->mass_skip_last; d.mass_expansion = cfg->mass_expansion;
+    d.nuts_max_depth = cfg->nuts_max_depth;
     HIPCHK(hipSetDevice(m->device));
     const int n = (int)m->prog.n_params;
-    const size_t state_bytes = (size_t)chains * m->state_words * sizeof(uint64_t);
+    const size_t state_bytes = (size_t)chains * s->state_words * sizeof(uint64_t);
     HIPCHK(hipMalloc(&s->d_state, state_bytes));
     HIPCHK(hipMalloc(&s->d_seeds, sizeof(int64_t) * chains));
     HIPCHK(hipMalloc(&s->d_mass, sizeof(double) * n));
@@ -488,7 +540,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
                     &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
-    launch(m->k_tick, (unsigned)chains, 64, m->stream, args);
+    launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
   auto grad = [&]() {
     void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
@@ -557,7 +609,7 @@ void advance_to(rh_sampler *s, int it_stop) {
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running,
                     &chains, &stop, &max_ticks, &fresh};
     HIPCHK(hipEventRecord(s->e0, m->stream));
-    launch(m->k_chain, (unsigned)chains, 64, m->stream, args);
+    launch(s->k_chain, (unsigned)chains, 64, m->stream, args);
     HIPCHK(hipEventRecord(s->e1, m->stream));
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -630,7 +682,7 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
     }
     if (mass_diag) {
       // M is the 10th vector of the state image (RH_STATE_VECS order in rh_engine.hip.h): Pp Pq Pg Bp Bq Bg Sp Sq Sg M
-      const int n = (int)s->m->prog.n_params, slots = (n + 63) / 64, W = s->m->state_words;
+      const int n = (int)s->m->prog.n_params, slots = (n + 63) / 64, W = s->state_words;
       const size_t width = (size_t)slots * 64 * sizeof(uint64_t);
       std::vector<uint64_t> img((size_t)slots * 64 * s->chains);
       const char *base = (const char *)s->d_state + (size_t)9 * slots * 64 * sizeof(uint64_t);

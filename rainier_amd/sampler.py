@@ -38,6 +38,12 @@ class EHMCSampler:
 
 
 @dataclass
+class NUTSSampler:
+    """Extension (not in the reference): iterative multinomial NUTS behind the Sampler plugin point."""
+    maxDepth: int = 10
+
+
+@dataclass
 class DualAvgTuner:
     delta: float
 
@@ -122,6 +128,8 @@ def to_c_config(config: SamplerConfig, nvars: int):
     elif isinstance(s, EHMCSampler):
         c.sampler = _capi.SAMPLER_EHMC
         c.ehmc_max_steps, c.ehmc_min_steps, c.ehmc_buf_size, c.ehmc_p_count = s.maxSteps, s.minSteps, s.bufSize, s.pCount
+    elif isinstance(s, NUTSSampler):
+        c.sampler, c.nuts_max_depth = _capi.SAMPLER_NUTS, int(s.maxDepth)
     else:
         raise TypeError("unsupported Sampler %r" % (s,))
     if isinstance(st, DualAvgTuner):
@@ -246,14 +254,16 @@ class Model:
     """A compiled model: Compiler.compileTargets' replacement (compute/Compiler.scala:14-30) + Model.sample."""
 
     def __init__(self, spec, device: int = -1, math_mode: int = _capi.MATH_FAST, fp_contract: bool = False,
-                 rows_unroll: int = 0, grad_chains: int = 0, grad_unroll: int = 0, factor_outputs: bool = False):
+                 rows_unroll: int = 0, grad_chains: int = 0, grad_unroll: int = 0, factor_outputs: bool = False,
+                 with_nuts: bool = False):
         L = _capi.lib()
         self.spec = spec
         self.nVars = spec.n_params
         self._cols = [np.ascontiguousarray(c, dtype=np.float64) for c in spec.columns]
         colarr = (C.POINTER(C.c_double) * max(1, len(self._cols)))(*[_capi.dptr(c) for c in self._cols])
         nrows = (C.c_int64 * len(spec.nrows))(*spec.nrows)
-        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll, grad_chains, grad_unroll, factor_outputs)
+        opts = _capi.compile_opts(device, math_mode, fp_contract, rows_unroll, grad_chains, grad_unroll, factor_outputs,
+                                   with_nuts)
         blob = C.create_string_buffer(spec.rir, len(spec.rir))
         self._h = C.c_void_p()
         _capi.check(L.rh_model_create(blob, len(spec.rir), colarr, nrows, C.byref(opts), C.byref(self._h)))

@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 JM_LIBM, JM_DET = 0, 1
-HMC, EHMC = 0, 1
+HMC, EHMC, NUTS = 0, 1, 2
 STEP_DUALAVG, STEP_STATIC = 0, 1
 MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG = 0, 1, 2
 
@@ -26,7 +26,7 @@ class OrcConfig(C.Structure):
         ("step_tuner", C.c_int), ("delta", C.c_double), ("static_step", C.c_double),
         ("mass_tuner", C.c_int), ("init_window", C.c_int), ("expansion", C.c_double),
         ("skip_first", C.c_int), ("skip_last", C.c_int), ("static_mass", C.POINTER(C.c_double)),
-        ("iterations", C.c_int), ("warmup", C.c_int), ("math_mode", C.c_int),
+        ("nuts_max_depth", C.c_int), ("iterations", C.c_int), ("warmup", C.c_int), ("math_mode", C.c_int),
     ]
 
 
@@ -139,7 +139,7 @@ class OracleDensity:
 def make_config(sampler=HMC, n_steps=1, max_steps=1024, min_steps=1, buf_size=100, p_count=0.1,
                 step_tuner=STEP_DUALAVG, delta=0.8, static_step=0.1,
                 mass_tuner=MASS_IDENTITY, init_window=50, expansion=1.5, skip_first=50, skip_last=50,
-                static_mass=None, iterations=100, warmup=100, math_mode=JM_LIBM):
+                static_mass=None, iterations=100, warmup=100, math_mode=JM_LIBM, nuts_max_depth=10):
     cfg = OrcConfig()
     cfg.sampler, cfg.n_steps = sampler, n_steps
     cfg.max_steps, cfg.min_steps, cfg.buf_size, cfg.p_count = max_steps, min_steps, buf_size, p_count
@@ -152,6 +152,7 @@ def make_config(sampler=HMC, n_steps=1, max_steps=1024, min_steps=1, buf_size=10
         cfg._static_mass_keep = sm
         cfg.static_mass = _dp(sm)
     cfg.iterations, cfg.warmup, cfg.math_mode = iterations, warmup, math_mode
+    cfg.nuts_max_depth = nuts_max_depth
     return cfg
 
 

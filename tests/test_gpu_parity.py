@@ -149,6 +149,7 @@ def _oracle_cfg(config, math_mode):
     s, st, mt = config.sampler(), config.stepSizeTuner(), config.massMatrixTuner()
     kw = dict(iterations=config.iterations, warmup=config.warmupIterations, math_mode=math_mode)
     if isinstance(s, R.HMCSampler): kw.update(sampler=O.HMC, n_steps=s.nSteps)
+    elif isinstance(s, R.NUTSSampler): kw.update(sampler=O.NUTS, nuts_max_depth=s.maxDepth)
     else: kw.update(sampler=O.EHMC, max_steps=s.maxSteps, min_steps=s.minSteps, buf_size=s.bufSize, p_count=s.pCount)
     if isinstance(st, R.DualAvgTuner): kw.update(step_tuner=O.STEP_DUALAVG, delta=st.delta)
     else: kw.update(step_tuner=O.STEP_STATIC, static_step=st.stepSize)
@@ -415,3 +416,36 @@ def test_gpu_reproduces_reference_sbc_goldset(engine):
     tr = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(cfg, seeds=[seed])
     got = G.predict(tr.chains[0])
     assert np.abs((got - gold) / gold).max() < 1e-10
+
+
+# ---- NUTS (extension; the reference has none -- parity is GPU vs the oracle's statement of the same algorithm) ----
+def test_nuts_bit_exact_vs_oracle():
+    cfg = R.make_config(150, 250, R.NUTSSampler(10))                      # + DualAvg(0.8) + windowed diagonal mass
+    _assert_chains_bit_exact(models.eight_schools(), cfg, [2000, 2001, 2002])
+    cfg = R.make_config(120, 150, R.NUTSSampler(6), R.DualAvgTuner(0.65), R.IdentityMassMatrixTuner())
+    tr = _assert_chains_bit_exact(models.funnel(10), cfg, [3, 4])
+    assert all(2 ** 6 >= st.leapfrogSteps / 120 >= 1 for st in tr.stats)
+    cfg = R.make_config(60, 60, R.NUTSSampler(1), R.StaticStepSize(0.3))  # depth 1: a single leaf per iteration
+    _assert_chains_bit_exact(models.normal_1d(), cfg, [9])
+
+
+def test_nuts_recovers_posteriors_on_both_engines():
+    spec = models.funnel(10)
+    tr = R.Model(spec, device=0).sample(R.make_config(400, 300, R.NUTSSampler(10)), seeds=range(64))
+    flat = tr.chains.reshape(-1, 10)
+    assert np.all(np.abs(flat.mean(axis=0)) < 0.05) and np.all(np.abs(flat.var(axis=0) - 1.0) < 0.08)
+    assert all(r < 1.02 for r, _ in tr.diagnostics())
+    assert 0.7 < np.mean([st.meanAcceptProb for st in tr.stats]) < 0.9    # dual averaging targets 0.8
+    spec = models.linreg(n=3000, k=3)
+    m = R.Model(spec, device=0)
+    a = m.sample(R.make_config(200, 200, R.NUTSSampler(8), engine=_capi.ENGINE_TICK), seeds=range(16))
+    post = a.chains.reshape(-1, 5).mean(axis=0)
+    assert np.allclose(post[1:], [0.5, 1.0, -2.0, 0.5], atol=0.08) and abs(post[0] - np.log(0.7)) < 0.08
+    # tame dynamics: tick engine == chain engine to rounding, through the NUTS tree logic
+    tame = lambda e: R.make_config(6, 0, R.NUTSSampler(4), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=e)
+    ms = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    x = ms.sample(tame(_capi.ENGINE_CHAIN), seeds=[5, 6, 7]); y = ms.sample(tame(_capi.ENGINE_TICK), seeds=[5, 6, 7])
+    np.testing.assert_allclose(y.chains, x.chains, rtol=1e-9, atol=1e-11)
+    assert [st.leapfrogSteps for st in x.stats] == [st.leapfrogSteps for st in y.stats]
+    with pytest.raises(R.RainierHipError):
+        m.sample(R.make_config(5, 5, R.NUTSSampler(13)), seeds=[1])

@@ -195,3 +195,12 @@ def test_driver_runs_and_recovers_posterior(oracle):
     draws, mass, st = O.sample_model(models.eight_schools(), cfg, 7)
     assert np.all(np.isfinite(draws)) and np.all(mass > 0) and not np.allclose(mass, 1.0)
     assert abs(draws[:, 2:].mean()) < 0.3
+
+
+def test_nuts_extension_recovers_standard_normal(oracle):
+    # NUTS is NOT in the reference: statistical sanity of the oracle's statement of the algorithm
+    cfg = O.make_config(sampler=O.NUTS, iterations=3000, warmup=800, mass_tuner=O.MASS_DIAG_WINDOWED, nuts_max_depth=10,
+                        math_mode=O.JM_DET)
+    draws, mass, st = O.sample_model(models.funnel(10), cfg, 11)
+    assert np.all(np.abs(draws.mean(axis=0)) < 0.12) and np.all(np.abs(draws.var(axis=0) - 1.0) < 0.2)
+    assert 0.7 < st.mean_accept_prob < 0.9 and 1 <= st.leapfrog_steps / 3000 <= 2 ** 10
