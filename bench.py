@@ -67,6 +67,8 @@ def side_workload(a, R, models, rank, local_rank, world):
     model = R.Model(spec, device=local_rank)
     cpg = a.chains_per_gpu
     cfg = R.HMC(a.warmup, a.steps, 5) if a.workload == "cfg1" else R.make_config(a.steps, a.warmup)
+    if a.sampler == "nuts":
+        cfg.sampler = lambda: R.NUTSSampler(10)
     if a.workload == "cfg1":
         cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
     s = R.Sampler(model, cfg, [2000 + rank * cpg + c for c in range(cpg)])
@@ -79,7 +81,7 @@ def side_workload(a, R, models, rank, local_rank, world):
     print(json.dumps({"metric": "leapfrog steps/sec (all chains)", "value": steps / dt, "unit": "leapfrog steps/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                       "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": a.workload + ": " + spec.name, "chains": cpg},
+                      "config": {"workload": a.workload + ": " + spec.name, "chains": cpg, "sampler": a.sampler},
                       "warmup_leapfrog_steps_per_s": wsteps / tw, "ess_per_s": ess / dt if ess else None,
                       "mean_leapfrog_per_iteration": steps / (a.steps * cpg),
                       "roofline": None, "note": "data-free model: latency-bound, no HBM/MFMA roofline applies"}))
@@ -94,6 +96,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--leapfrog", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
+                    help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC")
     ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3"], default="cfg2",
                     help="cfg2 is the BASELINE metric's configuration (default); cfg1 / cfg3 are data-free parity "
                          "configurations that can be timed for reference (no roofline: <= 100 doubles per chain)")
