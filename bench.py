@@ -210,7 +210,7 @@ def main():
         pc = json.load(open(prof))["counters"]
         out["roofline"]["traffic"] = (pc["FETCH_SIZE"]["mean_per_launch"] + pc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
         out["roofline"]["traffic_source"] = "profiles/r1_b_tick_engine/pmc_grad_kernel.json (separate rocprofv3 --pmc passes)"
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(spec, L)
     print(json.dumps(out))
     if dist is not None:
