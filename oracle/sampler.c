@@ -376,6 +376,12 @@ static void sampler_run(samplerst *s, double *params, orc_leapfrog *lf, double s
 int orc_sample_chain(const orc_config *cfg, orc_density_fn f, void *ctx, int n, int64_t seed,
                      double *draws, double *mass_out, orc_stats *stats) {
   jrandom rng; jrandom_init(&rng, seed); /* ScalaRNG(seed) */
+  return orc_sample_chain_state(cfg, f, ctx, n, &rng, draws, mass_out, stats);
+}
+/* the same, continuing an existing stream (e.g. the one SBC.synthesize already consumed from, incl. a cached gaussian) */
+int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, int n, const jrandom *init,
+                           double *draws, double *mass_out, orc_stats *stats) {
+  jrandom rng = *init;
   orc_leapfrog *lf = orc_lf_new(f, ctx, n, &rng, cfg->math_mode);
   double *params = calloc(2 * n + 1, sizeof(double));
   double *massbuf = calloc(n, sizeof(double));

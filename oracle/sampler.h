@@ -47,6 +47,9 @@ typedef struct {
 int orc_sample_chain(const orc_config *cfg, orc_density_fn f, void *ctx, int nvars, int64_t seed,
                      double *draws, double *mass_out, orc_stats *stats);
 
+int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, int nvars, const jrandom *init,
+                           double *draws, double *mass_out, orc_stats *stats);
+
 /* ---- exposed pieces (unit tests) ------------------------------------------------------- */
 typedef struct orc_leapfrog orc_leapfrog;
 orc_leapfrog *orc_lf_new(orc_density_fn f, void *ctx, int nvars, jrandom *rng, int math_mode);

@@ -70,6 +70,9 @@ def load():
     lib.orc_sample_chain.restype = C.c_int
     lib.orc_sample_chain.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int64, dp, dp,
                                      C.POINTER(OrcStats)]
+    lib.orc_sample_chain_state.restype = C.c_int
+    lib.orc_sample_chain_state.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(JRandom), dp, dp,
+                                           C.POINTER(OrcStats)]
     lib.orc_lf_new.restype = C.c_void_p
     lib.orc_lf_new.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(JRandom), C.c_int]
     lib.orc_lf_free.argtypes = [C.c_void_p]
@@ -163,6 +166,14 @@ def sample_chain(density_fn_ptr, ctx, nvars, cfg, seed):
     mass = np.zeros(nvars)
     st = OrcStats()
     rc = lib.orc_sample_chain(C.byref(cfg), density_fn_ptr, ctx, nvars, seed, _dp(draws), _dp(mass), C.byref(st))
+    return draws, mass, st, rc
+
+
+def sample_chain_state(density_fn_ptr, ctx, nvars, cfg, rstate):
+    """Driver.sample continuing an existing java.util.Random state (JRandom struct)."""
+    lib = load()
+    draws = np.zeros((cfg.iterations, nvars)); mass = np.zeros(nvars); st = OrcStats()
+    rc = lib.orc_sample_chain_state(C.byref(cfg), density_fn_ptr, ctx, nvars, C.byref(rstate), _dp(draws), _dp(mass), C.byref(st))
     return draws, mass, st, rc
 
 

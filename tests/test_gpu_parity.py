@@ -449,3 +449,16 @@ def test_nuts_recovers_posteriors_on_both_engines():
     assert [st.leapfrogSteps for st in x.stats] == [st.leapfrogSteps for st in y.stats]
     with pytest.raises(R.RainierHipError):
         m.sample(R.make_config(5, 5, R.NUTSSampler(13)), seeds=[1])
+
+
+@pytest.mark.parametrize("name", ["SBCBernoulli", "SBCGeometric"])
+def test_gpu_reproduces_more_reference_goldsets(name):
+    # Lookup/Compare (Bernoulli) and data-linear (Geometric) likelihoods against the JVM-recorded outputs, rel 1e-10
+    from tests import test_reference_goldset as G
+    spec, rstate, predict_fn = {"SBCBernoulli": G.bernoulli_spec, "SBCGeometric": G.geometric_spec}[name]()
+    assert not rstate.have_next
+    gold = np.array(G.ALL["models"][name]["goldset"])
+    cfg = R.make_config(len(gold), G.ALL["warmup"], R.HMCSampler(1), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    for kw in (dict(math_mode=_capi.MATH_STRICT), dict(fp_contract=True, factor_outputs=True)):
+        tr = R.Model(spec, device=0, **kw).sample(cfg, seeds=[rstate.seed ^ 0x5DEECE66D])
+        assert np.abs((predict_fn(tr.chains[0]) - gold) / gold).max() < 1e-10, kw

@@ -74,3 +74,66 @@ def sample_chain_with_rng_state(oracle, density, cfg, rstate):
     draws, mass, st, rc = O.sample_chain(density.fn_ptr, density.handle, 1, cfg, seed)
     assert rc == 0
     return draws
+
+
+# ---- more of the reference's goldsets (SBCModel.scala:46-267 via tests/golden/sbc_goldsets.json) -----------------
+ALL = json.load(open(os.path.join(HERE, "golden", "sbc_goldsets.json")))
+
+
+def _uniform01_prior(g):
+    v = g.param(0)
+    x = 1.0 / ((v * -1.0).exp() + 1.0)          # BoundedSupport(0,1).transform = logistic (core/Support.scala:62-68)
+    return x, x.log() + (1.0 - x).log()         # logJacobian; Beta(1,1).logDensity folds to 0
+
+
+def bernoulli_spec():
+    """SBCBernoulli: Bernoulli(x), x ~ Uniform(0,1).  Data: u <= x0 ? 1 : 0 (core/Discrete.scala:43-48);
+    logDensity = Real.eq(v, 0, log(1-p), log p) (Discrete.scala:50-51) -> Lookup(Compare) on the engine."""
+    rng = O.JavaRandom(ALL["seed"]); x0 = rng.next_double()
+    ys = np.array([1.0 if rng.next_double() <= x0 else 0.0 for _ in range(1000)])
+    g = Graph(1, [0, 1]); x, prior = _uniform01_prior(g); y = g.col(1, 0)
+    row = g.eq(y, 0.0, (1.0 - x).log(), x.log())
+    return models.ModelSpec("sbc_bernoulli", g.compile([prior, row]), [ys], [0, 1000], 1), rng.r, lambda d: 1 / (1 + np.exp(-d[:, 0]))
+
+
+def geometric_spec():
+    """SBCGeometric: data floor(log(u)/log(1-x0)) (Discrete.scala:64-69); logDensity = log p + v log(1-p) (:71-72)."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = rng.next_double()
+    ys = np.array([float(math.floor(math.log(rng.next_double()) / math.log(1 - x0))) for _ in range(1000)])
+    g = Graph(1, [0, 1]); x, prior = _uniform01_prior(g); y = g.col(1, 0)
+    row = x.log() + y * (1.0 - x).log()
+    return models.ModelSpec("sbc_geometric", g.compile([prior, row]), [ys], [0, 1000], 1), rng.r, lambda d: 1 / (1 + np.exp(-d[:, 0]))
+
+
+def laplace_spec():
+    """SBCLaplace: Laplace(x, x), x ~ LogNormal(0,1) = exp(z), z standard normal (Continuous.scala:63-67,194-197;
+    Injection.scala:82-103).  Data: x0 = exp(g1); y = signum(u)(-1)log(1-2|u|) * x0 + x0, u = uniform - 0.5
+    (Continuous.scala:83-90).  logDensity(y) = log 0.5 - |(y-x)/x| - log x.  The first gaussian leaves its twin cached, so
+    the sampler's first standardNormal returns it: the stream is continued by STATE, not by seed."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = math.exp(rng.next_gaussian() * 1.0 + 0.0)
+    ys = []
+    for _ in range(1000):
+        u = rng.next_double() - 0.5
+        sgn = (u > 0) - (u < 0)
+        ys.append((sgn * -1 * math.log(1 - (2 * abs(u)))) * x0 + x0)
+    g = Graph(1, [0, 1]); z = g.param(0); x = z.exp(); y = g.col(1, 0)
+    prior = models.std_normal_logpdf(z)
+    row = (math.log(0.5) - ((y - x) / x).abs()) - x.log()
+    return models.ModelSpec("sbc_laplace", g.compile([prior, row]), [np.array(ys)], [0, 1000], 1), rng.r, lambda d: np.exp(d[:, 0])
+
+
+@pytest.mark.parametrize("name,builder", [("SBCBernoulli", bernoulli_spec), ("SBCGeometric", geometric_spec),
+                                          ("SBCLaplace", laplace_spec)])
+def test_oracle_reproduces_more_reference_goldsets(oracle, name, builder):
+    spec, rstate, predict_fn = builder()
+    gold = np.array(ALL["models"][name]["goldset"])
+    for mode in (O.JM_LIBM, O.JM_DET):
+        cfg = O.make_config(sampler=O.HMC, n_steps=1, iterations=len(gold), warmup=ALL["warmup"], step_tuner=O.STEP_DUALAVG,
+                            delta=0.8, mass_tuner=O.MASS_IDENTITY, math_mode=mode)
+        d = O.OracleDensity(spec, mode)
+        draws, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, cfg, rstate)
+        assert rc == 0
+        rel = np.abs((predict_fn(draws) - gold) / gold)
+        assert rel.max() < 1e-10, (name, mode, rel.max())
