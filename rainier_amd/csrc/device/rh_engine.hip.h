@@ -917,6 +917,7 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
     for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
   }
+  if (!__syncthreads_or(any ? 1 : 0)) return;
   int err = 0;
   rh_grad_lds_targets<0>(th, d, lane, wave, split, nsplit, chain0, chains, any, partial, rh_lds, err);
   if (err && lane == 0) atomicOr(err_out, 1);
@@ -942,7 +943,10 @@ typedef double rh_v4d __attribute__((ext_vector_type(4)));
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
-extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W)
+#ifndef RH_GLM_WAVES_PER_SIMD
+#define RH_GLM_WAVES_PER_SIMD 2
+#endif
+extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIMD)
 rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
@@ -967,6 +971,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const int mychain = chain0 + li;
   const int cl = mychain < chains ? mychain : chains - 1;
   const bool compute = __any((mychain < chains) && (active[cl] != 0));
+  if (!__syncthreads_or(compute ? 1 : 0)) return; // no chain of this workgroup is waiting for a gradient
   // forward B operands: lane (li, lg) holds theta[chain li][pred 4 ks + lg]
   double Bf[PT];
   int acol[PT];
@@ -1026,14 +1031,20 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll 1
       for (int sub = 0; sub < 4; sub++) {
         const int row0s = sub * 16;
-        rh_v4d D = (rh_v4d){0.0, 0.0, 0.0, 0.0};
+        // two independent accumulators halve the dependent-MFMA chain of the forward product
+        rh_v4d D = (rh_v4d){0.0, 0.0, 0.0, 0.0}, D2 = (rh_v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < PT; ks++) {
           const double a = acol[ks] >= 0 ? tile[acol[ks] * RH_GLM_TRP + row0s + li] : (acol[ks] == -1 ? 1.0 : 0.0);
-          D = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bf[ks], D, 0, 0, 0);
+          if (ks & 1) D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bf[ks], D2, 0, 0, 0);
+          else D = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bf[ks], D, 0, 0, 0);
         }
+        D += D2;
         rh_v4d Wv;
-#pragma unroll
+#ifndef RH_GLM_ELEM_UNROLL
+#define RH_GLM_ELEM_UNROLL 4
+#endif
+#pragma unroll RH_GLM_ELEM_UNROLL
         for (int r = 0; r < 4; r++) {
           const int rrow = row0s + lg + 4 * r;
           const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);

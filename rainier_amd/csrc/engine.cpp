@@ -175,6 +175,11 @@ void assemble_source(rh_model *m) {
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
   { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
   m->has_glm = defines.find("#define RH_GLM_TARGET ") != std::string::npos;
+  // experiment knobs of the MFMA GLM kernel (workgroup waves, forced waves per SIMD, scalar-part unroll)
+  if (const char *e = std::getenv("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
+  defines += "#define RH_GLM_W " + std::to_string(m->glm_w) + "\n";
+  if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
