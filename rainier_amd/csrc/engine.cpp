@@ -129,7 +129,7 @@ struct rh_model {
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
-  int glm_w = 4;
+  int glm_w = 8;
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   int state_words = 0;
   rh_model_data data{};
