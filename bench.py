@@ -64,7 +64,7 @@ def side_workload(a, R, models, rank, local_rank, world):
     """cfg1 (funnel, HMC L=5) / cfg3 (eight schools, DefaultConfig: EHMC(1024) + DualAvg + windowed diagonal mass):
     data-free models on the chain-per-wavefront engine.  Single-process timing only."""
     spec = models.funnel(10) if a.workload == "cfg1" else models.eight_schools()
-    model = R.Model(spec, device=local_rank)
+    model = R.Model(spec, device=local_rank, fp_contract=not a.strict, factor_outputs=not a.strict)
     cpg = a.chains_per_gpu
     cfg = R.HMC(a.warmup, a.steps, 5) if a.workload == "cfg1" else R.make_config(a.steps, a.warmup)
     if a.sampler == "nuts":

@@ -49,6 +49,9 @@ struct TargetEmitter {
   Program P;  // private copy: factoring appends synthesized nodes
   uint32_t t;
   bool factor;
+  bool fast_div = false;       // fast mode: x / const -> x * (1/const)
+  uint32_t run_end = 0;        // data-free targets t..run_end are emitted together (shared sub-expressions once)
+  bool merged_away = false;    // this data-free target was emitted by an earlier one of its run
   std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;  // hash-consing of synthesized nodes
   std::map<uint32_t, Lin> memo;
   std::vector<uint32_t> basis;            // basis term node ids, accumulator order
@@ -56,7 +59,7 @@ struct TargetEmitter {
   std::map<uint32_t, int> inv_slot;       // non-trivial invariant node -> index in inv[]
   std::vector<char> reach_row, reach_inv;
 
-  TargetEmitter(const Program &p, uint32_t ti, bool f) : P(p), t(ti), factor(f) {
+  TargetEmitter(const Program &p, uint32_t ti, bool f) : P(p), t(ti), factor(f), run_end(ti) {
     for (uint32_t i = 0; i < P.nodes.size(); i++)  // let synthesized nodes reuse identical existing ones
       if (P.nodes[i].op >= RH_RIR_ADD && P.nodes[i].op <= RH_RIR_DIV) cons.emplace(std::make_tuple(P.nodes[i].op, P.nodes[i].a, P.nodes[i].b), i);
   }
@@ -194,7 +197,8 @@ struct TargetEmitter {
       for (auto &kv : inv_slot) reach_inv[kv.first] = 1;
       sweep(reach_inv);
     } else {
-      for (uint32_t o : T.outputs) reach_row[o] = 1;
+      for (uint32_t tt = t; tt <= run_end; tt++)
+        for (uint32_t o : P.targets[tt].outputs) reach_row[o] = 1;
       sweep(reach_row);
     }
   }
@@ -212,6 +216,14 @@ struct TargetEmitter {
     if (ctx != 0 && has_rows() && nd.dep == 0) return "inv[" + std::to_string(inv_slot.at(id)) + "]";
     return "n" + std::to_string(id);
   }
+  // fast mode only: division by a finite non-zero constant becomes a multiplication by its reciprocal (<= 1 ulp apart)
+  bool recip_const(uint32_t b, std::string &out) const {
+    if (!fast_div || b >= P.nodes.size()) return false;
+    const Node &nb = P.nodes[b];
+    if (nb.op != RH_RIR_CONST || nb.cval == 0.0 || !std::isfinite(nb.cval) || !std::isfinite(1.0 / nb.cval)) return false;
+    out = lit(1.0 / nb.cval);
+    return true;
+  }
   bool emit_node(std::ostringstream &os, uint32_t id, int ctx, std::string &err) const {
     const Node &nd = P.nodes[id];
     auto R = [&](uint32_t x) { return ref(x, ctx); };
@@ -220,7 +232,7 @@ struct TargetEmitter {
       case RH_RIR_ADD: os << lhs << R(nd.a) << " + " << R(nd.b) << ";\n"; break;
       case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
       case RH_RIR_MUL: os << lhs << R(nd.a) << " * " << R(nd.b) << ";\n"; break;
-      case RH_RIR_DIV: os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break;
+      case RH_RIR_DIV: { std::string rc; if (recip_const(nd.b, rc)) os << lhs << R(nd.a) << " * " << rc << ";\n"; else os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break; }
       case RH_RIR_POW: os << lhs << "rh_java_pow(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_COMPARE: os << lhs << "rh_compare(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_EXP: os << lhs << "RH_EXP(" << R(nd.a) << ");\n"; break;
@@ -402,7 +414,7 @@ struct TargetEmitter {
       case RH_RIR_ADD: os << lhs << R(nd.a) << " + " << R(nd.b) << ";\n"; break;
       case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
       case RH_RIR_MUL: os << lhs << R(nd.a) << " * " << R(nd.b) << ";\n"; break;
-      case RH_RIR_DIV: os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break;
+      case RH_RIR_DIV: { std::string rc; if (recip_const(nd.b, rc)) os << lhs << R(nd.a) << " * " << rc << ";\n"; else os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break; }
       case RH_RIR_POW: os << lhs << "rh_java_pow(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_COMPARE: os << lhs << "rh_compare(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_EXP: os << lhs << "RH_EXP(" << R(nd.a) << ");\n"; break;
@@ -474,14 +486,18 @@ struct TargetEmitter {
       // data-free target: evaluated once, outputs(o) += f_o(theta)  (DataFunction.scala:73-83)
       os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
             "    (void)th; (void)inv; (void)c; (void)err;\n";
-      for (size_t n = 0; n < P.nodes.size(); n++) {
-        if (!reach_row[n] || trivial((uint32_t)n)) continue;
-        if (!emit_node(os, (uint32_t)n, 1, err)) return false;
-      }
-      for (size_t o = 0; o < T.outputs.size(); o++) {
-        const Node &on = P.nodes[T.outputs[o]];
-        if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
-        os << "    acc[" << o << "] += " << ref(T.outputs[o], 1) << ";\n";
+      if (!merged_away) {
+        for (size_t n = 0; n < P.nodes.size(); n++) {
+          if (!reach_row[n] || trivial((uint32_t)n)) continue;
+          if (!emit_node(os, (uint32_t)n, 1, err)) return false;
+        }
+        // accumulate target by target, in DataFunction order; every node above was evaluated exactly once
+        for (uint32_t tt = t; tt <= run_end; tt++)
+          for (size_t o = 0; o < P.targets[tt].outputs.size(); o++) {
+            const Node &on = P.nodes[P.targets[tt].outputs[o]];
+            if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
+            os << "    acc[" << o << "] += " << ref(P.targets[tt].outputs[o], 1) << ";\n";
+          }
       }
       os << "  }\n";
     }
@@ -499,6 +515,11 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   int nacc_max = 1, nrowt = 0, glm_target = -1;
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
+    te.fast_div = o.fp_contract;
+    if (P.targets[t].n_cols == 0) {  // runs of consecutive data-free targets share one evaluation
+      if (t > 0 && P.targets[t - 1].n_cols == 0) te.merged_away = true;
+      else { uint32_t e = t; while (e + 1 < P.targets.size() && P.targets[e + 1].n_cols == 0) e++; te.run_end = e; }
+    }
     te.plan();
     if (!te.emit(os, err)) return false;
     if (glm_target < 0 && o.glm_mfma) {

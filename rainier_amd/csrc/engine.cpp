@@ -50,6 +50,15 @@ struct Fail {
     if (e_ != hipSuccess) throw Fail{RH_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; \
   } while (0)
 
+// device allocation released on scope exit (also when a HIP call throws)
+struct DevBuf {
+  void *p = nullptr;
+  explicit DevBuf(size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 8); if (e != hipSuccess) throw Fail{RH_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)}; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+
 uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ULL) {
   for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ULL; }
   return h;
@@ -201,18 +210,7 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
-void build_code(rh_model *m) {
-  int hv = 0;
-  hiprtcVersion(&hv, &hv);
-  const uint64_t h = fnv1a(m->arch + "|" + std::to_string(hv) + "|" + m->source);
-  char name[64];
-  std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
-  const std::string path = cache_dir() + name;
-  if (!std::getenv("RH_NO_KERNEL_CACHE") && read_file(path, m->code)) return;
-  std::string log;
-  m->code = compile_hip(m->source, m->arch, log);
-  if (!std::getenv("RH_NO_KERNEL_CACHE")) write_file(path, m->code);
-}
+void build_code(rh_model *m) { m->code = build_source(m->arch, m->source); }
 
 void load_module(rh_model *m) {
   HIPCHK(hipSetDevice(m->device));
@@ -388,11 +386,8 @@ extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, dou
   const int rc = guard(m, [&] {
     HIPCHK(hipSetDevice(m->device));
     const int n = (int)m->prog.n_params;
-    void *dq = nullptr, *dl = nullptr, *dg = nullptr, *de = nullptr;
-    HIPCHK(hipMalloc(&dq, sizeof(double) * n * chains));
-    HIPCHK(hipMalloc(&dl, sizeof(double) * chains));
-    HIPCHK(hipMalloc(&dg, sizeof(double) * n * chains));
-    HIPCHK(hipMalloc(&de, sizeof(int)));
+    DevBuf bq(sizeof(double) * n * chains), bl(sizeof(double) * chains), bg(sizeof(double) * n * chains), be(sizeof(int));
+    void *dq = bq.p, *dl = bl.p, *dg = bg.p, *de = be.p;
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(de, 0, sizeof(int), m->stream));
     int ch = chains;
@@ -402,7 +397,6 @@ extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, dou
     HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * n * chains, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(&lookup_err, de, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    hipFree(dq); hipFree(dl); hipFree(dg); hipFree(de);
   });
   if (rc == RH_OK && lookup_err) { m->err = g_err = "Lookup index out of range during evaluation"; return RH_E_LOOKUP; }
   return rc;
@@ -413,17 +407,15 @@ extern "C" int rh_selftest(rh_model *m, int32_t mode, int64_t seed, const double
   std::lock_guard<std::mutex> lk(m->mu);
   return guard(m, [&] {
     HIPCHK(hipSetDevice(m->device));
-    void *din = nullptr, *dout = nullptr;
     const size_t in_n = mode == 5 ? 2 * (size_t)n : (size_t)n;
-    HIPCHK(hipMalloc(&din, sizeof(double) * in_n));
-    HIPCHK(hipMalloc(&dout, sizeof(double) * n));
+    DevBuf bin(sizeof(double) * in_n), bout(sizeof(double) * n);
+    void *din = bin.p, *dout = bout.p;
     if (mode >= 2) HIPCHK(hipMemcpyAsync(din, in, sizeof(double) * in_n, hipMemcpyHostToDevice, m->stream));
     int md = mode, nn = n; long long sd = seed;
     void *args[] = {&md, &sd, &din, &dout, &nn};
     launch(m->k_selftest, mode <= 1 ? 1u : 64u, 64, m->stream, args);
     HIPCHK(hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    hipFree(din); hipFree(dout);
   });
 }
 
