@@ -13,7 +13,8 @@
  *
  * All fields are uint32 unless noted; a double is stored as its IEEE-754 bits, low word first.
  *
- *   header   : magic 0x31524952 ("RIR1"), version = 1, n_params, n_targets, n_nodes, reserved = 0
+ *   header   : magic 0x31524952 ("RIR1"), version = 1, n_params, n_targets, n_nodes, kind (0 = density program,
+ *              1 = requirements program for rh_requirements_eval: data-free targets, outputs[0] = one requirement each)
  *   targets  : n_targets x { n_cols, reserved = 0, outputs[n_params + 1] }
  *              outputs are node ids: [value, d/d theta_0 .. d/d theta_{n-1}]  (compute/Target.scala:50-56)
  *              target order is the DataFunction's: "prior" first, then one per likelihood.

@@ -213,3 +213,19 @@ static int update_impl(rir_density *d, const double *q, double *out, int acc_mod
 int rir_density_update(void *d, const double *q, double *out) { return update_impl((rir_density *)d, q, out, ACC_F64); }
 int rir_density_abs_sums(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_ABS); }
 int rir_density_update_ld(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_LD); }
+
+/* Generator.prepare (core/Generator.scala:76-84): the compiled requirements evaluated at one draw.
+ * A requirements program has one data-free target per requirement, outputs[0] = the requirement. */
+int rir_requirements_eval(rir_density *d, const double *q, double *out) {
+  const rir_prog *p = d->prog;
+  double *in = calloc(p->n_inputs ? p->n_inputs : 1, sizeof(double));
+  memcpy(in, q, sizeof(double) * p->n_params);
+  d->lookup_error = 0;
+  for (uint32_t t = 0; t < p->n_targets; t++) {
+    const rir_target *tg = &p->targets[t];
+    for (uint32_t i = 0; i < tg->n_once; i++) eval_node(d, tg->once_nodes[i], in);
+    out[t] = d->val[tg->outputs[0]];
+  }
+  free(in);
+  return d->lookup_error;
+}

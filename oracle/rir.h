@@ -70,4 +70,6 @@ int rir_density_update(void *d, const double *q, double *out);
 int rir_density_abs_sums(rir_density *d, const double *q, double *abs_out);
 /* long-double accumulation variant (which side is closer to the true sum) */
 int rir_density_update_ld(rir_density *d, const double *q, double *out);
+/* requirements program (header kind 1): out[t] = value of target t's outputs[0] at q */
+int rir_requirements_eval(rir_density *d, const double *q, double *out);
 #endif

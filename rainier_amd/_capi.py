@@ -26,7 +26,7 @@ EXPORTS = [
     "rh_model_create", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
     "rh_density_eval", "rh_config_default", "rh_sample", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
-    "rh_sampler_timing", "rh_diagnostics", "rh_abi_version", "rh_device_count",
+    "rh_sampler_timing", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
     L.rh_sampler_stats.argtypes = [vp, C.POINTER(ChainStats), dp]
     L.rh_sampler_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
     L.rh_diagnostics.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
+    L.rh_requirements_eval.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), dp, C.c_int64, dp]
     L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.rh_free.argtypes = [vp]
     L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]

@@ -544,4 +544,32 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   defines = d.str();
   return true;
 }
+bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {
+  // one shared evaluation of the union DAG (like a run of data-free targets), then out[m] = requirement m
+  TargetEmitter te(P, 0, false);
+  te.fast_div = o.fp_contract;
+  te.run_end = (uint32_t)P.targets.size() - 1;
+  for (uint32_t t = 0; t < P.targets.size(); t++)
+    if (P.targets[t].n_cols) { err = "requirements program with data columns"; return false; }
+  te.reach_row.assign(P.nodes.size(), 0);
+  for (auto &T : P.targets) te.reach_row[T.outputs[0]] = 1;
+  te.sweep(te.reach_row);
+  std::ostringstream os;
+  if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
+  os << "RH_DEV void rh_req_eval(const double (&th)[RH_NVARS], double (&out)[RH_NREQ], int &err) {\n  (void)th; (void)err;\n"
+        "  const double *inv = nullptr, *c = nullptr; (void)inv; (void)c;\n";
+  for (size_t n = 0; n < P.nodes.size(); n++) {
+    if (!te.reach_row[n] || te.trivial((uint32_t)n)) continue;
+    if (!te.emit_node(os, (uint32_t)n, 1, err)) return false;
+  }
+  for (size_t m = 0; m < P.targets.size(); m++) os << "  out[" << m << "] = " << te.ref(P.targets[m].outputs[0], 1) << ";\n";
+  os << "}\n#pragma clang fp contract(off)\n";
+  body = os.str();
+  std::ostringstream d;
+  d << "#define RH_NVARS " << P.n_params << "\n#define RH_SLOTS " << ((P.n_params + 63) / 64) << "\n#define RH_NREQ " << P.targets.size() << "\n";
+  if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
+  else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
+  defines = d.str();
+  return true;
+}
 }  // namespace rh

@@ -276,6 +276,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
   const int rc = guard(m, [&] {
     std::string err;
     if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
+    if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "rh_model_create needs a density program (header kind 0)"};
     int dev = -1;
     if (opts) {
       if (opts->struct_size != (int32_t)sizeof(rh_compile_opts)) throw Fail{RH_E_INVALID, "rh_compile_opts.struct_size mismatch"};
@@ -359,6 +360,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
   const int rc = guard(nullptr, [&] {
     std::string err;
     if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
+    if (m.prog.kind != 0) throw Fail{RH_E_INVALID, "rh_lower_only needs a density program (header kind 0)"};
     if (opts) {
       m.eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
       m.eopt.fp_contract = opts->fp_contract != 0;
@@ -717,6 +719,70 @@ extern "C" int rh_sample(rh_model *m, const rh_config *cfg, const int64_t *seeds
   if (rc == RH_OK && draws && cfg->iterations > 0) rc = rh_sampler_draws(s, 0, cfg->iterations, draws);
   if (rc == RH_OK) rc = rh_sampler_stats(s, stats, mass_diag);
   rh_sampler_destroy(s);
+  return rc;
+}
+
+// ---- Generator.prepare / Trace.predict: requirements evaluated for every draw on the device ---------------------------
+static const char *kReqKernel = R"RHSRC(
+// one thread per draw: th = draws[d][:], out[d][:] = the requirements (core/Generator.scala:76-84 per draw, batched)
+extern "C" __global__ void __launch_bounds__(256)
+rh_req_kernel(const double *__restrict__ draws, double *__restrict__ out, const long long ndraws, int *__restrict__ err_out) {
+  const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (d >= ndraws) return;
+  double th[RH_NVARS];
+#pragma unroll
+  for (int i = 0; i < RH_NVARS; i++) th[i] = draws[d * RH_NVARS + i];
+  double o[RH_NREQ];
+  int err = 0;
+  rh_req_eval(th, o, err);
+#pragma unroll
+  for (int m = 0; m < RH_NREQ; m++) out[d * RH_NREQ + m] = o[m];
+  if (err) atomicOr(err_out, 1);
+}
+)RHSRC";
+
+extern "C" int rh_requirements_eval(const void *rir, size_t rir_len, const rh_compile_opts *opts, const double *draws,
+                                    int64_t ndraws, double *out) {
+  if (!draws || !out || ndraws < 0) { g_err = "rh_requirements_eval: bad arguments"; return RH_E_INVALID; }
+  int lookup_err = 0;
+  const int rc = guard(nullptr, [&] {
+    rh::Program P; std::string err;
+    if (!rh::parse_rir(rir, rir_len, P, err)) throw Fail{RH_E_INVALID, err};
+    if (P.kind != 1) throw Fail{RH_E_INVALID, "not a requirements program (header kind != 1)"};
+    rh::EmitOptions eo;
+    int dev = -1;
+    if (opts) { eo.strict_math = opts->math_mode == RH_MATH_STRICT; eo.fp_contract = opts->fp_contract != 0; dev = opts->device; }
+    std::string defines, body;
+    if (!rh::emit_requirements(P, eo, defines, body, err)) throw Fail{RH_E_UNSUPPORTED, err};
+    const std::string src = "// generated by rainier-hip: requirements program\n" + defines + kSharedSrc + "\n" + kPreludeSrc + "\n" + body + kReqKernel;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      if (std::getenv("RH_LOWER_ONLY")) { (void)build_source("gfx950", src); return; }   // build()/CPU tests: cross-compile only
+      throw Fail{RH_E_DEVICE, "no HIP device available: the engine has no CPU fallback"};
+    }
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    std::string arch = prop.gcnArchName;
+    if (arch.find(':') != std::string::npos) arch = arch.substr(0, arch.find(':'));
+    const std::vector<char> code = build_source(arch, src);
+    hipModule_t mod; hipFunction_t fn;
+    HIPCHK(hipModuleLoadData(&mod, code.data()));
+    struct Unload { hipModule_t m; ~Unload() { (void)hipModuleUnload(m); } } unload{mod};
+    HIPCHK(hipModuleGetFunction(&fn, mod, "rh_req_kernel"));
+    if (ndraws == 0) return;
+    const size_t nv = P.n_params, nr = P.targets.size();
+    DevBuf bd(sizeof(double) * nv * ndraws), bo(sizeof(double) * nr * ndraws), be(sizeof(int));
+    HIPCHK(hipMemcpy(bd.p, draws, sizeof(double) * nv * ndraws, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(be.p, 0, sizeof(int)));
+    void *dd = bd.p, *dout = bo.p, *de = be.p; long long nd = ndraws;
+    void *args[] = {&dd, &dout, &nd, &de};
+    launch(fn, (unsigned)((ndraws + 255) / 256), 256, nullptr, args);
+    HIPCHK(hipMemcpy(out, bo.p, sizeof(double) * nr * ndraws, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&lookup_err, be.p, sizeof(int), hipMemcpyDeviceToHost));
+  });
+  if (rc == RH_OK && lookup_err) { g_err = "Lookup index out of range during evaluation"; return RH_E_LOOKUP; }
   return rc;
 }
 

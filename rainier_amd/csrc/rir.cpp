@@ -30,8 +30,9 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
   if (r.u32() != RH_RIR_VERSION) { err = "RIR: unsupported version"; return false; }
   P.n_params = r.u32();
   const uint32_t n_targets = r.u32(), n_nodes = r.u32();
-  (void)r.u32();
-  if (P.n_params == 0 || n_targets == 0 || n_targets > RH_MAX_TARGETS) { err = "RIR: bad header (params/targets)"; return false; }
+  P.kind = r.u32();
+  if (P.kind > 1) { err = "RIR: unknown program kind"; return false; }
+  if (P.n_params == 0 || n_targets == 0 || n_targets > (P.kind == 1 ? 4096u : (uint32_t)RH_MAX_TARGETS)) { err = "RIR: bad header (params/targets)"; return false; }
   if ((size_t)n_nodes * 8 > len) { err = "RIR: node count exceeds blob"; return false; }
   P.targets.resize(n_targets);
   uint32_t in = P.n_params, col = 0;
@@ -44,6 +45,7 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
     if (r.bad) { err = "RIR: truncated target table"; return false; }
   }
   if (col > RH_MAX_COLS) { err = "RIR: too many data columns"; return false; }
+  if (P.kind == 1 && col != 0) { err = "RIR: a requirements program cannot have data columns"; return false; }
   P.n_inputs = in; P.n_cols_total = col;
   P.nodes.resize(n_nodes);
   for (uint32_t i = 0; i < n_nodes; i++) {

@@ -23,7 +23,7 @@ struct Target {
 };
 
 struct Program {
-  uint32_t n_params = 0, n_inputs = 0, n_cols_total = 0;
+  uint32_t n_params = 0, n_inputs = 0, n_cols_total = 0, kind = 0;  // kind 1 = requirements program
   std::vector<Target> targets;
   std::vector<Node> nodes;
 };
@@ -46,5 +46,8 @@ struct EmitOptions {
 // Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).
 // The replacement for the reference's ASM generators (ir/ExprMethodGenerator.scala, ir/OutputClassGenerator.scala).
 bool emit_hip(const Program &p, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err);
+
+// Lowers a requirements program (kind 1) to  rh_req_eval(th, out, err)  + defines RH_NVARS / RH_NREQ.
+bool emit_requirements(const Program &p, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 
 }  // namespace rh

@@ -244,6 +244,20 @@ class Graph:
         return seen
 
     # -- serialisation -------------------------------------------------------------------
+    def compile_requirements(self, exprs: Sequence[Expr]) -> bytes:
+        """Requirements program (header kind 1) for rh_requirements_eval: what Generator.prepare compiles with
+        Compiler.default.compile(parameters, namedReqs) (core/Generator.scala:76-78).  Parameter-only expressions."""
+        assert all(c == 0 for c in self.target_cols), "requirements cannot read data columns"
+        zero = self.const(0.0)
+        saved = self.target_cols
+        self.target_cols = [0] * len(exprs)
+        try:
+            blob = bytearray(self.compile(list(exprs), gradients=[[zero] * self.n_params for _ in exprs]))
+        finally:
+            self.target_cols = saved
+        blob[20:24] = struct.pack("<I", 1)
+        return bytes(blob)
+
     def compile(self, targets: Sequence[Expr], gradients: Sequence[Sequence[Expr]] = None) -> bytes:
         """targets[t] = log-density contribution of target t (per row if it has columns).
         Returns the RIR blob with outputs [value, d/dθ_0 .. d/dθ_{n-1}] per target."""

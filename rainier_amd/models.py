@@ -156,3 +156,11 @@ def normal_1d() -> ModelSpec:
     x = g.param(0)
     rir = g.compile([(x * x) / -2.0])
     return ModelSpec("normal1d", rir, [], [0], 1, {"kind": "normal1d"})
+
+
+def funnel_predict(dim: int = 10):
+    """Requirements of cfg 1's predict(): y = 3 z0, x_i = z_i exp(y/2) -- where the funnel shape appears."""
+    g = Graph(dim, [])
+    y = g.param(0) * 3.0
+    xs = [g.param(i) * (y / 2.0).exp() for i in range(1, dim)]
+    return g.compile_requirements([y] + xs), dim

@@ -202,6 +202,19 @@ def diagnostics(chains: np.ndarray):
     return list(zip(rhat.tolist(), ess.tolist()))
 
 
+def predict(requirements_rir: bytes, draws: np.ndarray, n_requirements: int, device: int = -1,
+            math_mode: int = _capi.MATH_FAST) -> np.ndarray:
+    """Trace.predict's compiled part (core/Trace.scala:34-41, core/Generator.scala:59-94): evaluate the requirements
+    program for every draw on the device.  draws [..., nVars] -> [..., n_requirements]."""
+    d = np.ascontiguousarray(draws, dtype=np.float64)
+    flat = d.reshape(-1, d.shape[-1])
+    out = np.zeros((flat.shape[0], n_requirements))
+    blob = C.create_string_buffer(requirements_rir, len(requirements_rir))
+    opts = _capi.compile_opts(device, math_mode)
+    _capi.check(_capi.lib().rh_requirements_eval(blob, len(requirements_rir), C.byref(opts), _capi.dptr(flat), flat.shape[0], _capi.dptr(out)))
+    return out.reshape(d.shape[:-1] + (n_requirements,))
+
+
 class Sampler:
     """Device-resident chains: split form of Driver.sample used by bench.py (create -> warmup -> run)."""
 

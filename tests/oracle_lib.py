@@ -67,6 +67,7 @@ def load():
     lib.rir_density_free.argtypes = [C.c_void_p]
     for f in (lib.rir_density_update, lib.rir_density_abs_sums, lib.rir_density_update_ld):
         f.restype = C.c_int; f.argtypes = [C.c_void_p, dp, dp]
+    lib.rir_requirements_eval.restype = C.c_int; lib.rir_requirements_eval.argtypes = [C.c_void_p, dp, dp]
     lib.orc_sample_chain.restype = C.c_int
     lib.orc_sample_chain.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int64, dp, dp,
                                      C.POINTER(OrcStats)]
@@ -126,6 +127,12 @@ class OracleDensity:
     def update(self, q):
         rc, out = self._call(self.lib.rir_density_update, q)
         if rc:
+            raise RuntimeError("lookup index out of range")
+        return out
+
+    def requirements(self, q, n_req):
+        q = np.ascontiguousarray(q, dtype=np.float64); out = np.zeros(n_req)
+        if self.lib.rir_requirements_eval(self.handle, _dp(q), _dp(out)):
             raise RuntimeError("lookup index out of range")
         return out
 

@@ -96,3 +96,18 @@ def test_diagnostics_match_oracle(lib):
         assert got[p][0] == pytest.approx(rhat, rel=1e-13) and got[p][1] == pytest.approx(ess, rel=1e-12)
     with pytest.raises(ValueError):
         R.diagnostics(x[:1])
+
+
+def test_requirements_program_lowers(lib, monkeypatch):
+    import ctypes as C
+    rir, nreq = models.funnel_predict(10)
+    monkeypatch.setenv("RH_LOWER_ONLY", "1")
+    draws = np.zeros((2, 10)); out = np.zeros((2, nreq))
+    blob = C.create_string_buffer(rir, len(rir))
+    rc = lib.rh_requirements_eval(blob, len(rir), None, _capi.dptr(draws), 2, _capi.dptr(out))
+    assert rc == (_capi.RH_OK if lib.rh_device_count() == 0 else rc)
+    # a density program is rejected by the predict entry point and vice versa
+    bad = C.create_string_buffer(models.funnel().rir, len(models.funnel().rir))
+    assert lib.rh_requirements_eval(bad, len(models.funnel().rir), None, _capi.dptr(draws), 2, _capi.dptr(out)) == _capi.RH_E_INVALID
+    with pytest.raises(_capi.RainierHipError):
+        _capi.lower_only(rir)

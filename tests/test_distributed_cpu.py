@@ -27,7 +27,7 @@ WORKER = textwrap.dedent("""
     dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the max-over-ranks timing reduction of bench.py
     assert t.item() == world
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    print("rank%%d_ok" %% rank, flush=True)
 """) % ROOT
 
 
@@ -41,4 +41,4 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert "rank0_ok" in out.stdout and "rank1_ok" in out.stdout

@@ -462,3 +462,20 @@ def test_gpu_reproduces_more_reference_goldsets(name):
     for kw in (dict(math_mode=_capi.MATH_STRICT), dict(fp_contract=True, factor_outputs=True)):
         tr = R.Model(spec, device=0, **kw).sample(cfg, seeds=[rstate.seed ^ 0x5DEECE66D])
         assert np.abs((predict_fn(tr.chains[0]) - gold) / gold).max() < 1e-10, kw
+
+
+# ---- after the path: Trace.predict's compiled requirements, batched over draws (f3) --------------------------------
+def test_batched_predict_matches_oracle():
+    rir, nreq = models.funnel_predict(10)
+    draws = np.random.default_rng(8).normal(size=(7, 33, 10))
+    got = R.predict(rir, draws, nreq, device=0, math_mode=_capi.MATH_STRICT)
+    spec = models.ModelSpec("req", rir, [], [0] * nreq, 10)
+    d = O.OracleDensity(spec, O.JM_DET)
+    want = np.array([d.requirements(q, nreq) for q in draws.reshape(-1, 10)]).reshape(7, 33, nreq)
+    assert np.array_equal(got, want)
+    fast = R.predict(rir, draws, nreq, device=0)
+    np.testing.assert_allclose(fast, want, rtol=4e-16)
+    np.testing.assert_allclose(got[..., 1], draws[..., 1] * np.exp(1.5 * draws[..., 0]), rtol=1e-15)
+    assert R.predict(rir, draws[:0], nreq, device=0).shape == (0, 33, nreq)
+    with pytest.raises(R.RainierHipError):
+        R.predict(models.funnel().rir, draws, nreq, device=0)      # a density program is not a requirements program
