@@ -1088,6 +1088,170 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
 }
 #pragma clang fp contract(off)
+
+// ---- narrow GLMs (P <= 8 predictors): forward on the matrix cores, backward on the VALU ---------------------------
+// With few predictors the backward contraction would fill only P of the 16 MFMA output rows, so only
+// eta = X.theta goes to v_mfma_f64_16x16x4_f64 (ONE instruction per 16 rows x 16 chains when P <= 4) and the sums
+// w*x_k stay on the VALU -- the two pipes then run concurrently: per row-chain eval the VALU issues 1 (w) + others +
+// P accumulations instead of 2P+.. (cfg 2: 6 instead of 9 fp64 ops).  One wavefront walks a row split for
+// RH_GLMS_CT chain tiles (16 chains each): a lane's 4 rows of every 16-row sub-tile are read from the LDS tile once and
+// reused for all chain tiles; per-lane accumulators belong to chain (lane & 15) and are folded over the 4 lane groups
+// at the end.  Single-wave workgroups: no cross-wave barrier.
+#if RH_GLM_SMALL
+#ifndef RH_GLMS_CT
+#define RH_GLMS_CT 4
+#endif
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+template <bool TAIL>
+RH_DEV void rh_glms_tile(const double *tile, const long long rows_left, const int li, const int lg, const bool (&cvalid)[RH_GLMS_CT],
+                         const double (&Bf)[RH_GLMS_CT][(rh_glm<RH_GLM_TARGET>::P + 3) / 4],
+                         const int (&acol)[(rh_glm<RH_GLM_TARGET>::P + 3) / 4],
+                         const double (&thu)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::NTHU > 0 ? rh_glm<RH_GLM_TARGET>::NTHU : 1],
+                         double (&accp)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::P],
+                         double (&acco)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::NOTHER > 0 ? rh_glm<RH_GLM_TARGET>::NOTHER : 1], int &err) {
+  typedef rh_glm<RH_GLM_TARGET> GL;
+  constexpr int P = GL::P, NC = GL::NCOLS, PT = (P + 3) / 4, CTN = RH_GLMS_CT;
+#pragma unroll 1
+  for (int sub = 0; sub < 4; sub++) {
+    const int row0s = sub * 16;
+    if (TAIL && row0s >= rows_left) break;
+    double xr[4][NC]; // this lane's 4 rows (lg + 4 r) of the sub-tile, all columns
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) xr[r][j] = tile[j * RH_GLM_TRP + row0s + lg + 4 * r];
+    double a[PT];
+#pragma unroll
+    for (int ks = 0; ks < PT; ks++) a[ks] = acol[ks] >= 0 ? tile[acol[ks] * RH_GLM_TRP + row0s + li] : (acol[ks] == -1 ? 1.0 : 0.0);
+#pragma unroll
+    for (int t = 0; t < CTN; t++) {
+      rh_v4d D = (rh_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < PT; ks++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], Bf[t][ks], D, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+        GL::elem(thu[t], D[r], [&](int j) { return xr[r][j]; }, w, o, err);
+        if (TAIL) {
+          const bool valid = (row0s + lg + 4 * r) < rows_left;
+          w = valid ? w : 0.0;
+#pragma unroll
+          for (int k = 0; k < GL::NOTHER; k++) o[k] = valid ? o[k] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+          if (GL::pred_col[j] >= 0) accp[t][j] += w * xr[r][GL::pred_col[j] >= 0 ? GL::pred_col[j] : 0];
+          else accp[t][j] += w;
+        }
+#pragma unroll
+        for (int k = 0; k < GL::NOTHER; k++) acco[t][k] += o[k];
+      }
+    }
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                    const int chains, const int nsplit, const int xcd_aware) {
+  typedef rh_glm<RH_GLM_TARGET> GL;
+  typedef rh_target<RH_GLM_TARGET> TG;
+  constexpr int P = GL::P, NC = GL::NCOLS, PT = (P + 3) / 4, CTN = RH_GLMS_CT;
+  __shared__ __attribute__((aligned(16))) double lds[2 * NC * RH_GLM_TRP];
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x;
+  if (b == 0 && lane == 0) *n_running = 0;
+  int group, split;
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    group = idx / spx;
+  } else { split = b % nsplit; group = b / nsplit; }
+  const int chain0 = group * 16 * CTN;
+  if (chain0 >= chains) return;
+  bool cvalid[CTN], any = false;
+  int cl[CTN];
+  double Bf[CTN][PT], thu[CTN][GL::NTHU > 0 ? GL::NTHU : 1];
+  int acol[PT];
+#pragma unroll
+  for (int ks = 0; ks < PT; ks++) { const int pred = 4 * ks + lg; acol[ks] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2; }
+#pragma unroll
+  for (int t = 0; t < CTN; t++) {
+    const int c = chain0 + 16 * t + li;
+    cvalid[t] = c < chains;
+    cl[t] = cvalid[t] ? c : chains - 1;
+    any = any || (cvalid[t] && active[cl[t]] != 0);
+#pragma unroll
+    for (int ks = 0; ks < PT; ks++) {
+      const int pred = 4 * ks + lg;
+      Bf[t][ks] = (pred < P) ? q[(size_t)cl[t] * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < GL::NTHU; k++) thu[t][k] = q[(size_t)cl[t] * RH_NVARS + GL::thu_param[k]];
+  }
+  if (!__any(any)) return;
+  double accp[CTN][P], acco[CTN][GL::NOTHER > 0 ? GL::NOTHER : 1];
+#pragma unroll
+  for (int t = 0; t < CTN; t++) {
+#pragma unroll
+    for (int j = 0; j < P; j++) accp[t][j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < GL::NOTHER; k++) acco[t][k] = 0.0;
+  }
+  int err = 0;
+  const long long n = d.nrows[RH_GLM_TARGET];
+  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
+  long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
+  if (r0 > n) r0 = n;
+  if (r1 > n) r1 = n;
+  const long long ntiles = (r1 - r0 + 63) / 64;
+  double stage[NC];
+  auto fetch = [&](long long tile) {
+    long long row = r0 + tile * 64 + lane;
+    if (row >= n) row = n - 1;
+#pragma unroll
+    for (int j = 0; j < NC; j++) stage[j] = n > 0 ? d.cols[TG::COL0 + j][row] : 0.0;
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NC; j++) lds[(buf * NC + j) * RH_GLM_TRP + lane] = stage[j];
+  };
+  if (ntiles > 0) { fetch(0); park(0); }
+  __syncthreads();
+  for (long long t = 0; t < ntiles; t++) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < ntiles) fetch(t + 1);
+    const double *tile = lds + (size_t)buf * NC * RH_GLM_TRP;
+    const long long rows_left = r1 - (r0 + t * 64);
+    if (rows_left >= 64) rh_glms_tile<false>(tile, 64, li, lg, cvalid, Bf, acol, thu, accp, acco, err);
+    else rh_glms_tile<true>(tile, rows_left, li, lg, cvalid, Bf, acol, thu, accp, acco, err);
+    if (t + 1 < ntiles) park(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < CTN; t++) {
+    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cl[t]) * RH_NACC_MAX;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      double v = accp[t][j];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && cvalid[t]) out[GL::pred_acc[j]] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < GL::NOTHER; k++) {
+      double v = acco[t][k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && cvalid[t]) out[GL::other_acc[k]] = v;
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
+}
+#pragma clang fp contract(off)
+#endif  // RH_GLM_SMALL
 #endif  // RH_GLM_TARGET
 
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order

@@ -299,7 +299,7 @@ struct TargetEmitter {
     for (size_t n = 0; n < P.nodes.size(); n++) {
       if (!reach_row[n] || P.nodes[n].dep == 0 || P.nodes[n].op != RH_RIR_ADD) continue;
       std::vector<std::pair<int, int>> terms;
-      if (lincomb((uint32_t)n, terms) && terms.size() >= 8 && terms.size() > best) { best = terms.size(); glm.L = (uint32_t)n; }
+      if (lincomb((uint32_t)n, terms) && terms.size() >= 2 && terms.size() > best) { best = terms.size(); glm.L = (uint32_t)n; }
     }
     if (!best) return;
     std::vector<std::pair<int, int>> terms;
@@ -513,6 +513,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   os << "template <int T> struct rh_target;\ntemplate <int T> struct rh_glm;\n";
   if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
   int nacc_max = 1, nrowt = 0, glm_target = -1;
+  bool glm_small = false;
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
@@ -524,7 +525,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
     if (!te.emit(os, err)) return false;
     if (glm_target < 0 && o.glm_mfma) {
       te.detect_glm();
-      if (te.glm.ok) { if (!te.emit_glm(os, err)) return false; glm_target = (int)t; }
+      if (te.glm.ok) { if (!te.emit_glm(os, err)) return false; glm_target = (int)t; glm_small = te.glm.pred_param.size() <= 8; }
     }
     nacc_max = std::max(nacc_max, te.nacc());
     if (P.targets[t].n_cols) nrowt++;
@@ -538,7 +539,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << (o.grad_chains > 0 ? o.grad_chains : 4) << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
     << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
-  if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n";
+  if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();

@@ -137,6 +137,8 @@ struct rh_model {
   int grad_w = 8, ncols_max = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
+  bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
+  int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int glm_w = 8;
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
@@ -184,6 +186,9 @@ void assemble_source(rh_model *m) {
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
   { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
   m->has_glm = defines.find("#define RH_GLM_TARGET ") != std::string::npos;
+  m->glm_small = defines.find("#define RH_GLM_SMALL 1") != std::string::npos;
+  if (const char *e = std::getenv("RH_GLMS_CT")) { m->glms_ct = std::max(1, std::min(8, std::atoi(e))); }
+  defines += "#define RH_GLMS_CT " + std::to_string(m->glms_ct) + "\n";
   // experiment knobs of the MFMA GLM kernel (workgroup waves, forced waves per SIMD, scalar-part unroll)
   if (const char *e = std::getenv("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
   defines += "#define RH_GLM_W " + std::to_string(m->glm_w) + "\n";
@@ -231,7 +236,8 @@ void load_module(rh_model *m) {
   // wide models: stage row tiles through LDS and share them between the wavefronts of a workgroup
   m->use_lds_grad = false;  // opt-in: measured slower than the register kernel on cfg 4 (VALU/occupancy-bound, not L2-bound)
   if (const char *e = std::getenv("RH_GRAD_LDS")) m->use_lds_grad = std::atoi(e) != 0;
-  if (m->has_glm && m->n_row_targets == 1) HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, "rh_grad_glm_kernel"));
+  if (m->has_glm && m->n_row_targets == 1)
+    HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;
   hipDeviceptr_t p; size_t sz;
@@ -496,6 +502,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
         nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
         if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
         if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
+        if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
         nsplit = ((nsplit + 7) / 8) * 8;
         const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);   // keep >= 2048 rows per split
         nsplit = (int)std::min<int64_t>(nsplit, cap);
@@ -543,7 +550,10 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   };
   auto grad = [&]() {
     void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
-    if (m->k_grad_glm) {
+    if (m->k_grad_glm && m->glm_small) {
+      const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
+      launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
+    } else if (m->k_grad_glm) {
       const int ctiles = (chains + 15) / 16;
       const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
       const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
@@ -704,7 +714,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->k_grad_glm ? "rh_grad_glm_kernel" : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

@@ -479,3 +479,20 @@ def test_batched_predict_matches_oracle():
     assert R.predict(rir, draws[:0], nreq, device=0).shape == (0, 33, nreq)
     with pytest.raises(R.RainierHipError):
         R.predict(models.funnel().rir, draws, nreq, device=0)      # a density program is not a requirements program
+
+
+@pytest.mark.parametrize("n,chains,k", [(1, 1, 3), (17, 5, 1), (64, 64, 3), (65, 65, 7), (1000, 130, 3), (70001, 33, 5)])
+def test_narrow_glm_kernel_matches_valu_path_and_oracle(n, chains, k):
+    # <= 8 predictors: rh_grad_glms_kernel (eta on the fp64 matrix cores, sums w*x_k on the VALU)
+    spec = models.linreg(n=n, k=k, seed=n + 3)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT, factor_outputs=True)
+    assert "#define RH_GLM_SMALL 1" in m.hip_source
+    seeds = [300 + c for c in range(chains)]
+    s = R.Sampler(m, _tame(3, _capi.ENGINE_TICK), seeds); s.warmup(); s.run(3)
+    assert s.timing()["dominant_kernel"] == "rh_grad_glms_kernel"
+    b = s.draws(); s.close()
+    a = m.sample(_tame(3, _capi.ENGINE_CHAIN), seeds=seeds).chains
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-11)
+    if n <= 1000:
+        want, _, _ = O.sample_model(spec, _oracle_cfg(_tame(3, 0), O.JM_DET), seeds[-1])
+        np.testing.assert_allclose(b[-1], want, rtol=1e-9, atol=1e-11)
