@@ -236,7 +236,10 @@ void load_module(rh_model *m) {
   // wide models: stage row tiles through LDS and share them between the wavefronts of a workgroup
   m->use_lds_grad = false;  // opt-in: measured slower than the register kernel on cfg 4 (VALU/occupancy-bound, not L2-bound)
   if (const char *e = std::getenv("RH_GRAD_LDS")) m->use_lds_grad = std::atoi(e) != 0;
-  if (m->has_glm && m->n_row_targets == 1)
+  // <= 8 predictors: the plain VALU kernel wins (measured, profiles/r1_c: fp64 MFMA and fp64 VALU do not overlap and
+  // have the same peak, so moving eta to the matrix cores only adds AGPR traffic); the hybrid kernel stays opt-in.
+  const bool small_mfma = std::getenv("RH_GLM_SMALL_MFMA") && std::atoi(std::getenv("RH_GLM_SMALL_MFMA")) != 0;
+  if (m->has_glm && m->n_row_targets == 1 && (!m->glm_small || small_mfma))
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;

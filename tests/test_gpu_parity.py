@@ -482,8 +482,9 @@ def test_batched_predict_matches_oracle():
 
 
 @pytest.mark.parametrize("n,chains,k", [(1, 1, 3), (17, 5, 1), (64, 64, 3), (65, 65, 7), (1000, 130, 3), (70001, 33, 5)])
-def test_narrow_glm_kernel_matches_valu_path_and_oracle(n, chains, k):
-    # <= 8 predictors: rh_grad_glms_kernel (eta on the fp64 matrix cores, sums w*x_k on the VALU)
+def test_narrow_glm_kernel_matches_valu_path_and_oracle(n, chains, k, monkeypatch):
+    # <= 8 predictors: opt-in rh_grad_glms_kernel (eta on the fp64 matrix cores, sums w*x_k on the VALU)
+    monkeypatch.setenv("RH_GLM_SMALL_MFMA", "1")
     spec = models.linreg(n=n, k=k, seed=n + 3)
     m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT, factor_outputs=True)
     assert "#define RH_GLM_SMALL 1" in m.hip_source
