@@ -21,6 +21,7 @@
 
 template <int T> struct rh_target;
 
+#if !RH_HAS_GATHER
 // ---- DataFunction.apply for one chain ------------------------------------------------------------
 #ifndef RH_ROWS_UNROLL
 #define RH_ROWS_UNROLL 4
@@ -30,7 +31,7 @@ template <int T> struct rh_target;
 #pragma clang fp contract(fast)
 #endif
 template <int T>
-RH_DEV void rh_accumulate_target(const double (&th)[RH_NVARS], const rh_model_data &d, const int lane,
+RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data &d, const int lane,
                                  double (&tot)[RH_NOUT], int &err) {
   typedef rh_target<T> TG;
   double inv[TG::NINV > 0 ? TG::NINV : 1];
@@ -72,7 +73,7 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NVARS], const rh_model_da
   }
 }
 template <int T>
-RH_DEV void rh_accumulate_all(const double (&th)[RH_NVARS], const rh_model_data &d, const int lane,
+RH_DEV void rh_accumulate_all(const double (&th)[RH_NTH], const rh_model_data &d, const int lane,
                               double (&tot)[RH_NOUT], int &err) {
   if constexpr (T < RH_NTARGETS) {
     rh_accumulate_target<T>(th, d, lane, tot, err);
@@ -83,9 +84,9 @@ RH_DEV void rh_accumulate_all(const double (&th)[RH_NVARS], const rh_model_data 
 
 // q (lane-distributed) -> logp (wave-uniform), grad (lane-distributed)
 RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, double &logp, wvec &grad, int &err) {
-  double th[RH_NVARS];
+  double th[RH_NTH];
 #pragma unroll
-  for (int i = 0; i < RH_NVARS; i++) th[i] = rh_readlane(q.s[i >> 6], i & 63); // theta in SGPR pairs
+  for (int i = 0; i < RH_NTH; i++) th[i] = rh_readlane(q.s[i >> 6], i & 63); // theta in SGPR pairs
   double tot[RH_NOUT];
 #pragma unroll
   for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
@@ -95,6 +96,8 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
 #pragma unroll
   for (int i = 0; i < RH_NVARS; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
 }
+
+#endif  // !RH_HAS_GATHER
 
 // ---- chain state ----------------------------------------------------------------------------------
 #ifndef RH_WITH_NUTS
@@ -630,6 +633,7 @@ RH_DEV void rh_stats_write(const rh_chain &c, rh_chain_stats_dev *out, const int
   }
 }
 
+#if !RH_HAS_GATHER
 // ---- kernels ----------------------------------------------------------------------------------------
 // One chain per wavefront (64-thread workgroup), the whole Driver loop on the device.  `fresh` starts the
 // chains from their seeds; otherwise the state image is resumed.  The launch ends for a chain when it reaches
@@ -674,12 +678,15 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
 // accumulators) for one contiguous row split, and writes per-split partial sums; rh_tick_kernel combines the
 // partials in fixed split order (plus the data-free targets, in target order), feeds the result to the chain's
 // automaton and publishes the next q.  The sampler automaton is the same rh_advance as in rh_chain_kernel.
+#endif  // !RH_HAS_GATHER
+
 #if RH_NROWTARGETS > 0
+#if !RH_HAS_GATHER
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
 template <int T>
-RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_model_data &d, const int lane,
+RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const int lane,
                             const int split, const int nsplit, const int chain0, const int chains,
                             double *__restrict__ partial, int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -788,7 +795,7 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
   const int chain0 = group * RH_GRAD_K;
   if (chain0 >= chains) return;
   bool any = false;
-  double th[RH_GRAD_K][RH_NVARS];
+  double th[RH_GRAD_K][RH_NTH];
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
@@ -818,7 +825,7 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 #pragma clang fp contract(fast)
 #endif
 template <int T>
-RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NVARS], const rh_model_data &d, const int lane,
+RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const int lane,
                                 const int wave, const int split, const int nsplit, const int chain0, const int chains,
                                 const bool compute, double *__restrict__ partial, double *lds, int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -908,7 +915,7 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const int group = __builtin_amdgcn_readfirstlane(bgroup * RH_GRAD_W + wave);
   const int chain0 = group * RH_GRAD_K;
   bool any = false;
-  double th[RH_GRAD_K][RH_NVARS];
+  double th[RH_GRAD_K][RH_NTH];
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     int c = chain0 + kk;
@@ -1254,9 +1261,108 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
 #endif  // RH_GLM_SMALL
 #endif  // RH_GLM_TARGET
 
+#else  // RH_HAS_GATHER
+// ---- gather mode: a parameter table indexed by a data column (cfg 5: group effects alphas(site)) ------------------
+// Reference semantics: Lookup(index, table of G parameter expressions) evaluates ALL table entries per row and the
+// gradient adds one eq-lookup per entry per row (compute/Translator.scala:51-61, compute/Gradient.scala:148-152):
+// O(rows x G).  Here rows are sorted by index and walked GROUP by GROUP: the group's table parameter is a wave-uniform
+// scalar load for each of the K chains of the wavefront (no per-lane gather), the row term is evaluated with it, and the
+// scatter value (the common adjoint g of all the eq-lookups) is summed over the group's rows by the fixed-order wave
+// butterfly and stored once per (chain, group): a segmented reduction, no atomics, deterministic.  Shared outputs are
+// accumulated per lane across all groups of the split exactly as in rh_grad_kernel.
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+template <int T>
+RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
+                              const double *__restrict__ q, const int lane, const int split, const int nsplit,
+                              const int chain0, const int chains, double *__restrict__ partial, int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (TG::HAS_ROWS) {
+      constexpr int NC = TG::NCOLS, K = RH_GRAD_K;
+      double inv[K][TG::NINV > 0 ? TG::NINV : 1];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) TG::invariants(th[kk], inv[kk], err);
+      const double *cp[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
+      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
+      double acc[K][NA];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++)
+#pragma unroll
+        for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
+      const int *goff = gd.goff[TG::ROWT];
+      const int g0 = gd.gsplit[TG::ROWT][split], g1 = gd.gsplit[TG::ROWT][split + 1];
+      for (int g = g0; g < g1; g++) {
+        const int r0 = goff[g], r1 = goff[g + 1];
+        double gz[K], sv[K];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+          const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
+          gz[kk] = TG::HAS_GATHER ? q[(size_t)c * RH_NVARS + TG::G_FIRST + g] : 0.0;
+          sv[kk] = 0.0;
+        }
+        for (int r = r0 + lane; r < r1; r += 64) {
+          double cc[NC];
+#pragma unroll
+          for (int j = 0; j < NC; j++) cc[j] = cp[j][r];
+#pragma unroll
+          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
+        }
+        if constexpr (TG::HAS_GATHER) {
+#pragma unroll
+          for (int kk = 0; kk < K; kk++) {
+            const double v = rh_wave_sum(sv[kk]);
+            if (lane == 0 && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + g] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) {
+        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
+#pragma unroll
+        for (int o = 0; o < NA; o++) {
+          const double v = rh_wave_sum(acc[kk][o]);
+          if (lane == 0 && chain0 + kk < chains) out[o] = v;
+        }
+      }
+    }
+    rh_gather_targets<T + 1>(th, d, gd, q, lane, split, nsplit, chain0, chains, partial, err);
+  }
+}
+#pragma clang fp contract(off)
+
+extern "C" __global__ void __launch_bounds__(64)
+rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
+                      const int *__restrict__ active, double *__restrict__ partial, int *__restrict__ err_out,
+                      int *__restrict__ n_running, const int chains, const int nsplit) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b == 0 && lane == 0) *n_running = 0;
+  const int split = b % nsplit, group = b / nsplit;
+  const int chain0 = group * RH_GRAD_K;
+  if (chain0 >= chains) return;
+  bool any = false;
+  double th[RH_GRAD_K][RH_NTH];
+#pragma unroll
+  for (int kk = 0; kk < RH_GRAD_K; kk++) {
+    const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
+    any = any || (active[c] != 0);
+#pragma unroll
+    for (int i = 0; i < RH_NTH; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
+  }
+  if (!any) return;
+  int err = 0;
+  rh_gather_targets<0>(th, d, gd, q, lane, split, nsplit, chain0, chains, partial, err);
+  if (err && lane == 0) atomicOr(err_out, 1);
+}
+#endif  // RH_HAS_GATHER
+
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
-RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__restrict__ partial, const long long *nrows,
+RH_DEV void rh_combine_targets(const double (&th)[RH_NTH], const double *__restrict__ partial, const long long *nrows,
                                const int nsplit, const int chain, const int chains, const int lane,
                                double (&tot)[RH_NOUT], int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -1286,8 +1392,60 @@ RH_DEV void rh_combine_targets(const double (&th)[RH_NVARS], const double *__res
   }
 }
 
+// (logp, grad) of one chain from the tick engine's buffers: shared outputs via rh_combine_targets, and in gather mode
+// the table parameters' gradients = the per-group scatter sums of every gather target, in target order
+template <int T>
+RH_DEV void rh_scatter_sum(
+#if RH_HAS_GATHER
+    const rh_gather_data &gd,
+#endif
+    const int chain, const int idx, double &g) {
+#if RH_HAS_GATHER
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (TG::HAS_ROWS && TG::HAS_GATHER) g += gd.sbuf[TG::ROWT][(size_t)chain * TG::G_COUNT + idx];
+    rh_scatter_sum<T + 1>(gd, chain, idx, g);
+  }
+#else
+  (void)chain; (void)idx; (void)g;
+#endif
+}
+RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
+#if RH_HAS_GATHER
+                             const rh_gather_data &gd,
+#endif
+                             const double *__restrict__ partial, const int nsplit, const int chain, const int chains,
+                             const int lane, double &logp, wvec &grad, int &err) {
+  double th[RH_NTH];
+#pragma unroll
+  for (int i = 0; i < RH_NTH; i++) th[i] = rh_readlane(q.s[i >> 6], i & 63);
+  double tot[RH_NOUT];
+#pragma unroll
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+  logp = tot[0];
+  wv_zero(grad);
+#pragma unroll
+  for (int i = 0; i < RH_NTH; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
+#if RH_HAS_GATHER
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) {
+    const int i = k * 64 + lane;
+    if (i >= RH_NSHARED && i < RH_NVARS) {
+      double g = 0.0;
+      rh_scatter_sum<0>(gd, chain, i - RH_NSHARED, g);
+      grad.s[k] = g;
+    }
+  }
+#endif
+}
+
 extern "C" __global__ void __launch_bounds__(64)
-rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *__restrict__ seeds,
+rh_tick_kernel(const rh_model_data d,
+#if RH_HAS_GATHER
+               const rh_gather_data gd,
+#endif
+               const rh_cfg_dev cfg, rh_u64 *__restrict__ state, const rh_i64 *__restrict__ seeds,
                const double *__restrict__ static_mass, double *__restrict__ draws,
                rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running, double *__restrict__ qbuf,
                int *__restrict__ active, const double *__restrict__ partial, const int *__restrict__ grad_err,
@@ -1300,18 +1458,12 @@ rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__
   if (fresh) rh_chain_zero(st, lane);
   rh_chain_load(c, st, lane);
   if (c.need_eval) { // the gradient requested at the previous tick is in `partial`
-    double th[RH_NVARS];
-#pragma unroll
-    for (int i = 0; i < RH_NVARS; i++) th[i] = rh_readlane(c.Bq.s[i >> 6], i & 63);
-    double tot[RH_NOUT];
-#pragma unroll
-    for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
     int err = grad_err[0];
-    rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
-    c.pend_logp = tot[0];
-    wv_zero(c.pend_g);
-#pragma unroll
-    for (int i = 0; i < RH_NVARS; i++) c.pend_g.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : c.pend_g.s[i >> 6];
+    rh_combine_chain(c.Bq, d,
+#if RH_HAS_GATHER
+                     gd,
+#endif
+                     partial, nsplit, chain, chains, lane, c.pend_logp, c.pend_g, err);
     c.err |= err; c.need_eval = 0;
   }
   double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
@@ -1329,6 +1481,7 @@ rh_tick_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__
 }
 #endif  // RH_NROWTARGETS > 0
 
+#if !RH_HAS_GATHER
 // Seam 2: batched DensityFunction.  q [chains][nvars] -> logp [chains], grad [chains][nvars]; one wavefront per chain.
 extern "C" __global__ void __launch_bounds__(64)
 rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,
@@ -1346,6 +1499,28 @@ rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *_
   for (int k = 0; k < RH_SLOTS; k++)
     if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
 }
+
+#endif  // !RH_HAS_GATHER
+#if RH_HAS_GATHER
+// Seam 2 in gather mode: the gradient kernel fills `partial` / the scatter sums for q, this kernel finishes them
+extern "C" __global__ void __launch_bounds__(64)
+rh_density_fin_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
+                      const double *__restrict__ partial, double *__restrict__ logp, double *__restrict__ grad,
+                      int *__restrict__ err_out, const int chains, const int nsplit) {
+  const int chain = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (chain >= chains) return;
+  wvec qv, gv;
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
+  double lp; int err = 0;
+  rh_combine_chain(qv, d, gd, partial, nsplit, chain, chains, lane, lp, gv, err);
+  if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
+#pragma unroll
+  for (int k = 0; k < RH_SLOTS; k++)
+    if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
+}
+#endif
 
 // Device self-test of the bit-exact pieces: mode 0 = n gaussians of ScalaRNG(seed), 1 = n uniforms,
 // 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75

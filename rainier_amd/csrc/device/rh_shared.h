@@ -31,6 +31,14 @@ typedef struct rh_model_data {
   long long nrows[RH_MAX_TARGETS];
 } rh_model_data;
 
+/* gather mode (a parameter table indexed by a data column): rows are sorted by index, group g = rows whose index is
+ * low + g; per row target (by ROWT) the group offsets, the group range of every row split and the scatter sums */
+typedef struct rh_gather_data {
+  const int *goff[RH_MAX_TARGETS];   /* [ngroups + 1] first row of each group */
+  const int *gsplit[RH_MAX_TARGETS]; /* [nsplit + 1] first group of each split */
+  double *sbuf[RH_MAX_TARGETS];      /* [chains][G_COUNT] per-group sums of the scatter value (gather targets only) */
+} rh_gather_data;
+
 /* per-chain result record written by the kernels (mirrors rh_chain_stats) */
 typedef struct rh_chain_stats_dev {
   long long leapfrog_steps, warmup_leapfrog_steps, gradient_evaluations, accepted;

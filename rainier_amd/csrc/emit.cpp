@@ -52,6 +52,13 @@ struct TargetEmitter {
   bool fast_div = false;       // fast mode: x / const -> x * (1/const)
   uint32_t run_end = 0;        // data-free targets t..run_end are emitted together (shared sub-expressions once)
   bool merged_away = false;    // this data-free target was emitted by an earlier one of its run
+  // gather mode (models with a big parameter table indexed by a data column -- cfg 5):
+  //   value side   : LOOKUP(index column, [theta_first .. theta_first+count-1], low)   -> `gz`, the gathered parameter
+  //   gradient side: output(1 + first + k) = eq(index, low + k, Gv, 0) for every k (compute/Gradient.scala:148-152) -> one
+  //                  scatter value Gv per row, summed per group by rh_grad_gather_kernel instead of `count` eq-lookups
+  bool gmode = false;
+  uint32_t n_shared = 0;       // parameters [0, n_shared) are ordinary; [n_shared, n_params) are the gathered table
+  struct Gather { bool ok = false; uint32_t node = 0, sv = 0; int col = -1, first = 0, count = 0, low = 0; } gather;
   std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;  // hash-consing of synthesized nodes
   std::map<uint32_t, Lin> memo;
   std::vector<uint32_t> basis;            // basis term node ids, accumulator order
@@ -160,13 +167,68 @@ struct TargetEmitter {
     }
   }
 
+  bool is_param(uint32_t x) const { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input < P.n_params; }
+  int col_index(uint32_t x) const {
+    const Node &nd = P.nodes[x];
+    return (nd.op == RH_RIR_INPUT && nd.input >= P.n_params) ? (int)(nd.input - P.targets[t].input_start) : -1;
+  }
+  // gather mode: find this target's gather node and check that every table parameter's gradient output is the
+  // matching eq-lookup of one common scatter value
+  bool detect_gather(std::string &err) {
+    const Target &T = P.targets[t];
+    const uint32_t ns = n_shared, cnt = P.n_params - n_shared;
+    if (!has_rows()) {
+      for (uint32_t k = 0; k < cnt; k++)
+        if (!(is_const(T.outputs[1 + ns + k], 0.0))) { err = "gather mode: a data-free target depends on a table parameter"; return false; }
+      return true;
+    }
+    std::vector<char> reach(P.nodes.size(), 0);
+    for (uint32_t o = 0; o <= ns; o++) reach[T.outputs[o]] = 1;
+    sweep(reach);
+    for (size_t n = 0; n < P.nodes.size(); n++) {
+      if (!reach[n]) continue;
+      const Node &nd = P.nodes[n];
+      if (nd.op == RH_RIR_LOOKUP && col_index(nd.a) >= 0 && nd.table.size() == cnt && is_param(nd.table[0]) && P.nodes[nd.table[0]].input == ns) {
+        bool consecutive = true;
+        for (uint32_t k = 0; k < cnt; k++) consecutive = consecutive && is_param(nd.table[k]) && P.nodes[nd.table[k]].input == ns + k;
+        if (!consecutive) continue;
+        if (gather.ok) { err = "gather mode: more than one gather per target"; return false; }
+        gather.ok = true; gather.node = (uint32_t)n; gather.col = col_index(nd.a); gather.first = (int)ns; gather.count = (int)cnt; gather.low = nd.low;
+      } else if (nd.op == RH_RIR_INPUT && nd.input >= ns && nd.input < P.n_params) {
+        bool only_in_table = true;  // table parameters may only be reached through the gather node's table
+        (void)only_in_table;
+      }
+    }
+    // table parameters must not be used directly by any value/shared-gradient node except through the table
+    for (size_t n = 0; n < P.nodes.size(); n++) {
+      if (!reach[n] || (gather.ok && n == gather.node)) continue;
+      std::vector<uint32_t> ops; operands(P.nodes[n], ops);
+      for (uint32_t o : ops) if (is_param(o) && P.nodes[o].input >= ns) { err = "gather mode: a table parameter is used outside the gather"; return false; }
+    }
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t oid = T.outputs[1 + ns + k];
+      if (!gather.ok) { if (!is_const(oid, 0.0)) { err = "gather mode: table gradient without a gather"; return false; } continue; }
+      const Node &on = P.nodes[oid];
+      bool ok = on.op == RH_RIR_LOOKUP && on.low == -1 && on.table.size() == 3 && is_const(on.table[0], 0.0) && is_const(on.table[2], 0.0);
+      if (ok) {
+        const Node &cmp = P.nodes[on.a];
+        ok = cmp.op == RH_RIR_COMPARE && cmp.a == P.nodes[gather.node].a && P.nodes[cmp.b].op == RH_RIR_CONST &&
+             P.nodes[cmp.b].cval == (double)(gather.low + (int)k);
+      }
+      if (ok) { if (k == 0) gather.sv = on.table[1]; else ok = on.table[1] == gather.sv; }
+      if (!ok) { err = "gather mode: gradient output of table parameter " + std::to_string(k) + " is not eq(index, k, g, 0)"; return false; }
+    }
+    return true;
+  }
+
   // synthesized nodes are appended after their operands, so ascending id stays a topological order
   void plan() {
     const Target &T = P.targets[t];
-    outs.resize(T.outputs.size());
+    const size_t n_out = gmode ? (size_t)n_shared + 1 : T.outputs.size();
+    outs.resize(n_out);
     std::map<uint32_t, int> bidx;
     auto basis_of = [&](uint32_t term) { auto it = bidx.find(term); if (it != bidx.end()) return it->second; int i = (int)basis.size(); basis.push_back(term); bidx[term] = i; return i; };
-    for (size_t o = 0; o < T.outputs.size(); o++) {
+    for (size_t o = 0; o < n_out; o++) {
       const uint32_t id = T.outputs[o];
       Lin l;
       if (!has_rows()) { l.term = NONE; l.alpha = ZERO; l.beta = id; }
@@ -180,6 +242,7 @@ struct TargetEmitter {
     reach_inv.assign(P.nodes.size(), 0);
     if (has_rows()) {
       for (uint32_t b : basis) reach_row[b] = 1;
+      if (gather.ok) reach_row[gather.sv] = 1;
       sweep(reach_row);
       // invariants needed: parameter-only operands of row nodes, plus every alpha / beta
       std::vector<uint32_t> ops;
@@ -198,7 +261,7 @@ struct TargetEmitter {
       sweep(reach_inv);
     } else {
       for (uint32_t tt = t; tt <= run_end; tt++)
-        for (uint32_t o : P.targets[tt].outputs) reach_row[o] = 1;
+        for (size_t o = 0; o < (gmode ? (size_t)n_shared + 1 : P.targets[tt].outputs.size()); o++) reach_row[P.targets[tt].outputs[o]] = 1;
       sweep(reach_row);
     }
   }
@@ -207,6 +270,7 @@ struct TargetEmitter {
   std::string ref(uint32_t id, int ctx) const {
     if (id == ONE) return "0x1p+0";
     if (id == ZERO) return "0x0p+0";
+    if (gather.ok && id == gather.node) return "gz";
     const Node &nd = P.nodes[id];
     if (nd.op == RH_RIR_CONST) return lit(nd.cval);
     if (nd.op == RH_RIR_INPUT) {
@@ -452,8 +516,10 @@ struct TargetEmitter {
     os << "  static constexpr int NCOLS = " << T.n_cols << ", COL0 = " << T.col0 << ", NINV = " << inv_slot.size()
        << ", NACC = " << nacc() << ", ROWT = " << rowt << ";\n";
     os << "  static constexpr bool HAS_ROWS = " << (rows ? "true" : "false") << ";\n";
+    os << "  static constexpr bool HAS_GATHER = " << (gather.ok ? "true" : "false") << ";\n  static constexpr int G_COL = " << gather.col
+       << ", G_FIRST = " << gather.first << ", G_COUNT = " << gather.count << ", G_LOW = " << gather.low << ";\n";
     // ---- invariants
-    os << "  static RH_DEV void invariants(const double (&th)[RH_NVARS], double *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
+    os << "  static RH_DEV void invariants(const double (&th)[RH_NTH], double *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
     if (rows) {
       for (size_t n = 0; n < P.nodes.size(); n++)
         if (reach_inv[n] && P.nodes[n].dep == 0 && !trivial((uint32_t)n))
@@ -463,16 +529,22 @@ struct TargetEmitter {
     os << "  }\n";
     // ---- row
     if (rows) {
-      os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double *acc, int &err) {\n"
-            "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n";
+      if (gmode)
+        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, const double gz, double *acc, double &sv, int &err) {\n"
+              "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n";
+      else
+        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double *acc, int &err) {\n"
+              "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n";
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
+        if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
         if (!emit_node(os, (uint32_t)n, 1, err)) return false;
       }
       for (size_t j = 0; j < basis.size(); j++) os << "    acc[" << j << "] += " << ref(basis[j], 1) << ";\n";
+      if (gather.ok) os << "    sv += " << ref(gather.sv, 1) << ";\n";
       os << "  }\n";
       // ---- finish: tot[o] += alpha * S[j] + nrows * beta
-      os << "  static RH_DEV void finish(const double (&th)[RH_NVARS], const double *inv, const double *S, const double nrows, double (&tot)[RH_NOUT]) {\n"
+      os << "  static RH_DEV void finish(const double (&th)[RH_NTH], const double *inv, const double *S, const double nrows, double (&tot)[RH_NOUT]) {\n"
             "    (void)th; (void)inv; (void)S; (void)nrows;\n";
       for (size_t o = 0; o < outs.size(); o++) {
         const Lin &l = outs[o];
@@ -484,7 +556,7 @@ struct TargetEmitter {
       os << "  }\n";
     } else {
       // data-free target: evaluated once, outputs(o) += f_o(theta)  (DataFunction.scala:73-83)
-      os << "  static RH_DEV void row(const double (&th)[RH_NVARS], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
+      os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
             "    (void)th; (void)inv; (void)c; (void)err;\n";
       if (!merged_away) {
         for (size_t n = 0; n < P.nodes.size(); n++) {
@@ -493,7 +565,7 @@ struct TargetEmitter {
         }
         // accumulate target by target, in DataFunction order; every node above was evaluated exactly once
         for (uint32_t tt = t; tt <= run_end; tt++)
-          for (size_t o = 0; o < P.targets[tt].outputs.size(); o++) {
+          for (size_t o = 0; o < (gmode ? (size_t)n_shared + 1 : P.targets[tt].outputs.size()); o++) {
             const Node &on = P.nodes[P.targets[tt].outputs[o]];
             if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
             os << "    acc[" << o << "] += " << ref(P.targets[tt].outputs[o], 1) << ";\n";
@@ -508,12 +580,24 @@ struct TargetEmitter {
 
 }  // namespace
 
-bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err) {
+bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
+              EmitInfo *info) {
+  EmitInfo local_info; EmitInfo &I = info ? *info : local_info;
+  I = EmitInfo();
   std::ostringstream os;
   os << "template <int T> struct rh_target;\ntemplate <int T> struct rh_glm;\n";
   if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
   int nacc_max = 1, nrowt = 0, glm_target = -1;
   bool glm_small = false;
+  // gather mode: some LOOKUP over >= `gather_min` consecutive trailing parameters indexed by a data column
+  bool gmode = false; uint32_t n_shared = P.n_params;
+  for (const Node &nd : P.nodes) {
+    if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < o.gather_min) continue;
+    const Node &ix = P.nodes[nd.a], &t0 = P.nodes[nd.table[0]];
+    if (ix.op == RH_RIR_INPUT && ix.input >= P.n_params && t0.op == RH_RIR_INPUT && t0.input < P.n_params &&
+        t0.input + nd.table.size() == P.n_params) { gmode = true; n_shared = std::min(n_shared, t0.input); }
+  }
+  int ngather = 0;
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
@@ -521,9 +605,13 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
       if (t > 0 && P.targets[t - 1].n_cols == 0) te.merged_away = true;
       else { uint32_t e = t; while (e + 1 < P.targets.size() && P.targets[e + 1].n_cols == 0) e++; te.run_end = e; }
     }
+    te.gmode = gmode; te.n_shared = n_shared;
+    if (gmode) { if (!te.detect_gather(err)) return false; if (te.gather.ok) ngather++; }
     te.plan();
     if (!te.emit(os, err)) return false;
-    if (glm_target < 0 && o.glm_mfma) {
+    { EmitInfo::TargetInfo ti; ti.has_rows = P.targets[t].n_cols > 0; ti.has_gather = te.gather.ok; ti.g_col = te.gather.col;
+      ti.g_count = te.gather.count; ti.g_low = te.gather.low; I.targets.push_back(ti); }
+    if (glm_target < 0 && o.glm_mfma && !gmode) {
       te.detect_glm();
       if (te.glm.ok) { if (!te.emit_glm(os, err)) return false; glm_target = (int)t; glm_small = te.glm.pred_param.size() <= 8; }
     }
@@ -533,11 +621,16 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   os << "#pragma clang fp contract(off)\n";
   targets = os.str();
   std::ostringstream d;
-  d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (P.n_params + 1) << "\n#define RH_SLOTS "
+  d << "#define RH_HAS_GATHER " << (gmode ? 1 : 0) << "\n#define RH_NSHARED " << n_shared << "\n#define RH_NTH " << n_shared
+    << "\n#define RH_NGATHER " << ngather << "\n";
+  d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (n_shared + 1) << "\n#define RH_SLOTS "
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";
+  // chains per wavefront in the gradient kernels: K * NACC fp64 accumulators per lane must fit the register budget
+  const int grad_k = o.grad_chains > 0 ? o.grad_chains : std::max(1, std::min(8, 48 / std::max(1, nacc_max + (gmode ? 1 : 0))));
+  I.gather_mode = gmode; I.n_shared = (int)n_shared; I.grad_k = grad_k; I.nacc_max = nacc_max; I.glm_target = glm_target; I.glm_small = glm_small;
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
-    << (o.grad_chains > 0 ? o.grad_chains : 4) << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
+    << grad_k << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
     << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
   if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
@@ -557,7 +650,7 @@ bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defi
   te.sweep(te.reach_row);
   std::ostringstream os;
   if (o.fp_contract) os << "#pragma clang fp contract(fast)\n";
-  os << "RH_DEV void rh_req_eval(const double (&th)[RH_NVARS], double (&out)[RH_NREQ], int &err) {\n  (void)th; (void)err;\n"
+  os << "RH_DEV void rh_req_eval(const double (&th)[RH_NTH], double (&out)[RH_NREQ], int &err) {\n  (void)th; (void)err;\n"
         "  const double *inv = nullptr, *c = nullptr; (void)inv; (void)c;\n";
   for (size_t n = 0; n < P.nodes.size(); n++) {
     if (!te.reach_row[n] || te.trivial((uint32_t)n)) continue;
@@ -567,7 +660,7 @@ bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defi
   os << "}\n#pragma clang fp contract(off)\n";
   body = os.str();
   std::ostringstream d;
-  d << "#define RH_NVARS " << P.n_params << "\n#define RH_SLOTS " << ((P.n_params + 63) / 64) << "\n#define RH_NREQ " << P.targets.size() << "\n";
+  d << "#define RH_NVARS " << P.n_params << "\n#define RH_NTH " << P.n_params << "\n#define RH_SLOTS " << ((P.n_params + 63) / 64) << "\n#define RH_NREQ " << P.targets.size() << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
   defines = d.str();

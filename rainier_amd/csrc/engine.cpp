@@ -128,6 +128,7 @@ struct rh_model {
   bool want_nuts = false;
   rh::Program prog;
   rh::EmitOptions eopt;
+  rh::EmitInfo info;
   std::string source, err, arch;
   std::vector<char> code;
   int device = 0;
@@ -142,6 +143,11 @@ struct rh_model {
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int glm_w = 8;
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
+  // gather mode: per row target (ROWT order) the host copy of the group offsets (rows sorted by table index)
+  hipFunction_t k_grad_gather = nullptr, k_density_fin = nullptr;
+  std::vector<std::vector<int>> goff_host;   // [rowt][ngroups + 1]
+  std::vector<void *> goff_dev;              // device copies
+  std::vector<int> gather_count;             // per rowt: table size (0 = no gather)
   int state_words = 0;
   rh_model_data data{};
   std::vector<void *> dev_cols;
@@ -149,6 +155,8 @@ struct rh_model {
   hipStream_t stream = nullptr;
   std::mutex mu;
 };
+
+namespace { struct GatherBufs; }
 
 struct rh_sampler {
   hipFunction_t k_chain = nullptr, k_tick = nullptr;
@@ -167,6 +175,7 @@ struct rh_sampler {
   int nsplit = 0, xcd_aware = 1;
   void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
   std::vector<hipEvent_t> ev;
+  GatherBufs *gb = nullptr;
   std::vector<rh_chain_stats_dev> last_stats;
   int64_t grads_at_reset = 0;
 };
@@ -176,17 +185,17 @@ namespace {
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
   if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
     int ncols_max = 1;
     for (auto &T : m->prog.targets) ncols_max = std::max<int>(ncols_max, (int)T.n_cols);
-    const int nacc_guess = (int)m->prog.n_params + 1;
-    if (m->eopt.grad_chains <= 0) m->eopt.grad_chains = std::max(1, std::min(8, 48 / nacc_guess));
     if (m->eopt.grad_unroll <= 0) m->eopt.grad_unroll = std::max(1, std::min(4, 16 / ncols_max));
   }
-  if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err)) throw Fail{RH_E_UNSUPPORTED, err};
-  { const auto pos = defines.find("#define RH_NACC_MAX "); if (pos != std::string::npos) m->nacc_max = std::atoi(defines.c_str() + pos + 20); }
-  m->has_glm = defines.find("#define RH_GLM_TARGET ") != std::string::npos;
-  m->glm_small = defines.find("#define RH_GLM_SMALL 1") != std::string::npos;
+  if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
+  m->nacc_max = m->info.nacc_max;
+  m->grad_k = m->info.grad_k;
+  m->has_glm = m->info.glm_target >= 0;
+  m->glm_small = m->info.glm_small;
   if (const char *e = std::getenv("RH_GLMS_CT")) { m->glms_ct = std::max(1, std::min(8, std::atoi(e))); }
   defines += "#define RH_GLMS_CT " + std::to_string(m->glms_ct) + "\n";
   // experiment knobs of the MFMA GLM kernel (workgroup waves, forced waves per SIMD, scalar-part unroll)
@@ -220,12 +229,18 @@ void build_code(rh_model *m) { m->code = build_source(m->arch, m->source); }
 void load_module(rh_model *m) {
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipModuleLoadData(&m->module, m->code.data()));
-  HIPCHK(hipModuleGetFunction(&m->k_chain, m->module, "rh_chain_kernel"));
-  HIPCHK(hipModuleGetFunction(&m->k_density, m->module, "rh_density_kernel"));
   HIPCHK(hipModuleGetFunction(&m->k_selftest, m->module, "rh_selftest_kernel"));
   m->n_row_targets = 0;
   for (auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets++;
-  if (m->n_row_targets > 0) {  // the tick engine only exists for models that stream rows
+  if (m->info.gather_mode) {  // parameter table indexed by a data column: tick engine with the group-major gather kernel only
+    HIPCHK(hipModuleGetFunction(&m->k_grad_gather, m->module, "rh_grad_gather_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
+  } else {
+    HIPCHK(hipModuleGetFunction(&m->k_chain, m->module, "rh_chain_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_density, m->module, "rh_density_kernel"));
+  }
+  if (m->n_row_targets > 0 && !m->info.gather_mode) {  // the tick engine only exists for models that stream rows
     HIPCHK(hipModuleGetFunction(&m->k_grad, m->module, "rh_grad_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_grad_lds, m->module, "rh_grad_lds_kernel"));
@@ -239,10 +254,9 @@ void load_module(rh_model *m) {
   // <= 8 predictors: the plain VALU kernel wins (measured, profiles/r1_c: fp64 MFMA and fp64 VALU do not overlap and
   // have the same peak, so moving eta to the matrix cores only adds AGPR traffic); the hybrid kernel stays opt-in.
   const bool small_mfma = std::getenv("RH_GLM_SMALL_MFMA") && std::atoi(std::getenv("RH_GLM_SMALL_MFMA")) != 0;
-  if (m->has_glm && m->n_row_targets == 1 && (!m->glm_small || small_mfma))
+  if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
-  m->grad_k = m->eopt.grad_chains > 0 ? m->eopt.grad_chains : 4;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
   HIPCHK(hipMemcpy(&m->state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
@@ -256,7 +270,7 @@ void load_nuts_variant(rh_model *m) {
   HIPCHK(hipSetDevice(m->device));
   const std::vector<char> code = build_source(m->arch, std::string(kNutsDefine) + m->source);
   HIPCHK(hipModuleLoadData(&m->nuts.module, code.data()));
-  HIPCHK(hipModuleGetFunction(&m->nuts.k_chain, m->nuts.module, "rh_chain_kernel"));
+  if (!m->info.gather_mode) HIPCHK(hipModuleGetFunction(&m->nuts.k_chain, m->nuts.module, "rh_chain_kernel"));
   if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&m->nuts.k_tick, m->nuts.module, "rh_tick_kernel"));
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->nuts.module, "rh_state_words"));
@@ -334,6 +348,42 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
         m->data.cols[T.col0 + j] = (const double *)d;
       }
     }
+    if (m->info.gather_mode) {
+      // rows of a gather target must be sorted by the table index; group g = rows with index low + g.  Row targets
+      // without a gather are cut into pseudo-groups of 4096 rows so that the same group-major kernel walks them.
+      for (size_t t = 0; t < m->prog.targets.size(); t++) {
+        const auto &T = m->prog.targets[t];
+        if (!T.n_cols) continue;
+        const auto &ti = m->info.targets[t];
+        const int64_t nr = nrows[t];
+        if (nr >= (int64_t)1 << 31) throw Fail{RH_E_UNSUPPORTED, "gather mode: more than 2^31 rows in one target"};
+        std::vector<int> off;
+        if (ti.has_gather) {
+          const double *idx = columns[T.col0 + ti.g_col];
+          off.assign((size_t)ti.g_count + 1, 0);
+          int64_t prev = 0;
+          for (int64_t r = 0; r < nr; r++) {
+            const double v = idx[r];
+            const int64_t k = (int64_t)v - ti.g_low;   // D2I truncation like the Lookup it replaces
+            if (!(v == v) || k < 0 || k >= ti.g_count) throw Fail{RH_E_LOOKUP, "Lookup index out of range in the data (row " + std::to_string(r) + ")"};
+            if (k < prev) throw Fail{RH_E_UNSUPPORTED, "gather mode needs the rows sorted by the table index column"};
+            prev = k;
+            off[(size_t)k + 1]++;
+          }
+          for (int g = 0; g < ti.g_count; g++) off[(size_t)g + 1] += off[(size_t)g];
+        } else {
+          for (int64_t r = 0; r < nr; r += 4096) off.push_back((int)r);
+          off.push_back((int)nr);
+          if (off.size() == 1) off.push_back(0);
+        }
+        void *dp = nullptr;
+        HIPCHK(hipMalloc(&dp, off.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(dp, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        m->goff_dev.push_back(dp);
+        m->goff_host.push_back(std::move(off));
+        m->gather_count.push_back(ti.has_gather ? ti.g_count : 0);
+      }
+    }
   });
   if (rc != RH_OK) { rh_model_destroy(m); return rc; }
   *out = m;
@@ -345,6 +395,7 @@ extern "C" void rh_model_destroy(rh_model *m) {
   if (m->loaded) {
     hipSetDevice(m->device);
     for (void *d : m->dev_cols) hipFree(d);
+    for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     if (m->module) hipModuleUnload(m->module);
     if (m->nuts.module) hipModuleUnload(m->nuts.module);
@@ -388,6 +439,44 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
 }
 extern "C" void rh_free(void *p) { std::free(p); }
 
+namespace {
+// per-use device buffers of gather mode: split -> group boundaries and the scatter sums
+struct GatherBufs {
+  rh_gather_data gd{};
+  std::vector<void *> owned;
+  void build(rh_model *m, int chains, int nsplit) {
+    for (size_t rt = 0; rt < m->goff_host.size(); rt++) {
+      const std::vector<int> &off = m->goff_host[rt];
+      const int ng = (int)off.size() - 1;
+      const int64_t nr = off.back();
+      std::vector<int> gs((size_t)nsplit + 1, ng);
+      gs[0] = 0;
+      int g = 0;
+      for (int sidx = 1; sidx < nsplit; sidx++) {  // balanced by rows, cut at group boundaries only
+        const int64_t want = nr * sidx / nsplit;
+        while (g < ng && off[(size_t)g] < want) g++;
+        gs[(size_t)sidx] = g;
+      }
+      void *dg = nullptr;
+      HIPCHK(hipMalloc(&dg, gs.size() * sizeof(int)));
+      owned.push_back(dg);
+      HIPCHK(hipMemcpy(dg, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
+      gd.goff[rt] = (const int *)m->goff_dev[rt];
+      gd.gsplit[rt] = (const int *)dg;
+      if (m->gather_count[rt] > 0) {
+        void *sb = nullptr;
+        const size_t bytes = sizeof(double) * (size_t)chains * m->gather_count[rt];
+        HIPCHK(hipMalloc(&sb, bytes));
+        owned.push_back(sb);
+        HIPCHK(hipMemset(sb, 0, bytes));
+        gd.sbuf[rt] = (double *)sb;
+      }
+    }
+  }
+  ~GatherBufs() { for (void *p : owned) (void)hipFree(p); }
+};
+}  // namespace
+
 // ---- seam 2 -----------------------------------------------------------------------------------------
 extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, double *logp, double *grad) {
   if (!m || !m->loaded) { g_err = "rh_density_eval: model not loaded"; return RH_E_INVALID; }
@@ -402,6 +491,25 @@ extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, dou
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(de, 0, sizeof(int), m->stream));
     int ch = chains;
+    if (m->info.gather_mode) {  // gradient kernel -> partial sums / scatter sums -> finish kernel
+      int nsplit = 64;
+      GatherBufs gb; gb.build(m, chains, nsplit);
+      const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+      DevBuf bact(sizeof(int) * chains), bpart(sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max), brun(sizeof(int));
+      std::vector<int> ones((size_t)chains, 1);
+      HIPCHK(hipMemcpyAsync(bact.p, ones.data(), sizeof(int) * chains, hipMemcpyHostToDevice, m->stream));
+      HIPCHK(hipMemsetAsync(bpart.p, 0, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max, m->stream));
+      void *dact = bact.p, *dpart = bpart.p, *drun = brun.p;
+      void *ga[] = {&m->data, &gb.gd, &dq, &dact, &dpart, &de, &drun, &ch, &nsplit};
+      launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
+      void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
+      launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
+      HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
+      HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * n * chains, hipMemcpyDeviceToHost, m->stream));
+      HIPCHK(hipMemcpyAsync(&lookup_err, de, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+      HIPCHK(hipStreamSynchronize(m->stream));
+      return;
+    }
     void *args[] = {&m->data, &dq, &dl, &dg, &de, &ch};
     launch(m->k_density, (unsigned)chains, 64, m->stream, args);
     HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
@@ -495,7 +603,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     s->last_stats.resize(chains);
     if (cfg->engine < RH_ENGINE_AUTO || cfg->engine > RH_ENGINE_TICK) throw Fail{RH_E_INVALID, "unknown engine"};
     if (cfg->engine == RH_ENGINE_TICK && m->n_row_targets == 0) throw Fail{RH_E_INVALID, "the tick engine needs a model that streams rows"};
-    s->tick_engine = cfg->engine == RH_ENGINE_TICK || (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && m->rows_total >= 65536);
+    if (cfg->engine == RH_ENGINE_CHAIN && m->info.gather_mode) throw Fail{RH_E_UNSUPPORTED, "gather-mode models run on the tick engine only"};
+    s->tick_engine = m->info.gather_mode || cfg->engine == RH_ENGINE_TICK || (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && m->rows_total >= 65536);
     if (s->tick_engine) {
       const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
       int64_t max_rows = 1;
@@ -520,6 +629,10 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
       HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
+      if (m->info.gather_mode) {
+        HIPCHK(hipMemset(s->d_partial, 0, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
+        s->gb = new GatherBufs(); s->gb->build(m, chains, nsplit);
+      }
     }
   });
   if (rc != RH_OK) { rh_sampler_destroy(s); return rc; }
@@ -533,6 +646,7 @@ extern "C" void rh_sampler_destroy(rh_sampler *s) {
   for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr})
     if (p) hipFree(p);
   for (hipEvent_t e : s->ev) hipEventDestroy(e);
+  delete s->gb;
   if (s->e0) hipEventDestroy(s->e0);
   if (s->e1) hipEventDestroy(s->e1);
   delete s;
@@ -547,11 +661,22 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   auto tick = [&](int fresh, bool reset_counter) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
+    if (m->info.gather_mode) {
+      void *args[] = {&m->data, &s->gb->gd, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+                      &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+      launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
+      return;
+    }
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
                     &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
     launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
   auto grad = [&]() {
+    if (m->info.gather_mode) {
+      void *ga[] = {&m->data, &s->gb->gd, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit};
+      launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
+      return;
+    }
     void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
     if (m->k_grad_glm && m->glm_small) {
       const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
@@ -717,7 +842,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

@@ -38,14 +38,25 @@ struct EmitOptions {
   bool factor_outputs = false;  // peel invariant affine wrappers off the accumulated outputs (fast mode)
   int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
   int grad_unroll = 0;
+  int gather_min = 65;   // Lookup tables of at least this many trailing parameters switch the model to gather mode
   bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool grad_pipeline = false;  // software-pipelined row loop in the batched gradient kernel  // row-loop unroll of the batched gradient kernel (0 = default)
 };
 
+// What the engine needs to know about the lowered program (besides the source text)
+struct EmitInfo {
+  bool gather_mode = false;
+  int n_shared = 0, grad_k = 4, nacc_max = 1, glm_target = -1;
+  bool glm_small = false;
+  struct TargetInfo { bool has_rows = false, has_gather = false; int g_col = -1, g_count = 0, g_low = 0; };
+  std::vector<TargetInfo> targets;
+};
+
 // Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).
 // The replacement for the reference's ASM generators (ir/ExprMethodGenerator.scala, ir/OutputClassGenerator.scala).
-bool emit_hip(const Program &p, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err);
+bool emit_hip(const Program &p, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
+              EmitInfo *info = nullptr);
 
 // Lowers a requirements program (kind 1) to  rh_req_eval(th, out, err)  + defines RH_NVARS / RH_NREQ.
 bool emit_requirements(const Program &p, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);

@@ -164,3 +164,57 @@ def funnel_predict(dim: int = 10):
     y = g.param(0) * 3.0
     xs = [g.param(i) * (y / 2.0).exp() for i in range(1, dim)]
     return g.compile_requirements([y] + xs), dim
+
+
+def nemes_log_gamma(z):
+    """Combinatorics.gamma (core/Combinatorics.scala:10-35): log Gamma by Nemes' approximation on z+1 minus log z, with the
+    reference's exact special cases gamma(0) = inf, gamma(1) = gamma(2) = 0.  (numpy, for data-only columns.)"""
+    z = np.asarray(z, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v = z + 1.0
+        w = v + 1.0 / ((12.0 * v) - (1.0 / (10.0 * v)))
+        out = (np.log(2 * math.pi) / 2.0) - (np.log(v) / 2.0) + (v * (np.log(w) - 1.0)) - np.log(z)
+    out = np.where(z == 0.0, np.inf, out)
+    return np.where((z == 1.0) | (z == 2.0), 0.0, out)
+
+
+def hier_negbin_data(groups: int, per_group: int, seed: int = 5, n_fail: float = 10.0):
+    """cfg-5 data: alpha_g ~ N(1, 0.5), 2 covariates, NegBin(n = 10) counts; rows sorted by group."""
+    rng = np.random.default_rng(seed)
+    alpha = 1.0 + 0.5 * rng.standard_normal(groups)
+    beta = np.array([0.3, -0.2])
+    n = groups * per_group
+    gid = np.repeat(np.arange(groups), per_group).astype(np.float64)   # the reference stores indices as doubles
+    X = rng.standard_normal((2, n))
+    lam = np.exp(alpha[gid.astype(int)] + beta @ X)
+    v = rng.negative_binomial(n_fail, n_fail / (n_fail + lam)).astype(np.float64)
+    # data-only part of NegativeBinomial.logDensity, folded into a column at build time like the reference does
+    crow = nemes_log_gamma(n_fail + v - 1 + 1) - nemes_log_gamma(v + 1) - float(nemes_log_gamma(n_fail - 1 + 1))
+    return v, crow, gid, X[0].copy(), X[1].copy()
+
+
+def hier_negbin(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fail: float = 10.0) -> ModelSpec:
+    """cfg 5 -- hierarchical negative-binomial GLM.  theta = (m, s, b0, b1, z_0..z_{G-1}):
+    mu = 10 m (Normal(0,10).latent), sigma_alpha = exp(s) (prior s - e^s), b ~ N(0,1), alpha_g = mu + sigma_alpha z_g.
+    The group effect is `alphas(site)` with `site` a Column: RealVec.apply(index: Real) = Lookup(index, reals)
+    (compute/Vec.scala:54-59); here the table holds the z parameters and the affine map follows the lookup.
+    NegativeBinomial(p, n).logDensity(v) = [data-only factorial terms] + n log(1-p) + v log p (core/Discrete.scala:111-114)
+    with p = 1 / (1 + n exp(-eta)) so that the mean n p/(1-p) is exp(eta).  The z prior is written as a row target over
+    the G group ids (one row per group) so that it is lowered by the same gather/scatter machinery."""
+    G = int(groups)
+    n_params = 4 + G
+    g = Graph(n_params, [0, 1, 5])
+    m, s, b0, b1 = (g.param(i) for i in range(4))
+    zs = [g.param(4 + k) for k in range(G)]
+    prior = std_normal_logpdf(m) + (s - s.exp()) + std_normal_logpdf(b0) + std_normal_logpdf(b1)
+    zprior = std_normal_logpdf(g.lookup(g.col(1, 0), zs, 0))
+    v, crow, gid, x0, x1 = (g.col(2, j) for j in range(5))
+    alpha = m * 10.0 + s.exp() * g.lookup(gid, zs, 0)
+    eta = alpha + b0 * x0 + b1 * x1
+    p = 1.0 / ((eta * -1.0).exp() * n_fail + 1.0)
+    row = crow + (1.0 - p).log() * n_fail + v * p.log()
+    rir = g.compile([prior, zprior, row])
+    dv, dc, dg, dx0, dx1 = hier_negbin_data(G, per_group, seed, n_fail)
+    cols = [np.arange(G, dtype=np.float64), dv, dc, dg, dx0, dx1]
+    return ModelSpec("hier_negbin_%dx%d" % (G, per_group), rir, cols, [0, G, G * per_group], n_params,
+                     {"kind": "hier_negbin", "groups": G})

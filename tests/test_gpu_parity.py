@@ -497,3 +497,47 @@ def test_narrow_glm_kernel_matches_valu_path_and_oracle(n, chains, k, monkeypatc
     if n <= 1000:
         want, _, _ = O.sample_model(spec, _oracle_cfg(_tame(3, 0), O.JM_DET), seeds[-1])
         np.testing.assert_allclose(b[-1], want, rtol=1e-9, atol=1e-11)
+
+
+# ---- gather mode: parameter table indexed by a data column (cfg 5 shape) -----------------------------------------
+@pytest.mark.parametrize("groups,per_group,chains", [(6, 7, 1), (20, 3, 5), (60, 11, 9), (33, 1, 4)])
+def test_gather_mode_matches_generic_lookup_path_and_oracle(groups, per_group, chains, monkeypatch):
+    # the same small model through (a) the generic Lookup lowering (select chains, eq-lookup gradients) and
+    # (b) gather mode forced on (group-major gather kernel + scatter sums); both against the oracle interpreter
+    spec = models.hier_negbin(groups, per_group, seed=groups)
+    qs = np.random.default_rng(groups).normal(size=(chains, spec.n_params)) * 0.4
+    generic = R.Model(spec, device=0)
+    assert "#define RH_HAS_GATHER 0" in generic.hip_source
+    monkeypatch.setenv("RH_GATHER_MIN", "2")
+    gm = R.Model(spec, device=0)
+    assert "#define RH_HAS_GATHER 1" in gm.hip_source and "#define RH_NSHARED 4" in gm.hip_source
+    _check_density(spec, generic, qs, 1e-12)
+    _check_density(spec, gm, qs, 1e-12)
+    gf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    _check_density(spec, gf, qs, 1e-12)
+    # chains: tick engine in gather mode vs the generic chain engine, tame dynamics
+    tame = lambda e: R.make_config(4, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=e)
+    seeds = [800 + c for c in range(chains)]
+    a = generic.sample(tame(_capi.ENGINE_CHAIN), seeds=seeds)
+    b = gm.sample(tame(_capi.ENGINE_AUTO), seeds=seeds)
+    np.testing.assert_allclose(b.chains, a.chains, rtol=1e-9, atol=1e-11)
+    with pytest.raises(R.RainierHipError):
+        gm.sample(tame(_capi.ENGINE_CHAIN), seeds=seeds)
+
+
+def test_gather_mode_medium_table_full_driver():
+    # 200 groups x 40 rows: the table (200 > 64 entries) is beyond the generic Lookup lowering, so gather mode is automatic
+    spec = models.hier_negbin(200, 40, seed=1)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "#define RH_HAS_GATHER 1" in m.hip_source
+    qs = np.random.default_rng(0).normal(size=(2, spec.n_params)) * 0.3
+    lp, g = m.density_batch(qs)
+    d = O.OracleDensity(spec)
+    for c in range(2):
+        ref = d.update(qs[c]); tol = 1e-12 * d.abs_sums(qs[c]) + 1e-300
+        assert abs(lp[c] - ref[0]) <= tol[0] and np.all(np.abs(g[c] - ref[1:]) <= tol[1:])
+    tr = m.sample(R.make_config(150, 250, R.NUTSSampler(8)), seeds=range(8))
+    assert np.all(np.isfinite(tr.chains))
+    post = tr.chains.reshape(-1, spec.n_params).mean(axis=0)
+    assert abs(post[0] * 10.0 - 1.0) < 0.25 and abs(post[2] - 0.3) < 0.1 and abs(post[3] + 0.2) < 0.1   # mu, beta
+    assert abs(np.exp(post[1]) - 0.5) < 0.2                                                             # sigma_alpha
