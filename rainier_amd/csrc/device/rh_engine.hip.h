@@ -152,8 +152,61 @@ struct rh_chain {
 #define RH_STATE_NSCALAR ((0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + (0 RH_STATE_I64(RH_CNT)))
 // u64 words of one chain's state image: lane-distributed vectors and the ring buffer take 64 words per slot,
 // wave-uniform scalars are stored once (lane 0 writes, every lane reads the same address -> scalar loads).
-#define RH_STATE_U64 (((RH_STATE_NVEC + RH_STATE_NCK) * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
+#if RH_BIGN
+#define RH_STATE_NPOOL RH_POOL_VECS
+#else
+#define RH_STATE_NPOOL 0
+#endif
+#define RH_STATE_U64 (((RH_STATE_NVEC + RH_STATE_NCK + RH_STATE_NPOOL) * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
 
+#if RH_BIGN
+// big mode: the vectors are used IN PLACE in the state block (vector v at st + v*RH_SLOTS*64, element i at [i]); only the
+// ring buffer and the scalars travel through registers.  Layout: vectors | ring | NUTS checkpoints | pool | scalars.
+RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
+  size_t w = (size_t)RH_STATE_NVEC * RH_SLOTS;
+  for (int k = 0; k < RH_RING_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ring[k]);
+  w += (size_t)(RH_STATE_NCK + RH_STATE_NPOOL) * RH_SLOTS;
+  if (lane == 0) {
+    rh_u64 *sc = st + w * 64;
+    int j = 0;
+#define X(n) sc[j++] = (rh_u64)__double_as_longlong(c.n);
+    RH_STATE_F64(X)
+#undef X
+#define X(n) sc[j++] = (rh_u64)(rh_i64)c.n;
+    RH_STATE_INT(X)
+#undef X
+#define X(n) sc[j++] = (rh_u64)c.n;
+    RH_STATE_I64(X)
+#undef X
+  }
+}
+RH_DEV void rh_chain_load(rh_chain &c, rh_u64 *st, const int lane) {
+  size_t w = 0;
+#define X(n) c.n.s.p = (double *)(st + w * 64); w += RH_SLOTS;
+  RH_STATE_VECS(X)
+#undef X
+  for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+#if RH_WITH_NUTS
+  for (int j = 0; j < RH_NUTS_MAXD; j++) {
+    c.ckr[j].s.p = (double *)(st + w * 64); w += RH_SLOTS;
+    c.ckrs[j].s.p = (double *)(st + w * 64); w += RH_SLOTS;
+  }
+#endif
+  rh_pool_base = (double *)(st + w * 64); w += (size_t)RH_STATE_NPOOL * RH_SLOTS;
+  rh_pool_depth[lane] = 0;
+  const rh_u64 *sc = st + w * 64;
+  int j = 0;
+#define X(n) c.n = __longlong_as_double((rh_i64)sc[j++]);
+  RH_STATE_F64(X)
+#undef X
+#define X(n) c.n = rh_uniform_i((int)(rh_i64)sc[j++]);
+  RH_STATE_INT(X)
+#undef X
+#define X(n) c.n = (rh_i64)sc[j++];
+  RH_STATE_I64(X)
+#undef X
+}
+#else
 // image of chain c starts at st = state + c * RH_STATE_U64: [vector slot w][lane] ..., [ring slot][lane] ..., scalars
 RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
   int w = 0;
@@ -209,6 +262,7 @@ RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
   RH_STATE_I64(X)
 #undef X
 }
+#endif  // RH_BIGN
 RH_DEV void rh_chain_zero(rh_u64 *st, const int lane) {
   for (int w = lane; w < RH_STATE_U64; w += 64) st[w] = 0;
 }
@@ -239,7 +293,7 @@ RH_DEV void rh_velocity(const rh_chain &c, const wvec &p, wvec &out, const bool 
 }
 // energy (LeapFrog.scala:131-136)
 RH_DEV double rh_energy(const rh_chain &c, const wvec &p, const double U, const bool identity) {
-  wvec v, pr;
+  RH_TMP(v); RH_TMP(pr);
   rh_velocity(c, p, v, identity);
   wv_mul(pr, v, p);
   const double kinetic = wv_sum_seq(pr) / 2.0;
@@ -250,13 +304,13 @@ RH_DEV double rh_log_accept(const double deltaH) { // LeapFrog.scala:138-142
   return (-deltaH) < 0.0 ? (-deltaH) : 0.0;
 }
 RH_DEV void rh_new_qs_e(rh_chain &c, const double e, const bool identity) { // LeapFrog.scala:144-151, signed step
-  wvec v;
+  RH_TMP(v);
   rh_velocity(c, c.Bp, v, identity);
   wv_axpy(c.Bq, e, v);
   if (c.sampling_started) c.n_leapfrog += 1; else c.n_warm_leapfrog += 1;
 }
 RH_DEV void rh_new_qs(rh_chain &c, const bool identity) { // LeapFrog.scala:144-151
-  wvec v;
+  RH_TMP(v);
   rh_velocity(c, c.Bp, v, identity);
   wv_axpy(c.Bq, c.eps, v);
   if (c.sampling_started) c.n_leapfrog += 1; else c.n_warm_leapfrog += 1;
@@ -265,11 +319,11 @@ RH_DEV void rh_copy_P_to_B(rh_chain &c) { c.Bp = c.Pp; c.Bq = c.Pq; c.Bg = c.Pg;
 RH_DEV void rh_copy_B_to_P(rh_chain &c) { c.Pp = c.Bp; c.Pq = c.Bq; c.Pg = c.Bg; c.PU = c.BU; }
 // initializePs (LeapFrog.scala:229-251)
 RH_DEV void rh_initialize_ps(rh_chain &c, const bool identity, const int lane) {
-  wvec buf;
+  RH_TMP(buf);
   rh_fill_normal(c, buf, lane);
   if (identity) c.Pp = buf;
   else {
-#pragma unroll
+RH_UNROLL_SLOTS
     for (int k = 0; k < RH_SLOTS; k++) c.Pp.s[k] = (k * 64 + lane < RH_NVARS) ? buf.s[k] / c.SD.s[k] : 0.0;
   }
 }
@@ -298,7 +352,7 @@ RH_DEV bool rh_mass_update(rh_chain &c, const rh_cfg_dev &cfg, const int lane) {
   c.win_i += 1;
   c.ve_samples += 1;
   const double ns = (double)c.ve_samples;
-#pragma unroll
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) {
     const double oldDiff = c.Pq.s[k] - c.ve_mean.s[k];
     c.ve_mean.s[k] += (oldDiff / ns);
@@ -308,7 +362,7 @@ RH_DEV bool rh_mass_update(rh_chain &c, const rh_cfg_dev &cfg, const int lane) {
   if (c.win_i == c.win_size) {
     c.win_i = 0;
     c.win_size = (int)(c.win_size * cfg.mass_expansion);
-#pragma unroll
+RH_UNROLL_SLOTS
     for (int k = 0; k < RH_SLOTS; k++) {
       const bool live = (k * 64 + lane < RH_NVARS);
       c.M.s[k] = live ? c.ve_raw.s[k] / ns : 1.0;         // variance = raw / samples (population form)
@@ -339,7 +393,7 @@ RH_DEV double rh_ring_sample(rh_chain &c, const int size) { // Stats.scala:40-45
   return out;
 }
 RH_DEV bool rh_is_uturn(const rh_chain &c) { // LeapFrog.scala:35-47
-  wvec dq, pr;
+  RH_TMP(dq); RH_TMP(pr);
   wv_sub(dq, c.Bq, c.Pq);
   wv_mul(pr, dq, c.Bp);
   const double out = wv_sum_seq(pr);
@@ -364,7 +418,7 @@ RH_DEV void rh_iteration_done(rh_chain &c, const rh_cfg_dev &cfg, const double a
     c.sum_accept += acc_prob;
     c.n_samp_iters += 1;
     double *out = draws + (size_t)(c.it - cfg.warmup) * RH_NVARS;
-#pragma unroll
+RH_UNROLL_SLOTS
     for (int k = 0; k < RH_SLOTS; k++)
       if (k * 64 + lane < RH_NVARS) out[k * 64 + lane] = c.Pq.s[k];
   }
@@ -379,8 +433,8 @@ RH_DEV double rh_logaddexp(const double a, const double b) {
 }
 // v = M^-1 r; r_sum' = r_sum - (r_left + r_right)/2; turning iff v_left . r_sum' <= 0 or v_right . r_sum' <= 0 (NaN: turning)
 RH_DEV bool rh_nuts_is_turning(const rh_chain &c, const wvec &rl, const wvec &rr, const wvec &rsum, const bool identity) {
-  wvec adj, vl, vr, pl, pr;
-#pragma unroll
+  RH_TMP(adj); RH_TMP(vl); RH_TMP(vr); RH_TMP(pl); RH_TMP(pr);
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) adj.s[k] = rsum.s[k] - (rl.s[k] + rr.s[k]) / 2.0;
   rh_velocity(c, rl, vl, identity);
   rh_velocity(c, rr, vr, identity);
@@ -439,7 +493,7 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
     }
     case RH_S_WARM_SETUP: { // massMatrixTuner.initialize (MassMatrix.scala:139-143, Sampler.scala:47-50)
       if (cfg.mass_tuner == 2 /*StaticMassMatrix(DiagonalMassMatrix)*/) {
-#pragma unroll
+RH_UNROLL_SLOTS
         for (int k = 0; k < RH_SLOTS; k++) {
           const int i = k * 64 + lane;
           c.M.s[k] = i < RH_NVARS ? static_mass[i] : 1.0;
@@ -571,7 +625,7 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
       rh_rng r = rh_rng_of(c); const double u = rh_rng_uniform(r); rh_rng_put(c, r);
       if (c.n_leaf == 0 || u < rh_strict_exp(leaf_logw - new_logw)) { c.Sq = c.Bq; c.Sg = c.Bg; c.SU = c.BU; }
       c.n_sub_logw = new_logw;
-#pragma unroll
+RH_UNROLL_SLOTS
       for (int k = 0; k < RH_SLOTS; k++) c.Sp.s[k] += c.Bp.s[k]; // subtree momentum sum lives in Sp
       // checkpoints (NumPyro _leaf_idx_to_ckpt_idxs)
       int idx_max = 0;
@@ -586,13 +640,13 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
           if (j == idx_max) { c.ckr[j] = c.Bp; c.ckrs[j] = c.Sp; }
       } else {
         for (int k = idx_max; k >= idx_min && !sub_turning; k--) {
-          wvec rk, rsk;
+          RH_TMP(rk); RH_TMP(rsk);
           wv_zero(rk); wv_zero(rsk);
 #pragma unroll
           for (int j = 0; j < RH_NUTS_MAXD; j++)
             if (j == k) { rk = c.ckr[j]; rsk = c.ckrs[j]; }
-          wvec sub;
-#pragma unroll
+          RH_TMP(sub);
+RH_UNROLL_SLOTS
           for (int s2 = 0; s2 < RH_SLOTS; s2++) sub.s[s2] = c.Sp.s[s2] - rsk.s[s2] + rk.s[s2];
           sub_turning = rh_nuts_is_turning(c, rk, c.Bp, sub, ident);
         }
@@ -604,7 +658,7 @@ RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, con
         rh_rng r2 = rh_rng_of(c); const double u2 = rh_rng_uniform(r2); rh_rng_put(c, r2);
         if (u2 < rh_strict_exp(c.n_sub_logw - c.n_tree_logw)) { c.Pq = c.Sq; c.Pg = c.Sg; c.PU = c.SU; }
         c.n_tree_logw = rh_logaddexp(c.n_tree_logw, c.n_sub_logw);
-#pragma unroll
+RH_UNROLL_SLOTS
         for (int k = 0; k < RH_SLOTS; k++) c.Nrsum.s[k] += c.Sp.s[k];
         if (c.n_right) { c.NRq = c.Bq; c.NRp = c.Bp; c.NRg = c.Bg; } else { c.NLq = c.Bq; c.NLp = c.Bp; c.NLg = c.Bg; }
         c.n_depth += 1;
@@ -1418,17 +1472,23 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
                              const int lane, double &logp, wvec &grad, int &err) {
   double th[RH_NTH];
 #pragma unroll
-  for (int i = 0; i < RH_NTH; i++) th[i] = rh_readlane(q.s[i >> 6], i & 63);
+  for (int i = 0; i < RH_NTH; i++) th[i] = wv_elem(q, i);
   double tot[RH_NOUT];
 #pragma unroll
   for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
   rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
   logp = tot[0];
+#if RH_BIGN
+  RH_UNROLL_SLOTS
+  for (int k = 0; k < RH_SLOTS; k++)
+    if (k * 64 + lane < RH_NVARS) grad.s[k] = 0.0; // `grad` may be a view on an exactly-sized array
+#else
   wv_zero(grad);
+#endif
 #pragma unroll
   for (int i = 0; i < RH_NTH; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
 #if RH_HAS_GATHER
-#pragma unroll
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) {
     const int i = k * 64 + lane;
     if (i >= RH_NSHARED && i < RH_NVARS) {
@@ -1470,7 +1530,7 @@ rh_tick_kernel(const rh_model_data d,
   const int status = rh_advance(c, cfg, it_stop, seeds[chain], static_mass, my_draws, lane);
   if (status == RH_ADV_NEED_GRAD) {
     c.need_eval = 1;
-#pragma unroll
+RH_UNROLL_SLOTS
     for (int k = 0; k < RH_SLOTS; k++)
       if (k * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + k * 64 + lane] = c.Bq.s[k];
   }
@@ -1490,12 +1550,12 @@ rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *_
   const int lane = threadIdx.x;
   if (chain >= chains) return;
   wvec qv, gv;
-#pragma unroll
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
   double lp; int err = 0;
   rh_density(qv, d, lane, lp, gv, err);
   if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
-#pragma unroll
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++)
     if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
 }
@@ -1510,15 +1570,23 @@ rh_density_fin_kernel(const rh_model_data d, const rh_gather_data gd, const doub
   const int chain = blockIdx.x;
   const int lane = threadIdx.x;
   if (chain >= chains) return;
-  wvec qv, gv;
-#pragma unroll
-  for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
   double lp; int err = 0;
+#if RH_BIGN
+  wvec qv, gv; // views on the caller's arrays (element i at [i])
+  qv.s.p = const_cast<double *>(q) + (size_t)chain * RH_NVARS;
+  gv.s.p = grad + (size_t)chain * RH_NVARS;
   rh_combine_chain(qv, d, gd, partial, nsplit, chain, chains, lane, lp, gv, err);
   if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
-#pragma unroll
+#else
+  wvec qv, gv;
+RH_UNROLL_SLOTS
+  for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
+  rh_combine_chain(qv, d, gd, partial, nsplit, chain, chains, lane, lp, gv, err);
+  if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
+RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++)
     if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
+#endif
 }
 #endif
 

@@ -179,42 +179,91 @@ RH_DEV double rh_wave_sum(double v) {
   return v;
 }
 
-// length-RH_NVARS vector, element i in lane (i % 64), slot (i / 64); unused lanes hold 0
+// length-RH_NVARS vector, element i in lane (i % 64), slot (i / 64); unused lanes hold 0.
+// Two storage classes behind one interface (v.s[k], wv_* helpers, assignment copies the data):
+//   register mode (RH_BIGN == 0, nVars <= 512): RH_SLOTS doubles per lane in VGPRs, slot loops fully unrolled;
+//   big mode      (RH_BIGN == 1, e.g. cfg 5's 10 004 parameters): the vector lives in the chain's state block in HBM,
+//                 element i at base[i]; v.s[k] is a reference to base[k*64 + lane]; slot loops stay rolled;
+//                 temporaries (RH_TMP) come from a small per-chain pool in the same block (stack discipline).
+#ifndef RH_BIGN
+#define RH_BIGN 0
+#endif
+#if !RH_BIGN
+#define RH_UNROLL_SLOTS _Pragma("unroll")
 struct wvec { double s[RH_SLOTS]; };
+#define RH_TMP(name) wvec name
+RH_DEV double wv_elem(const wvec &v, int i) { // wave-uniform i -> wave-uniform value (SGPR pair)
+  return rh_readlane(v.s[i >> 6], i & 63);
+}
+#else
+#define RH_UNROLL_SLOTS _Pragma("unroll 1")
+struct rh_slotref {
+  double *p;
+  RH_DEV double &operator[](int k) const { return p[(size_t)k * 64 + threadIdx.x]; }
+};
+#define RH_POOL_VECS 12
+__shared__ double *rh_pool_base; // per chain (one chain per workgroup): RH_POOL_VECS scratch vectors
+__shared__ int rh_pool_depth[64];
+struct wvec {
+  rh_slotref s;
+  bool pooled;
+  RH_DEV wvec() { s.p = nullptr; pooled = false; }
+  struct from_pool {};
+  RH_DEV explicit wvec(from_pool) {
+    const int d = rh_pool_depth[threadIdx.x];
+    rh_pool_depth[threadIdx.x] = d + 1;
+    s.p = rh_pool_base + (size_t)d * RH_SLOTS * 64;
+    pooled = true;
+  }
+  RH_DEV ~wvec() { if (pooled) rh_pool_depth[threadIdx.x] -= 1; }
+  RH_DEV wvec(const wvec &) = delete;
+  RH_DEV wvec &operator=(const wvec &o) { // copies the DATA (each lane its own elements)
+    _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k++) s[k] = o.s[k];
+    return *this;
+  }
+};
+#define RH_TMP(name) wvec name{wvec::from_pool{}}
+RH_DEV double wv_elem(const wvec &v, int i) { return v.s.p[i]; } // wave-uniform address
+#endif
 RH_DEV void wv_zero(wvec &v) {
-#pragma unroll
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) v.s[k] = 0.0;
 }
 RH_DEV void wv_fill(wvec &v, double x, int lane) {
-#pragma unroll
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) v.s[k] = (k * 64 + lane < RH_NVARS) ? x : 0.0;
 }
 // y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
 RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) {
-#pragma unroll
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) y.s[k] += a * x.s[k];
 }
 RH_DEV void wv_mul(wvec &out, const wvec &x, const wvec &y) {
-#pragma unroll
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] * y.s[k];
 }
 RH_DEV void wv_sub(wvec &out, const wvec &x, const wvec &y) {
-#pragma unroll
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] - y.s[k];
 }
 RH_DEV void wv_set(wvec &v, int i, double x, int lane) { // i wave-uniform
-#pragma unroll
+#if RH_BIGN
+  if (lane == (i & 63)) v.s.p[i] = x;
+#else
+  RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) v.s[k] = (k * 64 + lane == i) ? x : v.s[k];
+#endif
 }
-RH_DEV double wv_get(const wvec &v, int i) { // i wave-uniform; returns wave-uniform value
-  double out = 0.0;
-#pragma unroll
-  for (int k = 0; k < RH_SLOTS; k++)
-    if ((i >> 6) == k) out = rh_readlane(v.s[k], i & 63);
-  return out;
-}
+RH_DEV double wv_get(const wvec &v, int i) { return wv_elem(v, i); } // i wave-uniform; returns wave-uniform value
 // sum_{i<n} x(i), strictly left to right like the reference's while loops (LeapFrog.scala:218-227)
 RH_DEV double wv_sum_seq(const wvec &x) {
+#if RH_BIGN
+  // big mode: per-lane partial sums over ascending slots + the fixed-order butterfly (deterministic; not the
+  // reference's strictly sequential order -- tolerance parity, like the row sums)
+  double part = 0.0;
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k++) part += (k * 64 + (int)threadIdx.x < RH_NVARS) ? x.s[k] : 0.0;
+  return rh_wave_sum(part);
+#else
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < RH_SLOTS; k++) {
@@ -227,4 +276,5 @@ RH_DEV double wv_sum_seq(const wvec &x) {
     }
   }
   return acc;
+#endif
 }

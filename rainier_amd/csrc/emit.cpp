@@ -623,6 +623,11 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   std::ostringstream d;
   d << "#define RH_HAS_GATHER " << (gmode ? 1 : 0) << "\n#define RH_NSHARED " << n_shared << "\n#define RH_NTH " << n_shared
     << "\n#define RH_NGATHER " << ngather << "\n";
+  const int slots = (int)((P.n_params + 63) / 64);
+  const bool bign = o.force_bign || slots > 8;
+  if (bign && !gmode) { err = "models with more than 512 parameters are supported in gather mode only (a parameter table indexed by a data column)"; return false; }
+  I.bign = bign;
+  d << "#define RH_BIGN " << (bign ? 1 : 0) << "\n";
   d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (n_shared + 1) << "\n#define RH_SLOTS "
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";

@@ -38,6 +38,7 @@ struct EmitOptions {
   bool factor_outputs = false;  // peel invariant affine wrappers off the accumulated outputs (fast mode)
   int grad_chains = 0;  // chains per wavefront in the batched gradient kernel (0 = default)
   int grad_unroll = 0;
+  bool force_bign = false;  // tests: HBM-resident chain vectors (big mode) even for small models
   int gather_min = 65;   // Lookup tables of at least this many trailing parameters switch the model to gather mode
   bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
@@ -46,7 +47,7 @@ struct EmitOptions {
 
 // What the engine needs to know about the lowered program (besides the source text)
 struct EmitInfo {
-  bool gather_mode = false;
+  bool gather_mode = false, bign = false;
   int n_shared = 0, grad_k = 4, nacc_max = 1, glm_target = -1;
   bool glm_small = false;
   struct TargetInfo { bool has_rows = false, has_gather = false; int g_col = -1, g_count = 0, g_low = 0; };

@@ -541,3 +541,42 @@ def test_gather_mode_medium_table_full_driver():
     post = tr.chains.reshape(-1, spec.n_params).mean(axis=0)
     assert abs(post[0] * 10.0 - 1.0) < 0.25 and abs(post[2] - 0.3) < 0.1 and abs(post[3] + 0.2) < 0.1   # mu, beta
     assert abs(np.exp(post[1]) - 0.5) < 0.2                                                             # sigma_alpha
+
+
+def test_big_mode_chain_vectors_in_hbm(monkeypatch):
+    # big mode (chain vectors resident in HBM, used in place) forced on a small gather model: same chains as register mode
+    spec = models.hier_negbin(40, 6, seed=2)
+    monkeypatch.setenv("RH_GATHER_MIN", "2")
+    reg = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    monkeypatch.setenv("RH_FORCE_BIGN", "1")
+    big = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "#define RH_BIGN 1" in big.hip_source and "#define RH_BIGN 0" in reg.hip_source
+    qs = np.random.default_rng(3).normal(size=(3, spec.n_params)) * 0.4
+    la, ga = reg.density_batch(qs); lb, gb = big.density_batch(qs)
+    assert np.array_equal(la, lb) and np.array_equal(ga, gb)
+    seeds = [11, 12, 13, 14, 15]
+    for cfg in (R.make_config(5, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner()),
+                R.make_config(6, 0, R.NUTSSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner()),
+                R.make_config(6, 0, R.EHMCSampler(8), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner())):
+        a = reg.sample(cfg, seeds=seeds); b = big.sample(cfg, seeds=seeds)
+        np.testing.assert_allclose(b.chains, a.chains, rtol=1e-9, atol=1e-11)
+        assert [s.leapfrogSteps for s in a.stats] == [s.leapfrogSteps for s in b.stats]
+    # full driver with adaptation in big mode
+    tr = big.sample(R.make_config(100, 200, R.NUTSSampler(6)), seeds=range(6))
+    assert np.all(np.isfinite(tr.chains)) and not np.allclose(tr.mass, 1.0)
+
+
+def test_big_table_2000_groups():
+    # nVars = 2004 (32 slots): gather mode + big mode are automatic; density against the oracle's O(rows x G) interpreter
+    spec = models.hier_negbin(2000, 5, seed=4)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "#define RH_BIGN 1" in m.hip_source and "#define RH_HAS_GATHER 1" in m.hip_source
+    q = np.random.default_rng(1).normal(size=(2, spec.n_params)) * 0.3
+    lp, g = m.density_batch(q)
+    d = O.OracleDensity(spec)
+    for c in range(2):
+        ref = d.update(q[c]); tol = 1e-12 * d.abs_sums(q[c]) + 1e-300
+        assert abs(lp[c] - ref[0]) <= tol[0] and np.all(np.abs(g[c] - ref[1:]) <= tol[1:])
+    tr = m.sample(R.make_config(30, 60, R.NUTSSampler(6)), seeds=range(4))
+    assert np.all(np.isfinite(tr.chains)) and tr.chains.shape == (4, 30, 2004)
+    assert all(st.leapfrogSteps > 0 for st in tr.stats)
