@@ -4,8 +4,10 @@ import numpy as np
 import rainier_amd as R
 from rainier_amd import models, _capi
 G, per, chains = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+nuts = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 t = time.time(); spec = models.hier_negbin(G, per); print("build %.1fs rir %d bytes" % (time.time() - t, len(spec.rir)), flush=True)
-t = time.time(); m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True); print("model %.1fs" % (time.time() - t), flush=True)
+t = time.time(); m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True, grad_chains=K); print("model %.1fs" % (time.time() - t), flush=True)
 # closed form check (numpy) at one point
 q = np.random.default_rng(0).normal(size=(2, spec.n_params)) * 0.3
 t = time.time(); lp, g = m.density_batch(q); print("density_batch %.3fs" % (time.time() - t), flush=True)
@@ -29,3 +31,15 @@ t = time.time(); s.run(4); dt = time.time() - t
 tim = s.timing()
 print(json.dumps({"G": G, "per": per, "chains": chains, "s_per_tick": dt / 32, "row_chain_evals_per_s": G * per * chains * 32 / dt,
                   "grad_kernel_ms": tim["kernel_ms"] / max(1, tim["launches"]), "all_ms": tim["total_ms"] / 32, "kernel": tim["dominant_kernel"]}))
+
+if nuts:
+    cfg = R.make_config(nuts, nuts, R.NUTSSampler(10))
+    s2 = R.Sampler(m, cfg, [2000 + c for c in range(chains)])
+    t = time.time(); s2.warmup(); tw = time.time() - t
+    t = time.time(); s2.run(nuts); dt = time.time() - t
+    st, _ = s2.stats()
+    steps = sum(x.leapfrogSteps for x in st)
+    d = s2.draws()
+    ess = min(e for _, e in R.diagnostics(d[:, :, :8])) if nuts >= 4 else None
+    print(json.dumps({"nuts_iters": nuts, "warmup_s": tw, "run_s": dt, "leapfrog_steps_per_s": steps / dt, "mean_steps_per_iter": steps / (nuts * chains),
+                      "mean_accept": float(np.mean([x.meanAcceptProb for x in st])), "ess_min_first8_per_s": ess / dt if ess else None}))
