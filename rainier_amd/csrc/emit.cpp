@@ -194,9 +194,6 @@ struct TargetEmitter {
         if (!consecutive) continue;
         if (gather.ok) { err = "gather mode: more than one gather per target"; return false; }
         gather.ok = true; gather.node = (uint32_t)n; gather.col = col_index(nd.a); gather.first = (int)ns; gather.count = (int)cnt; gather.low = nd.low;
-      } else if (nd.op == RH_RIR_INPUT && nd.input >= ns && nd.input < P.n_params) {
-        bool only_in_table = true;  // table parameters may only be reached through the gather node's table
-        (void)only_in_table;
       }
     }
     // table parameters must not be used directly by any value/shared-gradient node except through the table
