@@ -580,3 +580,19 @@ def test_big_table_2000_groups():
     tr = m.sample(R.make_config(30, 60, R.NUTSSampler(6)), seeds=range(4))
     assert np.all(np.isfinite(tr.chains)) and tr.chains.shape == (4, 30, 2004)
     assert all(st.leapfrogSteps > 0 for st in tr.stats)
+
+
+def test_gather_mode_rejects_bad_index_columns():
+    spec = models.hier_negbin(100, 3, seed=9)
+    cols = [c.copy() for c in spec.columns]
+    cols[3] = cols[3][::-1].copy()                       # group ids no longer sorted
+    bad = models.ModelSpec(spec.name, spec.rir, cols, spec.nrows, spec.n_params)
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(bad, device=0)
+    assert e.value.code == _capi.RH_E_UNSUPPORTED
+    cols = [c.copy() for c in spec.columns]
+    cols[3][-1] = 100.0                                  # index beyond the table: the reference's Lookup would throw
+    bad = models.ModelSpec(spec.name, spec.rir, cols, spec.nrows, spec.n_params)
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(bad, device=0)
+    assert e.value.code == _capi.RH_E_LOOKUP

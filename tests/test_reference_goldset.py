@@ -137,3 +137,54 @@ def test_oracle_reproduces_more_reference_goldsets(oracle, name, builder):
         assert rc == 0
         rel = np.abs((predict_fn(draws) - gold) / gold)
         assert rel.max() < 1e-10, (name, mode, rel.max())
+
+
+def lognormal_spec():
+    """SBCLogNormal: LogNormal(x, x) with x ~ LogNormal(0,1) = exp(z).  LogNormal(l, s) = Normal(l, s).exp
+    (Continuous.scala:194-197): logDensity(y) = Normal(l,s).logDensity(log y) - log y (Injection.scala:82-103);
+    data y = Math.exp(g * x0 + x0).  1 + 1000 gaussians: the first data point consumes the prior draw's cached twin and
+    one cached value is left over for the sampler."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = math.exp(rng.next_gaussian() * 1.0 + 0.0)
+    ys = np.array([math.exp(rng.next_gaussian() * x0 + x0) for _ in range(1000)])
+    g = Graph(1, [0, 1]); z = g.param(0); x = z.exp(); ly = g.col(1, 0)
+    u = (ly - x) / x
+    row = (models.std_normal_logpdf(u) - x.log()) + ly * -1.0
+    return models.ModelSpec("sbc_lognormal", g.compile([models.std_normal_logpdf(z), row]), [np.log(ys)], [0, 1000], 1), rng.r, lambda d: np.exp(d[:, 0])
+
+
+def exponential_spec():
+    """SBCExponential: Exponential(x) = Gamma.standard(1).scale(1/x) (Continuous.scala:152-158): logDensity(y) =
+    -(y / (1/x)) - log(1/x).  Data: Marsaglia-Tsang Gamma(1) draws (Continuous.scala:120-146) times 1/x0."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = math.exp(rng.next_gaussian() * 1.0 + 0.0)
+
+    def gamma1():
+        a = 1.0
+        d = a - 1.0 / 3.0
+        c = (1.0 / 3.0) / math.sqrt(d)
+        while True:
+            xx = rng.next_gaussian(); v = 1.0 + c * xx
+            while v <= 0:
+                xx = rng.next_gaussian(); v = 1.0 + c * xx
+            v3 = v * v * v
+            u = rng.next_double()
+            if (u < 1 - 0.0331 * xx * xx * xx * xx) or (math.log(u) < 0.5 * xx * xx + d * (1 - v3 + math.log(v3))):
+                return d * v3
+    ys = np.array([gamma1() * (1.0 / x0) for _ in range(1000)])
+    g = Graph(1, [0, 1]); z = g.param(0); x = z.exp(); y = g.col(1, 0)
+    inv = 1.0 / x
+    row = (y / inv) * -1.0 - inv.log()
+    return models.ModelSpec("sbc_exponential", g.compile([models.std_normal_logpdf(z), row]), [ys], [0, 1000], 1), rng.r, lambda d: np.exp(d[:, 0])
+
+
+@pytest.mark.parametrize("name,builder", [("SBCLogNormal", lognormal_spec), ("SBCExponential", exponential_spec)])
+def test_oracle_reproduces_lognormal_prior_goldsets(oracle, name, builder):
+    spec, rstate, predict_fn = builder()
+    gold = np.array(ALL["models"][name]["goldset"])
+    cfg = O.make_config(sampler=O.HMC, n_steps=1, iterations=len(gold), warmup=ALL["warmup"], step_tuner=O.STEP_DUALAVG,
+                        delta=0.8, mass_tuner=O.MASS_IDENTITY, math_mode=O.JM_LIBM)
+    d = O.OracleDensity(spec, O.JM_LIBM)
+    draws, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, cfg, rstate)
+    rel = np.abs((predict_fn(draws) - gold) / gold)
+    assert rc == 0 and rel.max() < 1e-10, (name, rel.max())
