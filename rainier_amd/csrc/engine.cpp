@@ -335,43 +335,41 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     build_code(m);
     load_module(m);
     if (m->want_nuts) load_nuts_variant(m);
-    // observation columns -> HBM (the engine copies; the caller keeps ownership)
+    // observation columns -> HBM (the engine copies; the caller keeps ownership).  In gather mode the rows of a gather
+    // target are first brought into index order (stable counting sort; only the summation order of the rows changes):
+    // group g = rows whose table index is low + g.  Row targets without a gather are cut into pseudo-groups of 4096 rows.
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
       const auto &T = m->prog.targets[t];
       m->data.nrows[t] = T.n_cols ? nrows[t] : 0;
-      if (T.n_cols) m->rows_total += nrows[t];
-      for (uint32_t j = 0; j < T.n_cols; j++) {
-        void *d = nullptr;
-        const size_t bytes = (size_t)nrows[t] * sizeof(double);
-        HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
-        m->dev_cols.push_back(d);
-        if (bytes) HIPCHK(hipMemcpy(d, columns[T.col0 + j], bytes, hipMemcpyHostToDevice));
-        m->data.cols[T.col0 + j] = (const double *)d;
-      }
-    }
-    if (m->info.gather_mode) {
-      // rows of a gather target must be sorted by the table index; group g = rows with index low + g.  Row targets
-      // without a gather are cut into pseudo-groups of 4096 rows so that the same group-major kernel walks them.
-      for (size_t t = 0; t < m->prog.targets.size(); t++) {
-        const auto &T = m->prog.targets[t];
-        if (!T.n_cols) continue;
+      if (!T.n_cols) continue;
+      m->rows_total += nrows[t];
+      const int64_t nr = nrows[t];
+      std::vector<int64_t> perm;  // empty = identity
+      if (m->info.gather_mode) {
         const auto &ti = m->info.targets[t];
-        const int64_t nr = nrows[t];
         if (nr >= (int64_t)1 << 31) throw Fail{RH_E_UNSUPPORTED, "gather mode: more than 2^31 rows in one target"};
         std::vector<int> off;
         if (ti.has_gather) {
           const double *idx = columns[T.col0 + ti.g_col];
           off.assign((size_t)ti.g_count + 1, 0);
+          bool sorted = true;
           int64_t prev = 0;
+          std::vector<int> key((size_t)nr);
           for (int64_t r = 0; r < nr; r++) {
             const double v = idx[r];
             const int64_t k = (int64_t)v - ti.g_low;   // D2I truncation like the Lookup it replaces
             if (!(v == v) || k < 0 || k >= ti.g_count) throw Fail{RH_E_LOOKUP, "Lookup index out of range in the data (row " + std::to_string(r) + ")"};
-            if (k < prev) throw Fail{RH_E_UNSUPPORTED, "gather mode needs the rows sorted by the table index column"};
+            if (k < prev) sorted = false;
             prev = k;
+            key[(size_t)r] = (int)k;
             off[(size_t)k + 1]++;
           }
           for (int g = 0; g < ti.g_count; g++) off[(size_t)g + 1] += off[(size_t)g];
+          if (!sorted) {
+            perm.resize((size_t)nr);
+            std::vector<int> next(off.begin(), off.end() - 1);
+            for (int64_t r = 0; r < nr; r++) perm[(size_t)next[(size_t)key[(size_t)r]]++] = r;
+          }
         } else {
           for (int64_t r = 0; r < nr; r += 4096) off.push_back((int)r);
           off.push_back((int)nr);
@@ -379,10 +377,25 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
         }
         void *dp = nullptr;
         HIPCHK(hipMalloc(&dp, off.size() * sizeof(int)));
-        HIPCHK(hipMemcpy(dp, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
         m->goff_dev.push_back(dp);
+        HIPCHK(hipMemcpy(dp, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
         m->goff_host.push_back(std::move(off));
         m->gather_count.push_back(ti.has_gather ? ti.g_count : 0);
+      }
+      std::vector<double> tmp;
+      for (uint32_t j = 0; j < T.n_cols; j++) {
+        void *d = nullptr;
+        const size_t bytes = (size_t)nr * sizeof(double);
+        HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
+        m->dev_cols.push_back(d);
+        const double *src = columns[T.col0 + j];
+        if (!perm.empty()) {
+          tmp.resize((size_t)nr);
+          for (int64_t r = 0; r < nr; r++) tmp[(size_t)r] = src[perm[(size_t)r]];
+          src = tmp.data();
+        }
+        if (bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        m->data.cols[T.col0 + j] = (const double *)d;
       }
     }
   });

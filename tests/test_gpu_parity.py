@@ -582,14 +582,15 @@ def test_big_table_2000_groups():
     assert all(st.leapfrogSteps > 0 for st in tr.stats)
 
 
-def test_gather_mode_rejects_bad_index_columns():
+def test_gather_mode_unsorted_rows_and_bad_indices():
     spec = models.hier_negbin(100, 3, seed=9)
-    cols = [c.copy() for c in spec.columns]
-    cols[3] = cols[3][::-1].copy()                       # group ids no longer sorted
-    bad = models.ModelSpec(spec.name, spec.rir, cols, spec.nrows, spec.n_params)
-    with pytest.raises(R.RainierHipError) as e:
-        R.Model(bad, device=0)
-    assert e.value.code == _capi.RH_E_UNSUPPORTED
+    q = np.random.default_rng(2).normal(size=(2, spec.n_params)) * 0.3
+    want = R.Model(spec, device=0).density_batch(q)
+    perm = np.random.default_rng(3).permutation(300)     # shuffle the observations: the engine sorts them by group id
+    cols = [spec.columns[0]] + [c[perm].copy() for c in spec.columns[1:]]
+    got = R.Model(models.ModelSpec(spec.name, spec.rir, cols, spec.nrows, spec.n_params), device=0).density_batch(q)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-13)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-10, atol=1e-9)
     cols = [c.copy() for c in spec.columns]
     cols[3][-1] = 100.0                                  # index beyond the table: the reference's Lookup would throw
     bad = models.ModelSpec(spec.name, spec.rir, cols, spec.nrows, spec.n_params)
