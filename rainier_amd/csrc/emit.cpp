@@ -285,6 +285,29 @@ struct TargetEmitter {
     out = lit(1.0 / nb.cval);
     return true;
   }
+  // LookupIR: D2I truncation, select table[k - low], out of range is an error (ExprMethodGenerator.scala:57-63).
+  // <= 64 entries: a select chain in registers; all-constant tables of any size: a read-only array; otherwise a
+  // per-evaluation local array (correct for any table, slow for large ones -- parameter tables belong in gather mode).
+  template <class RefFn>
+  bool emit_lookup(std::ostringstream &os, uint32_t id, RefFn R, std::string &err) const {
+    const Node &nd = P.nodes[id];
+    const std::string k = "k" + std::to_string(id), lhs = "    const double n" + std::to_string(id) + " = ";
+    os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n";
+    if (nd.table.size() <= 64) {
+      os << lhs;
+      for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
+      os << R(nd.table.back()) << ";\n";
+    } else {
+      if (nd.table.size() > 65536) { err = "Lookup tables with more than 65536 entries are only supported in gather mode"; return false; }
+      bool all_const = true;
+      for (uint32_t e : nd.table) all_const = all_const && P.nodes[e].op == RH_RIR_CONST;
+      os << "    " << (all_const ? "static const double" : "const double") << " t" << id << "[" << nd.table.size() << "] = {";
+      for (size_t e = 0; e < nd.table.size(); e++) os << (e ? ", " : "") << R(nd.table[e]);
+      os << "};\n" << lhs << "((unsigned)" << k << " < " << nd.table.size() << "u) ? t" << id << "[" << k << "] : RH_NAN;\n";
+    }
+    os << "    if ((unsigned)" << k << " >= " << nd.table.size() << "u) err = 1;\n";
+    return true;
+  }
   bool emit_node(std::ostringstream &os, uint32_t id, int ctx, std::string &err) const {
     const Node &nd = P.nodes[id];
     auto R = [&](uint32_t x) { return ref(x, ctx); };
@@ -307,16 +330,7 @@ struct TargetEmitter {
       case RH_RIR_ACOS: os << lhs << "acos(" << R(nd.a) << ");\n"; break;
       case RH_RIR_ATAN: os << lhs << "atan(" << R(nd.a) << ");\n"; break;
       case RH_RIR_SEQ: os << lhs << R(nd.b) << ";\n"; break;  // evaluate first, POP2, evaluate second
-      case RH_RIR_LOOKUP: {
-        if (nd.table.size() > 64) { err = "Lookup tables with more than 64 entries are not supported yet"; return false; }
-        const std::string k = "k" + std::to_string(id);
-        os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n";
-        os << lhs;
-        for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
-        os << R(nd.table.back()) << ";\n";
-        os << "    if ((unsigned)" << k << " >= " << nd.table.size() << "u) err = 1;\n";
-        break;
-      }
+      case RH_RIR_LOOKUP: if (!emit_lookup(os, id, [&](uint32_t x) { return R(x); }, err)) return false; break;
       default: err = "emit: unexpected opcode"; return false;
     }
     return true;
@@ -489,14 +503,7 @@ struct TargetEmitter {
       case RH_RIR_ACOS: os << lhs << "acos(" << R(nd.a) << ");\n"; break;
       case RH_RIR_ATAN: os << lhs << "atan(" << R(nd.a) << ");\n"; break;
       case RH_RIR_SEQ: os << lhs << R(nd.b) << ";\n"; break;
-      case RH_RIR_LOOKUP: {
-        if (nd.table.size() > 64) { err = "Lookup tables with more than 64 entries are not supported yet"; return false; }
-        const std::string k = "k" + std::to_string(id);
-        os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n" << lhs;
-        for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
-        os << R(nd.table.back()) << ";\n    if ((unsigned)" << k << " >= " << nd.table.size() << "u) err = 1;\n";
-        break;
-      }
+      case RH_RIR_LOOKUP: if (!emit_lookup(os, id, [&](uint32_t x) { return R(x); }, err)) return false; break;
       default: err = "emit: unexpected opcode"; return false;
     }
     return true;

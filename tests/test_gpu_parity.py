@@ -597,3 +597,20 @@ def test_gather_mode_unsorted_rows_and_bad_indices():
     with pytest.raises(R.RainierHipError) as e:
         R.Model(bad, device=0)
     assert e.value.code == _capi.RH_E_LOOKUP
+
+
+def test_large_lookup_tables_generic_path():
+    # > 64 entries without gather mode: constant table (read-only array) and a table of parameter expressions (local array)
+    from rainier_amd.frontend import Graph
+    g = Graph(3, [0, 1]); a, b, c = g.param(0), g.param(1), g.param(2); idx = g.col(1, 0)
+    tab = [g.const(float(i * i) * 1e-3) for i in range(300)]
+    row = g.lookup(idx, tab, 0) * a + g.lookup(idx, [a * float(i) * 1e-2 + b for i in range(100)], 0) * c
+    data = (np.arange(257, dtype=float) * 7) % 100
+    spec = models.ModelSpec("lk", g.compile([a * a * -0.5, row]), [data], [0, 257], 3)
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "#define RH_HAS_GATHER 0" in m.hip_source
+    _check_density(spec, m, np.random.default_rng(0).normal(size=(4, 3)), 1e-12, O.JM_DET)
+    bad = models.ModelSpec("lk", spec.rir, [data + 250.0], [0, 257], 3)      # index 250..349: inside the 300-table only
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(bad, device=0).density_batch(np.zeros((1, 3)))
+    assert e.value.code == _capi.RH_E_LOOKUP
