@@ -38,6 +38,8 @@ struct orc_leapfrog {
   int64_t leapfrogSteps;       /* not in the reference: number of newQs calls */
   int64_t iterations; int64_t accepted; double sumAccept;
   int density_error;
+  const double *dense; /* DenseMassMatrix.elements [n*n] when the current mass is dense (mass == dense) */
+  double *chol_u;      /* its choleskyUpperTriangular, packed */
 };
 
 orc_leapfrog *orc_lf_new(orc_density_fn f, void *ctx, int nvars, jrandom *rng, int math_mode) {
@@ -58,9 +60,48 @@ static void copyQsAndUpdateDensity(orc_leapfrog *lf) {
   if (lf->f(lf->ctx, lf->buf, lf->out)) lf->density_error = 1;
   lf->gradientEvaluations += 1;
 }
-/* :202-216 (Identity and Diagonal) */
+/* ---- S/MassMatrix.scala:33-117 DenseMassMatrix ---------------------------------------------- */
+static int tri(int k) { return (k * (k + 1)) / 2; }
+void orc_square_multiply(const double *matrix, const double *vector, int n, double *out) { /* :34-48 */
+  for (int i = 0; i < n; i++) {
+    double y = 0.0;
+    for (int j = 0; j < n; j++) y += vector[j] * matrix[(i * n) + j];
+    out[i] = y;
+  }
+}
+void orc_upper_triangular_solve(const double *packed, const double *vector, int n, double *out) { /* :52-69 */
+  int i = n - 1;
+  int m = tri(i + 1) - 1;
+  while (i >= 0) {
+    int j = n - 1;
+    double dot = 0.0;
+    while (j > i) { dot += out[j] * packed[m]; j -= 1; m -= 1; }
+    out[i] = (vector[i] - dot) / packed[m];
+    i -= 1; m -= 1;
+  }
+}
+void orc_cholesky_upper(const double *matrix, int n, double *upper) { /* :74-116 */
+  double *lower = calloc(tri(n) ? tri(n) : 1, sizeof(double));
+  int l = 0;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k <= i; k++) {
+      double sum = 0.0;
+      for (int j = 0; j < k; j++) sum += lower[tri(i) + j] * lower[tri(k) + j];
+      double x = matrix[(i * n) + k] - sum;
+      if (i == k) lower[l] = sqrt(x);
+      else { double diag = lower[tri(k + 1) - 1]; lower[l] = (1.0 / diag * x); }
+      l += 1;
+    }
+  l = 0;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < (n - i); k++) { upper[l] = lower[tri(k + i) + i]; l += 1; }
+  free(lower);
+}
+
+/* :202-216 (Identity, Diagonal, Dense) */
 static void velocity(const orc_leapfrog *lf, const double *in, double *out, const double *mass) {
   if (!mass) memcpy(out, in, sizeof(double) * lf->n);
+  else if (mass == lf->dense) orc_square_multiply(mass, in, lf->n, out);
   else for (int i = 0; i < lf->n; i++) out[i] = in[i] * mass[i];
 }
 /* :218-227 */
@@ -113,6 +154,7 @@ static void finalHalfStep(orc_leapfrog *lf, double stepSize) { fullPs(lf, stepSi
 static void initializePs(orc_leapfrog *lf, double *params, const double *mass) {
   for (int i = 0; i < lf->n; i++) lf->buf[i] = rng_normal(lf->rng);
   if (!mass) memcpy(params, lf->buf, sizeof(double) * lf->n);
+  else if (mass == lf->dense) orc_upper_triangular_solve(lf->chol_u, lf->buf, lf->n, params);
   else for (int i = 0; i < lf->n; i++) params[i] = lf->buf[i] / sqrt(mass[i]); /* stdDevs S/MassMatrix.scala:10-12 */
 }
 
@@ -227,18 +269,26 @@ static void varest_variance(const varest *v, double *elements) { /* :93-101 */
 typedef struct {
   int kind; int windowSize; double windowExpansion; int skipFirst, skipLast;
   int i, j, totalIterations; varest est;
+  double *cov; /* CovarianceEstimator.cov [n*n] (S/MassMatrixEstimator.scala:9-50) */
 } masstuner;
 /* returns 1 and writes `mass` when a new matrix is produced (Some(m)) */
 static int masstuner_update(masstuner *t, const double *sample, double *mass) { /* :147-164 */
-  if (t->kind != ORC_MASS_DIAG_WINDOWED) return 0;
+  if (t->kind != ORC_MASS_DIAG_WINDOWED && t->kind != ORC_MASS_DENSE_WINDOWED) return 0;
   t->j += 1;
   if (t->j < t->skipFirst || (t->totalIterations - t->j) < t->skipLast) return 0;
   t->i += 1;
   varest_update(&t->est, sample);
+  const int n = t->est.size;
+  if (t->kind == ORC_MASS_DENSE_WINDOWED) /* CovarianceEstimator.update :23-36 */
+    for (int j = 0; j < n; j++)
+      for (int k = 0; k < n; k++) t->cov[j * n + k] += t->est.newDiff[j] * t->est.oldDiff[k];
   if (t->i == t->windowSize) {
     t->i = 0;
     t->windowSize = (int)(t->windowSize * t->windowExpansion);
-    varest_variance(&t->est, mass);
+    if (t->kind == ORC_MASS_DENSE_WINDOWED) { /* covariance :38-47, reset :13-21 */
+      const double z = (double)(t->est.samples - 1);
+      for (int e = 0; e < n * n; e++) { mass[e] = t->cov[e] / z; t->cov[e] = 0.0; }
+    } else varest_variance(&t->est, mass);
     varest_reset(&t->est);
     return 1;
   }
@@ -263,13 +313,15 @@ static double logaddexp_det(int mode, double a, double b) {
   return m + jm_log(mode, jm_exp(mode, a - m) + jm_exp(mode, b - m));
 }
 /* _is_turning: v = M^-1 r; r_sum' = r_sum - (r_left + r_right)/2; turning iff v_left.r_sum' <= 0 or v_right.r_sum' <= 0 */
-static int nuts_is_turning(int n, const double *mass, const double *rl, const double *rr, const double *rsum) {
+static int nuts_is_turning(const orc_leapfrog *lf, int n, const double *mass, const double *rl, const double *rr, const double *rsum) {
   double dl = 0.0, dr = 0.0;
+  double *vl = malloc(sizeof(double) * n), *vr = malloc(sizeof(double) * n);
+  velocity(lf, rl, vl, mass); velocity(lf, rr, vr, mass);
   for (int i = 0; i < n; i++) {
     double adj = rsum[i] - (rl[i] + rr[i]) / 2.0;
-    double vl = mass ? rl[i] * mass[i] : rl[i], vr = mass ? rr[i] * mass[i] : rr[i];
-    dl += vl * adj; dr += vr * adj;
+    dl += vl[i] * adj; dr += vr[i] * adj;
   }
+  free(vl); free(vr);
   return !(dl > 0.0) || !(dr > 0.0); /* NaN counts as turning */
 }
 static double nuts_iteration(const orc_config *cfg, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
@@ -314,7 +366,7 @@ static double nuts_iteration(const orc_config *cfg, double *params, orc_leapfrog
           double *sub = lf->buf; /* subtree r_sum = r_sum - r_sum_ckpt + r_ckpt */
           for (int i = 0; i < n; i++) sub[i] = srsum[i] - ckrs[(size_t)k * n + i] + ckr[(size_t)k * n + i];
           double *tmp = malloc(sizeof(double) * n); memcpy(tmp, sub, sizeof(double) * n);
-          sub_turning = nuts_is_turning(n, mass, ckr + (size_t)k * n, lf->pqBuf, tmp);
+          sub_turning = nuts_is_turning(lf, n, mass, ckr + (size_t)k * n, lf->pqBuf, tmp);
           free(tmp);
         }
       }
@@ -327,7 +379,7 @@ static double nuts_iteration(const orc_config *cfg, double *params, orc_leapfrog
     for (int i = 0; i < n; i++) rsum[i] += srsum[i];
     lf_snapshot(lf, going_right ? R : L);
     depth++;
-    if (nuts_is_turning(n, mass, L, R, rsum)) stop = 1;
+    if (nuts_is_turning(lf, n, mass, L, R, rsum)) stop = 1;
   }
   /* the draw: position, potential (and its gradient) of the selected point; momentum is irrelevant from here on */
   memcpy(params + n, prop + n, sizeof(double) * (n + 1));
@@ -384,7 +436,8 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
   jrandom rng = *init;
   orc_leapfrog *lf = orc_lf_new(f, ctx, n, &rng, cfg->math_mode);
   double *params = calloc(2 * n + 1, sizeof(double));
-  double *massbuf = calloc(n, sizeof(double));
+  double *massbuf = calloc((size_t)n * n + n, sizeof(double)); /* diag [n] or dense [n*n] */
+  lf->chol_u = calloc((size_t)n * (n + 1) / 2 + 1, sizeof(double));
   const double *mass = NULL; /* IdentityMassMatrix */
   samplerst s; s.cfg = cfg; s.snap = calloc(2 * n + 1, sizeof(double));
   ring_init(&s.steps, cfg->sampler == ORC_EHMC ? cfg->buf_size : 1);
@@ -400,7 +453,8 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
   } else { stepSize = cfg->static_step; memset(&da, 0, sizeof(da)); }
   masstuner mt; memset(&mt, 0, sizeof(mt));
   mt.kind = cfg->mass_tuner;
-  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED) { /* S/MassMatrix.scala:139-143 */
+  if (cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) mt.cov = calloc((size_t)n * n, sizeof(double));
+  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED || cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) { /* S/MassMatrix.scala:139-143 */
     mt.windowSize = cfg->init_window; mt.windowExpansion = cfg->expansion; mt.skipFirst = cfg->skip_first; mt.skipLast = cfg->skip_last;
     mt.totalIterations = cfg->warmup; varest_init(&mt.est, n);
   } else if (cfg->mass_tuner == ORC_MASS_STATIC_DIAG) { memcpy(massbuf, cfg->static_mass, sizeof(double) * n); mass = massbuf; }
@@ -411,7 +465,8 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
     if (cfg->step_tuner == ORC_STEP_DUALAVG) { dualavg_update(&da, logAcceptProb); stepSize = jm_exp(cfg->math_mode, da.logStepSize); }
     memcpy(sample, params + n, sizeof(double) * n); /* lf.variables */
     if (masstuner_update(&mt, sample, massbuf)) {
-      mass = massbuf; /* DiagonalMassMatrix(variance) -- require(!elements.contains(0.0)) not enforced here */
+      mass = massbuf; /* DiagonalMassMatrix(variance) / DenseMassMatrix(covariance) -- require(!elements.contains(0.0)) not enforced here */
+      if (cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) { lf->dense = massbuf; orc_cholesky_upper(massbuf, n, lf->chol_u); }
       if (cfg->step_tuner == ORC_STEP_DUALAVG) { /* DualAvgTuner.reset S/DualAvg.scala:17-21 */
         double ss = jm_exp(cfg->math_mode, da.logStepSizeBar);
         da = dualavg_new(cfg->delta, ss, cfg->math_mode);
@@ -428,14 +483,16 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
     sampler_run(&s, params, lf, finalStep, mass);
     memcpy(draws + (size_t)i * n, params + n, sizeof(double) * n);
   }
-  for (int i = 0; i < n; i++) mass_out[i] = mass ? mass[i] : 1.0;
+  for (int i = 0; i < n; i++) mass_out[i] = !mass ? 1.0 : (mass == lf->dense ? mass[i * n + i] : mass[i]);
+  if (cfg->dense_out) for (int e = 0; e < n * n; e++) cfg->dense_out[e] = (mass && mass == lf->dense) ? mass[e] : ((e / n == e % n) ? mass_out[e / n] : 0.0);
   if (stats) {
     stats->gradient_evaluations = lf->gradientEvaluations; stats->leapfrog_steps = lf->leapfrogSteps;
     stats->accepted = lf->accepted; stats->mean_accept_prob = lf->iterations ? lf->sumAccept / lf->iterations : 0.0;
     stats->step_size = finalStep; stats->density_error = lf->density_error;
   }
   int rc = lf->density_error;
-  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED) varest_free(&mt.est);
+  if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED || cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) varest_free(&mt.est);
+  free(mt.cov); free(lf->chol_u); lf->chol_u = NULL;
   free(sample); free(s.snap); free(s.steps.buf); free(params); free(massbuf); orc_lf_free(lf);
   return rc;
 }

@@ -14,7 +14,7 @@ typedef int (*orc_density_fn)(void *ctx, const double *q, double *out);
 
 enum { ORC_HMC = 0, ORC_EHMC = 1, ORC_NUTS = 2 };
 enum { ORC_STEP_DUALAVG = 0, ORC_STEP_STATIC = 1 };
-enum { ORC_MASS_IDENTITY = 0, ORC_MASS_DIAG_WINDOWED = 1, ORC_MASS_STATIC_DIAG = 2 };
+enum { ORC_MASS_IDENTITY = 0, ORC_MASS_DIAG_WINDOWED = 1, ORC_MASS_STATIC_DIAG = 2, ORC_MASS_DENSE_WINDOWED = 3 };
 
 typedef struct {
   int sampler;         /* ORC_HMC | ORC_EHMC */
@@ -29,6 +29,7 @@ typedef struct {
   int nuts_max_depth;        /* ORC_NUTS (extension; NOT in the reference -- see sampler.c) */
   int iterations, warmup;    /* SamplerConfig   S/Sampler.scala:3-11 */
   int math_mode;             /* JM_LIBM | JM_DET (oracle/jmath.h) */
+  double *dense_out;         /* optional [nvars*nvars]: final DenseMassMatrix.elements (DenseMassMatrixTuner) */
 } orc_config;
 
 typedef struct {
@@ -61,6 +62,11 @@ void orc_lf_take_steps(orc_leapfrog *lf, int l, double step, const double *mass)
 double orc_lf_finish_iteration(orc_leapfrog *lf, double *params, const double *mass);
 double orc_lf_try_stepping(orc_leapfrog *lf, const double *params, double step, const double *mass);
 int orc_lf_is_uturn(orc_leapfrog *lf, const double *params);
+
+/* DenseMassMatrix.choleskyUpperTriangular / upperTriangularSolve / squareMultiply (S/MassMatrix.scala:33-117), exposed for tests */
+void orc_cholesky_upper(const double *matrix, int n, double *upper_packed);
+void orc_upper_triangular_solve(const double *packed, const double *vector, int n, double *out);
+void orc_square_multiply(const double *matrix, const double *vector, int n, double *out);
 
 /* Trace.diagnostics (rainier-core/.../core/Trace.scala:52-120): traces [m chains][n draws] of one parameter */
 void orc_diagnostics(const double *traces, int m, int n, double *rhat, double *ess);

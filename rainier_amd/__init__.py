@@ -5,7 +5,7 @@
   frontend.py      small expression DSL that writes RIR (stands in for the JVM front-end in tests/bench)
   models.py        the BASELINE.json configurations as RIR + synthetic data
 """
-from .sampler import (DefaultConfig, DensityFunction, DiagonalMassMatrix, DiagonalMassMatrixTuner,  # noqa: F401
+from .sampler import (DefaultConfig, DenseMassMatrixTuner, DensityFunction, DiagonalMassMatrix, DiagonalMassMatrixTuner,  # noqa: F401
                       DualAvgTuner, EHMC, EHMCSampler, HMC, HMCSampler, IdentityMassMatrixTuner, Model, NUTSSampler,
                       RainierHipError, Sampler, SamplerConfig, StaticMassMatrix, StaticStepSize, Trace,
                       diagnostics, make_config, predict)

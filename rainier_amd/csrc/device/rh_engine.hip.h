@@ -112,6 +112,16 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
 #define RH_STATE_F64_NUTS(X)
 #define RH_STATE_INT_NUTS(X)
 #endif
+#ifndef RH_WITH_DENSE
+#define RH_WITH_DENSE 0
+#endif
+#if RH_WITH_DENSE
+#define RH_STATE_INT_DENSE(X) X(mass_dense)
+#define RH_STATE_NDENSE (3 * RH_NVARS)
+#else
+#define RH_STATE_INT_DENSE(X)
+#define RH_STATE_NDENSE 0
+#endif
 #define RH_STATE_VECS(X) \
   X(Pp) X(Pq) X(Pg) X(Bp) X(Bq) X(Bg) X(Sp) X(Sq) X(Sg) X(M) X(SD) X(ve_mean) X(ve_raw) X(pend_g) RH_STATE_VECS_NUTS(X)
 #define RH_STATE_F64(X) \
@@ -120,7 +130,7 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
 #define RH_STATE_INT(X) \
   X(rng_have) X(pc) X(ret) X(it) X(ts_l) X(ts_i) X(cnt_l) X(find_first) X(sampling_started) X(need_eval) \
   X(mass_identity) X(ve_samples) X(win_size) X(win_i) X(win_j) X(da_iter) X(ring_i) X(ring_full) X(n_accept) \
-  X(n_samp_iters) X(err) RH_STATE_INT_NUTS(X)
+  X(n_samp_iters) X(err) RH_STATE_INT_NUTS(X) RH_STATE_INT_DENSE(X)
 #define RH_STATE_I64(X) X(rng_seed) X(n_leapfrog) X(n_warm_leapfrog) X(n_grad)
 
 struct rh_chain {
@@ -140,6 +150,11 @@ struct rh_chain {
 #if RH_WITH_NUTS
   wvec ckr[RH_NUTS_MAXD], ckrs[RH_NUTS_MAXD]; // NUTS momentum / momentum-sum checkpoints
 #endif
+#if RH_WITH_DENSE
+  // DenseMassMatrix (MassMatrix.scala:15-117), row i in lane i: Drow[j] = elements(i*n + j), Lrow[j] = Cholesky lower
+  // L[i][j] (choleskyUpperTriangular's U[j][i]), Crow[k] = CovarianceEstimator.cov(i*n + k)
+  double Drow[RH_NVARS], Lrow[RH_NVARS], Crow[RH_NVARS];
+#endif
 };
 #if RH_WITH_NUTS
 #define RH_STATE_NCK (2 * RH_NUTS_MAXD)
@@ -157,7 +172,8 @@ struct rh_chain {
 #else
 #define RH_STATE_NPOOL 0
 #endif
-#define RH_STATE_U64 (((RH_STATE_NVEC + RH_STATE_NCK + RH_STATE_NPOOL) * RH_SLOTS + RH_RING_SLOTS) * 64 + RH_STATE_NSCALAR)
+#define RH_STATE_DENSE_OFF ((RH_STATE_NVEC + RH_STATE_NCK + RH_STATE_NPOOL) * RH_SLOTS + RH_RING_SLOTS)
+#define RH_STATE_U64 ((RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64 + RH_STATE_NSCALAR)
 
 #if RH_BIGN
 // big mode: the vectors are used IN PLACE in the state block (vector v at st + v*RH_SLOTS*64, element i at [i]); only the
@@ -222,6 +238,11 @@ RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
       st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ckrs[j].s[k]);
     }
 #endif
+#if RH_WITH_DENSE
+  for (int j = 0; j < RH_NVARS; j++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.Drow[j]);
+  for (int j = 0; j < RH_NVARS; j++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.Lrow[j]);
+  for (int j = 0; j < RH_NVARS; j++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.Crow[j]);
+#endif
   if (lane == 0) {
     rh_u64 *sc = st + (size_t)w * 64;
     int j = 0;
@@ -249,6 +270,11 @@ RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
       c.ckr[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
       c.ckrs[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
     }
+#endif
+#if RH_WITH_DENSE
+  for (int j = 0; j < RH_NVARS; j++) c.Drow[j] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  for (int j = 0; j < RH_NVARS; j++) c.Lrow[j] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+  for (int j = 0; j < RH_NVARS; j++) c.Crow[j] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
 #endif
   const rh_u64 *sc = st + (size_t)w * 64;
   int j = 0;
@@ -289,6 +315,14 @@ RH_DEV void rh_fill_normal(rh_chain &c, wvec &v, const int lane) {
 }
 // velocity (LeapFrog.scala:202-216): Identity -> p, Diagonal -> p * elements
 RH_DEV void rh_velocity(const rh_chain &c, const wvec &p, wvec &out, const bool identity) {
+#if RH_WITH_DENSE
+  if (!identity && c.mass_dense) { // DenseMassMatrix.squareMultiply (MassMatrix.scala:34-48): out(i) = sum_j vector(j) * matrix(i*n+j)
+    double y = 0.0;
+    for (int j = 0; j < RH_NVARS; j++) y += rh_readlane(p.s[0], j) * c.Drow[j];
+    out.s[0] = ((int)threadIdx.x < RH_NVARS) ? y : 0.0;
+    return;
+  }
+#endif
   if (identity) out = p; else wv_mul(out, p, c.M);
 }
 // energy (LeapFrog.scala:131-136)
@@ -321,6 +355,19 @@ RH_DEV void rh_copy_B_to_P(rh_chain &c) { c.Pp = c.Bp; c.Pq = c.Bq; c.Pg = c.Bg;
 RH_DEV void rh_initialize_ps(rh_chain &c, const bool identity, const int lane) {
   RH_TMP(buf);
   rh_fill_normal(c, buf, lane);
+#if RH_WITH_DENSE
+  if (!identity && c.mass_dense) { // DenseMassMatrix.upperTriangularSolve(choleskyUpperTriangular, buf, params) (MassMatrix.scala:52-69)
+    double out = 0.0;              // U[i][j] = L[j][i] = lane j's Lrow[i]; back substitution, dot over j descending
+    for (int i = RH_NVARS - 1; i >= 0; i--) {
+      double dot = 0.0;
+      for (int j = RH_NVARS - 1; j > i; j--) dot += rh_readlane(out, j) * rh_readlane(c.Lrow[i], j);
+      const double o = (rh_readlane(buf.s[0], i) - dot) / rh_readlane(c.Lrow[i], i);
+      out = (lane == i) ? o : out;
+    }
+    c.Pp.s[0] = out;
+    return;
+  }
+#endif
   if (identity) c.Pp = buf;
   else {
 RH_UNROLL_SLOTS
@@ -346,6 +393,41 @@ RH_DEV void rh_dualavg_update(rh_chain &c, const double delta, const double logA
 }
 // WindowedMassMatrixTuner.update + VarianceEstimator (MassMatrix.scala:147-164, MassMatrixEstimator.scala:60-101)
 RH_DEV bool rh_mass_update(rh_chain &c, const rh_cfg_dev &cfg, const int lane) {
+#if RH_WITH_DENSE
+  if (cfg.mass_tuner == 3 /*RH_MASS_DENSE_WINDOWED: DenseMassMatrixTuner + CovarianceEstimator*/) {
+    c.win_j += 1;
+    if (c.win_j < cfg.mass_skip_first || (cfg.warmup - c.win_j) < cfg.mass_skip_last) return false;
+    c.win_i += 1;
+    c.ve_samples += 1;
+    const double ns = (double)c.ve_samples;
+    const double oldDiff = c.Pq.s[0] - c.ve_mean.s[0];   // VarianceEstimator.update (MassMatrixEstimator.scala:69-84)
+    c.ve_mean.s[0] += (oldDiff / ns);
+    const double newDiff = c.Pq.s[0] - c.ve_mean.s[0];
+    c.ve_raw.s[0] += oldDiff * newDiff;
+    for (int k = 0; k < RH_NVARS; k++) c.Crow[k] += newDiff * rh_readlane(oldDiff, k); // cov(j*n+k) += newDiff(j) * oldDiff(k)
+    if (c.win_i != c.win_size) return false;
+    c.win_i = 0;
+    c.win_size = (int)(c.win_size * cfg.mass_expansion);
+    const double z = (double)(c.ve_samples - 1);          // covariance = cov / (samples - 1); reset() keeps `samples`
+    for (int k = 0; k < RH_NVARS; k++) { c.Drow[k] = c.Crow[k] / z; c.Crow[k] = 0.0; c.Lrow[k] = 0.0; }
+    c.ve_mean.s[0] = 0.0; c.ve_raw.s[0] = 0.0;
+    // choleskyUpperTriangular (MassMatrix.scala:74-116): packed lower triangle, row by row
+    for (int i = 0; i < RH_NVARS; i++)
+      for (int k = 0; k <= i; k++) {
+        double sum = 0.0;
+        for (int j = 0; j < k; j++) sum += rh_readlane(c.Lrow[j], i) * rh_readlane(c.Lrow[j], k);
+        const double x = rh_readlane(c.Drow[k], i) - sum;
+        const double val = (i == k) ? rh_strict_sqrt(x) : (1.0 / rh_readlane(c.Lrow[k], k) * x);
+        c.Lrow[k] = (lane == i) ? val : c.Lrow[k];
+      }
+    double dg = 0.0; // diagonal, for reporting through M / mass_diag
+    for (int k = 0; k < RH_NVARS; k++) dg = (lane == k) ? c.Drow[k] : dg;
+    c.M.s[0] = (lane < RH_NVARS) ? dg : 1.0;
+    c.SD.s[0] = (lane < RH_NVARS) ? rh_strict_sqrt(dg) : 1.0;
+    c.mass_identity = 0; c.mass_dense = 1;
+    return true;
+  }
+#endif
   if (cfg.mass_tuner != 1 /*RH_MASS_DIAG_WINDOWED*/) return false;
   c.win_j += 1;
   if (c.win_j < cfg.mass_skip_first || (cfg.warmup - c.win_j) < cfg.mass_skip_last) return false;
@@ -1615,3 +1697,4 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
 }
 
 extern "C" __device__ __attribute__((used)) const int rh_state_words = RH_STATE_U64; // u64 words per chain image
+extern "C" __device__ __attribute__((used)) const int rh_state_dense_off = RH_STATE_DENSE_OFF;

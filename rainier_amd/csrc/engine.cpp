@@ -119,12 +119,12 @@ std::vector<char> compile_hip(const std::string &src, const std::string &arch, s
 struct KSet {  // the per-chain sampler kernels of one compiled variant (with / without NUTS support)
   hipModule_t module = nullptr;
   hipFunction_t k_chain = nullptr, k_tick = nullptr;
-  int state_words = 0;
+  int state_words = 0, dense_off = 0;  // dense_off: u64 word offset of the dense-mass rows in the state image
   bool loaded = false;
 };
 
 struct rh_model {
-  KSet nuts;  // variant compiled with RH_WITH_NUTS (larger chain state); built on first use
+  KSet variants[4];  // sampler-kernel variants by (NUTS ? 1 : 0) | (dense mass ? 2 : 0); [0] aliases the base module; built on first use
   bool want_nuts = false;
   rh::Program prog;
   rh::EmitOptions eopt;
@@ -160,7 +160,7 @@ namespace { struct GatherBufs; }
 
 struct rh_sampler {
   hipFunction_t k_chain = nullptr, k_tick = nullptr;
-  int state_words = 0;
+  int state_words = 0, dense_off = 0;
   rh_model *m = nullptr;
   rh_cfg_dev cfg{};
   int chains = 0;
@@ -265,18 +265,32 @@ void load_module(rh_model *m) {
   m->loaded = true;
 }
 
-// the NUTS variant: same translation unit with RH_WITH_NUTS, only its per-chain kernels are used
-void load_nuts_variant(rh_model *m) {
-  if (m->nuts.loaded) return;
+// sampler-kernel variants: the same translation unit with RH_WITH_NUTS / RH_WITH_DENSE defined (larger chain state);
+// only their per-chain kernels are used, so plain HMC/EHMC with diagonal mass pay nothing for them
+std::string variant_defines(int v) {
+  std::string d;
+  if (v & 1) d += kNutsDefine;
+  if (v & 2) d += "#define RH_WITH_DENSE 1\n";
+  return d;
+}
+KSet &load_variant(rh_model *m, int v) {
+  KSet &ks = m->variants[v];
+  if (ks.loaded) return ks;
   HIPCHK(hipSetDevice(m->device));
-  const std::vector<char> code = build_source(m->arch, std::string(kNutsDefine) + m->source);
-  HIPCHK(hipModuleLoadData(&m->nuts.module, code.data()));
-  if (!m->info.gather_mode) HIPCHK(hipModuleGetFunction(&m->nuts.k_chain, m->nuts.module, "rh_chain_kernel"));
-  if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&m->nuts.k_tick, m->nuts.module, "rh_tick_kernel"));
+  if (v == 0) { ks.module = m->module; ks.k_chain = m->k_chain; ks.k_tick = m->k_tick; ks.state_words = m->state_words; ks.loaded = true; return ks; }
+  const std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source);
+  HIPCHK(hipModuleLoadData(&ks.module, code.data()));
+  if (!m->info.gather_mode) HIPCHK(hipModuleGetFunction(&ks.k_chain, ks.module, "rh_chain_kernel"));
+  if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&ks.k_tick, ks.module, "rh_tick_kernel"));
   hipDeviceptr_t p; size_t sz;
-  HIPCHK(hipModuleGetGlobal(&p, &sz, m->nuts.module, "rh_state_words"));
-  HIPCHK(hipMemcpy(&m->nuts.state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
-  m->nuts.loaded = true;
+  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_words"));
+  HIPCHK(hipMemcpy(&ks.state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  if (v & 2) {
+    HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_dense_off"));
+    HIPCHK(hipMemcpy(&ks.dense_off, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  }
+  ks.loaded = true;
+  return ks;
 }
 
 int guard(rh_model *m, const std::function<void()> &fn) {
@@ -334,7 +348,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     if (colon != std::string::npos) m->arch = m->arch.substr(0, colon);
     build_code(m);
     load_module(m);
-    if (m->want_nuts) load_nuts_variant(m);
+    if (m->want_nuts) (void)load_variant(m, 1);
     // observation columns -> HBM (the engine copies; the caller keeps ownership).  In gather mode the rows of a gather
     // target are first brought into index order (stable counting sort; only the summation order of the rows changes):
     // group g = rows whose table index is low + g.  Row targets without a gather are cut into pseudo-groups of 4096 rows.
@@ -412,7 +426,7 @@ extern "C" void rh_model_destroy(rh_model *m) {
     for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     if (m->module) hipModuleUnload(m->module);
-    if (m->nuts.module) hipModuleUnload(m->nuts.module);
+    for (int v = 1; v < 4; v++) if (m->variants[v].module) hipModuleUnload(m->variants[v].module);
   }
   delete m;
 }
@@ -447,7 +461,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
     build_code(&m);
     if (code_size) *code_size = m.code.size();
-    if (opts && opts->with_nuts) (void)build_source(m.arch, std::string(kNutsDefine) + m.source);
+    if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 3) + m.source);
   });
   return rc;
 }
@@ -586,10 +600,12 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     }
     s->m = m; s->chains = chains;
     HIPCHK(hipSetDevice(m->device));
-    if (cfg->sampler == RH_SAMPLER_NUTS) {
-      load_nuts_variant(m);
-      s->k_chain = m->nuts.k_chain; s->k_tick = m->nuts.k_tick; s->state_words = m->nuts.state_words;
-    } else { s->k_chain = m->k_chain; s->k_tick = m->k_tick; s->state_words = m->state_words; }
+    {
+      const int v = (cfg->sampler == RH_SAMPLER_NUTS ? 1 : 0) | (cfg->mass_tuner == RH_MASS_DENSE_WINDOWED ? 2 : 0);
+      if ((v & 2) && (m->prog.n_params > 64 || m->info.bign)) throw Fail{RH_E_UNSUPPORTED, "DenseMassMatrixTuner supports at most 64 parameters"};
+      KSet &ks = load_variant(m, v);
+      s->k_chain = ks.k_chain; s->k_tick = ks.k_tick; s->state_words = ks.state_words; s->dense_off = ks.dense_off;
+    }
     rh_cfg_dev &d = s->cfg;
     d.iterations = cfg->iterations; d.warmup = cfg->warmup; d.sampler = cfg->sampler; d.hmc_steps = cfg->hmc_steps;
     d.ehmc_max_steps = cfg->ehmc_max_steps; d.ehmc_min_steps = cfg->ehmc_min_steps; d.ehmc_buf_size = cfg->ehmc_buf_size;
@@ -844,6 +860,22 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
   });
   if (rc == RH_OK && any_lookup) { s->m->err = g_err = "Lookup index out of range during sampling"; return RH_E_LOOKUP; }
   return rc;
+}
+extern "C" int rh_sampler_mass_dense(rh_sampler *s, double *out) {
+  if (!s || !out) { g_err = "rh_sampler_mass_dense: NULL"; return RH_E_INVALID; }
+  if (s->cfg.mass_tuner != RH_MASS_DENSE_WINDOWED) { g_err = "rh_sampler_mass_dense: the sampler has no dense mass matrix"; return RH_E_INVALID; }
+  std::lock_guard<std::mutex> lk(s->m->mu);
+  return guard(s->m, [&] {
+    HIPCHK(hipSetDevice(s->m->device));
+    // row i of DenseMassMatrix.elements lives in lane i: word (dense_off + j) * 64 + i holds M[i][j]
+    const int n = (int)s->m->prog.n_params;
+    std::vector<uint64_t> img((size_t)n * 64 * s->chains);
+    const char *base = (const char *)s->d_state + (size_t)s->dense_off * 64 * sizeof(uint64_t);
+    HIPCHK(hipMemcpy2D(img.data(), (size_t)n * 64 * 8, base, (size_t)s->state_words * sizeof(uint64_t), (size_t)n * 64 * 8, (size_t)s->chains, hipMemcpyDeviceToHost));
+    for (int c = 0; c < s->chains; c++)
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) std::memcpy(&out[((size_t)c * n + i) * n + j], &img[((size_t)c * n + j) * 64 + i], sizeof(double));
+  });
 }
 extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
   if (!s || !out) { g_err = "rh_sampler_timing: NULL"; return RH_E_INVALID; }

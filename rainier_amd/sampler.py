@@ -67,6 +67,15 @@ class DiagonalMassMatrixTuner:
 
 
 @dataclass
+class DenseMassMatrixTuner:
+    """DenseMassMatrixTuner (MassMatrix.scala:175-181): CovarianceEstimator + packed Cholesky; at most 64 parameters."""
+    initialWindowSize: int = 50
+    windowExpansion: float = 1.5
+    skipFirst: int = 50
+    skipLast: int = 50
+
+
+@dataclass
 class DiagonalMassMatrix:
     elements: Sequence[float]
 
@@ -142,6 +151,10 @@ def to_c_config(config: SamplerConfig, nvars: int):
         c.mass_tuner = _capi.MASS_IDENTITY
     elif isinstance(mt, DiagonalMassMatrixTuner):
         c.mass_tuner = _capi.MASS_DIAG_WINDOWED
+        c.mass_init_window, c.mass_expansion = mt.initialWindowSize, mt.windowExpansion
+        c.mass_skip_first, c.mass_skip_last = mt.skipFirst, mt.skipLast
+    elif isinstance(mt, DenseMassMatrixTuner):
+        c.mass_tuner = _capi.MASS_DENSE_WINDOWED
         c.mass_init_window, c.mass_expansion = mt.initialWindowSize, mt.windowExpansion
         c.mass_skip_first, c.mass_skip_last = mt.skipFirst, mt.skipLast
     elif isinstance(mt, StaticMassMatrix):
@@ -247,6 +260,13 @@ class Sampler:
         _capi.check(_capi.lib().rh_sampler_stats(self._h, st, _capi.dptr(mass)), self.model._h)
         return [Stats(s.leapfrog_steps, s.warmup_leapfrog_steps, s.gradient_evaluations, s.accepted,
                       s.mean_accept_prob, s.step_size) for s in st], mass
+
+    def mass_dense(self) -> np.ndarray:
+        """DenseMassMatrix.elements of every chain: [chains][nVars][nVars] (DenseMassMatrixTuner only)."""
+        n = self.model.nVars
+        out = np.zeros((self.chains, n, n))
+        _capi.check(_capi.lib().rh_sampler_mass_dense(self._h, _capi.dptr(out)), self.model._h)
+        return out
 
     def timing(self, reset: bool = False):
         t = _capi.Timing()

@@ -10,7 +10,7 @@ ODIR = os.path.join(ROOT, "oracle")
 JM_LIBM, JM_DET = 0, 1
 HMC, EHMC, NUTS = 0, 1, 2
 STEP_DUALAVG, STEP_STATIC = 0, 1
-MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG = 0, 1, 2
+MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG, MASS_DENSE_WINDOWED = 0, 1, 2, 3
 
 DENSITY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -26,7 +26,7 @@ class OrcConfig(C.Structure):
         ("step_tuner", C.c_int), ("delta", C.c_double), ("static_step", C.c_double),
         ("mass_tuner", C.c_int), ("init_window", C.c_int), ("expansion", C.c_double),
         ("skip_first", C.c_int), ("skip_last", C.c_int), ("static_mass", C.POINTER(C.c_double)),
-        ("nuts_max_depth", C.c_int), ("iterations", C.c_int), ("warmup", C.c_int), ("math_mode", C.c_int),
+        ("nuts_max_depth", C.c_int), ("iterations", C.c_int), ("warmup", C.c_int), ("math_mode", C.c_int), ("dense_out", C.POINTER(C.c_double)),
     ]
 
 
@@ -81,6 +81,9 @@ def load():
     lib.orc_lf_start_iteration.argtypes = [C.c_void_p, dp, dp]
     lib.orc_lf_take_steps.argtypes = [C.c_void_p, C.c_int, C.c_double, dp]
     lib.orc_lf_finish_iteration.restype = C.c_double; lib.orc_lf_finish_iteration.argtypes = [C.c_void_p, dp, dp]
+    lib.orc_cholesky_upper.argtypes = [dp, C.c_int, dp]
+    lib.orc_upper_triangular_solve.argtypes = [dp, dp, C.c_int, dp]
+    lib.orc_square_multiply.argtypes = [dp, dp, C.c_int, dp]
     lib.orc_diagnostics.argtypes = [dp, C.c_int, C.c_int, dp, dp]
     _lib = lib
     return lib

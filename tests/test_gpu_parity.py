@@ -154,8 +154,8 @@ def _oracle_cfg(config, math_mode):
     if isinstance(st, R.DualAvgTuner): kw.update(step_tuner=O.STEP_DUALAVG, delta=st.delta)
     else: kw.update(step_tuner=O.STEP_STATIC, static_step=st.stepSize)
     if isinstance(mt, R.IdentityMassMatrixTuner): kw.update(mass_tuner=O.MASS_IDENTITY)
-    elif isinstance(mt, R.DiagonalMassMatrixTuner):
-        kw.update(mass_tuner=O.MASS_DIAG_WINDOWED, init_window=mt.initialWindowSize, expansion=mt.windowExpansion,
+    elif isinstance(mt, (R.DiagonalMassMatrixTuner, R.DenseMassMatrixTuner)):
+        kw.update(mass_tuner=O.MASS_DIAG_WINDOWED if isinstance(mt, R.DiagonalMassMatrixTuner) else O.MASS_DENSE_WINDOWED, init_window=mt.initialWindowSize, expansion=mt.windowExpansion,
                   skip_first=mt.skipFirst, skip_last=mt.skipLast)
     else: kw.update(mass_tuner=O.MASS_STATIC_DIAG, static_mass=np.array(mt.mass.elements, dtype=np.float64))
     return O.make_config(**kw)
@@ -614,3 +614,33 @@ def test_large_lookup_tables_generic_path():
     with pytest.raises(R.RainierHipError) as e:
         R.Model(bad, device=0).density_batch(np.zeros((1, 3)))
     assert e.value.code == _capi.RH_E_LOOKUP
+
+
+# ---- DenseMassMatrixTuner (sampler/MassMatrix.scala:15-117,175-181; MassMatrixEstimator.scala:9-50) -----------------
+def test_dense_mass_matrix_bit_exact_vs_oracle():
+    spec = models.eight_schools()
+    for cfg in (R.make_config(120, 400, R.EHMCSampler(64), R.DualAvgTuner(0.8), R.DenseMassMatrixTuner(50, 1.5, 50, 50)),
+                R.make_config(80, 300, R.NUTSSampler(8), R.DualAvgTuner(0.8), R.DenseMassMatrixTuner(30, 2.0, 20, 20)),
+                R.make_config(100, 250, R.HMCSampler(7), R.DualAvgTuner(0.7), R.DenseMassMatrixTuner(40, 1.5, 10, 50))):
+        m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+        s = R.Sampler(m, cfg, [2000, 2001]); s.warmup(); s.run(cfg.iterations)
+        got, dense = s.draws(), s.mass_dense(); stats, mdiag = s.stats(); s.close()
+        ocfg = _oracle_cfg(cfg, O.JM_DET)
+        for c, seed in enumerate((2000, 2001)):
+            want_dense = np.zeros(100); ocfg.dense_out = O._dp(want_dense)
+            want, mass, st = O.sample_model(spec, ocfg, seed)
+            assert np.array_equal(got[c], want), (type(cfg.sampler()).__name__, c)
+            assert np.array_equal(dense[c].ravel(), want_dense) and np.array_equal(mdiag[c], mass)
+            assert stats[c].leapfrogSteps == st.leapfrog_steps and stats[c].stepSize == st.step_size
+        assert np.linalg.eigvalsh(dense[0]).min() > 0 and not np.allclose(dense[0], np.diag(np.diag(dense[0])))
+
+
+def test_dense_mass_matrix_limits_and_known_answer(oracle):
+    # the packed upper-triangular solve convention, on CholeskyTest's worked example (compute/CholeskyTest.scala:50-81)
+    pk = np.array([1, 2, 4, 7, 3, 5, 8, 6, 9, 10], dtype=float); y = np.array([45, 53, 54, 40], dtype=float); x = np.zeros(4)
+    oracle.orc_upper_triangular_solve(O._dp(pk), O._dp(y), 4, O._dp(x))
+    assert list(x) == [1.0, 2.0, 3.0, 4.0]
+    spec = models.logistic(n=200, k=70)            # 71 parameters > 64
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(spec, device=0).sample(R.make_config(5, 60, massMatrixTuner=R.DenseMassMatrixTuner()), seeds=[1])
+    assert e.value.code == _capi.RH_E_UNSUPPORTED

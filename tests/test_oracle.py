@@ -204,3 +204,27 @@ def test_nuts_extension_recovers_standard_normal(oracle):
     draws, mass, st = O.sample_model(models.funnel(10), cfg, 11)
     assert np.all(np.abs(draws.mean(axis=0)) < 0.12) and np.all(np.abs(draws.var(axis=0) - 1.0) < 0.2)
     assert 0.7 < st.mean_accept_prob < 0.9 and 1 <= st.leapfrog_steps / 3000 <= 2 ** 10
+
+
+def test_dense_mass_matrix_pieces(oracle):
+    # S/MassMatrix.scala:33-117: U^T U = M, the packed triangular solve, and CholeskyTest's worked example
+    rng = np.random.default_rng(0); n = 7
+    A = rng.normal(size=(n, n)); M = A @ A.T + n * np.eye(n)
+    U = np.zeros(n * (n + 1) // 2)
+    oracle.orc_cholesky_upper(O._dp(np.ascontiguousarray(M.ravel())), n, O._dp(U))
+    Um = np.zeros((n, n)); l = 0
+    for i in range(n):
+        for k in range(n - i):
+            Um[i, i + k] = U[l]; l += 1
+    np.testing.assert_allclose(Um.T @ Um, M, rtol=1e-12)
+    b = rng.normal(size=n); x = np.zeros(n)
+    oracle.orc_upper_triangular_solve(O._dp(U), O._dp(b), n, O._dp(x))
+    np.testing.assert_allclose(Um @ x, b, rtol=1e-12)
+    pk = np.array([1, 2, 4, 7, 3, 5, 8, 6, 9, 10], dtype=float); y = np.array([45, 53, 54, 40], dtype=float); x = np.zeros(4)
+    oracle.orc_upper_triangular_solve(O._dp(pk), O._dp(y), 4, O._dp(x))     # compute/CholeskyTest.scala:50-81
+    assert list(x) == [1.0, 2.0, 3.0, 4.0]
+    cfg = O.make_config(sampler=O.EHMC, iterations=800, warmup=600, mass_tuner=O.MASS_DENSE_WINDOWED, math_mode=O.JM_DET)
+    dense = np.zeros(100); cfg.dense_out = O._dp(dense)
+    draws, mass, st = O.sample_model(models.eight_schools(), cfg, 3)
+    assert np.linalg.eigvalsh(dense.reshape(10, 10)).min() > 0 and np.allclose(np.diag(dense.reshape(10, 10)), mass)
+    assert np.all(np.isfinite(draws)) and 0.6 < st.mean_accept_prob < 0.95
