@@ -18,6 +18,7 @@ RH_OK, RH_E_INVALID, RH_E_COMPILE, RH_E_DEVICE, RH_E_LOOKUP, RH_E_UNSUPPORTED = 
 MATH_FAST, MATH_STRICT = 0, 1
 SAMPLER_HMC, SAMPLER_EHMC, SAMPLER_NUTS = 0, 1, 2
 STEP_DUALAVG, STEP_STATIC = 0, 1
+OPT_CONVERGED, OPT_NOT_DESCENT, OPT_MAX_EVALS = 0, 1, 2
 MASS_IDENTITY, MASS_DIAG_WINDOWED, MASS_STATIC_DIAG, MASS_DENSE_WINDOWED = 0, 1, 2, 3
 ENGINE_AUTO, ENGINE_CHAIN, ENGINE_TICK = 0, 1, 2
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "rh_model_create", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
     "rh_density_eval", "rh_config_default", "rh_sample", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
-    "rh_sampler_timing", "rh_sampler_mass_dense", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
+    "rh_sampler_timing", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
 ]
 
 
@@ -94,6 +95,7 @@ def lib():
     L.rh_sampler_draws_device.argtypes = [vp, C.POINTER(vp)]
     L.rh_sampler_stats.argtypes = [vp, C.POINTER(ChainStats), dp]
     L.rh_sampler_mass_dense.argtypes = [vp, dp]
+    L.rh_optimize.argtypes = [vp, dp, C.c_int32, C.c_int32, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rh_sampler_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
     L.rh_diagnostics.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
     L.rh_requirements_eval.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), dp, C.c_int64, dp]

@@ -25,6 +25,7 @@
 #include "../../include/rainier_hip.h"
 #include "device/rh_shared.h"
 #include "rir.hpp"
+#include "optimize.hpp"
 
 // device sources embedded at build time (see Makefile: device_src.inc)
 static const char *kSharedSrc =
@@ -432,6 +433,18 @@ extern "C" void rh_model_destroy(rh_model *m) {
 }
 extern "C" int rh_model_nvars(const rh_model *m) { return m ? (int)m->prog.n_params : -RH_E_INVALID; }
 extern "C" const char *rh_model_hip_source(const rh_model *m) { return m ? m->source.c_str() : ""; }
+extern "C" int rh_optimize(rh_model *m, const double *x0, int32_t starts, int32_t max_evals, double *x_out,
+                           int32_t *evals_out, int32_t *status_out) {
+  if (!m || !m->loaded) { g_err = "rh_optimize: model not loaded"; return RH_E_INVALID; }
+  if (!x_out || starts <= 0) { m->err = g_err = "rh_optimize: bad arguments"; return RH_E_INVALID; }
+  std::string err;
+  int rc = rh::lbfgs_multistart((int)m->prog.n_params, starts, x0, max_evals,
+                                [m](const double *q, int k, double *lp, double *gr) { return rh_density_eval(m, q, k, lp, gr); },
+                                x_out, evals_out, status_out, err);
+  (void)err; // rh_density_eval has already recorded the failure in m->err
+  return rc;
+}
+
 extern "C" const char *rh_last_error(const rh_model *m) { return m ? m->err.c_str() : g_err.c_str(); }
 extern "C" int rh_abi_version(void) { return RH_ABI_VERSION; }
 extern "C" int rh_device_count(void) {

@@ -67,6 +67,24 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_densityEval(
   if (rc != RH_OK) throw_rh(env, m, rc);
 }
 
+/* void optimize(long model, double[] x0 (null = zeros), int starts, int maxEvals, double[] x, int[] evals, int[] status) */
+JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_optimize(
+    JNIEnv *env, jobject self, jlong h, jdoubleArray x0, jint starts, jint maxEvals, jdoubleArray x, jintArray evals,
+    jintArray status) {
+  (void)self;
+  rh_model *m = (rh_model *)(intptr_t)h;
+  jdouble *x0p = x0 ? (*env)->GetDoubleArrayElements(env, x0, NULL) : NULL;
+  jdouble *xp = (*env)->GetDoubleArrayElements(env, x, NULL);
+  jint *ep = (*env)->GetIntArrayElements(env, evals, NULL);
+  jint *sp = (*env)->GetIntArrayElements(env, status, NULL);
+  const int rc = rh_optimize(m, x0p, starts, maxEvals, xp, (int32_t *)ep, (int32_t *)sp);
+  if (x0p) (*env)->ReleaseDoubleArrayElements(env, x0, x0p, JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, x, xp, 0);
+  (*env)->ReleaseIntArrayElements(env, evals, ep, 0);
+  (*env)->ReleaseIntArrayElements(env, status, sp, 0);
+  if (rc != RH_OK) throw_rh(env, m, rc);
+}
+
 /* void sample(long model, int[] icfg, double[] dcfg, double[] staticMass, long[] seeds, double[] draws, double[] mass,
  *             double[] stats)   -- icfg/dcfg carry rh_config field by field (see Native.scala in INTEGRATION.md) */
 JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_sample(

@@ -158,6 +158,22 @@ def normal_1d() -> ModelSpec:
     return ModelSpec("normal1d", rir, [], [0], 1, {"kind": "normal1d"})
 
 
+def fit_normal(data=(1.0, 2.0, 3.0)) -> ModelSpec:
+    """OptimizerTest's "fit normal" (rainier-test/.../optimizer/OptimizerTest.scala:8-13): mu = Normal(0,10).latent = 10 z,
+    sigma = Uniform(0,1).latent = logistic(u) with log-Jacobian log sigma + log(1 - sigma) (core/Support.scala:56-96),
+    observations Normal(mu, sigma).  theta = (z, u)."""
+    g = Graph(2, [0, 1])
+    z, u = g.param(0), g.param(1)
+    sigma = 1.0 / ((u * -1.0).exp() + 1.0)
+    prior = std_normal_logpdf(z) + sigma.log() + (1.0 - sigma).log()
+    y = g.col(1, 0)
+    e = (y - z * 10.0) / sigma
+    row = (e * e) / -2.0 - sigma.log() - HALF_LOG_2PI
+    rir = g.compile([prior, row])
+    ys = np.asarray(data, dtype=np.float64)
+    return ModelSpec("fit_normal", rir, [ys], [0, len(ys)], 2, {"kind": "fit_normal"})
+
+
 def funnel_predict(dim: int = 10):
     """Requirements of cfg 1's predict(): y = 3 z0, x_i = z_i exp(y/2) -- where the funnel shape appears."""
     g = Graph(dim, [])

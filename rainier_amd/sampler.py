@@ -327,6 +327,22 @@ class Model:
             s.close()
         return Trace(draws, mass, stats)
 
+    def optimize(self, starts: np.ndarray = None, max_evals: int = 0):
+        """Model.optimize's numeric part = Optimizer.lbfgs(density()) (core/Model.scala:26-30, optimizer/Optimizer.scala:6-24).
+        starts None: the reference's single start at 0 -> x [nVars]; starts [k][nVars]: k independent searches sharing
+        each batched density launch -> (x [k][nVars], evals [k], status [k])"""
+        single = starts is None
+        x0 = np.zeros((1, self.nVars)) if single else np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, self.nVars)
+        k = x0.shape[0]
+        x, evals, status = np.zeros((k, self.nVars)), np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        _capi.check(_capi.lib().rh_optimize(self._h, _capi.dptr(x0), k, max_evals, _capi.dptr(x), ip(evals), ip(status)), self._h)
+        if single:
+            if status[0] == _capi.OPT_NOT_DESCENT:
+                raise RuntimeError("dginit")       # LBFGS.java:236-237
+            return x[0]
+        return x, evals, status
+
     def selftest(self, mode: int, seed: int = 0, x: np.ndarray = None, n: int = None) -> np.ndarray:
         x = np.zeros(1) if x is None else np.ascontiguousarray(x, dtype=np.float64)
         n = (x.size // 2 if mode == 5 else x.size) if n is None else n

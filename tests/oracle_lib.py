@@ -85,6 +85,10 @@ def load():
     lib.orc_upper_triangular_solve.argtypes = [dp, dp, C.c_int, dp]
     lib.orc_square_multiply.argtypes = [dp, dp, C.c_int, dp]
     lib.orc_diagnostics.argtypes = [dp, C.c_int, C.c_int, dp, dp]
+    lib.orc_lbfgs_new.restype = C.c_void_p; lib.orc_lbfgs_new.argtypes = [dp, C.c_int, C.c_int, C.c_double]
+    lib.orc_lbfgs_free.argtypes = [C.c_void_p]
+    lib.orc_lbfgs_apply.restype = C.c_int; lib.orc_lbfgs_apply.argtypes = [C.c_void_p, C.c_double, dp]
+    lib.orc_optimize.restype = C.c_int; lib.orc_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, C.c_int, dp]
     _lib = lib
     return lib
 
@@ -191,6 +195,31 @@ def sample_model(spec, cfg, seed, math_mode=None):
     d = OracleDensity(spec, cfg.math_mode if math_mode is None else math_mode)
     draws, mass, st, rc = sample_chain(d.fn_ptr, d.handle, spec.n_params, cfg, seed)
     return draws, mass, st
+
+
+def optimize_model(spec, x0=None, max_evals=100000, math_mode=JM_LIBM):
+    """Optimizer.lbfgs over the RIR interpreter: (x, evals) -- evals < 0: -1 dginit, -2 max_evals, -3 density error."""
+    d = OracleDensity(spec, math_mode)
+    x = np.zeros(spec.n_params)
+    x0p = None if x0 is None else _dp(np.ascontiguousarray(x0, dtype=np.float64))
+    rc = load().orc_optimize(d.fn_ptr, d.handle, spec.n_params, x0p, max_evals, _dp(x))
+    return x, rc
+
+
+class Lbfgs:
+    """new LBFGS(x, m, eps) driven from Python: apply(f, g) -> 1 converged / 0 evaluate again / -1 dginit."""
+
+    def __init__(self, n, m=5, eps=0.1):
+        self.x = np.zeros(n)
+        self._h = load().orc_lbfgs_new(_dp(self.x), n, m, eps)
+
+    def apply(self, f, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        return load().orc_lbfgs_apply(self._h, float(f), _dp(g))
+
+    def __del__(self):
+        try: load().orc_lbfgs_free(self._h)
+        except Exception: pass
 
 
 def diagnostics(traces):

@@ -644,3 +644,47 @@ def test_dense_mass_matrix_limits_and_known_answer(oracle):
     with pytest.raises(R.RainierHipError) as e:
         R.Model(spec, device=0).sample(R.make_config(5, 60, massMatrixTuner=R.DenseMassMatrixTuner()), seeds=[1])
     assert e.value.code == _capi.RH_E_UNSUPPORTED
+
+
+# ---- Model.optimize / Optimizer.lbfgs (optimizer/Optimizer.scala:6-24, LBFGS.java:44-632) -----------------------------
+def test_optimize_data_free_bit_exact_vs_oracle():
+    # strict math: the device density is bit-identical to the oracle's, so every L-BFGS iterate must be too
+    spec = models.eight_schools()
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    rng = np.random.default_rng(11)
+    starts = np.concatenate([np.zeros((1, 10)), rng.normal(size=(47, 10))])
+    x, evals, status = m.optimize(starts)
+    for s in range(len(starts)):
+        want, ev = O.optimize_model(spec, starts[s], math_mode=O.JM_DET)
+        assert (status[s] == _capi.OPT_CONVERGED and evals[s] == ev) if ev > 0 else (status[s] == _capi.OPT_NOT_DESCENT and ev == -1), s
+        assert np.array_equal(x[s], want), s
+    assert np.array_equal(m.optimize(), x[0])                      # the reference's single start at 0
+    assert len(set(evals.tolist())) > 3                            # starts retire at different rounds (compaction path)
+    # a zero gradient at the start is the reference's RuntimeException("dginit")
+    f = R.Model(models.funnel(), device=0, math_mode=_capi.MATH_STRICT)
+    with pytest.raises(RuntimeError, match="dginit"):
+        f.optimize()
+    xs, ev, st = m.optimize(starts[1:5], max_evals=2)
+    assert list(st) == [_capi.OPT_MAX_EVALS] * 4 and list(ev) == [2] * 4
+
+
+def test_optimize_fit_normal_and_streamed_models():
+    # OptimizerTest's "fit normal" (3 observations): same iterates as the oracle up to the row-sum order
+    spec = models.fit_normal()
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    want, ev = O.optimize_model(spec, math_mode=O.JM_DET)
+    got = m.optimize()
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # streamed linear regression (cfg 2's model, 1e5 rows), several starts: the termination criterion holds on the device
+    # gradient, every start lands on the same posterior mode, and it is the oracle's optimum
+    spec = models.linreg(n=100_000)
+    m = R.Model(spec, device=0, factor_outputs=True)
+    starts = np.random.default_rng(3).normal(size=(16, 5)) * 0.3
+    starts[0] = 0
+    x, evals, status = m.optimize(starts)
+    assert np.all(status == _capi.OPT_CONVERGED) and evals.max() < 200
+    lp, g = m.density_batch(x)
+    assert np.all(np.linalg.norm(g, axis=1) / np.maximum(1.0, np.linalg.norm(x, axis=1)) <= 0.1)
+    want, ev = O.optimize_model(spec)
+    np.testing.assert_allclose(x[0], want, rtol=1e-6, atol=1e-8)
+    assert np.abs(x - want).max() < 0.02

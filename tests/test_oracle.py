@@ -228,3 +228,37 @@ def test_dense_mass_matrix_pieces(oracle):
     draws, mass, st = O.sample_model(models.eight_schools(), cfg, 3)
     assert np.linalg.eigvalsh(dense.reshape(10, 10)).min() > 0 and np.allclose(np.diag(dense.reshape(10, 10)), mass)
     assert np.all(np.isfinite(draws)) and 0.6 < st.mean_accept_prob < 0.95
+
+
+def test_lbfgs_fit_normal_and_termination(oracle):
+    # optimizer/OptimizerTest.scala:8-13 "fit normal"; Optimizer.lbfgs (optimizer/Optimizer.scala:6-24): m = 5, eps = 0.1
+    import scipy.optimize as so
+    spec = models.fit_normal()
+    x, evals = O.optimize_model(spec)
+    d = O.OracleDensity(spec)
+    out = d.update(x)
+    assert evals == 12                                                       # regression pin of the restatement
+    assert np.linalg.norm(out[1:]) / max(1.0, np.linalg.norm(x)) <= 0.1      # LBFGS.java:171-175
+    ref = so.minimize(lambda q: -d.update(q)[0], np.zeros(2), jac=lambda q: -d.update(q)[1:], method="L-BFGS-B", tol=1e-12)
+    assert np.allclose(x, ref.x, atol=0.02)                                  # eps = 0.1 stops this close to the MAP
+    mu, sigma = 10 * x[0], 1 / (1 + np.exp(-x[1]))
+    assert abs(mu - 2.0) < 0.02 and abs(sigma - 0.69) < 0.01                 # data (1,2,3): mean 2; sigma < 1 by the prior
+    # a zero gradient at the start is the reference's RuntimeException("dginit") (LBFGS.java:236-237)
+    assert O.optimize_model(models.funnel())[1] == -1
+    # max_evals guard
+    assert O.optimize_model(spec, max_evals=3)[1] == -2
+
+
+def test_lbfgs_reverse_communication_on_quadratic(oracle):
+    # LBFGS.apply as the reference test drives it (OptimizerTest.scala:32-41): f, g in, x updated in place
+    rng = np.random.default_rng(5); n = 12
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n); b = rng.normal(size=n)
+    lb = O.Lbfgs(n, m=5, eps=1e-7)
+    for it in range(500):
+        f, g = 0.5 * lb.x @ A @ lb.x - b @ lb.x, A @ lb.x - b
+        r = lb.apply(f, g)
+        assert r >= 0
+        if r == 1:
+            break
+    assert r == 1 and it < 200
+    np.testing.assert_allclose(lb.x, np.linalg.solve(A, b), atol=1e-7)
