@@ -65,6 +65,15 @@ RH_DEV double rh_strict_log(double x) {
   return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+// 1.0 the optimiser cannot see through: fma(x, rh_one(), y) stays a v_fma_f64 (it is x + y exactly) instead of folding back
+// into v_add_f64.  Used by the emitter's opt-in fma_adds spelling (RH_FMA_ADDS=1); cycle-accurate measurements
+// (tools/ubench/fma64_cycles.hip, profiles/r1_d_fp64_ceiling) show fma/add mixes issue as fast as pure FMA streams.
+RH_DEV double rh_one() {
+  double o = 1.0;
+  asm("" : "+v"(o));
+  return o;
+}
+
 // ---- fdlibm 5.3 e_exp.c (== java.lang.StrictMath.exp) --------------------------------------------
 RH_DEV double rh_strict_exp(double x) {
   const double huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302,

@@ -50,6 +50,7 @@ struct TargetEmitter {
   uint32_t t;
   bool factor;
   bool fast_div = false;       // fast mode: x / const -> x * (1/const)
+  bool fma_adds = false;       // per-row code: adds/subs as fma(x, +-1.0, y); with fast_div (= contraction allowed) mul+add is fused here
   uint32_t run_end = 0;        // data-free targets t..run_end are emitted together (shared sub-expressions once)
   bool merged_away = false;    // this data-free target was emitted by an earlier one of its run
   // gather mode (models with a big parameter table indexed by a data column -- cfg 5):
@@ -308,10 +309,31 @@ struct TargetEmitter {
     os << "    if ((unsigned)" << k << " >= " << nd.table.size() << "u) err = 1;\n";
     return true;
   }
+  // the fma-only spelling applies to the per-row code of streamed targets (the hot loop of every gradient kernel)
+  bool fma_row(int ctx) const { return fma_adds && ctx == 1 && has_rows(); }
+  // a product computed per row (not a hoisted invariant) that contraction may fold into the add consuming it
+  bool fusable(uint32_t id, int ctx) const {
+    return fast_div && fma_row(ctx) && id < P.nodes.size() && P.nodes[id].op == RH_RIR_MUL && P.nodes[id].dep != 0 &&
+           !(gather.ok && id == gather.node);
+  }
+  std::string accumulate(const std::string &dst, uint32_t v, int ctx) const {
+    if (!fma_row(ctx)) return "    " + dst + " += " + ref(v, ctx) + ";\n";
+    if (fusable(v, ctx)) return "    " + dst + " = __builtin_fma(" + ref(P.nodes[v].a, ctx) + ", " + ref(P.nodes[v].b, ctx) + ", " + dst + ");\n";
+    return "    " + dst + " = __builtin_fma(" + ref(v, ctx) + ", rh1, " + dst + ");\n";
+  }
   bool emit_node(std::ostringstream &os, uint32_t id, int ctx, std::string &err) const {
     const Node &nd = P.nodes[id];
     auto R = [&](uint32_t x) { return ref(x, ctx); };
     const std::string lhs = "    const double n" + std::to_string(id) + " = ";
+    if (fma_row(ctx) && (nd.op == RH_RIR_ADD || nd.op == RH_RIR_SUB)) {
+      // x + y == fma(x, 1.0, y) and x - y == fma(y, -1.0, x) exactly; where contraction is allowed a row-level product
+      // feeding the sum is fused here, explicitly, instead of by the compiler
+      const bool sub = nd.op == RH_RIR_SUB;
+      if (fusable(nd.a, ctx)) os << lhs << "__builtin_fma(" << R(P.nodes[nd.a].a) << ", " << R(P.nodes[nd.a].b) << ", " << (sub ? "-(" + R(nd.b) + ")" : R(nd.b)) << ");\n";
+      else if (fusable(nd.b, ctx)) os << lhs << "__builtin_fma(" << (sub ? "-(" + R(P.nodes[nd.b].a) + ")" : R(P.nodes[nd.b].a)) << ", " << R(P.nodes[nd.b].b) << ", " << R(nd.a) << ");\n";
+      else os << lhs << "__builtin_fma(" << R(nd.b) << ", " << (sub ? "-rh1" : "rh1") << ", " << R(nd.a) << ");\n";
+      return true;
+    }
     switch (nd.op) {
       case RH_RIR_ADD: os << lhs << R(nd.a) << " + " << R(nd.b) << ";\n"; break;
       case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
@@ -535,17 +557,17 @@ struct TargetEmitter {
     if (rows) {
       if (gmode)
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, const double gz, double *acc, double &sv, int &err) {\n"
-              "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n";
+              "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       else
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double *acc, int &err) {\n"
-              "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n";
+              "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
         if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
         if (!emit_node(os, (uint32_t)n, 1, err)) return false;
       }
-      for (size_t j = 0; j < basis.size(); j++) os << "    acc[" << j << "] += " << ref(basis[j], 1) << ";\n";
-      if (gather.ok) os << "    sv += " << ref(gather.sv, 1) << ";\n";
+      for (size_t j = 0; j < basis.size(); j++) os << accumulate("acc[" + std::to_string(j) + "]", basis[j], 1);
+      if (gather.ok) os << accumulate("sv", gather.sv, 1);
       os << "  }\n";
       // ---- finish: tot[o] += alpha * S[j] + nrows * beta
       os << "  static RH_DEV void finish(const double (&th)[RH_NTH], const double *inv, const double *S, const double nrows, double (&tot)[RH_NOUT]) {\n"
@@ -605,6 +627,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
+    te.fma_adds = o.fma_adds;
     if (P.targets[t].n_cols == 0) {  // runs of consecutive data-free targets share one evaluation
       if (t > 0 && P.targets[t - 1].n_cols == 0) te.merged_away = true;
       else { uint32_t e = t; while (e + 1 < P.targets.size() && P.targets[e + 1].n_cols == 0) e++; te.run_end = e; }

@@ -93,13 +93,26 @@ void write_file(const std::string &path, const std::vector<char> &data) {
 }
 
 // hiprtc: source -> gfx950 code object
-std::vector<char> compile_hip(const std::string &src, const std::string &arch, std::string &log) {
+std::vector<std::string> split_flags(const std::string &flags) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < flags.size()) {
+    size_t j = flags.find_first_of(" ,", i);
+    if (j == std::string::npos) j = flags.size();
+    if (j > i) out.push_back(flags.substr(i, j - i));
+    i = j + 1;
+  }
+  return out;
+}
+std::vector<char> compile_hip(const std::string &src, const std::string &arch, const std::string &extra, std::string &log) {
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "rainier_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     throw Fail{RH_E_COMPILE, "hiprtcCreateProgram failed"};
   const std::string archopt = "--offload-arch=" + arch;
-  const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  std::vector<const char *> opts = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+  const std::vector<std::string> more = split_flags(extra);
+  for (const std::string &f : more) opts.push_back(f.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   hiprtcGetProgramLogSize(prog, &ls);
   log.assign(ls, '\0');
@@ -186,6 +199,7 @@ namespace {
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
   if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
@@ -210,23 +224,26 @@ void assemble_source(rh_model *m) {
               kEngineSrc;
 }
 
-std::vector<char> build_source(const std::string &arch, const std::string &source) {
+std::vector<char> build_source(const std::string &arch, const std::string &source, const std::string &extra = std::string()) {
   int hv = 0;
   hiprtcVersion(&hv, &hv);
-  const uint64_t h = fnv1a(arch + "|" + std::to_string(hv) + "|" + source);
+  const uint64_t h = fnv1a(arch + "|" + std::to_string(hv) + "|" + extra + "|" + source);
   char name[64];
   std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
   const std::string path = cache_dir() + name;
   std::vector<char> code;
   if (!std::getenv("RH_NO_KERNEL_CACHE") && read_file(path, code)) return code;
   std::string log;
-  code = compile_hip(source, arch, log);
+  code = compile_hip(source, arch, extra, log);
   if (!std::getenv("RH_NO_KERNEL_CACHE")) write_file(path, code);
   return code;
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
-void build_code(rh_model *m) { m->code = build_source(m->arch, m->source); }
+void build_code(rh_model *m) {
+  const char *e = std::getenv("RH_HIPRTC_EXTRA");
+  m->code = build_source(m->arch, m->source, e ? e : "");
+}
 
 void load_module(rh_model *m) {
   HIPCHK(hipSetDevice(m->device));

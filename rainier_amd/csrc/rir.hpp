@@ -42,6 +42,8 @@ struct EmitOptions {
   int gather_min = 65;   // Lookup tables of at least this many trailing parameters switch the model to gather mode
   bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
+  bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
+                         // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
   bool grad_pipeline = false;  // software-pipelined row loop in the batched gradient kernel  // row-loop unroll of the batched gradient kernel (0 = default)
 };
 

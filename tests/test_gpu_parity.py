@@ -12,6 +12,7 @@ import pytest
 
 import rainier_amd as R
 from rainier_amd import _capi, models
+from rainier_amd.frontend import Graph
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -688,3 +689,33 @@ def test_optimize_fit_normal_and_streamed_models():
     want, ev = O.optimize_model(spec)
     np.testing.assert_allclose(x[0], want, rtol=1e-6, atol=1e-8)
     assert np.abs(x - want).max() < 0.02
+
+
+# ---- compute/RealTest.scala at the IR boundary: every expression of the reference's suite through the generated HIP -------
+def test_realtest_expressions_on_device():
+    from tests.realtest_cases import CASES, POINTS, Alg, constant, within_epsilon
+    import math
+    for group in ([c for c in CASES if c[0] != "lookup"], [c for c in CASES if c[0] == "lookup"]):
+        g = Graph(1, [0])
+        x = g.param(0)
+        vals = [c[1](Alg(g), x) for c in group]
+        ders = [g.gradient(v)[0] for v in vals]
+        pts = [v for v in POINTS if all(c[2] is None or c[2](v) for c in group)] if len(group) == 1 else POINTS
+        draws = np.array(pts)[:, None]
+        for exprs, is_der in ((vals, False), (ders, True)):
+            rir = g.compile_requirements(exprs)
+            spec = models.ModelSpec("req", rir, [], [0] * len(exprs), 1)
+            for mode, omode in ((_capi.MATH_STRICT, O.JM_DET), (_capi.MATH_FAST, O.JM_LIBM)):
+                got = R.predict(rir, draws, len(exprs), device=0, math_mode=mode)
+                d = O.OracleDensity(spec, omode)
+                for i, v in enumerate(pts):
+                    want = d.requirements(np.array([v]), len(exprs))
+                    for k, (name, fn, defined, derivable, reference) in enumerate(group):
+                        if defined is not None and not defined(v):
+                            continue
+                        assert within_epsilon(want[k], got[i, k]), ("ir/hip", name, v, is_der, mode, want[k], got[i, k])
+                        if not is_der:
+                            assert within_epsilon(constant(fn, v), got[i, k]), ("c/hip", name, v, mode)
+                        elif (derivable is None or derivable(v)) and not math.isinf(v):
+                            num = (constant(fn, v + 10e-6) - constant(fn, v - 10e-6)) / (10e-6 * 2)
+                            assert within_epsilon(num, got[i, k]), ("numDiff/hip", name, v, mode, num, got[i, k])
