@@ -293,6 +293,14 @@ struct TargetEmitter {
   bool emit_lookup(std::ostringstream &os, uint32_t id, RefFn R, std::string &err) const {
     const Node &nd = P.nodes[id];
     const std::string k = "k" + std::to_string(id), lhs = "    const double n" + std::to_string(id) + " = ";
+    const Node &ix = P.nodes[nd.a];
+    if (ix.op == RH_RIR_COMPARE && nd.low == -1 && nd.table.size() == 3) {
+      // the index is DCMPL's -1/0/+1 itself: select on it directly, no D2I, no range check (after inlining rh_compare the
+      // compiler folds these tests into the original comparisons)
+      os << lhs << "(" << R(nd.a) << " > 0x0p+0) ? " << R(nd.table[2]) << " : ((" << R(nd.a) << " == 0x0p+0) ? " << R(nd.table[1]) << " : "
+         << R(nd.table[0]) << ");\n";
+      return true;
+    }
     os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n";
     if (nd.table.size() <= 64) {
       os << lhs;
@@ -606,8 +614,8 @@ struct TargetEmitter {
 
 }  // namespace
 
-bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
-              EmitInfo *info) {
+static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
+                          EmitInfo *info) {
   EmitInfo local_info; EmitInfo &I = info ? *info : local_info;
   I = EmitInfo();
   std::ostringstream os;
@@ -670,7 +678,17 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   defines = d.str();
   return true;
 }
+bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
+              EmitInfo *info) {
+  if (!o.simplify) return emit_hip_impl(P, o, defines, targets, err, info);
+  return emit_hip_impl(simplify(P), o, defines, targets, err, info);
+}
+static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {
+  if (!o.simplify) return emit_requirements_impl(P, o, defines, body, err);
+  return emit_requirements_impl(simplify(P), o, defines, body, err);
+}
+static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {
   // one shared evaluation of the union DAG (like a run of data-free targets), then out[m] = requirement m
   TargetEmitter te(P, 0, false);
   te.fast_div = o.fp_contract;

@@ -31,7 +31,11 @@ struct Program {
 // Parses and validates a blob; returns false and sets err on malformed input.
 bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 
+// Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
+Program simplify(const Program &p);
+
 struct EmitOptions {
+  bool simplify = true;      // run simplify() before lowering (RH_SIMPLIFY=0 switches it off)
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
   int rows_unroll = 4;

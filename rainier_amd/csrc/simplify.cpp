@@ -1,0 +1,175 @@
+// simplify.cpp -- exact, value-preserving clean-up of an RIR program before it is lowered to HIP.
+//
+// The reference hands its back end the DAG that symbolic differentiation produced (compute/Gradient.scala): piecewise
+// terms arrive as Lookup(Compare(..)) selects (Real.eq / Real.gt, compute/Real.scala:83-99) and their derivatives as
+// selects of selects.  The JVM back end emits them literally (ir/ExprMethodGenerator.scala:57-63); on a GPU every fp64
+// log / divide / select costs issue slots of the pipe that bounds the kernel, so the obvious redundancies are removed here.
+// Every rewrite returns bit-identical values for every input (NaN and infinities included) and keeps the out-of-range
+// Lookup error; nothing here depends on the math mode.
+//
+//   R1  Lookup(Compare(Compare(p, q), c), T)      -> Lookup(Compare(p, q), T')   the inner compare is -1/0/+1: re-index T
+//   R2  Lookup(Compare(..), [x, x, x]) (low = -1) -> x
+//   R3  Lookup(k, [f(a), f(b), ..])               -> f(Lookup(k, [a, b, ..]))    f one pure unary op, entries not used elsewhere
+//   R4  Lookup(k, C1) (+|-|*|/) Lookup(k, C2)     -> Lookup(k, C1 op C2)         all-constant tables; also against a constant
+//   CSE identical (op, a, b) nodes are built once (what VarDef/VarRef sharing already guarantees in the reference)
+#include "rir.hpp"
+#include "../../include/rainier_hip_rir.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+namespace rh {
+namespace {
+
+bool unary_op(uint32_t op) { return (op >= RH_RIR_EXP && op <= RH_RIR_ATAN); }
+bool arith_op(uint32_t op) { return op >= RH_RIR_ADD && op <= RH_RIR_DIV; }
+
+struct Builder {
+  Program Q;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;
+  std::map<uint64_t, uint32_t> consts;
+  std::map<uint32_t, uint32_t> inputs;
+
+  uint32_t push(const Node &n) { Q.nodes.push_back(n); return (uint32_t)Q.nodes.size() - 1; }
+  uint8_t dep2(uint32_t a, uint32_t b) const { return Q.nodes[a].dep ? Q.nodes[a].dep : Q.nodes[b].dep; }
+  uint32_t constant(double v) {
+    uint64_t bits; std::memcpy(&bits, &v, 8);
+    auto it = consts.find(bits);
+    if (it != consts.end()) return it->second;
+    Node n; n.op = RH_RIR_CONST; n.cval = v;
+    return consts[bits] = push(n);
+  }
+  uint32_t input(const Node &old) {
+    auto it = inputs.find(old.input);
+    if (it != inputs.end()) return it->second;
+    Node n; n.op = RH_RIR_INPUT; n.input = old.input; n.dep = old.dep;
+    return inputs[old.input] = push(n);
+  }
+  uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
+    auto key = std::make_tuple(op, a, b);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.b = b; n.dep = dep2(a, b);
+    return cons[key] = push(n);
+  }
+  uint32_t op1(uint32_t op, uint32_t a) {
+    auto key = std::make_tuple(op, a, 0xffffffffu);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.dep = Q.nodes[a].dep;
+    return cons[key] = push(n);
+  }
+  uint32_t lookup_raw(uint32_t idx, int32_t low, const std::vector<uint32_t> &table) {
+    Node n; n.op = RH_RIR_LOOKUP; n.a = idx; n.low = low; n.table = table; n.dep = Q.nodes[idx].dep;
+    for (uint32_t e : table) if (Q.nodes[e].dep) n.dep = Q.nodes[e].dep;
+    return push(n);
+  }
+  bool is_const(uint32_t id) const { return Q.nodes[id].op == RH_RIR_CONST; }
+  bool all_const(const Node &n) const {
+    for (uint32_t e : n.table) if (!is_const(e)) return false;
+    return true;
+  }
+};
+
+double fold(uint32_t op, double x, double y) {
+  switch (op) {
+    case RH_RIR_ADD: return x + y;
+    case RH_RIR_SUB: return x - y;
+    case RH_RIR_MUL: return x * y;
+    default: return x / y;
+  }
+}
+int dcmpl(double x, double y) { return x > y ? 1 : (x == y ? 0 : -1); }  // DCMPL: NaN -> -1
+
+}  // namespace
+
+Program simplify(const Program &P) {
+  // how often each node of the input program is referenced (sinking a unary op only pays when its operands die with it)
+  std::vector<uint32_t> uses(P.nodes.size(), 0);
+  for (const Node &n : P.nodes) {
+    if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+    if (n.op == RH_RIR_LOOKUP) { uses[n.a]++; for (uint32_t e : n.table) uses[e]++; continue; }
+    uses[n.a]++;
+    if (!unary_op(n.op)) uses[n.b]++;
+  }
+  for (const Target &t : P.targets) for (uint32_t o : t.outputs) uses[o]++;
+
+  Builder B;
+  B.Q.n_params = P.n_params; B.Q.n_inputs = P.n_inputs; B.Q.n_cols_total = P.n_cols_total; B.Q.kind = P.kind;
+  B.Q.targets = P.targets;
+  std::vector<uint32_t> m(P.nodes.size(), 0);
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST) { m[i] = B.constant(n.cval); continue; }
+    if (n.op == RH_RIR_INPUT) { m[i] = B.input(n); continue; }
+    if (unary_op(n.op)) { m[i] = B.op1(n.op, m[n.a]); continue; }
+    if (n.op != RH_RIR_LOOKUP) {
+      const uint32_t a = m[n.a], b = m[n.b];
+      if (arith_op(n.op)) {  // R4
+        const Node na = B.Q.nodes[a], nb = B.Q.nodes[b];  // copies: the node vector grows below
+        const bool la = na.op == RH_RIR_LOOKUP && B.all_const(na), lb = nb.op == RH_RIR_LOOKUP && B.all_const(nb);
+        if (la && lb && na.a == nb.a && na.low == nb.low && na.table.size() == nb.table.size() && uses[n.a] == 1 && uses[n.b] == 1) {
+          std::vector<uint32_t> t;
+          for (size_t e = 0; e < na.table.size(); e++)
+            t.push_back(B.constant(fold(n.op, B.Q.nodes[na.table[e]].cval, B.Q.nodes[nb.table[e]].cval)));
+          const uint32_t idx = na.a; const int32_t low = na.low;
+          m[i] = B.lookup_raw(idx, low, t);
+          continue;
+        }
+        if ((la && B.is_const(b) && uses[n.a] == 1) || (lb && B.is_const(a) && uses[n.b] == 1)) {
+          const Node &lk = la ? na : nb;  // (na / nb are local copies)
+          std::vector<uint32_t> t;
+          for (uint32_t e : lk.table)
+            t.push_back(B.constant(la ? fold(n.op, B.Q.nodes[e].cval, nb.cval) : fold(n.op, na.cval, B.Q.nodes[e].cval)));
+          const uint32_t idx = lk.a; const int32_t low = lk.low;
+          m[i] = B.lookup_raw(idx, low, t);
+          continue;
+        }
+      }
+      m[i] = B.op2(n.op, a, b);
+      continue;
+    }
+    // ---- LOOKUP
+    uint32_t idx = m[n.a];
+    int32_t low = n.low;
+    std::vector<uint32_t> table;
+    for (uint32_t e : n.table) table.push_back(m[e]);
+    for (;;) {  // R1
+      const Node I = B.Q.nodes[idx];
+      if (I.op != RH_RIR_COMPARE || B.Q.nodes[I.a].op != RH_RIR_COMPARE || !B.is_const(I.b)) break;
+      const double c = B.Q.nodes[I.b].cval;
+      std::vector<uint32_t> t;
+      bool ok = true;
+      for (int s = -1; s <= 1 && ok; s++) {
+        const long pos = (long)dcmpl((double)s, c) - low;
+        if (pos < 0 || pos >= (long)table.size()) ok = false; else t.push_back(table[(size_t)pos]);
+      }
+      if (!ok) break;
+      idx = I.a; low = -1; table = t;
+    }
+    const bool cmp3 = B.Q.nodes[idx].op == RH_RIR_COMPARE && low == -1 && table.size() == 3;
+    if (cmp3 && table[0] == table[1] && table[1] == table[2]) { m[i] = table[0]; continue; }  // R2
+    {  // R3
+      const uint32_t f = B.Q.nodes[table[0]].op;
+      bool sink = unary_op(f);
+      for (size_t e = 0; e < n.table.size() && sink; e++) {
+        if (B.Q.nodes[table[e]].op != f) { sink = false; break; }
+        uint32_t occ = 0;
+        for (uint32_t e2 : n.table) occ += e2 == n.table[e];
+        if (P.nodes[n.table[e]].op != f || uses[n.table[e]] != occ) sink = false;  // the entry must die with this select
+      }
+      if (sink) {
+        std::vector<uint32_t> args;
+        for (uint32_t e : table) args.push_back(B.Q.nodes[e].a);
+        m[i] = B.op1(f, B.lookup_raw(idx, low, args));
+        continue;
+      }
+    }
+    m[i] = B.lookup_raw(idx, low, table);
+  }
+  for (Target &t : B.Q.targets) for (uint32_t &o : t.outputs) o = m[o];
+  return B.Q;
+}
+
+}  // namespace rh
