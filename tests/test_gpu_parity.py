@@ -452,11 +452,13 @@ def test_nuts_recovers_posteriors_on_both_engines():
         m.sample(R.make_config(5, 5, R.NUTSSampler(13)), seeds=[1])
 
 
-@pytest.mark.parametrize("name", ["SBCBernoulli", "SBCGeometric"])
+@pytest.mark.parametrize("name", ["SBCBernoulli", "SBCGeometric", "SBCBinomial", "SBCBinomialPoissonApproximation",
+                                  "SBCNegativeBinomial", "SBCLargePoisson"])
 def test_gpu_reproduces_more_reference_goldsets(name):
-    # Lookup/Compare (Bernoulli) and data-linear (Geometric) likelihoods against the JVM-recorded outputs, rel 1e-10
+    # Lookup/Compare (Bernoulli, Binomial), data-linear (Geometric, NegativeBinomial, Poisson) likelihoods against the
+    # JVM-recorded outputs, rel 1e-10 (every goldset whose synthetic data leave no cached gaussian in the RNG stream)
     from tests import test_reference_goldset as G
-    spec, rstate, predict_fn = {"SBCBernoulli": G.bernoulli_spec, "SBCGeometric": G.geometric_spec}[name]()
+    spec, rstate, predict_fn = dict([("SBCBernoulli", G.bernoulli_spec), ("SBCGeometric", G.geometric_spec)] + G.MORE)[name]()
     assert not rstate.have_next
     gold = np.array(G.ALL["models"][name]["goldset"])
     cfg = R.make_config(len(gold), G.ALL["warmup"], R.HMCSampler(1), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())

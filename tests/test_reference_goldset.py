@@ -188,3 +188,166 @@ def test_oracle_reproduces_lognormal_prior_goldsets(oracle, name, builder):
     draws, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, cfg, rstate)
     rel = np.abs((predict_fn(draws) - gold) / gold)
     assert rc == 0 and rel.max() < 1e-10, (name, rel.max())
+
+
+# ---- the remaining enabled goldsets of SBCTest.scala:19-34: Gamma, Binomial, Binomial (Poisson regime), NegativeBinomial, LargePoisson ----
+def _nemes(z):
+    """Combinatorics.gamma -> approxGamma (core/Combinatorics.scala:27-36), on doubles or numpy arrays."""
+    v = z + 1
+    w = v + (1.0 / ((12 * v) - (1.0 / (10 * v))))
+    return (np.log(np.pi * 2) / 2) - (np.log(v) / 2) + (v * (np.log(w) - 1)) - np.log(z)
+
+
+def _nemes_expr(z):
+    v = z + 1.0
+    w = v + (1.0 / ((v * 12.0) - (1.0 / (v * 10.0))))
+    return (float(np.log(np.pi * 2)) / 2.0 - (v.log() / 2.0)) + (v * (w.log() - 1.0)) - z.log()
+
+
+def _scaled_uniform_prior(g, lo, hi):
+    """Uniform(lo, hi).latent = standard.latent * (hi - lo) + lo (Continuous.scala:205-215, Injection.scala:48-86)."""
+    x01, prior = _uniform01_prior(g)
+    return x01 * (hi - lo) + lo, prior
+
+
+def gamma_spec():
+    """SBCGamma: Gamma(x, x) = Gamma.standard(x).scale(x), x ~ LogNormal(0,1).  Generator (Continuous.scala:112-146): shape < 1 ->
+    u = uniform, then Marsaglia-Tsang at shape + 1, times u^(1/shape); then * scale.  logDensity(y) = standard(y / x) - log x,
+    standard(t) = (x - 1) log t - logGamma(x) - t."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = math.exp(rng.next_gaussian() * 1.0 + 0.0)
+
+    def generate(a):
+        d = a - 1.0 / 3.0
+        c = (1.0 / 3.0) / math.sqrt(d)
+        while True:
+            xx = rng.next_gaussian(); v = 1.0 + c * xx
+            while v <= 0:
+                xx = rng.next_gaussian(); v = 1.0 + c * xx
+            v3 = v * v * v
+            u = rng.next_double()
+            if (u < 1 - 0.0331 * xx * xx * xx * xx) or (math.log(u) < 0.5 * xx * xx + d * (1 - v3 + math.log(v3))):
+                return d * v3
+
+    def standard(a):
+        if a < 1:
+            u = rng.next_double()
+            return generate(a + 1) * math.pow(u, 1.0 / a)
+        return generate(a)
+    ys = np.array([standard(x0) * x0 for _ in range(1000)])
+    g = Graph(1, [0, 1]); z = g.param(0); x = z.exp(); y = g.col(1, 0)
+    t = y / x
+    row = (((x - 1.0) * t.log() - _nemes_expr(x)) - t) + x.log() * -1.0
+    return models.ModelSpec("sbc_gamma", g.compile([models.std_normal_logpdf(z), row]), [ys], [0, 1000], 1), rng.r, lambda d: np.exp(d[:, 0])
+
+
+def _binomial_rows(g, x, k, vs):
+    """Binomial(p, k).logDensity(v) = Multinomial(Map(true -> p, false -> 1 - p), k).logDensity(Map(true -> v, false -> k - v))
+    (Discrete.scala:186-232, Multinomial.scala:17-24): factorial(k) + sum_t (eq(i_t, 0, 0, i_t log p_t) - factorial(i_t))."""
+    vs = np.asarray(vs, dtype=np.float64); kv = k - vs
+    cols = [vs, kv, _nemes(vs + 1), _nemes(kv + 1)]
+    v, w, fv, fw = (g.col(1, j) for j in range(4))
+    row = float(_nemes(k + 1.0)) + ((g.eq(v, 0.0, 0.0, v * x.log()) - fv) + (g.eq(w, 0.0, 0.0, w * (1.0 - x).log()) - fw))
+    return row, cols
+
+
+def binomial_spec():
+    """SBCBinomial: Binomial(x, 10), x ~ Uniform(0,1).  k < 100 -> the Multinomial generator: k categorical draws, `true` when
+    cdf(true) = x0 >= uniform (Generator.scala:129-141)."""
+    rng = O.JavaRandom(ALL["seed"]); x0 = rng.next_double()
+    vs = [float(sum(1 for _ in range(10) if x0 >= rng.next_double())) for _ in range(1000)]
+    g = Graph(1, [0, 4]); x, prior = _uniform01_prior(g)
+    row, cols = _binomial_rows(g, x, 10.0, vs)
+    return models.ModelSpec("sbc_binomial", g.compile([prior, row]), cols, [0, 1000], 1), rng.r, lambda d: 1 / (1 + np.exp(-d[:, 0]))
+
+
+def binomial_poisson_spec():
+    """SBCBinomialPoissonApproximation: Binomial(x, 200), x ~ Uniform(0, 0.04).  k >= 100 and k p <= 10 -> Poisson(p k) draws
+    (Knuth's product method, lambda < 30: Discrete.scala:141-153) capped at k (Discrete.scala:198-204)."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = rng.next_double() * 0.04 + 0.0
+    lam = x0 * 200.0
+
+    def small():
+        l = math.exp(-lam)
+        if l >= 1.0:
+            return 0
+        k = 0; p = 1.0
+        while p > l:
+            k += 1; p *= rng.next_double()
+        return k - 1
+    vs = [float(min(small(), 200)) for _ in range(1000)]
+    g = Graph(1, [0, 4]); x, prior = _scaled_uniform_prior(g, 0.0, 0.04)
+    row, cols = _binomial_rows(g, x, 200.0, vs)
+    return (models.ModelSpec("sbc_binomial_poisson", g.compile([prior, row]), cols, [0, 1000], 1), rng.r,
+            lambda d: (1 / (1 + np.exp(-d[:, 0]))) * 0.04 + 0.0)
+
+
+def negative_binomial_spec():
+    """SBCNegativeBinomial: NegativeBinomial(p = x, n = 10), x ~ Uniform(0,1).  Generator: the sum of n Geometric(1 - p) draws
+    (Discrete.scala:88-110); logDensity(v) = factorial(n + v - 1) - factorial(v) - factorial(n - 1) + n log(1 - p) + v log p."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); x0 = rng.next_double()
+    q = 1.0 - x0
+
+    def geometric():
+        u = rng.next_double()
+        return int(math.floor(math.log(u) / math.log(1 - q)))
+    vs = np.array([float(sum(geometric() for _ in range(10))) for _ in range(1000)])
+    cols = [vs, _nemes(10.0 + vs - 1 + 1) - _nemes(vs + 1)]
+    g = Graph(1, [0, 2]); x, prior = _uniform01_prior(g); v, cf = g.col(1, 0), g.col(1, 1)
+    row = ((cf - float(_nemes(10.0 - 1 + 1))) + (1.0 - x).log() * 10.0) + v * x.log()
+    return models.ModelSpec("sbc_negbin", g.compile([prior, row]), cols, [0, 1000], 1), rng.r, lambda d: 1 / (1 + np.exp(-d[:, 0]))
+
+
+def large_poisson_spec():
+    """SBCLargePoisson: Poisson(1000 x), x ~ Uniform(0.8, 1).  lambda >= 30 -> the logistic-envelope rejection sampler with the
+    rough log-factorial (Discrete.scala:156-189); logDensity(v) = log(lambda) v - lambda - factorial(v)."""
+    import math
+    rng = O.JavaRandom(ALL["seed"]); width = 1.0 - 0.8
+    x0 = rng.next_double() * width + 0.8
+    lam = x0 * 1000.0
+    c = 0.767 - 3.36 / lam
+    beta = math.pi / math.sqrt(3.0 * lam)
+    alpha = beta * lam
+    kk = math.log(c) - lam - math.log(beta)
+
+    def log_factorial(n):
+        xx = float(n + 1)
+        return ((xx - 0.5) * math.log(xx)) - xx + (0.5 * math.log(2 * math.pi))
+
+    def large():
+        while True:
+            u = rng.next_double()
+            xx = (alpha - math.log((1.0 - u) / u)) / beta
+            n = int(math.floor(xx + 0.5))
+            if n >= 0:
+                v = rng.next_double()
+                yy = alpha - beta * xx
+                lhs = yy + math.log(v / math.pow(1.0 + math.exp(yy), 2))
+                rhs = kk + n * math.log(lam) - log_factorial(n)
+                if lhs <= rhs:
+                    return n
+    vs = np.array([float(large()) for _ in range(1000)])
+    cols = [vs, _nemes(vs + 1)]
+    g = Graph(1, [0, 2]); x, prior = _scaled_uniform_prior(g, 0.8, 0.8 + width); v, fv = g.col(1, 0), g.col(1, 1)
+    lam_e = x * 1000.0
+    row = (lam_e.log() * v - lam_e) - fv
+    return (models.ModelSpec("sbc_large_poisson", g.compile([prior, row]), cols, [0, 1000], 1), rng.r,
+            lambda d: (1 / (1 + np.exp(-d[:, 0]))) * width + 0.8)
+
+
+MORE = [("SBCGamma", gamma_spec), ("SBCBinomial", binomial_spec), ("SBCBinomialPoissonApproximation", binomial_poisson_spec),
+        ("SBCNegativeBinomial", negative_binomial_spec), ("SBCLargePoisson", large_poisson_spec)]
+
+
+@pytest.mark.parametrize("name,builder", MORE)
+def test_oracle_reproduces_remaining_goldsets(oracle, name, builder):
+    spec, rstate, predict_fn = builder()
+    gold = np.array(ALL["models"][name]["goldset"])
+    cfg = O.make_config(sampler=O.HMC, n_steps=1, iterations=len(gold), warmup=ALL["warmup"], step_tuner=O.STEP_DUALAVG,
+                        delta=0.8, mass_tuner=O.MASS_IDENTITY, math_mode=O.JM_LIBM)
+    d = O.OracleDensity(spec, O.JM_LIBM)
+    draws, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, cfg, rstate)
+    rel = np.abs((predict_fn(draws) - gold) / gold)
+    assert rc == 0 and rel.max() < 1e-10, (name, rel.max(), predict_fn(draws)[:3], gold[:3])
