@@ -45,7 +45,7 @@ class Config(C.Structure):
         ("mass_tuner", C.c_int32), ("dualavg_delta", C.c_double), ("static_step", C.c_double),
         ("mass_init_window", C.c_int32), ("mass_skip_first", C.c_int32), ("mass_skip_last", C.c_int32),
         ("nuts_max_depth", C.c_int32), ("mass_expansion", C.c_double), ("static_mass", C.POINTER(C.c_double)),
-        ("engine", C.c_int32), ("grad_splits", C.c_int32), ("reserved", C.c_int64 * 3),
+        ("engine", C.c_int32), ("grad_splits", C.c_int32), ("rng_next_gaussian", C.POINTER(C.c_double)), ("reserved", C.c_int64 * 2),
     ]
 
 

@@ -530,12 +530,17 @@ RH_UNROLL_SLOTS
 // Consumes the pending gradient (c.pend_logp / c.pend_g, evaluated at c.Bq) if the automaton was waiting for
 // one, and runs until it needs the next gradient (RH_ADV_NEED_GRAD), reaches iteration `it_stop`
 // (RH_ADV_PAUSED) or finishes (RH_ADV_DONE).  All control flow is wave-uniform.
-RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, const rh_i64 seed,
+RH_DEV int rh_advance(rh_chain &c, const rh_cfg_dev &cfg, const int it_stop, const rh_i64 *seedrec,
                       const double *static_mass, double *draws, const int lane) {
   for (;;) {
     switch (c.pc) {
     case RH_S_INIT: { // LeapFrog.initialize (LeapFrog.scala:102-116), first half
-      rh_rng r; rh_rng_init(r, seed); rh_rng_put(c, r);
+      rh_rng r; rh_rng_init(r, seedrec[0]);
+      { // a stream handed over mid-pair: its pending nextNextGaussian (NaN = none)
+        const double nn = __longlong_as_double(seedrec[1]);
+        if (nn == nn) { r.have = 1; r.nn = nn; }
+      }
+      rh_rng_put(c, r);
       wv_zero(c.Bp); wv_zero(c.Bg); c.BU = 0.0;
       rh_fill_normal(c, c.Bq, lane);
       wv_fill(c.M, 1.0, lane); wv_fill(c.SD, 1.0, lane); c.mass_identity = 1;
@@ -787,7 +792,7 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
   if (fresh) rh_chain_zero(st, lane);
   rh_chain_load(c, st, lane);
   double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
-  const rh_i64 seed = seeds[chain];
+  const rh_i64 *seed = seeds + 2 * (size_t)chain;
   int ticks = 0, status;
   if (c.need_eval) {
     int err = 0;
@@ -1609,7 +1614,7 @@ rh_tick_kernel(const rh_model_data d,
     c.err |= err; c.need_eval = 0;
   }
   double *my_draws = draws + (size_t)chain * cfg.iterations * RH_NVARS;
-  const int status = rh_advance(c, cfg, it_stop, seeds[chain], static_mass, my_draws, lane);
+  const int status = rh_advance(c, cfg, it_stop, seeds + 2 * (size_t)chain, static_mass, my_draws, lane);
   if (status == RH_ADV_NEED_GRAD) {
     c.need_eval = 1;
 RH_UNROLL_SLOTS

@@ -648,13 +648,21 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     const int n = (int)m->prog.n_params;
     const size_t state_bytes = (size_t)chains * s->state_words * sizeof(uint64_t);
     HIPCHK(hipMalloc(&s->d_state, state_bytes));
-    HIPCHK(hipMalloc(&s->d_seeds, sizeof(int64_t) * chains));
+    HIPCHK(hipMalloc(&s->d_seeds, sizeof(int64_t) * 2 * chains));  // per chain: seed, bits of the pending nextNextGaussian
     HIPCHK(hipMalloc(&s->d_mass, sizeof(double) * n));
     const size_t draws_bytes = (size_t)chains * (size_t)(cfg->iterations ? cfg->iterations : 1) * n * sizeof(double);
     HIPCHK(hipMalloc(&s->d_draws, draws_bytes));
     HIPCHK(hipMalloc(&s->d_stats, sizeof(rh_chain_stats_dev) * chains));
     HIPCHK(hipMalloc(&s->d_running, sizeof(int)));
-    HIPCHK(hipMemcpy(s->d_seeds, seeds, sizeof(int64_t) * chains, hipMemcpyHostToDevice));
+    {
+      std::vector<int64_t> rec((size_t)2 * chains);
+      for (int c = 0; c < chains; c++) {
+        const double nn = cfg->rng_next_gaussian ? cfg->rng_next_gaussian[c] : std::nan("");
+        rec[2 * c] = seeds[c];
+        std::memcpy(&rec[2 * c + 1], &nn, sizeof nn);
+      }
+      HIPCHK(hipMemcpy(s->d_seeds, rec.data(), sizeof(int64_t) * rec.size(), hipMemcpyHostToDevice));
+    }
     std::vector<double> mass(n, 1.0);
     if (cfg->mass_tuner == RH_MASS_STATIC_DIAG) mass.assign(cfg->static_mass, cfg->static_mass + n);
     HIPCHK(hipMemcpy(s->d_mass, mass.data(), sizeof(double) * n, hipMemcpyHostToDevice));

@@ -231,11 +231,19 @@ def predict(requirements_rir: bytes, draws: np.ndarray, n_requirements: int, dev
 class Sampler:
     """Device-resident chains: split form of Driver.sample used by bench.py (create -> warmup -> run)."""
 
-    def __init__(self, model: "Model", config: SamplerConfig, seeds: Sequence[int]):
+    def __init__(self, model: "Model", config: SamplerConfig, seeds: Sequence[int] = None, rng_states=None):
+        """seeds: chain c runs on ScalaRNG(seeds[c]).  rng_states: instead, continue existing java.util.Random streams --
+        one (internal 48-bit state, pending nextNextGaussian or None) per chain (what Driver.sample does with the caller's rng)."""
         self.model = model
+        self._nn = None
+        if rng_states is not None:
+            seeds = [int(st) ^ 0x5DEECE66D for st, _ in rng_states]
+            self._nn = np.array([np.nan if g is None else float(g) for _, g in rng_states], dtype=np.float64)
         self.chains = len(seeds)
         self.iterations = int(config.iterations)
         self._cfg, self._keep = to_c_config(config, model.nVars)
+        if self._nn is not None:
+            self._cfg.rng_next_gaussian = _capi.dptr(self._nn)
         self._seeds = (C.c_int64 * self.chains)(*[int(s) for s in seeds])
         self._h = C.c_void_p()
         _capi.check(_capi.lib().rh_sampler_create(model._h, C.byref(self._cfg), self._seeds, self.chains, C.byref(self._h)), model._h)
@@ -313,15 +321,15 @@ class Model:
         _capi.check(_capi.lib().rh_density_eval(self._h, _capi.dptr(q), chains, _capi.dptr(lp), _capi.dptr(g)), self._h)
         return lp, g
 
-    def sample(self, config: SamplerConfig = None, nChains: int = 4, seeds: Sequence[int] = None) -> Trace:
+    def sample(self, config: SamplerConfig = None, nChains: int = 4, seeds: Sequence[int] = None, rng_states=None) -> Trace:
         """Model.sample(config, nChains) (core/Model.scala:13-24).  Chain c is the reference run with
         nChains = 1 and ScalaRNG(seeds[c])."""
         config = config or SamplerConfig()
         seeds = list(range(1, nChains + 1)) if seeds is None else list(seeds)
-        s = Sampler(self, config, seeds)
+        s = Sampler(self, config, seeds, rng_states)
         try:
             s.warmup(); s.run(config.iterations)
-            draws = s.draws() if config.iterations > 0 else np.zeros((len(seeds), 0, self.nVars))
+            draws = s.draws() if config.iterations > 0 else np.zeros((s.chains, 0, self.nVars))
             stats, mass = s.stats()
         finally:
             s.close()

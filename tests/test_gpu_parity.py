@@ -721,3 +721,25 @@ def test_realtest_expressions_on_device():
                         elif (derivable is None or derivable(v)) and not math.isinf(v):
                             num = (constant(fn, v + 10e-6) - constant(fn, v - 10e-6)) / (10e-6 * 2)
                             assert within_epsilon(num, got[i, k]), ("numDiff/hip", name, v, mode, num, got[i, k])
+
+
+@pytest.mark.parametrize("name", ["SBCLaplace", "SBCLogNormal", "SBCExponential", "SBCGamma"])
+def test_gpu_reproduces_goldsets_from_a_continued_rng_stream(name):
+    # LogNormal-prior goldsets: the synthetic-data draws leave a pending nextNextGaussian in the stream, so the chain must
+    # continue the java.util.Random STATE (rh_config.rng_next_gaussian), exactly as Driver.sample does with the caller's rng
+    from tests import test_reference_goldset as G
+    builders = dict(G.MORE); builders.update(SBCLaplace=G.laplace_spec, SBCLogNormal=G.lognormal_spec, SBCExponential=G.exponential_spec)
+    spec, rstate, predict_fn = builders[name]()
+    gold = np.array(G.ALL["models"][name]["goldset"])
+    cfg = R.make_config(len(gold), G.ALL["warmup"], R.HMCSampler(1), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+    state = [(rstate.seed, rstate.next_next if rstate.have_next else None)]
+    for kw in (dict(math_mode=_capi.MATH_STRICT), dict(fp_contract=True, factor_outputs=True)):
+        tr = R.Model(spec, device=0, **kw).sample(cfg, rng_states=state)
+        assert np.abs((predict_fn(tr.chains[0]) - gold) / gold).max() < 1e-10, kw
+    # and the oracle continuing the same state (deterministic math; 1000 streamed rows: equal up to the row-sum order)
+    ocfg = _oracle_cfg(cfg, O.JM_DET)
+    d = O.OracleDensity(spec, O.JM_DET)
+    want, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, ocfg, rstate)
+    got = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(cfg, rng_states=state)
+    assert rc == 0
+    np.testing.assert_allclose(got.chains[0], want, rtol=1e-9)
