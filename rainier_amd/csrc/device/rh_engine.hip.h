@@ -51,16 +51,16 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
 #pragma unroll
     for (int o = 0; o < NA; o++) acc[o] = 0.0;
     long long k = lane;
-    for (; k + 64LL * (U - 1) < n; k += 64LL * U) {
+    for (; k + (long long)RH_LANES * (U - 1) < n; k += (long long)RH_LANES * U) {
       double c[U][NC];
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + 64LL * u];
+        for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + (long long)RH_LANES * u];
 #pragma unroll
       for (int u = 0; u < U; u++) TG::row(th, inv, c[u], acc, err);
     }
-    for (; k < n; k += 64) {
+    for (; k < n; k += RH_LANES) {
       double c[NC];
 #pragma unroll
       for (int j = 0; j < NC; j++) c[j] = cp[j][k];
@@ -146,7 +146,11 @@ struct rh_chain {
 #define X(n) rh_i64 n;
   RH_STATE_I64(X)
 #undef X
+#if RH_PACK_L == 64
   double ring[RH_RING_SLOTS]; // EHMC step counts, entry i in lane i%64 of slot i/64
+#else
+  double *ring;               // packed chains keep the ring buffer in their state image: entry i at ring[i]
+#endif
 #if RH_WITH_NUTS
   wvec ckr[RH_NUTS_MAXD], ckrs[RH_NUTS_MAXD]; // NUTS momentum / momentum-sum checkpoints
 #endif
@@ -230,7 +234,11 @@ RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
   for (int k = 0; k < RH_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.n.s[k]);
   RH_STATE_VECS(X)
 #undef X
+#if RH_PACK_L == 64
   for (int k = 0; k < RH_RING_SLOTS; k++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ring[k]);
+#else
+  w += RH_RING_SLOTS;
+#endif
 #if RH_WITH_NUTS
   for (int j = 0; j < RH_NUTS_MAXD; j++)
     for (int k = 0; k < RH_SLOTS; k++) {
@@ -257,13 +265,17 @@ RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
 #undef X
   }
 }
-RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
+RH_DEV void rh_chain_load(rh_chain &c, rh_u64 *st, const int lane) {
   int w = 0;
 #define X(n) \
   for (int k = 0; k < RH_SLOTS; k++) c.n.s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
   RH_STATE_VECS(X)
 #undef X
+#if RH_PACK_L == 64
   for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
+#else
+  c.ring = (double *)(st + (size_t)w * 64); w += RH_RING_SLOTS;
+#endif
 #if RH_WITH_NUTS
   for (int j = 0; j < RH_NUTS_MAXD; j++)
     for (int k = 0; k < RH_SLOTS; k++) {
@@ -290,7 +302,7 @@ RH_DEV void rh_chain_load(rh_chain &c, const rh_u64 *st, const int lane) {
 }
 #endif  // RH_BIGN
 RH_DEV void rh_chain_zero(rh_u64 *st, const int lane) {
-  for (int w = lane; w < RH_STATE_U64; w += 64) st[w] = 0;
+  for (int w = lane; w < RH_STATE_U64; w += RH_LANES) st[w] = 0;
 }
 
 // ---- automaton states ------------------------------------------------------------------------------
@@ -319,7 +331,7 @@ RH_DEV void rh_velocity(const rh_chain &c, const wvec &p, wvec &out, const bool 
   if (!identity && c.mass_dense) { // DenseMassMatrix.squareMultiply (MassMatrix.scala:34-48): out(i) = sum_j vector(j) * matrix(i*n+j)
     double y = 0.0;
     for (int j = 0; j < RH_NVARS; j++) y += rh_readlane(p.s[0], j) * c.Drow[j];
-    out.s[0] = ((int)threadIdx.x < RH_NVARS) ? y : 0.0;
+    out.s[0] = ((int)(threadIdx.x & (RH_LANES - 1)) < RH_NVARS) ? y : 0.0;
     return;
   }
 #endif
@@ -461,18 +473,26 @@ RH_DEV void rh_ring_add(rh_chain &c, const int size, const double v, const int l
   c.ring_i += 1;
   if (c.ring_i == size) c.ring_full = 1;
   c.ring_i = c.ring_i % size;
+#if RH_PACK_L == 64
 #pragma unroll
   for (int k = 0; k < RH_RING_SLOTS; k++) c.ring[k] = (k * 64 + lane == c.ring_i) ? v : c.ring[k];
+#else
+  c.ring[c.ring_i] = v;  // every lane of the chain writes the same value: each later reads back its own store
+#endif
 }
 RH_DEV double rh_ring_sample(rh_chain &c, const int size) { // Stats.scala:40-45
   rh_rng r = rh_rng_of(c);
   const int idx = rh_uniform_i(c.ring_full ? rh_rng_int(r, size) : rh_rng_int(r, c.ring_i + 1));
   rh_rng_put(c, r);
+#if RH_PACK_L == 64
   double out = 0.0;
 #pragma unroll
   for (int k = 0; k < RH_RING_SLOTS; k++)
     if ((idx >> 6) == k) out = rh_readlane(c.ring[k], idx & 63);
   return out;
+#else
+  return c.ring[idx];
+#endif
 }
 RH_DEV bool rh_is_uturn(const rh_chain &c) { // LeapFrog.scala:35-47
   RH_TMP(dq); RH_TMP(pr);
@@ -784,8 +804,8 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
                 const rh_i64 *__restrict__ seeds, const double *__restrict__ static_mass,
                 double *__restrict__ draws, rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running,
                 const int chains, const int it_stop, const int max_ticks, const int fresh) {
-  const int chain = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int chain = blockIdx.x * (64 / RH_LANES) + (int)(threadIdx.x / RH_LANES);  // RH_LANES lanes per chain (64 unless packed)
+  const int lane = threadIdx.x & (RH_LANES - 1);
   if (chain >= chains) return;
   rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   rh_chain c;
@@ -1633,8 +1653,8 @@ RH_UNROLL_SLOTS
 extern "C" __global__ void __launch_bounds__(64)
 rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,
                   double *__restrict__ grad, int *__restrict__ err_out, const int chains) {
-  const int chain = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int chain = blockIdx.x * (64 / RH_LANES) + (int)(threadIdx.x / RH_LANES);  // RH_LANES lanes per chain (64 unless packed)
+  const int lane = threadIdx.x & (RH_LANES - 1);
   if (chain >= chains) return;
   wvec qv, gv;
 RH_UNROLL_SLOTS

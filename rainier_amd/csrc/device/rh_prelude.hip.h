@@ -174,6 +174,15 @@ RH_DEV int rh_rng_int(rh_rng &r, int until) { // RNG.int (sampler/RNG.scala:9-10
 }
 
 // ---- wave64 primitives ---------------------------------------------------------------------------
+// Chain packing (data-free models with few parameters: cfg 1, cfg 3): RH_PACK_L lanes per chain, 64 / RH_PACK_L chains per
+// wavefront.  Everything a chain does is written against these few primitives; "wave-uniform" then means "identical in the
+// RH_PACK_L lanes of the chain" (such values simply live in VGPRs) and the automaton's control flow diverges between the
+// chains of a wavefront like any SIMT code.  The arithmetic of a chain does not change, so packed chains stay bit-exact.
+#ifndef RH_PACK_L
+#define RH_PACK_L 64
+#endif
+#define RH_LANES RH_PACK_L
+#if RH_PACK_L == 64
 RH_DEV double rh_readlane(double v, int lane) { // wave-uniform broadcast of one lane's value (SGPR pair)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -181,10 +190,17 @@ RH_DEV double rh_readlane(double v, int lane) { // wave-uniform broadcast of one
 }
 RH_DEV double rh_uniform(double v) { return rh_readlane(v, 0); }
 RH_DEV int rh_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// fixed-order butterfly: every lane ends with the bitwise-identical sum (run-to-run reproducible)
+#else
+RH_DEV double rh_readlane(double v, int lane) { // broadcast of lane `lane` of the chain's own lane group (ds_bpermute)
+  return __shfl(v, (int)(threadIdx.x & ~(unsigned)(RH_PACK_L - 1)) + lane, 64);
+}
+RH_DEV double rh_uniform(double v) { return v; }
+RH_DEV int rh_uniform_i(int v) { return v; }
+#endif
+// fixed-order butterfly over the chain's lanes: every lane ends with the bitwise-identical sum (run-to-run reproducible)
 RH_DEV double rh_wave_sum(double v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = RH_LANES / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 

@@ -201,6 +201,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
@@ -570,7 +571,7 @@ extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, dou
       return;
     }
     void *args[] = {&m->data, &dq, &dl, &dg, &de, &ch};
-    launch(m->k_density, (unsigned)chains, 64, m->stream, args);
+    launch(m->k_density, (unsigned)((chains + 64 / m->info.pack_l - 1) / (64 / m->info.pack_l)), 64, m->stream, args);  // packed: 64 / pack_l chains per wavefront
     HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * n * chains, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(&lookup_err, de, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -815,7 +816,7 @@ void advance_to(rh_sampler *s, int it_stop) {
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running,
                     &chains, &stop, &max_ticks, &fresh};
     HIPCHK(hipEventRecord(s->e0, m->stream));
-    launch(s->k_chain, (unsigned)chains, 64, m->stream, args);
+    launch(s->k_chain, (unsigned)((chains + 64 / m->info.pack_l - 1) / (64 / m->info.pack_l)), 64, m->stream, args);
     HIPCHK(hipEventRecord(s->e1, m->stream));
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));

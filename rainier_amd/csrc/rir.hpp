@@ -35,6 +35,7 @@ bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 Program simplify(const Program &p);
 
 struct EmitOptions {
+  bool pack = true;          // data-free models with <= 32 parameters: several chains per wavefront (RH_PACK=0 switches it off)
   bool simplify = true;      // run simplify() before lowering (RH_SIMPLIFY=0 switches it off)
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
@@ -55,6 +56,7 @@ struct EmitOptions {
 struct EmitInfo {
   bool gather_mode = false, bign = false;
   int n_shared = 0, grad_k = 4, nacc_max = 1, glm_target = -1;
+  int pack_l = 64;  // lanes per chain in the chain / density kernels (64 = one chain per wavefront)
   bool glm_small = false;
   struct TargetInfo { bool has_rows = false, has_gather = false; int g_col = -1, g_count = 0, g_low = 0; };
   std::vector<TargetInfo> targets;
