@@ -65,8 +65,9 @@ typedef struct rh_compile_opts {
   int32_t grad_unroll;   /* tick engine: row-loop unroll; 0 = default (2) */
   int32_t factor_outputs; /* 1 = accumulate basis terms t and apply alpha*sum(t) + nrows*beta once per gradient, for outputs of
                             the form alpha*t + beta with alpha, beta parameter-only (changes rounding only; default 0) */
-  int32_t with_nuts;      /* bit 0: compile the NUTS variant of the sampler kernels now, bit 1: the dense-mass variant
-                             (otherwise lazily on first use) */
+  int32_t with_nuts;      /* sampler-kernel variants to compile now instead of lazily on first use -- bit 0: NUTS, bit 1: dense
+                             mass matrix, bit 2: one chain per wavefront for a model whose chains are packed (data-free
+                             models; used for EHMC / NUTS below 4096 chains) */
   int32_t reserved;
 } rh_compile_opts;
 

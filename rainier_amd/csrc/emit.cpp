@@ -665,7 +665,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
   d << "#define RH_BIGN " << (bign ? 1 : 0) << "\n";
   // chain packing: without observation rows a chain only needs as many lanes as it has parameters
   if (o.pack && nrowt == 0 && !bign && !gmode && P.n_params <= 32) I.pack_l = P.n_params <= 8 ? 8 : (P.n_params <= 16 ? 16 : 32);
-  d << "#define RH_PACK_L " << I.pack_l << "\n";
+  d << "#ifndef RH_PACK_L\n#define RH_PACK_L " << I.pack_l << "\n#endif\n";
   d << "#define RH_NVARS " << P.n_params << "\n#define RH_NOUT " << (n_shared + 1) << "\n#define RH_SLOTS "
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";

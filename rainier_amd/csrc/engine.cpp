@@ -138,7 +138,7 @@ struct KSet {  // the per-chain sampler kernels of one compiled variant (with / 
 };
 
 struct rh_model {
-  KSet variants[4];  // sampler-kernel variants by (NUTS ? 1 : 0) | (dense mass ? 2 : 0); [0] aliases the base module; built on first use
+  KSet variants[8];  // sampler-kernel variants by (NUTS ? 1 : 0) | (dense mass ? 2 : 0); [0] aliases the base module; built on first use
   bool want_nuts = false;
   rh::Program prog;
   rh::EmitOptions eopt;
@@ -174,7 +174,7 @@ namespace { struct GatherBufs; }
 
 struct rh_sampler {
   hipFunction_t k_chain = nullptr, k_tick = nullptr;
-  int state_words = 0, dense_off = 0;
+  int state_words = 0, dense_off = 0, pack_l = 64;  // pack_l: lanes per chain of the chosen chain kernel
   rh_model *m = nullptr;
   rh_cfg_dev cfg{};
   int chains = 0;
@@ -291,6 +291,7 @@ std::string variant_defines(int v) {
   std::string d;
   if (v & 1) d += kNutsDefine;
   if (v & 2) d += "#define RH_WITH_DENSE 1\n";
+  if (v & 4) d += "#define RH_PACK_L 64\n";  // one chain per wavefront although the model packs (few or diverging chains)
   return d;
 }
 KSet &load_variant(rh_model *m, int v) {
@@ -493,7 +494,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
     build_code(&m);
     if (code_size) *code_size = m.code.size();
-    if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 3) + m.source);
+    if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 7) + m.source);
   });
   return rc;
 }
@@ -633,7 +634,11 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     s->m = m; s->chains = chains;
     HIPCHK(hipSetDevice(m->device));
     {
-      const int v = (cfg->sampler == RH_SAMPLER_NUTS ? 1 : 0) | (cfg->mass_tuner == RH_MASS_DENSE_WINDOWED ? 2 : 0);
+      int v = (cfg->sampler == RH_SAMPLER_NUTS ? 1 : 0) | (cfg->mass_tuner == RH_MASS_DENSE_WINDOWED ? 2 : 0);
+      // packed chains share a wavefront: free for lock-step static HMC, but EHMC / NUTS trajectories of different lengths
+      // serialise, which only pays once there are more chains than wavefront slots
+      s->pack_l = m->info.pack_l;
+      if (m->info.pack_l != 64 && cfg->sampler != RH_SAMPLER_HMC && chains < 4096) { v |= 4; s->pack_l = 64; }
       if ((v & 2) && (m->prog.n_params > 64 || m->info.bign)) throw Fail{RH_E_UNSUPPORTED, "DenseMassMatrixTuner supports at most 64 parameters"};
       KSet &ks = load_variant(m, v);
       s->k_chain = ks.k_chain; s->k_tick = ks.k_tick; s->state_words = ks.state_words; s->dense_off = ks.dense_off;
@@ -816,7 +821,7 @@ void advance_to(rh_sampler *s, int it_stop) {
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running,
                     &chains, &stop, &max_ticks, &fresh};
     HIPCHK(hipEventRecord(s->e0, m->stream));
-    launch(s->k_chain, (unsigned)((chains + 64 / m->info.pack_l - 1) / (64 / m->info.pack_l)), 64, m->stream, args);
+    launch(s->k_chain, (unsigned)((chains + 64 / s->pack_l - 1) / (64 / s->pack_l)), 64, m->stream, args);
     HIPCHK(hipEventRecord(s->e1, m->stream));
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));

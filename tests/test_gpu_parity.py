@@ -743,3 +743,27 @@ def test_gpu_reproduces_goldsets_from_a_continued_rng_stream(name):
     got = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(cfg, rng_states=state)
     assert rc == 0
     np.testing.assert_allclose(got.chains[0], want, rtol=1e-9)
+
+
+# ---- chain packing (several chains per wavefront for data-free models): every chain still equals the oracle's --------
+def test_packed_and_unpacked_chain_layouts_are_bit_exact():
+    spec = models.eight_schools()
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "#define RH_PACK_L 16" in m.hip_source
+    for cfg, nch in ((R.make_config(12, 40, R.EHMCSampler(64), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(10, 1.5, 5, 5)), 4099),
+                     (R.make_config(6, 30, R.NUTSSampler(5), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner()), 4097),
+                     (R.make_config(20, 40, R.HMCSampler(3), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(10, 1.5, 5, 5)), 7)):
+        seeds = list(range(5000, 5000 + nch))          # >= 4096 diverging chains (or static HMC): packed, 4 chains per wavefront
+        tr = m.sample(cfg, seeds=seeds)
+        ocfg = _oracle_cfg(cfg, O.JM_DET)
+        for c in sorted({0, 1, 2, 3, 5, nch // 2, nch - 2, nch - 1}):
+            want, mass, st = O.sample_model(spec, ocfg, seeds[c])
+            assert np.array_equal(tr.chains[c], want) and np.array_equal(tr.mass[c], mass), (type(cfg.sampler()).__name__, c)
+            assert tr.stats[c].leapfrogSteps == st.leapfrog_steps and tr.stats[c].stepSize == st.step_size
+    # the density seam is packed too (chains not a multiple of the pack factor)
+    q = np.random.default_rng(2).normal(size=(13, 10))
+    lp, g = m.density_batch(q)
+    d = O.OracleDensity(spec, O.JM_DET)
+    for i in range(13):
+        out = d.update(q[i])
+        assert lp[i] == out[0] and np.array_equal(g[i], out[1:])
