@@ -1698,7 +1698,7 @@ RH_UNROLL_SLOTS
 #endif
 
 // Device self-test of the bit-exact pieces: mode 0 = n gaussians of ScalaRNG(seed), 1 = n uniforms,
-// 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75
+// 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75, 7 = fast-mode log
 extern "C" __global__ void __launch_bounds__(64)
 rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__ in, double *__restrict__ out, const int n) {
   const int lane = threadIdx.x;
@@ -1715,6 +1715,7 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
       else if (mode == 3) v = rh_strict_exp(in[i]);
       else if (mode == 4) v = rh_strict_sqrt(in[i]);
       else if (mode == 5) v = in[2 * i] / in[2 * i + 1];
+      else if (mode == 7) v = rh_fast_log(in[i]);
       else v = rh_pow_neg075(in[i]);
       out[i] = v;
     }

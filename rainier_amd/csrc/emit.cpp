@@ -670,14 +670,16 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
     << ((P.n_params + 63) / 64) << "\n#define RH_NTARGETS " << P.targets.size() << "\n#define RH_FP_CONTRACT "
     << (o.fp_contract ? 1 : 0) << "\n#define RH_ROWS_UNROLL " << (o.rows_unroll > 0 ? o.rows_unroll : 4) << "\n";
   // chains per wavefront in the gradient kernels: K * NACC fp64 accumulators per lane must fit the register budget
-  const int grad_k = o.grad_chains > 0 ? o.grad_chains : std::max(1, std::min(8, 48 / std::max(1, nacc_max + (gmode ? 1 : 0))));
+  // chains per wavefront in the batched gradient kernels: as many as the accumulators leave room for; the gather kernel
+  // also carries the segmented scatter state per chain and is best at 4 (cfg 5: 8.4 ms vs 12.4 ms per gradient at 8)
+  const int grad_k = o.grad_chains > 0 ? o.grad_chains : std::max(1, std::min(gmode ? 4 : 8, 48 / std::max(1, nacc_max + (gmode ? 1 : 0))));
   I.gather_mode = gmode; I.n_shared = (int)n_shared; I.grad_k = grad_k; I.nacc_max = nacc_max; I.glm_target = glm_target; I.glm_small = glm_small;
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << grad_k << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
     << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
   if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
-  else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
+  else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) " << (o.fast_log ? "rh_fast_log(x)" : "log(x)") << "\n";
   defines = d.str();
   return true;
 }
@@ -715,7 +717,7 @@ static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::
   std::ostringstream d;
   d << "#define RH_NVARS " << P.n_params << "\n#define RH_NTH " << P.n_params << "\n#define RH_SLOTS " << ((P.n_params + 63) / 64) << "\n#define RH_NREQ " << P.targets.size() << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
-  else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) log(x)\n";
+  else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) " << (o.fast_log ? "rh_fast_log(x)" : "log(x)") << "\n";
   defines = d.str();
   return true;
 }

@@ -202,6 +202,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane

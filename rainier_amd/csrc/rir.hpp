@@ -35,6 +35,7 @@ bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 Program simplify(const Program &p);
 
 struct EmitOptions {
+  bool fast_log = true;      // fast mode: rh_fast_log (<= 1 ulp, ~40 instructions) instead of the device library's log (RH_FAST_LOG=0)
   bool pack = true;          // data-free models with <= 32 parameters: several chains per wavefront (RH_PACK=0 switches it off)
   bool simplify = true;      // run simplify() before lowering (RH_SIMPLIFY=0 switches it off)
   bool strict_math = false;  // EXP/LOG -> fdlibm

@@ -23,6 +23,24 @@ def funnel_strict():
     return R.Model(models.funnel(10), device=0, math_mode=_capi.MATH_STRICT)
 
 
+def test_fast_mode_log_is_within_one_ulp(funnel_strict):
+    # java.lang.Math.log is specified to 1 ulp; rh_fast_log must keep that over the whole range
+    rng = np.random.default_rng(12)
+    xs = np.concatenate([np.exp(rng.uniform(-745, 709, 400000)), rng.uniform(0.5, 2.0, 400000), 1.0 + rng.normal(size=200000) * 1e-6,
+                         np.ldexp(rng.uniform(0.5, 1, 48000), rng.integers(-1074, -1022, 48000)),
+                         [1.0, 0.5, 2.0, 0.70710678118654746, 0.70710678118654757, 1.4142135623730951, 5e-324, 2.2250738585072014e-308,
+                          1.7976931348623157e308]])
+    got = funnel_strict.selftest(7, x=xs)
+    want = np.log(xs)
+    ulp = np.spacing(np.abs(want)); ulp[want == 0] = np.spacing(0.0)
+    err = np.abs(got - want) / ulp
+    assert got[xs == 1.0].tolist() == [0.0] * int((xs == 1.0).sum())
+    assert err.max() <= 1.0, (err.max(), xs[np.argmax(err)])
+    assert (err > 0).mean() < 0.2                                  # mostly the correctly rounded value
+    sp = funnel_strict.selftest(7, x=np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan]))
+    assert sp[0] == -np.inf and sp[1] == -np.inf and np.isnan(sp[2]) and sp[3] == np.inf and np.isnan(sp[4]) and np.isnan(sp[5])
+
+
 # ---- bit-exact building blocks -----------------------------------------------------------------------
 def test_strict_math_is_bit_exact(funnel_strict, oracle):
     rng = np.random.default_rng(11)
