@@ -799,7 +799,10 @@ RH_DEV void rh_stats_write(const rh_chain &c, rh_chain_stats_dev *out, const int
 // One chain per wavefront (64-thread workgroup), the whole Driver loop on the device.  `fresh` starts the
 // chains from their seeds; otherwise the state image is resumed.  The launch ends for a chain when it reaches
 // iteration it_stop, finishes, or has spent max_ticks gradient evaluations (host relaunches until all paused).
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef RH_CHAIN_WAVES
+#define RH_CHAIN_WAVES 2  /* >= 2 wavefronts per SIMD: the automaton is latency-bound, a second wavefront hides it (cfg 3, 32768 chains: +47 %) */
+#endif
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_CHAIN_WAVES)))
 rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict__ state,
                 const rh_i64 *__restrict__ seeds, const double *__restrict__ static_mass,
                 double *__restrict__ draws, rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running,
