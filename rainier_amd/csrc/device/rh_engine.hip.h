@@ -319,10 +319,37 @@ RH_DEV void rh_rng_put(rh_chain &c, const rh_rng &r) { c.rng_seed = (rh_i64)r.se
 RH_DEV void rh_fill_normal(rh_chain &c, wvec &v, const int lane) {
   rh_rng r = rh_rng_of(c);
   wv_zero(v);
+#if !RH_BIGN && RH_SLOTS == 1 && RH_NVARS <= RH_LANES
+  // The stream is sequential, the expensive part of nextGaussian is not: walk the LCG and the polar method's rejection
+  // loop for all pairs first (cheap, wave-uniform), park accepted pair j in lane j, evaluate sqrt(-2 log(s) / s) for all
+  // pairs at once, then hand element e its half of pair (e - first) / 2.  Same operations per value: bit-identical.
+  int first = 0;
+  double out = 0.0;
+  if (r.have) { out = (lane == 0) ? r.nn : out; r.have = 0; first = 1; }   // the pending nextNextGaussian comes first
+  const int npairs = (RH_NVARS - first + 1) / 2;
+  double pv1 = 0.0, pv2 = 0.0, ps = 0.5;
+  for (int j = 0; j < npairs; j++) {
+    double v1, v2, sq;
+    do {
+      v1 = 2 * rh_rng_uniform(r) - 1;
+      v2 = 2 * rh_rng_uniform(r) - 1;
+      sq = v1 * v1 + v2 * v2;
+    } while (sq >= 1 || sq == 0);
+    pv1 = (lane == j) ? v1 : pv1; pv2 = (lane == j) ? v2 : pv2; ps = (lane == j) ? sq : ps;
+  }
+  const double multiplier = rh_strict_sqrt(-2 * rh_strict_log(ps) / ps);
+  const double g1 = pv1 * multiplier, g2 = pv2 * multiplier;
+  const int rel = lane - first, src = rel >= 0 ? (rel >> 1) : 0;
+  const double a = rh_gather(g1, src), b = rh_gather(g2, src);
+  if (rel >= 0 && lane < RH_NVARS) out = (rel & 1) ? b : a;
+  if ((RH_NVARS - first) & 1) { r.nn = rh_readlane(g2, npairs - 1); r.have = 1; }  // an odd count leaves one value pending
+  v.s[0] = (lane < RH_NVARS) ? out : 0.0;
+#else
   for (int i = 0; i < RH_NVARS; i++) {
     const double g = rh_rng_normal(r);
     wv_set(v, i, g, lane);
   }
+#endif
   rh_rng_put(c, r);
 }
 // velocity (LeapFrog.scala:202-216): Identity -> p, Diagonal -> p * elements

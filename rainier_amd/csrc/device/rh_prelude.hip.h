@@ -229,6 +229,14 @@ RH_DEV double rh_readlane(double v, int lane) { // broadcast of lane `lane` of t
 RH_DEV double rh_uniform(double v) { return v; }
 RH_DEV int rh_uniform_i(int v) { return v; }
 #endif
+// value of lane `src` (a per-lane index within the chain's lane group)
+RH_DEV double rh_gather(double v, int src) {
+#if RH_PACK_L == 64
+  return __shfl(v, src, 64);
+#else
+  return __shfl(v, (int)(threadIdx.x & ~(unsigned)(RH_PACK_L - 1)) + src, 64);
+#endif
+}
 // fixed-order butterfly over the chain's lanes: every lane ends with the bitwise-identical sum (run-to-run reproducible)
 RH_DEV double rh_wave_sum(double v) {
 #pragma unroll
