@@ -686,12 +686,12 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
               EmitInfo *info) {
   if (!o.simplify) return emit_hip_impl(P, o, defines, targets, err, info);
-  return emit_hip_impl(simplify(P), o, defines, targets, err, info);
+  return emit_hip_impl(simplify(P, o.fp_contract), o, defines, targets, err, info);
 }
 static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {
   if (!o.simplify) return emit_requirements_impl(P, o, defines, body, err);
-  return emit_requirements_impl(simplify(P), o, defines, body, err);
+  return emit_requirements_impl(simplify(P, o.fp_contract), o, defines, body, err);
 }
 static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {
   // one shared evaluation of the union DAG (like a run of data-free targets), then out[m] = requirement m

@@ -32,7 +32,7 @@ struct Program {
 bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 
 // Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
-Program simplify(const Program &p);
+Program simplify(const Program &p, bool fast = false);
 
 struct EmitOptions {
   bool fast_log = true;      // fast mode: rh_fast_log (<= 1 ulp, ~40 instructions) instead of the device library's log (RH_FAST_LOG=0)

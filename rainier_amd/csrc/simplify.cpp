@@ -5,12 +5,13 @@
 // selects of selects.  The JVM back end emits them literally (ir/ExprMethodGenerator.scala:57-63); on a GPU every fp64
 // log / divide / select costs issue slots of the pipe that bounds the kernel, so the obvious redundancies are removed here.
 // Every rewrite returns bit-identical values for every input (NaN and infinities included) and keeps the out-of-range
-// Lookup error; nothing here depends on the math mode.
+// Lookup error; the only exception is F1, applied in fast mode alone (where FMA contraction already changes last places).
 //
 //   R1  Lookup(Compare(Compare(p, q), c), T)      -> Lookup(Compare(p, q), T')   the inner compare is -1/0/+1: re-index T
 //   R2  Lookup(Compare(..), [x, x, x]) (low = -1) -> x
 //   R3  Lookup(k, [f(a), f(b), ..])               -> f(Lookup(k, [a, b, ..]))    f one pure unary op, entries not used elsewhere
 //   R4  Lookup(k, C1) (+|-|*|/) Lookup(k, C2)     -> Lookup(k, C1 op C2)         all-constant tables; also against a constant
+//   F1  1 / (1 / x)                               -> x                           fast mode only (<= 1 ulp apart)
 //   CSE identical (op, a, b) nodes are built once (what VarDef/VarRef sharing already guarantees in the reference)
 #include "rir.hpp"
 #include "../../include/rainier_hip_rir.h"
@@ -84,7 +85,7 @@ int dcmpl(double x, double y) { return x > y ? 1 : (x == y ? 0 : -1); }  // DCMP
 
 }  // namespace
 
-Program simplify(const Program &P) {
+Program simplify(const Program &P, bool fast) {
   // how often each node of the input program is referenced (sinking a unary op only pays when its operands die with it)
   std::vector<uint32_t> uses(P.nodes.size(), 0);
   for (const Node &n : P.nodes) {
@@ -126,6 +127,12 @@ Program simplify(const Program &P) {
           m[i] = B.lookup_raw(idx, low, t);
           continue;
         }
+      }
+      // fast mode only (results may differ in the last place, like FMA contraction does): 1 / (1 / x) -> x
+      if (fast && n.op == RH_RIR_DIV && B.is_const(a) && B.Q.nodes[a].cval == 1.0 && B.Q.nodes[b].op == RH_RIR_DIV &&
+          B.is_const(B.Q.nodes[b].a) && B.Q.nodes[B.Q.nodes[b].a].cval == 1.0) {
+        m[i] = B.Q.nodes[b].b;
+        continue;
       }
       m[i] = B.op2(n.op, a, b);
       continue;
