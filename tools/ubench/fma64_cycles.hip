@@ -40,6 +40,56 @@ __global__ void __launch_bounds__(64) k(double *out, unsigned long long *cyc, co
   }
 }
 
+// v_mfma_f64_16x16x4_f64: NT independent 16x16 accumulator tiles per wavefront (4 doubles per lane each)
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ void __launch_bounds__(64) k_mfma(double *out, unsigned long long *cyc, const double *in, int iters) {
+  d4 acc[NT];
+  const double a = in[2 + threadIdx.x], b = in[70 + threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = d4{in[i], in[i + 1], in[i + 2], in[i + 3]};
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < NT; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    cyc[4 * blockIdx.x] = t1 - t0; cyc[4 * blockIdx.x + 1] = r1 - r0;
+    cyc[4 * blockIdx.x + 2] = ((unsigned long long)(xcc & 0xf) << 32) | (hw & 0xfffffff0u);
+    cyc[4 * blockIdx.x + 3] = t0;
+  }
+}
+template <int NT>
+void run_mfma(int w, double *out, unsigned long long *cyc, double *in) {
+  const int iters = 20000, blocks = 256 * 4 * w;
+  k_mfma<NT><<<blocks, 64>>>(out, cyc, in, iters);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(4 * blocks);
+  hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  std::map<unsigned long long, std::pair<int, double>> simd;
+  std::vector<double> c(blocks), r(blocks);
+  for (int i = 0; i < blocks; i++) {
+    c[i] = (double)h[4 * i]; r[i] = (double)h[4 * i + 1];
+    auto &e = simd[h[4 * i + 2]];
+    e.first += 1; e.second = std::max(e.second, c[i]);
+  }
+  std::sort(c.begin(), c.end()); std::sort(r.begin(), r.end());
+  const double instr = (double)iters * NT;
+  double rate = 0; int n = 0;
+  for (auto &kv : simd) { rate += kv.second.first * instr / kv.second.second; n++; }
+  printf("v_mfma_f64_16x16x4_f64     tiles=%2d blocks/SIMD=%d  median cycles/mfma/wave %.2f  clock %.0f MHz | %.4f mfma/cycle/SIMD = %.1f flop/cycle/SIMD (2048 flop each; VALU fma: 64 lanes x 2 / 4 cycles = 32)\n",
+         NT, w, c[blocks / 2] / instr, c[blocks / 2] / r[blocks / 2] * 100.0, rate / n, rate / n * 2048.0);
+}
+
 template <int NACC, int MODE>
 void run(const char *name, int w, double *out, unsigned long long *cyc, double *in) {
   const int iters = 200000, blocks = 256 * 4 * w;
@@ -76,5 +126,6 @@ int main() {
     run<18, 2>("7 fma : 2 fma(v,1,acc)", w, out, cyc, in);
     run<16, 3>("add only", w, out, cyc, in);
   }
+  for (int w = 1; w <= 3; w++) { run_mfma<4>(w, out, cyc, in); run_mfma<8>(w, out, cyc, in); }
   return 0;
 }
