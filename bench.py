@@ -54,7 +54,17 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
     [x.start() for x in th]; [x.join() for x in th]
     dt = time.perf_counter() - t
     total = float(sum(steps))
-    return {"value": total / dt, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
+    # second figure ("speed build"): the same streamed gradient written out by hand and compiled -O3 with
+    # AVX2/FMA (oracle/closed_form.c) -- an upper bound for any JVM on these cores; one chain per thread, ~3 s
+    lib = O.load(); cols = [np.ascontiguousarray(c) for c in spec.columns]; n = len(cols[0])
+    t = time.perf_counter(); lib.orc_linreg_streamed_reps(*[O._dp(c) for c in cols], n, 2); per = (time.perf_counter() - t) / 2
+    reps = max(2, int(3.0 / per))
+    th2 = [threading.Thread(target=lambda: lib.orc_linreg_streamed_reps(*[O._dp(c) for c in cols], n, reps)) for _ in range(cores)]
+    t = time.perf_counter(); [x.start() for x in th2]; [x.join() for x in th2]; dt2 = time.perf_counter() - t
+    closed = {"value": cores * reps / dt2, "unit": "leapfrog steps/s (1 gradient per step)", "cores": cores,
+              "row_chain_evals_per_s": cores * reps * n / dt2,
+              "sample": "%d threads x %d streamed gradients over %d rows, hand-written C, -O3 -mavx2 -mfma, %.1f s" % (cores, reps, n, dt2)}
+    return {"value": total / dt, "compiled_closed_form": closed, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d HMC iterations (L=%d, %d rows), RIR interpreter, reference's 2L+1 gradient "
                       "evaluations per trajectory, %.1f s" % (cores, iters, L, spec.rows_streamed, dt),
             "row_chain_evals_per_s": total * spec.rows_streamed / dt}

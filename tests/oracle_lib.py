@@ -85,6 +85,8 @@ def load():
     lib.orc_upper_triangular_solve.argtypes = [dp, dp, C.c_int, dp]
     lib.orc_square_multiply.argtypes = [dp, dp, C.c_int, dp]
     lib.orc_diagnostics.argtypes = [dp, C.c_int, C.c_int, dp, dp]
+    lib.orc_linreg_streamed.argtypes = [dp, dp, dp, dp, C.c_long, dp, dp]
+    lib.orc_linreg_streamed_reps.restype = C.c_double; lib.orc_linreg_streamed_reps.argtypes = [dp, dp, dp, dp, C.c_long, C.c_int]
     lib.orc_lbfgs_new.restype = C.c_void_p; lib.orc_lbfgs_new.argtypes = [dp, C.c_int, C.c_int, C.c_double]
     lib.orc_lbfgs_free.argtypes = [C.c_void_p]
     lib.orc_lbfgs_apply.restype = C.c_int; lib.orc_lbfgs_apply.argtypes = [C.c_void_p, C.c_double, dp]

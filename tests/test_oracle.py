@@ -262,3 +262,11 @@ def test_lbfgs_reverse_communication_on_quadratic(oracle):
             break
     assert r == 1 and it < 200
     np.testing.assert_allclose(lb.x, np.linalg.solve(A, b), atol=1e-7)
+
+
+def test_closed_form_speed_build_matches_interpreter(oracle):
+    # oracle/closed_form.c (bench.py's second CPU figure) against the RIR interpreter on cfg 2's model
+    spec = models.linreg(n=5000)
+    th = np.array([-0.3, 0.5, 1.0, -2.0, 0.5]); out = np.zeros(6); c = spec.columns
+    oracle.orc_linreg_streamed(O._dp(c[0]), O._dp(c[1]), O._dp(c[2]), O._dp(c[3]), len(c[0]), O._dp(th), O._dp(out))
+    np.testing.assert_allclose(out, O.OracleDensity(spec).update(th), rtol=1e-11)
