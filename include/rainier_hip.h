@@ -183,6 +183,10 @@ typedef struct rh_timing {
   char dominant_kernel[64];  /* name of the kernel that accounts for kernel_ms */
 } rh_timing;
 int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset);
+/* Progress polling instead of a callback into the caller (Driver.sample's `progress: Progress` argument,
+ * sampler/Driver.scala:7-11, sampler/Progress.scala): how far the chains of this handle have been driven.
+ * warmed: 1 once the warm-up phase is complete; iterations_done: sampling iterations completed (of cfg.iterations). */
+int rh_sampler_progress(const rh_sampler *s, int32_t *warmed, int32_t *iterations_done);
 
 /* ---- after the path: Generator.prepare / Trace.predict (next-row f3) -----------------------------------------------
  * The reference compiles a generator's `requirements` with Compiler.default.compile(parameters, namedReqs) and evaluates

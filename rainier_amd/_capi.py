@@ -27,7 +27,7 @@ EXPORTS = [
     "rh_model_create", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
     "rh_density_eval", "rh_config_default", "rh_sample", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
-    "rh_sampler_timing", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
+    "rh_sampler_timing", "rh_sampler_progress", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
     L.rh_sampler_mass_dense.argtypes = [vp, dp]
     L.rh_optimize.argtypes = [vp, dp, C.c_int32, C.c_int32, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rh_sampler_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.rh_sampler_progress.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rh_diagnostics.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
     L.rh_requirements_eval.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), dp, C.c_int64, dp]
     L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]

@@ -924,6 +924,12 @@ extern "C" int rh_sampler_mass_dense(rh_sampler *s, double *out) {
         for (int j = 0; j < n; j++) std::memcpy(&out[((size_t)c * n + i) * n + j], &img[((size_t)c * n + j) * 64 + i], sizeof(double));
   });
 }
+extern "C" int rh_sampler_progress(const rh_sampler *s, int32_t *warmed, int32_t *iterations_done) {
+  if (!s) { g_err = "rh_sampler_progress: NULL"; return RH_E_INVALID; }
+  if (warmed) *warmed = s->warmed ? 1 : 0;
+  if (iterations_done) *iterations_done = s->it_done;
+  return RH_OK;
+}
 extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
   if (!s || !out) { g_err = "rh_sampler_timing: NULL"; return RH_E_INVALID; }
   std::lock_guard<std::mutex> lk(s->m->mu);

@@ -269,6 +269,12 @@ class Sampler:
         return [Stats(s.leapfrog_steps, s.warmup_leapfrog_steps, s.gradient_evaluations, s.accepted,
                       s.mean_accept_prob, s.step_size) for s in st], mass
 
+    def progress(self):
+        """(warmed, sampling iterations done): what a Progress callback would be told (sampler/Driver.scala:7-11), polled."""
+        w, it = C.c_int32(0), C.c_int32(0)
+        _capi.check(_capi.lib().rh_sampler_progress(self._h, C.byref(w), C.byref(it)), self.model._h)
+        return bool(w.value), int(it.value)
+
     def mass_dense(self) -> np.ndarray:
         """DenseMassMatrix.elements of every chain: [chains][nVars][nVars] (DenseMassMatrixTuner only)."""
         n = self.model.nVars

@@ -245,13 +245,21 @@ def test_many_chains_match_single_chain_runs():
     assert np.all(np.isfinite(tr.chains))
 
 
+def _progress_sequence(s, parts):
+    seen = [s.progress()]
+    s.warmup(); seen.append(s.progress())
+    for n in parts:
+        s.run(n); seen.append(s.progress())
+    return seen
+
+
 def test_split_warmup_run_equals_one_shot():
     spec = models.funnel(10)
     cfg = R.HMC(100, 90, 5)
     m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
     whole = m.sample(cfg, seeds=[1, 2, 3]).chains
     s = R.Sampler(m, cfg, [1, 2, 3])
-    s.warmup(); s.run(30); s.run(1); s.run(59)
+    assert _progress_sequence(s, (30, 1, 59)) == [(False, 0), (True, 0), (True, 30), (True, 31), (True, 90)]   # rh_sampler_progress
     assert np.array_equal(s.draws(), whole)
     assert np.array_equal(s.draws(30, 31), whole[:, 30:61])
     t = s.timing()
