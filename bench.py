@@ -144,8 +144,9 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64, help="timed HMC iterations (one step = one iteration of all chains)")
+    ap.add_argument("--warmup", type=int, default=128,
+                    help="untimed sampler warm-up iterations (step-size adaptation needs ~100 for a meaningful ESS/s)")
     ap.add_argument("--chains-per-gpu", type=int, default=1024)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--leapfrog", type=int, default=32)
