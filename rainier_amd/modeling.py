@@ -1,0 +1,510 @@
+"""A small restatement of Rainier's modelling surface, enough to write the reference's own test models
+the way the reference writes them:
+
+    mu = Normal(0, 10).latent ; sigma = Uniform(0, 1).latent
+    model = Model.observe([1.0, 2.0, 3.0], Normal(mu, sigma))          # optimizer/OptimizerTest.scala:8-13
+    SBC([Uniform(0, 1)], lambda x: Normal(x, 1))                         # core/SBCModel.scala:46-47
+
+It mirrors, name for name, the pieces of rainier-core that sit in front of the hot path:
+  Continuous / StandardContinuous / LocationScaleFamily, Normal, Cauchy, Laplace, Gamma, Exponential, Beta, LogNormal,
+  Uniform (core/Continuous.scala); Scale / Translate / Exp injections (core/Injection.scala); the Supports
+  (core/Support.scala); Bernoulli, Geometric, NegativeBinomial, Poisson, Binomial (core/Discrete.scala, Multinomial.scala);
+  Combinatorics (Nemes' log-Gamma); Model.observe (core/Model.scala:52-75); SBC.synthesize / fit (core/SBC.scala:61-69).
+`Real` here is a plain lazy expression tree; lowering to RIR goes through frontend.Graph (hash-consing + reverse-mode AD).
+Like the reference's PartialEvaluator, sub-expressions that depend on the observations but on no parameter are evaluated
+once on the host and become derived data columns; everything that involves a parameter stays un-inlined and is streamed.
+
+This is a TEST / AUTHORING aid (the product boundary is the C ABI; a JVM deployment keeps Rainier's own front-end).
+Generators take any object with `next_double()` / `next_gaussian()` (java.util.Random semantics): the tests pass the
+oracle's bit-exact stream; `JavaRandom` below is a pure-Python stand-in (its gaussians use libm's log).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Sequence
+
+import numpy as np
+
+from .frontend import Graph
+from . import models as _models
+
+
+# ---------------------------------------------------------------------------------------------------- Real
+class Real:
+    __slots__ = ("op", "args", "val", "density", "_dep")
+
+    def __init__(self, op, args=(), val=None):
+        self.op, self.args, self.val, self.density, self._dep = op, tuple(args), val, None, None
+
+    # -- construction
+    @staticmethod
+    def of(x) -> "Real":
+        return x if isinstance(x, Real) else Real("const", (), float(x))
+
+    @staticmethod
+    def parameter(density: Callable[["Real"], "Real"] = None) -> "Real":
+        """Real.parameter { x => density(x) } (compute/Real.scala): a new sampled parameter and its log-density term."""
+        p = Real("param")
+        p.density = Real.of(density(p)) if density is not None else Real.of(0.0)
+        return p
+
+    @staticmethod
+    def column(values) -> "Real":
+        return Real("col", (), np.ascontiguousarray(values, dtype=np.float64))
+
+    def _b(self, op, o, swap=False):
+        o = Real.of(o)
+        l, r = (o, self) if swap else (self, o)
+        if l.op == "const" and r.op == "const" and op in ("add", "sub", "mul", "div"):   # constants fold (compute/RealOps.scala)
+            with np.errstate(all="ignore"):
+                v = float(_NP[op](np.float64(l.val), np.float64(r.val)))
+            if not math.isnan(v):
+                return Real("const", (), v)
+        return Real(op, (l, r))
+    def __add__(self, o): return self._b("add", o)
+    def __radd__(self, o): return self._b("add", o, True)
+    def __sub__(self, o): return self._b("sub", o)
+    def __rsub__(self, o): return self._b("sub", o, True)
+    def __mul__(self, o): return self._b("mul", o)
+    def __rmul__(self, o): return self._b("mul", o, True)
+    def __truediv__(self, o): return self._b("div", o)
+    def __rtruediv__(self, o): return self._b("div", o, True)
+    def __neg__(self): return self * -1.0
+    def pow(self, o): return self._b("pow", o)
+    def _u(self, op):
+        if self.op == "const":
+            with np.errstate(all="ignore"):
+                v = float(_NP[op](np.float64(self.val)))
+            if not math.isnan(v):
+                return Real("const", (), v)
+        return Real(op, (self,))
+    def exp(self): return self._u("exp")
+    def log(self): return self._u("log")
+    def abs(self): return self._u("abs")
+    @property
+    def logistic(self): return Real.of(1.0) / (Real.of(1.0) + (self * -1.0).exp())   # compute/Real.scala:42
+
+    # Real.eq / gt / gte / lt / lte (compute/Real.scala:83-115): Lookup(Compare(l, r), table, low = -1)
+    @staticmethod
+    def _cmp(l, r, table): return Real("lookup", (Real("cmp", (Real.of(l), Real.of(r))),) + tuple(Real.of(t) for t in table), -1)
+    @staticmethod
+    def eq(l, r, t, f): return Real._cmp(l, r, (f, t, f))
+    @staticmethod
+    def gt(l, r, t, f): return Real._cmp(l, r, (f, f, t))
+    @staticmethod
+    def gte(l, r, t, f): return Real._cmp(l, r, (f, t, t))
+    @staticmethod
+    def sum(xs):
+        xs = list(xs); acc = Real.of(xs[0])
+        for x in xs[1:]:
+            acc = acc + x
+        return acc
+
+    # -- analysis
+    def deps(self):
+        """(depends on a parameter, depends on a data column)"""
+        if self._dep is None:
+            if self.op == "param": self._dep = (True, False)
+            elif self.op == "col": self._dep = (False, True)
+            elif self.op == "const": self._dep = (False, False)
+            else:
+                ds = [a.deps() for a in self.args]
+                self._dep = (any(d[0] for d in ds), any(d[1] for d in ds))
+        return self._dep
+
+
+_NP = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "exp": np.exp, "log": np.log, "abs": np.abs}
+
+
+def evaluate(r: Real, params: Dict[int, object] = None, memo=None):
+    """Numeric value of a Real: floats / numpy arrays; `params` maps id(parameter) -> value (Evaluator, compute/Evaluator.scala)."""
+    memo = {} if memo is None else memo
+    k = id(r)
+    if k in memo:
+        return memo[k]
+    with np.errstate(all="ignore"):
+        if r.op == "const": v = np.float64(r.val)
+        elif r.op == "col": v = r.val
+        elif r.op == "param": v = params[id(r)]
+        elif r.op == "pow":
+            a, b = (evaluate(x, params, memo) for x in r.args); v = np.where(b == 0, 1.0, np.power(a, b))
+        elif r.op == "cmp":
+            a, b = (evaluate(x, params, memo) for x in r.args); v = np.where(a > b, 1.0, np.where(a == b, 0.0, -1.0))
+        elif r.op == "lookup":
+            idx = evaluate(r.args[0], params, memo); tab = [evaluate(x, params, memo) for x in r.args[1:]]
+            k0 = np.trunc(np.nan_to_num(idx)).astype(np.int64) - r.val
+            if np.any((k0 < 0) | (k0 >= len(tab))):
+                raise IndexError("Lookup index out of range")
+            v = tab[0]
+            for j in range(1, len(tab)):
+                v = np.where(k0 == j, tab[j], v)
+        else:
+            v = _NP[r.op](*[evaluate(x, params, memo) for x in r.args])
+    memo[k] = v
+    return v
+
+
+# ---------------------------------------------------------------------------------------------------- RNG
+class JavaRandom:
+    """java.util.Random (the stream behind ScalaRNG, sampler/RNG.scala:20-26); gaussians via libm log/sqrt."""
+
+    def __init__(self, seed: int):
+        self.seed = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1); self.nn = None
+    def _next(self, bits):
+        self.seed = (self.seed * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        return self.seed >> (48 - bits)
+    def next_double(self): return ((self._next(26) << 27) + self._next(27)) * 2.0 ** -53
+    def next_gaussian(self):
+        if self.nn is not None:
+            g, self.nn = self.nn, None
+            return g
+        while True:
+            v1 = 2 * self.next_double() - 1; v2 = 2 * self.next_double() - 1; s = v1 * v1 + v2 * v2
+            if 0 < s < 1:
+                break
+        m = math.sqrt(-2 * math.log(s) / s)
+        self.nn = v2 * m
+        return v1 * m
+
+
+def _d(x) -> float:
+    return float(evaluate(Real.of(x)))
+
+
+# ---------------------------------------------------------------------------------------------------- Combinatorics
+class Combinatorics:
+    """core/Combinatorics.scala:10-37 (log of the function named)."""
+
+    @staticmethod
+    def gamma(z):
+        z = Real.of(z)
+        if z.op == "const" and z.val == 0.0: return Real.of(math.inf)
+        if z.op == "const" and z.val in (1.0, 2.0): return Real.of(0.0)
+        v = z + 1
+        w = v + (Real.of(1.0) / ((12 * v) - (Real.of(1.0) / (10 * v))))
+        return (Real.of(math.pi * 2).log() / 2) - (v.log() / 2) + (v * (w.log() - 1)) - z.log()
+    @staticmethod
+    def factorial(k): return Combinatorics.gamma(Real.of(k) + 1)
+    @staticmethod
+    def beta(a, b): return Combinatorics.gamma(a) + Combinatorics.gamma(b) - Combinatorics.gamma(Real.of(a) + b)
+
+
+# ---------------------------------------------------------------------------------------------------- supports, injections
+class UnboundedSupport:
+    def transform(self, v): return v
+    def logJacobian(self, v): return Real.of(0.0)
+
+class BoundedSupport:
+    def __init__(self, lo, hi): self.lo, self.hi = Real.of(lo), Real.of(hi)
+    def transform(self, v): return v.logistic * (self.hi - self.lo) + self.lo
+    def logJacobian(self, v): return v.logistic.log() + (1 - v.logistic).log() + (self.hi - self.lo).log()
+
+class BoundedBelowSupport:
+    def __init__(self, lo=0.0): self.lo = Real.of(lo)
+    def transform(self, v): return v.exp() + self.lo
+    def logJacobian(self, v): return v
+
+
+class Continuous:
+    """core/Continuous.scala:10-22."""
+    support = None
+    def logDensity(self, x) -> Real: raise NotImplementedError
+    def generate(self, rng) -> float: raise NotImplementedError
+    @property
+    def latent(self) -> Real: raise NotImplementedError
+    def scale(self, a): return _Scaled(self, Real.of(a))
+    def translate(self, b): return _Translated(self, Real.of(b))
+    def exp(self): return _Exped(self)
+
+
+class StandardContinuous(Continuous):
+    @property
+    def latent(self) -> Real:          # core/Continuous.scala:27-35
+        x = Real.parameter(lambda x: self.support.logJacobian(x) + self.logDensity(self.support.transform(x)))
+        return self.support.transform(x)
+
+
+class _Scaled(Continuous):             # Scale(a).transform(dist), core/Injection.scala:48-66
+    def __init__(self, d, a): self.d, self.a = d, a
+    def logDensity(self, y): return self.d.logDensity(Real.of(y) / self.a) + self.a.log() * -1
+    def generate(self, rng): return self.d.generate(rng) * _d(self.a)
+    @property
+    def latent(self): return self.d.latent * self.a
+
+class _Translated(Continuous):         # Translate(b), core/Injection.scala:68-86
+    def __init__(self, d, b): self.d, self.b = d, b
+    def logDensity(self, y): return self.d.logDensity(Real.of(y) - self.b) + Real.of(0.0)
+    def generate(self, rng): return self.d.generate(rng) + _d(self.b)
+    @property
+    def latent(self): return self.d.latent + self.b
+
+class _Exped(Continuous):              # Exp, core/Injection.scala:88-110
+    def __init__(self, d): self.d = d
+    def logDensity(self, y):
+        y = Real.of(y)
+        return Real.gt(y, 0.0, self.d.logDensity(y.log()) + y.log() * -1, -math.inf)
+    def generate(self, rng): return math.exp(self.d.generate(rng))
+    @property
+    def latent(self): return self.d.latent.exp()
+
+
+class _LocationScale:
+    class _Std(StandardContinuous):
+        support = UnboundedSupport()
+        def __init__(self, fam): self.fam = fam
+        def logDensity(self, x): return self.fam._logDensity(Real.of(x))
+        def generate(self, rng): return self.fam._generate(rng)
+    def __init__(self): self.standard = _LocationScale._Std(self)
+    def __call__(self, location, scale): return self.standard.scale(scale).translate(location)
+
+class _Normal(_LocationScale):         # core/Continuous.scala:63-67
+    def _logDensity(self, x): return ((x * x) / -2.0) - 0.5 * Real.of(2 * math.pi).log()
+    def _generate(self, rng): return rng.next_gaussian()
+class _Cauchy(_LocationScale):         # :72-77
+    def _logDensity(self, x): return (((x * x) + 1) * math.pi).log() * -1
+    def _generate(self, rng): return rng.next_gaussian() / rng.next_gaussian()
+class _Laplace(_LocationScale):        # :82-90
+    def _logDensity(self, x): return Real.of(0.5).log() - x.abs()
+    def _generate(self, rng):
+        u = rng.next_double() - 0.5
+        return ((u > 0) - (u < 0)) * -1 * math.log(1 - (2 * abs(u)))
+Normal, Cauchy, Laplace = _Normal(), _Cauchy(), _Laplace()
+
+
+class _GammaStandard(StandardContinuous):   # core/Continuous.scala:103-147
+    support = BoundedBelowSupport(0.0)
+    def __init__(self, shape): self.shape = Real.of(shape)
+    def logDensity(self, x):
+        x = Real.of(x)
+        return (self.shape - 1) * x.log() - Combinatorics.gamma(self.shape) - x
+    def generate(self, rng):
+        a = _d(self.shape)
+        if a < 1:
+            u = rng.next_double()
+            return self._mt(a + 1, rng) * math.pow(u, 1.0 / a)
+        return self._mt(a, rng)
+    @staticmethod
+    def _mt(a, rng):                       # Marsaglia-Tsang
+        d = a - 1.0 / 3.0; c = (1.0 / 3.0) / math.sqrt(d)
+        while True:
+            x = rng.next_gaussian(); v = 1.0 + c * x
+            while v <= 0:
+                x = rng.next_gaussian(); v = 1.0 + c * x
+            v3 = v * v * v; u = rng.next_double()
+            if (u < 1 - 0.0331 * x * x * x * x) or (math.log(u) < 0.5 * x * x + d * (1 - v3 + math.log(v3))):
+                return d * v3
+
+class Gamma:
+    @staticmethod
+    def standard(shape): return _GammaStandard(shape)
+    def __new__(cls, shape, scale): return _GammaStandard(shape).scale(scale)
+
+def Exponential(rate): return _GammaStandard(1.0).scale(Real.of(1.0) / Real.of(rate))     # :152-158
+def LogNormal(location, scale): return Normal(location, scale).exp()                      # :194-197
+
+class Beta(StandardContinuous):            # :163-189
+    support = BoundedSupport(0.0, 1.0)
+    def __init__(self, a, b): self.a, self.b = Real.of(a), Real.of(b)
+    def logDensity(self, u):
+        u = Real.of(u)
+        return (self.a - 1) * u.log() + (self.b - 1) * (1 - u).log() - Combinatorics.beta(self.a, self.b)
+    def generate(self, rng):
+        z1 = _GammaStandard(self.a).generate(rng); z2 = _GammaStandard(self.b).generate(rng)
+        return z1 / (z1 + z2)
+
+class _UniformStandard(StandardContinuous):  # :202-213
+    support = BoundedSupport(0.0, 1.0)
+    def logDensity(self, x): return Beta(1, 1).logDensity(x)
+    def generate(self, rng): return rng.next_double()
+def Uniform(lo, hi): return _UniformStandard().scale(Real.of(hi) - Real.of(lo)).translate(lo)
+
+
+# ---------------------------------------------------------------------------------------------------- discrete
+class Discrete:
+    def logDensity(self, v) -> Real: raise NotImplementedError
+    def generate(self, rng) -> float: raise NotImplementedError
+
+class Bernoulli(Discrete):                 # core/Discrete.scala:38-52
+    def __init__(self, p): self.p = Real.of(p)
+    def logDensity(self, v): return Real.eq(v, 0.0, (1 - self.p).log(), self.p.log())
+    def generate(self, rng): return 1.0 if rng.next_double() <= _d(self.p) else 0.0
+
+class Geometric(Discrete):                 # :59-73
+    def __init__(self, p): self.p = Real.of(p)
+    def logDensity(self, v): return self.p.log() + Real.of(v) * (1 - self.p).log()
+    def generate(self, rng):
+        u = rng.next_double(); q = _d(self.p)
+        return float(math.floor(math.log(u) / math.log(1 - q)))
+
+class NegativeBinomial(Discrete):          # :81-120
+    def __init__(self, p, n): self.p, self.n = Real.of(p), Real.of(n)
+    def logDensity(self, v):
+        v = Real.of(v); n, p = self.n, self.p
+        return (Combinatorics.factorial(n + v - 1) - Combinatorics.factorial(v) - Combinatorics.factorial(n - 1)
+                + n * (1 - p).log() + v * p.log())
+    def generate(self, rng):
+        p, n = _d(self.p), _d(self.n)
+        if p < -100 / n + 1 and p > 100 / n - .25:
+            return float(max(int(Normal(n * p / (1 - p), math.sqrt(n * p) / (1 - p)).generate(rng)), 0))
+        g = Geometric(1 - self.p)
+        return float(sum(g.generate(rng) for _ in range(int(n))))
+
+class Poisson(Discrete):                   # :127-189
+    def __init__(self, lam): self.lam = Real.of(lam)
+    def logDensity(self, v): return self.lam.log() * v - self.lam - Combinatorics.factorial(v)
+    def generate(self, rng):
+        lam = _d(self.lam)
+        if lam < 30.0:
+            l = math.exp(-lam)
+            if l >= 1.0:
+                return 0.0
+            k, p = 0, 1.0
+            while p > l:
+                k += 1; p *= rng.next_double()
+            return float(k - 1)
+        c = 0.767 - 3.36 / lam; beta = math.pi / math.sqrt(3.0 * lam); alpha = beta * lam
+        kk = math.log(c) - lam - math.log(beta)
+        while True:
+            u = rng.next_double()
+            x = (alpha - math.log((1.0 - u) / u)) / beta
+            n = int(math.floor(x + 0.5))
+            if n >= 0:
+                v = rng.next_double(); y = alpha - beta * x
+                lhs = y + math.log(v / math.pow(1.0 + math.exp(y), 2))
+                xx = float(n + 1)
+                rhs = kk + n * math.log(lam) - (((xx - 0.5) * math.log(xx)) - xx + (0.5 * math.log(2 * math.pi)))
+                if lhs <= rhs:
+                    return float(n)
+
+class Binomial(Discrete):                  # :196-232 + Multinomial.scala:17-29
+    def __init__(self, p, k): self.p, self.k = Real.of(p), Real.of(k)
+    def logDensity(self, v):
+        v = Real.of(v); terms = []
+        for i, p in ((v, self.p), (self.k - v, 1 - self.p)):
+            terms.append(Real.eq(i, 0.0, 0.0, i * p.log()) - Combinatorics.factorial(i))
+        return Combinatorics.factorial(self.k) + Real.sum(terms)
+    def generate(self, rng):
+        p, k = _d(self.p), _d(self.k)
+        if k >= 100 and k * p <= 10:
+            return float(min(Poisson(p * k).generate(rng), int(k)))
+        if k >= 100 and k * p >= 9 and k * (1.0 - p) >= 9:
+            return float(min(max(int(Normal(k * p, math.sqrt(k * p * (1 - p))).generate(rng)), 0), int(k)))
+        return float(sum(1 for _ in range(int(k)) if p >= rng.next_double()))   # categorical cdf(true) = p >= u
+
+
+# ---------------------------------------------------------------------------------------------------- Model, SBC
+class Model:
+    """core/Model.scala:52-75: a list of (observations, distribution) likelihoods over shared parameters."""
+
+    def __init__(self, likelihoods):
+        self.likelihoods = list(likelihoods)       # [(column Real, per-row log-density Real)]
+
+    @staticmethod
+    def observe(values: Sequence[float], dist) -> "Model":
+        col = Real.column(values)
+        return Model([(col, dist.logDensity(col))])
+
+    def merge(self, other: "Model") -> "Model":
+        return Model(self.likelihoods + other.likelihoods)
+
+    def parameters(self) -> List[Real]:
+        seen, order = set(), []
+        def walk(r):
+            if id(r) in seen:
+                return
+            seen.add(id(r))
+            for a in r.args:
+                walk(a)
+            if r.op == "param":
+                order.append(r)
+                walk(r.density)
+        for _, e in self.likelihoods:
+            walk(e)
+        return order
+
+    def compile(self, name: str = "model") -> "_models.ModelSpec":
+        """Lower to RIR: target 0 = prior (sum of the parameters' density terms), then one streamed target per likelihood.
+        Data-only sub-expressions become derived columns (what PartialEvaluator folds on the JVM)."""
+        params = self.parameters()
+        index = {id(p): i for i, p in enumerate(params)}
+        plans, columns, nrows = [], [], [0]
+
+        def make_derive(n):
+            cols: List[np.ndarray] = []
+            slot: Dict[int, int] = {}
+
+            def derive(r):
+                if id(r) not in slot:
+                    v = np.broadcast_to(np.asarray(evaluate(r), dtype=np.float64), (n,))
+                    slot[id(r)] = len(cols); cols.append(np.ascontiguousarray(v))
+                return slot[id(r)]
+            return derive, cols
+        for col, expr in self.likelihoods:
+            derive, cols = make_derive(len(col.val))
+            plans.append((expr, derive, cols)); nrows.append(len(col.val))
+        # first pass: find the derived columns of every target (needed before the Graph can be sized)
+        def scan(r, derive, seen):
+            if id(r) in seen:
+                return
+            seen.add(id(r))
+            hp, hd = r.deps()
+            if hd and not hp:
+                derive(r); return
+            for a in r.args:
+                scan(a, derive, seen)
+        for expr, derive, cols in plans:
+            scan(expr, derive, set())
+        g = Graph(len(params), [0] + [len(c) for _, _, c in plans])
+        memo: Dict[tuple, object] = {}
+        def lower(r, t, derive):
+            key = (id(r), t)
+            if key in memo:
+                return memo[key]
+            hp, hd = r.deps()
+            if hd and not hp:
+                e = g.col(t, derive(r))
+            elif r.op == "const": e = g.const(r.val)
+            elif r.op == "param": e = g.param(index[id(r)])
+            else:
+                a = [lower(x, t, derive) for x in r.args]
+                if r.op == "add": e = a[0] + a[1]
+                elif r.op == "sub": e = a[0] - a[1]
+                elif r.op == "mul": e = a[0] * a[1]
+                elif r.op == "div": e = a[0] / a[1]
+                elif r.op == "pow": e = a[0] ** a[1]
+                elif r.op == "cmp": e = a[0].compare(a[1])
+                elif r.op == "exp": e = a[0].exp()
+                elif r.op == "log": e = a[0].log()
+                elif r.op == "abs": e = a[0].abs()
+                elif r.op == "lookup": e = g.lookup(a[0], a[1:], r.val)
+                else: raise ValueError(r.op)
+            memo[key] = e
+            return e
+        prior = g.sum([lower(p.density, 0, None) for p in params]) if params else g.const(0.0)
+        targets = [prior] + [lower(expr, t + 1, derive) for t, (expr, derive, cols) in enumerate(plans)]
+        for _, _, cols in plans:
+            columns.extend(cols)
+        return _models.ModelSpec(name, g.compile(targets), columns, nrows, len(params), {"kind": "modeling"})
+
+    def predict(self, real: Real, draws: np.ndarray) -> np.ndarray:
+        """Trace.predict(real) for draws [..., nVars] (host evaluation of the tracked Real)."""
+        params = self.parameters()
+        d = np.asarray(draws, dtype=np.float64)
+        return np.asarray(evaluate(Real.of(real), {id(p): d[..., i] for i, p in enumerate(params)}))
+
+
+class SBC:
+    """core/SBC.scala:14-69: priors + a function from the prior draws to the likelihood (the summary is the first prior)."""
+
+    def __init__(self, priors: Sequence[Continuous], fn: Callable[..., object]):
+        self.priors, self.fn = list(priors), fn
+
+    def synthesize(self, samples: int, rng):
+        """(values, true value): prior draws first, then `samples` draws of the likelihood, all from the one stream."""
+        truth = [p.generate(rng) for p in self.priors]
+        dist = self.fn(*[Real.of(t) for t in truth])
+        return [dist.generate(rng) for _ in range(samples)], truth[0]
+
+    def fit(self, values):
+        latents = [p.latent for p in self.priors]
+        return Model.observe(values, self.fn(*latents)), latents[0]

@@ -793,3 +793,23 @@ def test_packed_and_unpacked_chain_layouts_are_bit_exact():
     for i in range(13):
         out = d.update(q[i])
         assert lp[i] == out[0] and np.array_equal(g[i], out[1:])
+
+
+# ---- the modelling surface (rainier_amd/modeling.py, §8 f5): reference-style model text -> RIR -> device ---------------
+def test_modelling_api_models_on_device():
+    from rainier_amd.modeling import SBC, Gamma, LogNormal, Model, Normal, Uniform, Binomial
+    from tests import test_reference_goldset as G
+    for name, sbc in (("SBCGamma", SBC([LogNormal(0, 1)], lambda x: Gamma(x, x))), ("SBCBinomial", SBC([Uniform(0, 1)], lambda x: Binomial(x, 10)))):
+        rng = O.JavaRandom(G.ALL["seed"])
+        values, _ = sbc.synthesize(1000, rng)
+        model, real = sbc.fit(values)
+        spec = model.compile(name)
+        gold = np.array(G.ALL["models"][name]["goldset"])
+        cfg = R.make_config(len(gold), G.ALL["warmup"], R.HMCSampler(1), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+        state = [(rng.r.seed, rng.r.next_next if rng.r.have_next else None)]
+        tr = R.Model(spec, device=0, fp_contract=True, factor_outputs=True).sample(cfg, rng_states=state)
+        assert np.abs((model.predict(real, tr.chains[0]) - gold) / gold).max() < 1e-10, name
+    mu, sigma = Normal(0, 10).latent, Uniform(0, 1).latent          # optimizer/OptimizerTest.scala:8-13 on the device
+    m = Model.observe([1.0, 2.0, 3.0], Normal(mu, sigma))
+    x = R.Model(m.compile("fit_normal"), device=0, math_mode=_capi.MATH_STRICT).optimize()
+    assert abs(float(m.predict(mu, x)) - 2.0) < 0.02 and 0.6 < float(m.predict(sigma, x)) < 0.75
