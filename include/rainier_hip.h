@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 1
+#define RH_ABI_VERSION 2  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense */
 
 enum rh_status {
   RH_OK = 0,
@@ -148,6 +148,8 @@ typedef struct rh_chain_stats {
   double step_size;              /* stepSizeTuner.stepSize used for sampling */
   int32_t error;                 /* rh_status of this chain (RH_E_LOOKUP ...) */
   int32_t reserved;
+  double bfmi;                   /* Stats.bfmi = energyTransitions2 / energyVariance.raw(0) over the sampling phase
+                                    (sampler/Stats.scala:14-16, LeapFrog.scala:68-74; HMC and EHMC; NaN for NUTS) */
 } rh_chain_stats;
 
 /* One call = Model.sample's loop over chains, run concurrently on the device.

@@ -37,6 +37,8 @@ struct orc_leapfrog {
   int64_t gradientEvaluations; /* Stats.gradientEvaluations :199 */
   int64_t leapfrogSteps;       /* not in the reference: number of newQs calls */
   int64_t iterations; int64_t accepted; double sumAccept;
+  /* Stats.energyVariance (a VarianceEstimator(1), S/MassMatrixEstimator.scala:69-91) and energyTransitions2 (S/Stats.scala:14-16) */
+  int64_t eSamples; double eMean, eRaw, eTrans2;
   int density_error;
   const double *dense; /* DenseMassMatrix.elements [n*n] when the current mass is dense (mass == dense) */
   double *chol_u;      /* its choleskyUpperTriangular, packed */
@@ -192,7 +194,17 @@ double orc_lf_finish_iteration(orc_leapfrog *lf, double *params, const double *m
   double endH = energy(lf, lf->pqBuf, mass);
   double deltaH = endH - startH;
   double a = logAcceptanceProb(lf, deltaH);
-  if (a > jm_log(lf->math_mode, rng_uniform(lf->rng))) { lf_copy(lf, lf->pqBuf, params); lf->accepted += 1; }
+  double h; /* the energy the chain ends the iteration with (:68-74) */
+  if (a > jm_log(lf->math_mode, rng_uniform(lf->rng))) { lf_copy(lf, lf->pqBuf, params); lf->accepted += 1; h = endH; }
+  else h = startH;
+  { /* stats.energyVariance.update(h); stats.energyTransitions2 += Math.pow(h - prevH, 2) */
+    lf->eSamples += 1;
+    const double oldDiff = h - lf->eMean;
+    lf->eMean += oldDiff / (double)lf->eSamples;
+    const double newDiff = h - lf->eMean;
+    lf->eRaw += oldDiff * newDiff;
+    lf->eTrans2 += (h - lf->prevH) * (h - lf->prevH);
+  }
   lf->iterations += 1;
   lf->sumAccept += jm_exp(lf->math_mode, a);
   return a;
@@ -477,6 +489,7 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
   if (stats) { stats->warmup_leapfrog_steps = lf->leapfrogSteps; stats->warmup_gradient_evaluations = lf->gradientEvaluations; }
   /* lf.resetStats() :31 */
   lf->gradientEvaluations = 0; lf->leapfrogSteps = 0; lf->iterations = 0; lf->accepted = 0; lf->sumAccept = 0;
+  lf->eSamples = 0; lf->eMean = 0; lf->eRaw = 0; lf->eTrans2 = 0;
   /* stepSizeTuner.stepSize :37 */
   double finalStep = cfg->step_tuner == ORC_STEP_DUALAVG ? jm_exp(cfg->math_mode, da.logStepSizeBar) : cfg->static_step;
   for (int i = 0; i < cfg->iterations; i++) { /* collectSamples :92-119 */
@@ -489,6 +502,7 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
     stats->gradient_evaluations = lf->gradientEvaluations; stats->leapfrog_steps = lf->leapfrogSteps;
     stats->accepted = lf->accepted; stats->mean_accept_prob = lf->iterations ? lf->sumAccept / lf->iterations : 0.0;
     stats->step_size = finalStep; stats->density_error = lf->density_error;
+    stats->bfmi = lf->eTrans2 / lf->eRaw; /* Stats.bfmi; meaningful for HMC / EHMC (finishIteration), NaN when no iteration ran */
   }
   int rc = lf->density_error;
   if (cfg->mass_tuner == ORC_MASS_DIAG_WINDOWED || cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) varest_free(&mt.est);

@@ -41,6 +41,7 @@ typedef struct {
   double mean_accept_prob;      /* sampling phase mean of exp(a) */
   double step_size;             /* step size used for sampling */
   int density_error;
+  double bfmi;                  /* Stats.bfmi = energyTransitions2 / energyVariance.raw(0), sampling phase (S/Stats.scala:14-16) */
 } orc_stats;
 
 /* Driver.sample for one chain (S/Driver.scala:7-46) with rng = ScalaRNG(seed).

@@ -52,7 +52,7 @@ class Config(C.Structure):
 class ChainStats(C.Structure):
     _fields_ = [("leapfrog_steps", C.c_int64), ("warmup_leapfrog_steps", C.c_int64),
                 ("gradient_evaluations", C.c_int64), ("accepted", C.c_int64), ("mean_accept_prob", C.c_double),
-                ("step_size", C.c_double), ("error", C.c_int32), ("reserved", C.c_int32)]
+                ("step_size", C.c_double), ("error", C.c_int32), ("reserved", C.c_int32), ("bfmi", C.c_double)]
 
 
 class Timing(C.Structure):

@@ -126,11 +126,11 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
   X(Pp) X(Pq) X(Pg) X(Bp) X(Bq) X(Bg) X(Sp) X(Sq) X(Sg) X(M) X(SD) X(ve_mean) X(ve_raw) X(pend_g) RH_STATE_VECS_NUTS(X)
 #define RH_STATE_F64(X) \
   X(PU) X(BU) X(SU) X(eps) X(da_logEps) X(da_logEpsBar) X(da_avgErr) X(da_mu) X(exponent) X(pend_logp) \
-  X(rng_nn) X(sum_accept) RH_STATE_F64_NUTS(X)
+  X(rng_nn) X(sum_accept) X(prevH) X(e_mean) X(e_raw) X(e_trans2) RH_STATE_F64_NUTS(X)
 #define RH_STATE_INT(X) \
   X(rng_have) X(pc) X(ret) X(it) X(ts_l) X(ts_i) X(cnt_l) X(find_first) X(sampling_started) X(need_eval) \
   X(mass_identity) X(ve_samples) X(win_size) X(win_i) X(win_j) X(da_iter) X(ring_i) X(ring_full) X(n_accept) \
-  X(n_samp_iters) X(err) RH_STATE_INT_NUTS(X) RH_STATE_INT_DENSE(X)
+  X(n_samp_iters) X(err) X(e_samples) RH_STATE_INT_NUTS(X) RH_STATE_INT_DENSE(X)
 #define RH_STATE_I64(X) X(rng_seed) X(n_leapfrog) X(n_warm_leapfrog) X(n_grad)
 
 struct rh_chain {
@@ -644,10 +644,12 @@ RH_UNROLL_SLOTS
       if (c.it >= cfg.warmup && !c.sampling_started) { // lf.resetStats(); stepSize = stepSizeTuner.stepSize
         if (cfg.step_tuner == 0) c.eps = rh_strict_exp(c.da_logEpsBar);
         c.sampling_started = 1; c.n_grad = 0;
+        c.e_samples = 0; c.e_mean = 0.0; c.e_raw = 0.0; c.e_trans2 = 0.0;  // a fresh Stats (Stats.scala:3-17)
       }
       if (c.it >= cfg.warmup + cfg.iterations) { c.pc = RH_S_DONE; return RH_ADV_DONE; }
       if (c.it >= it_stop) return RH_ADV_PAUSED;
-      // startIteration (LeapFrog.scala:52-59): fresh momenta, pqBuf := params
+      // startIteration (LeapFrog.scala:52-59): prevH with the old momenta, fresh momenta, pqBuf := params
+      c.prevH = rh_energy(c, c.Pp, c.PU, c.mass_identity != 0);
       rh_initialize_ps(c, c.mass_identity != 0, lane);
       rh_copy_P_to_B(c);
       if (cfg.sampler == 0) { // HMCSampler (HMC.scala:6-23)
@@ -714,6 +716,15 @@ RH_UNROLL_SLOTS
       rh_rng_put(c, r);
       const bool accept = a > rh_strict_log(u);
       if (accept) rh_copy_B_to_P(c);
+      { // stats.energyVariance.update(h); stats.energyTransitions2 += Math.pow(h - prevH, 2)   (LeapFrog.scala:68-74)
+        const double h = accept ? endH : startH;
+        c.e_samples += 1;
+        const double oldDiff = h - c.e_mean;
+        c.e_mean += oldDiff / (double)c.e_samples;
+        const double newDiff = h - c.e_mean;
+        c.e_raw += oldDiff * newDiff;
+        c.e_trans2 += (h - c.prevH) * (h - c.prevH);
+      }
       rh_iteration_done(c, cfg, a, accept, rh_strict_exp(a), draws, lane);
       break;
     }
@@ -817,6 +828,7 @@ RH_DEV void rh_stats_write(const rh_chain &c, rh_chain_stats_dev *out, const int
     out->leapfrog_steps = c.n_leapfrog; out->warmup_leapfrog_steps = c.n_warm_leapfrog;
     out->gradient_evaluations = c.n_grad; out->accepted = c.n_accept;
     out->sum_accept_prob = c.sum_accept; out->step_size = c.eps;
+    out->e_trans2 = c.e_trans2; out->e_raw = c.e_raw;
     out->sampling_iterations = c.n_samp_iters; out->error = c.err; out->status = status;
   }
 }

@@ -43,6 +43,7 @@ typedef struct rh_gather_data {
 typedef struct rh_chain_stats_dev {
   long long leapfrog_steps, warmup_leapfrog_steps, gradient_evaluations, accepted;
   double sum_accept_prob, step_size;
+  double e_trans2, e_raw; /* Stats.energyTransitions2, Stats.energyVariance.raw(0) of the sampling phase */
   long long sampling_iterations;
   int error, status; /* status: last RH_ADV_* */
 } rh_chain_stats_dev;

@@ -893,6 +893,7 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
       o.gradient_evaluations = d.gradient_evaluations; o.accepted = d.accepted;
       o.mean_accept_prob = d.sampling_iterations ? d.sum_accept_prob / (double)d.sampling_iterations : 0.0;
       o.step_size = d.step_size; o.error = d.error ? RH_E_LOOKUP : RH_OK; o.reserved = 0;
+      o.bfmi = s->cfg.sampler == RH_SAMPLER_NUTS ? std::nan("") : d.e_trans2 / d.e_raw;
     }
     if (mass_diag) {
       // M is the 10th vector of the state image (RH_STATE_VECS order in rh_engine.hip.h): Pp Pq Pg Bp Bq Bg Sp Sq Sg M

@@ -108,12 +108,12 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_sample(
   jdouble *ms = (*env)->GetDoubleArrayElements(env, mass, NULL);
   rh_chain_stats *st = (rh_chain_stats *)calloc(chains, sizeof(rh_chain_stats));
   const int rc = rh_sample(m, &cfg, (const int64_t *)sd, chains, dr, ms, st);
-  if (rc == RH_OK && stats) { /* 6 doubles per chain: steps, warmupSteps, gradEvals, accepted, meanAccept, stepSize */
+  if (rc == RH_OK && stats) { /* 7 doubles per chain: steps, warmupSteps, gradEvals, accepted, meanAccept, stepSize, bfmi */
     jdouble *sp = (*env)->GetDoubleArrayElements(env, stats, NULL);
     for (jsize c = 0; c < chains; c++) {
-      sp[6 * c + 0] = (double)st[c].leapfrog_steps; sp[6 * c + 1] = (double)st[c].warmup_leapfrog_steps;
-      sp[6 * c + 2] = (double)st[c].gradient_evaluations; sp[6 * c + 3] = (double)st[c].accepted;
-      sp[6 * c + 4] = st[c].mean_accept_prob; sp[6 * c + 5] = st[c].step_size;
+      sp[7 * c + 0] = (double)st[c].leapfrog_steps; sp[7 * c + 1] = (double)st[c].warmup_leapfrog_steps;
+      sp[7 * c + 2] = (double)st[c].gradient_evaluations; sp[7 * c + 3] = (double)st[c].accepted;
+      sp[7 * c + 4] = st[c].mean_accept_prob; sp[7 * c + 5] = st[c].step_size; sp[7 * c + 6] = st[c].bfmi;
     }
     (*env)->ReleaseDoubleArrayElements(env, stats, sp, 0);
   }

@@ -192,6 +192,7 @@ class Stats:
     accepted: int
     meanAcceptProb: float
     stepSize: float
+    bfmi: float = float("nan")   # Stats.bfmi (sampler/Stats.scala:14-16)
 
 
 class Trace:
@@ -267,7 +268,7 @@ class Sampler:
         mass = np.zeros((self.chains, self.model.nVars))
         _capi.check(_capi.lib().rh_sampler_stats(self._h, st, _capi.dptr(mass)), self.model._h)
         return [Stats(s.leapfrog_steps, s.warmup_leapfrog_steps, s.gradient_evaluations, s.accepted,
-                      s.mean_accept_prob, s.step_size) for s in st], mass
+                      s.mean_accept_prob, s.step_size, s.bfmi) for s in st], mass
 
     def progress(self):
         """(warmed, sampling iterations done): what a Progress callback would be told (sampler/Driver.scala:7-11), polled."""

@@ -35,7 +35,7 @@ class OrcStats(C.Structure):
         ("gradient_evaluations", C.c_int64), ("leapfrog_steps", C.c_int64),
         ("warmup_leapfrog_steps", C.c_int64), ("warmup_gradient_evaluations", C.c_int64),
         ("accepted", C.c_int64), ("mean_accept_prob", C.c_double), ("step_size", C.c_double),
-        ("density_error", C.c_int),
+        ("density_error", C.c_int), ("bfmi", C.c_double),
     ]
 
 

@@ -193,6 +193,8 @@ def _assert_chains_bit_exact(spec, config, seeds):
         assert tr.stats[c].accepted == st.accepted
         assert tr.stats[c].stepSize == st.step_size
         assert tr.stats[c].meanAcceptProb == pytest.approx(st.mean_accept_prob, rel=1e-12)
+        if type(config.sampler()).__name__ != "NUTSSampler" and config.iterations > 1:
+            assert tr.stats[c].bfmi == st.bfmi                       # Stats.bfmi: energyTransitions2 / energyVariance.raw
     return tr
 
 

@@ -190,6 +190,8 @@ def test_driver_runs_and_recovers_posterior(oracle):
     assert np.all(np.abs(draws.mean(axis=0)) < 0.15)
     assert np.all(np.abs(draws.var(axis=0) - 1.0) < 0.25)
     assert 0.6 < st.mean_accept_prob < 0.95
+    # Stats.bfmi (S/Stats.scala:14-16): for a d-dimensional Gaussian with full momentum refresh E-BFMI is ~1 (>= 0.3 is healthy)
+    assert 0.5 < st.bfmi < 1.6
     # EHMC + windowed diagonal mass adaptation (DefaultConfig, S/Sampler.scala:17-27)
     cfg = O.make_config(sampler=O.EHMC, max_steps=1024, iterations=2000, warmup=1000, mass_tuner=O.MASS_DIAG_WINDOWED)
     draws, mass, st = O.sample_model(models.eight_schools(), cfg, 7)
