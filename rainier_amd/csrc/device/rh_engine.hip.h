@@ -982,7 +982,10 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 
 // grid: 1-D, ngroups * nsplit single-wave workgroups.  XCD-aware mapping: workgroup b lands on XCD b % 8, so XCD x
 // takes the row splits {x, x+8, ...} of EVERY chain group: each XCD's private L2 then serves only 1/8 of the rows.
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef RH_GRAD_WAVES
+#define RH_GRAD_WAVES 1
+#endif
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
 rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                const int chains, const int nsplit, const int xcd_aware) {

@@ -220,6 +220,7 @@ void assemble_source(rh_model *m) {
   // experiment knobs of the MFMA GLM kernel (workgroup waves, forced waves per SIMD, scalar-part unroll)
   if (const char *e = std::getenv("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
   defines += "#define RH_GLM_W " + std::to_string(m->glm_w) + "\n";
+  if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_CHAIN_WAVES")) defines += "#define RH_CHAIN_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";

@@ -5,7 +5,7 @@ out=gpurun_out/sweep_cfg2.txt; : > $out
 while IFS='|' read -r envs flags; do
   [ -z "$flags" ] && continue
   echo "## $envs | $flags" >> $out
-  env $envs timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline $flags 2>&1 | tail -1 | python -c "
+  env $envs timeout 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline $flags 2>&1 | tail -1 | python -c "
 import sys, json
 l = sys.stdin.read().strip()
 try:
