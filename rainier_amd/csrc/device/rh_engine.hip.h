@@ -1166,8 +1166,13 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   typedef rh_glm<RH_GLM_TARGET> GL;
   typedef rh_target<RH_GLM_TARGET> TG;
   constexpr int P = GL::P, NC = GL::NCOLS, W = RH_GLM_W;
-  constexpr int PT = (P + 3) / 4;    // forward k-steps (4 predictors each)
-  constexpr int CT = (P + 15) / 16;  // backward predictor tiles
+  // A last, nearly empty predictor tile would cost 4 backward MFMAs (and a last forward k-step 1) per 16 rows for <= 4
+  // predictors; the fp64 matrix pipe delivers only 0.66x the VALU FMA rate (profiles/r1_d), so those RV predictors are
+  // contracted on the VALU instead: RV FMAs per eval forward + RV backward, from the same LDS reads (cfg 4: 29 -> 24 MFMAs).
+  constexpr int RV = (P % 16 != 0 && P % 16 <= 4 && P > 16) ? P % 16 : 0;
+  constexpr int PM = P - RV;          // predictors on the matrix pipe (a multiple of 16 when RV > 0)
+  constexpr int PT = (PM + 3) / 4;    // forward k-steps (4 predictors each)
+  constexpr int CT = (PM + 15) / 16;  // backward predictor tiles
   constexpr int MYC = (NC + W - 1) / W;
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1191,14 +1196,18 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
   for (int ks = 0; ks < PT; ks++) {
     const int pred = 4 * ks + lg;
-    Bf[ks] = (pred < P) ? q[(size_t)cl * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
-    acol[ks] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2;
+    Bf[ks] = (pred < PM) ? q[(size_t)cl * RH_NVARS + GL::pred_param[pred < PM ? pred : 0]] : 0.0;
+    acol[ks] = (pred < PM) ? GL::pred_col[pred < PM ? pred : 0] : -2;
   }
+  double thv[RV > 0 ? RV : 1], Gv[RV > 0 ? RV : 1];  // VALU remainder: this lane's chain's coefficients and gradient sums
+  int vcol[RV > 0 ? RV : 1];
+#pragma unroll
+  for (int k = 0; k < RV; k++) { thv[k] = q[(size_t)cl * RH_NVARS + GL::pred_param[PM + k]]; vcol[k] = GL::pred_col[PM + k]; Gv[k] = 0.0; }
   int bcol[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
     const int pred = 16 * ct + li;
-    bcol[ct] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2;
+    bcol[ct] = (pred < PM) ? GL::pred_col[pred < PM ? pred : 0] : -2;
   }
   double thu[GL::NTHU > 0 ? GL::NTHU : 1];
 #pragma unroll
@@ -1253,6 +1262,14 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
           else D = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bf[ks], D, 0, 0, 0);
         }
         D += D2;
+        double xv[RV > 0 ? RV : 1][4];  // remainder predictors at this lane's 4 rows
+#pragma unroll
+        for (int k = 0; k < RV; k++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            xv[k][r] = vcol[k] >= 0 ? tile[vcol[k] * RH_GLM_TRP + row0s + lg + 4 * r] : 1.0;
+            D[r] += thv[k] * xv[k][r];
+          }
         rh_v4d Wv;
 #ifndef RH_GLM_ELEM_UNROLL
 #define RH_GLM_ELEM_UNROLL 4
@@ -1267,6 +1284,10 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
           for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
         }
+#pragma unroll
+        for (int k = 0; k < RV; k++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) Gv[k] += xv[k][r] * Wv[r];
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -1288,8 +1309,15 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int pred = 16 * ct + lg + 4 * r;
-        if (pred < P && mychain < chains) out[GL::pred_acc[pred < P ? pred : 0]] = G[ct][r];
+        if (pred < PM && mychain < chains) out[GL::pred_acc[pred < PM ? pred : 0]] = G[ct][r];
       }
+#pragma unroll
+    for (int k = 0; k < RV; k++) {  // fold the 4 lane groups (rows lg + 4 r) of the VALU remainder
+      double v = Gv[k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0 && mychain < chains) out[GL::pred_acc[PM + k]] = v;
+    }
 #pragma unroll
     for (int k = 0; k < GL::NOTHER; k++) {
       double v = oth[k];

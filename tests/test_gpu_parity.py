@@ -347,7 +347,9 @@ def test_tick_engine_lds_staged_wide_models(n, chains, k, monkeypatch):
 
 
 @pytest.mark.parametrize("n,chains,k", [(1, 1, 8), (15, 3, 9), (64, 16, 12), (65, 17, 16), (1000, 33, 50), (5000, 40, 50),
-                                        (70001, 70, 31), (200000, 256, 50)])
+                                        (70001, 70, 31), (200000, 256, 50),
+                                        # P = k + 1 predictors: P % 16 in 1..4 puts the last predictors on the VALU (RV path)
+                                        (300, 20, 19), (300, 5, 35), (129, 18, 20), (77, 9, 32)])
 def test_glm_mfma_kernel_matches_valu_path_and_oracle(n, chains, k):
     # dense linear predictor -> rh_grad_glm_kernel (v_mfma_f64_16x16x4_f64, 16 chains per wavefront)
     spec = models.logistic(n=n, k=k, seed=n + 7)
