@@ -1668,13 +1668,19 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 #pragma unroll
   for (int i = 0; i < RH_NTH; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
 #if RH_HAS_GATHER
-RH_UNROLL_SLOTS
-  for (int k = 0; k < RH_SLOTS; k++) {
-    const int i = k * 64 + lane;
-    if (i >= RH_NSHARED && i < RH_NVARS) {
-      double g = 0.0;
-      rh_scatter_sum<0>(gd, chain, i - RH_NSHARED, g);
-      grad.s[k] = g;
+  // the table parameters' gradients: 8 slots' scatter sums are loaded before the first store (see RH_BIG2)
+  for (int k0 = 0; k0 < RH_SLOTS; k0 += 8) {
+    double g[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = (k0 + j) * 64 + lane;
+      g[j] = 0.0;
+      if (k0 + j < RH_SLOTS && i >= RH_NSHARED && i < RH_NVARS) rh_scatter_sum<0>(gd, chain, i - RH_NSHARED, g[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = (k0 + j) * 64 + lane;
+      if (k0 + j < RH_SLOTS && i >= RH_NSHARED && i < RH_NVARS) grad.s[k0 + j] = g[j];
     }
   }
 #endif
@@ -1710,9 +1716,20 @@ rh_tick_kernel(const rh_model_data d,
   const int status = rh_advance(c, cfg, it_stop, seeds + 2 * (size_t)chain, static_mass, my_draws, lane);
   if (status == RH_ADV_NEED_GRAD) {
     c.need_eval = 1;
+#if RH_BIGN
+    for (int k0 = 0; k0 < RH_SLOTS; k0 += 8) {  // 8 loads in flight before the stores (see RH_BIG2)
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = (k0 + j < RH_SLOTS) ? c.Bq.s[k0 + j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (k0 + j < RH_SLOTS && (k0 + j) * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + (k0 + j) * 64 + lane] = t[j];
+    }
+#else
 RH_UNROLL_SLOTS
     for (int k = 0; k < RH_SLOTS; k++)
       if (k * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + k * 64 + lane] = c.Bq.s[k];
+#endif
   }
   if (lane == 0) active[chain] = (status == RH_ADV_NEED_GRAD) ? 1 : 0;
   rh_chain_store(c, st, lane);

@@ -282,8 +282,14 @@ struct wvec {
   }
   RH_DEV ~wvec() { if (pooled) rh_pool_depth[threadIdx.x] -= 1; }
   RH_DEV wvec(const wvec &) = delete;
-  RH_DEV wvec &operator=(const wvec &o) { // copies the DATA (each lane its own elements)
-    _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k++) s[k] = o.s[k];
+  RH_DEV wvec &operator=(const wvec &o) { // copies the DATA (each lane its own elements); 8 loads in flight per lane
+    int k = 0;
+    _Pragma("unroll 1") for (; k + 8 <= RH_SLOTS; k += 8) {
+      double t[8];
+      _Pragma("unroll") for (int j = 0; j < 8; j++) t[j] = o.s[k + j];
+      _Pragma("unroll") for (int j = 0; j < 8; j++) s[k + j] = t[j];
+    }
+    _Pragma("unroll 1") for (; k < RH_SLOTS; k++) s[k] = o.s[k];
     return *this;
   }
 };
@@ -298,6 +304,23 @@ RH_DEV void wv_fill(wvec &v, double x, int lane) {
   RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) v.s[k] = (k * 64 + lane < RH_NVARS) ? x : 0.0;
 }
+#if RH_BIGN
+// big mode: the vectors live in HBM and one wavefront walks RH_SLOTS x 512 B of them; the loads of 8 slots are issued
+// before the first dependent store so that the walk is bandwidth- rather than latency-bound (the pointers may alias as far
+// as the compiler knows, so it cannot do this itself)
+#define RH_BIG2(expr)                                                                                  \
+  int k = 0;                                                                                             \
+  _Pragma("unroll 1") for (; k + 8 <= RH_SLOTS; k += 8) {                                              \
+    double xa[8], ya[8];                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { xa[j] = x.s[k + j]; ya[j] = y.s[k + j]; }          \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) { const double xv = xa[j], yv = ya[j]; (void)xv; (void)yv; o.s[k + j] = (expr); } \
+  }                                                                                                      \
+  _Pragma("unroll 1") for (; k < RH_SLOTS; k++) { const double xv = x.s[k], yv = y.s[k]; (void)xv; (void)yv; o.s[k] = (expr); }
+// y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
+RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) { wvec &o = y; RH_BIG2(yv + a * xv) }
+RH_DEV void wv_mul(wvec &o, const wvec &x, const wvec &y) { RH_BIG2(xv * yv) }
+RH_DEV void wv_sub(wvec &o, const wvec &x, const wvec &y) { RH_BIG2(xv - yv) }
+#else
 // y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
 RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) {
   RH_UNROLL_SLOTS
@@ -311,6 +334,7 @@ RH_DEV void wv_sub(wvec &out, const wvec &x, const wvec &y) {
   RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] - y.s[k];
 }
+#endif
 RH_DEV void wv_set(wvec &v, int i, double x, int lane) { // i wave-uniform
 #if RH_BIGN
   if (lane == (i & 63)) v.s.p[i] = x;
