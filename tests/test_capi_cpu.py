@@ -111,3 +111,30 @@ def test_requirements_program_lowers(lib, monkeypatch):
     assert lib.rh_requirements_eval(bad, len(models.funnel().rir), None, _capi.dptr(draws), 2, _capi.dptr(out)) == _capi.RH_E_INVALID
     with pytest.raises(_capi.RainierHipError):
         _capi.lower_only(rir)
+
+
+def test_headers_are_c_and_library_links_from_c(tmp_path):
+    """include/*.h as C99 (-pedantic -Werror), linked against librainier_hip.so from plain C; without a device the model
+    cannot be created (RH_E_DEVICE), i.e. no CPU fallback hides behind the ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "stubs", "abi_check.c"), "-o", exe, "-L", os.path.join(root, "rainier_amd"),
+                           "-lrainier_hip", "-Wl,-rpath," + os.path.join(root, "rainier_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([exe]).decode()
+    assert "abi 2 header 2" in out
+    assert "sizeof rh_config %d rh_chain_stats %d" % (C.sizeof(_capi.Config), C.sizeof(_capi.ChainStats)) in out
+    assert "default 1000 1000 sampler 1 ehmc 1024 mass 1 50 1.5" in out          # DefaultConfig, sampler/Sampler.scala:17-27
+    import torch
+    if not torch.cuda.is_available():
+        assert "create rc %d devices" % _capi.RH_E_DEVICE in out and "no CPU fallback" in out
+
+
+def test_jni_shim_typechecks():
+    """rainier_amd/jni/rainier_hip_jni.c against a declaration-only jni.h (tests/stubs): the shim that a Rainier maintainer
+    builds next to the library at least parses and type-checks against the current C ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "tests", "stubs"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "rainier_amd", "jni", "rainier_hip_jni.c")])
