@@ -102,6 +102,7 @@ def lib():
     L.rh_requirements_eval.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), dp, C.c_int64, dp]
     L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.rh_free.argtypes = [vp]
+    L.rh_simplify_rir.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]
     _lib = L
     return L
@@ -125,6 +126,18 @@ def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=
     o.grad_chains, o.grad_unroll, o.factor_outputs = grad_chains, grad_unroll, int(factor_outputs)
     o.with_nuts = int(with_nuts)
     return o
+
+
+def simplify_rir(rir: bytes, fast: bool = False) -> bytes:
+    """The emitter's clean-up pass (csrc/simplify.cpp) applied to an RIR blob, returned as RIR (test hook)."""
+    L = lib()
+    out, n = C.c_void_p(), C.c_size_t(0)
+    buf = C.create_string_buffer(rir, len(rir))
+    check(L.rh_simplify_rir(buf, len(rir), int(fast), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.rh_free(out)
 
 
 def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950"):

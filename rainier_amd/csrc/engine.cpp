@@ -502,6 +502,16 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
   return rc;
 }
 extern "C" void rh_free(void *p) { std::free(p); }
+// Test hook (no device needed): the program after the emitter's clean-up pass, as RIR again, so that the CPU suite can
+// check on the oracle's interpreter that simplify() is value-preserving.  fast != 0 adds the fast-mode-only rules.
+extern "C" int rh_simplify_rir(const void *rir, size_t rir_len, int fast, void **out, size_t *out_len) {
+  return guard(nullptr, [&] {
+    rh::Program P; std::string err;
+    if (!rh::parse_rir(rir, rir_len, P, err)) throw Fail{RH_E_INVALID, err};
+    const std::vector<unsigned char> b = rh::write_rir(rh::simplify(P, fast != 0));
+    *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
+  });
+}
 
 namespace {
 // per-use device buffers of gather mode: split -> group boundaries and the scatter sums

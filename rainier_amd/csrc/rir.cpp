@@ -103,4 +103,23 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
     }
   return true;
 }
+// Program -> RIR bytes (the inverse of parse_rir; used by the rh_simplify_rir test hook)
+std::vector<unsigned char> write_rir(const Program &P) {
+  std::vector<unsigned char> out;
+  auto u32 = [&](uint32_t v) { for (int b = 0; b < 4; b++) out.push_back((unsigned char)(v >> (8 * b))); };
+  u32(RH_RIR_MAGIC); u32(RH_RIR_VERSION); u32(P.n_params); u32((uint32_t)P.targets.size()); u32((uint32_t)P.nodes.size()); u32(P.kind);
+  for (const Target &t : P.targets) { u32(t.n_cols); u32(0); for (uint32_t o : t.outputs) u32(o); }
+  for (const Node &n : P.nodes) {
+    u32(n.op);
+    switch (n.op) {
+      case RH_RIR_CONST: { uint64_t bits; std::memcpy(&bits, &n.cval, 8); u32((uint32_t)bits); u32((uint32_t)(bits >> 32)); break; }
+      case RH_RIR_INPUT: u32(n.input); break;
+      case RH_RIR_LOOKUP: u32(n.a); u32((uint32_t)n.low); u32((uint32_t)n.table.size()); for (uint32_t e : n.table) u32(e); break;
+      case RH_RIR_EXP: case RH_RIR_LOG: case RH_RIR_ABS: case RH_RIR_NOOP: case RH_RIR_SIN: case RH_RIR_COS: case RH_RIR_TAN:
+      case RH_RIR_ASIN: case RH_RIR_ACOS: case RH_RIR_ATAN: u32(n.a); break;
+      default: u32(n.a); u32(n.b); break;
+    }
+  }
+  return out;
+}
 }  // namespace rh

@@ -31,6 +31,8 @@ struct Program {
 // Parses and validates a blob; returns false and sets err on malformed input.
 bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 
+std::vector<unsigned char> write_rir(const Program &p);
+
 // Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
 Program simplify(const Program &p, bool fast = false);
 

@@ -176,7 +176,34 @@ Program simplify(const Program &P, bool fast) {
     m[i] = B.lookup_raw(idx, low, table);
   }
   for (Target &t : B.Q.targets) for (uint32_t &o : t.outputs) o = m[o];
-  return B.Q;
+  // drop what the rewrites orphaned (operands always precede their users, so one backward sweep marks everything live)
+  Program &Q = B.Q;
+  std::vector<char> live(Q.nodes.size(), 0);
+  for (const Target &t : Q.targets) for (uint32_t o : t.outputs) live[o] = 1;
+  for (size_t i = Q.nodes.size(); i-- > 0;) {
+    if (!live[i]) continue;
+    const Node &n = Q.nodes[i];
+    if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+    live[n.a] = 1;
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) live[e] = 1; }
+    else if (!unary_op(n.op)) live[n.b] = 1;
+  }
+  std::vector<uint32_t> renum(Q.nodes.size(), 0);
+  std::vector<Node> kept;
+  for (size_t i = 0; i < Q.nodes.size(); i++) {
+    if (!live[i]) continue;
+    Node n = Q.nodes[i];
+    if (n.op != RH_RIR_CONST && n.op != RH_RIR_INPUT) {
+      n.a = renum[n.a];
+      if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : n.table) e = renum[e]; }
+      else if (!unary_op(n.op)) n.b = renum[n.b];
+    }
+    renum[i] = (uint32_t)kept.size();
+    kept.push_back(std::move(n));
+  }
+  Q.nodes.swap(kept);
+  for (Target &t : Q.targets) for (uint32_t &o : t.outputs) o = renum[o];
+  return Q;
 }
 
 }  // namespace rh

@@ -1,0 +1,116 @@
+"""The emitter's clean-up pass (rainier_amd/csrc/simplify.cpp) must be value-preserving: random expression DAGs built from
+the reference's node set -- biased towards what symbolic differentiation of Real.eq / Real.gt selects produces (selects of
+selects, selects between f(a) and f(b), constant selects) -- are simplified, written back as RIR (rh_simplify_rir) and
+evaluated with the oracle's interpreter next to the original program: every output (value and all gradients, every target)
+must be BIT-identical at random and at special points; with the fast-mode rule 1/(1/x) -> x, equal to a few ulp."""
+import math
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from rainier_amd import _capi, models
+from rainier_amd.frontend import Graph
+from tests import oracle_lib as O
+
+
+def random_program(rng: random.Random, n_params=3, data=False):
+    g = Graph(n_params, [0, 2] if data else [0])
+    leaves = [(g.param(i), False) for i in range(n_params)] + [(g.const(c), False) for c in (0.0, 1.0, -1.0, 2.0, 0.5)]
+    if data:
+        leaves += [(g.col(1, 0), True), (g.col(1, 1), True)]
+    pool = list(leaves)          # (expression, reads a data column)
+
+    def pick():
+        return rng.choice(pool)
+
+    def select():
+        (a, da), (b, db), (t, dt), (f, df) = pick(), pick(), pick(), pick()
+        kind = rng.randrange(4)
+        if kind == 0:                                  # select between f(x) and f(y): the sinking rule
+            op = rng.choice(["log", "exp", "abs"])
+            t, f = getattr(t.abs() + 0.5, op)(), getattr(f.abs() + 0.5, op)()
+        elif kind == 1:                                # all-constant select (indicator)
+            t, f, dt, df = g.const(rng.choice([0.0, 1.0, 2.0])), g.const(rng.choice([0.0, 1.0, -3.0])), False, False
+        table = rng.choice([[f, t, f], [f, f, t], [f, t, t], [t, f, f]])
+        return g.lookup(a.compare(b), table, -1), da or db or dt or df
+
+    for _ in range(rng.randrange(8, 30)):
+        r = rng.random()
+        if r < 0.30:
+            e = select()
+        elif r < 0.40:                                 # select of a select's compare (what d/dx of Real.eq produces)
+            (a, da), (b, db), (x, dx), (y, dy), (z, dz) = pick(), pick(), pick(), pick(), pick()
+            e = g.lookup(a.compare(b).compare(g.const(rng.choice([-1.0, 0.0, 1.0, 0.5]))), [x, y, z], -1), da or db or dx or dy or dz
+        elif r < 0.75:
+            (a, da), (b, db) = pick(), pick()
+            e = rng.choice([lambda: a + b, lambda: a - b, lambda: a * b, lambda: a / (b.abs() + 0.25),
+                            lambda: 1.0 / (1.0 / (a.abs() + 0.5))])(), da or db
+        else:
+            a, da = pick()
+            e = rng.choice([lambda: (a.abs() + 0.1).log(), lambda: (a * 0.3).exp(), lambda: a.abs(), lambda: a.sin(), lambda: a.atan()])(), da
+        pool.append(e)
+    made = pool[len(leaves):]
+    free = [e for e, d in made if not d] or [g.param(0) * 1.5]
+    outs = [g.sum(rng.sample(free, k=min(4, len(free))))]
+    if data:
+        rows = [e for e, d in made][-6:]
+        outs.append(g.sum(rows) + g.col(1, 0) * g.param(0))
+    rir = g.compile(outs)
+    cols = [np.array([0.0, 1.0, 2.0, -1.0, 0.5]), np.array([3.0, 0.0, -2.0, 1.0, 1.0])] if data else []
+    return models.ModelSpec("rand", rir, cols, [0, 5] if data else [0], n_params)
+
+
+POINTS = [np.array(p) for p in ([0.3, -0.7, 1.1], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [-1.0, 2.0, 0.5], [1e-300, -1e300, 5.0],
+                                [math.inf, 1.0, -1.0], [0.5, -math.inf, 2.0])]
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_simplify_is_bit_exact_on_random_dags(oracle, seed):
+    rng = random.Random(seed)
+    spec = random_program(rng, data=seed % 3 == 0)
+    simp = models.ModelSpec("simp", _capi.simplify_rir(spec.rir, fast=False), spec.columns, spec.nrows, spec.n_params)
+    a, b = O.OracleDensity(spec, O.JM_DET), O.OracleDensity(simp, O.JM_DET)
+    nodes = lambda blob: struct.unpack_from("<I", blob, 16)[0]
+    assert nodes(simp.rir) <= nodes(spec.rir) + 8
+    pts = POINTS + [np.array([rng.gauss(0, 2) for _ in range(3)]) for _ in range(6)]
+    for q in pts:
+        try:
+            want = a.update(q)
+        except RuntimeError:                           # Lookup out of range in the original: the simplified program must raise too
+            with pytest.raises(RuntimeError):
+                b.update(q)
+            continue
+        got = b.update(q)
+        assert np.array_equal(got, want, equal_nan=True), (seed, q, got, want)
+    fast = models.ModelSpec("fast", _capi.simplify_rir(spec.rir, fast=True), spec.columns, spec.nrows, spec.n_params)
+    c = O.OracleDensity(fast, O.JM_DET)
+    for q in pts[7:]:
+        want, got = a.update(q), c.update(q)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300, equal_nan=True)
+
+
+def test_simplify_removes_the_redundant_log_and_selects():
+    spec = models.logistic(n=16, k=8)
+    before, after = spec.rir, _capi.simplify_rir(spec.rir)
+    count = lambda blob, op: sum(1 for _ in _nodes(blob) if _[0] == op)
+    assert count(after, 9) < count(before, 9)          # LOG: log(select(p, 1-p)) instead of select(log p, log(1-p))
+    assert count(after, 7) < count(before, 7)          # COMPARE: selects of selects re-indexed onto the inner compare
+    d0, d1 = O.OracleDensity(spec, O.JM_DET), O.OracleDensity(models.ModelSpec("s", after, spec.columns, spec.nrows, spec.n_params), O.JM_DET)
+    q = np.random.default_rng(0).normal(size=spec.n_params) * 0.3
+    assert np.array_equal(d0.update(q), d1.update(q))
+
+
+def _nodes(blob):
+    magic, ver, n_params, n_targets, n_nodes, kind = struct.unpack_from("<6I", blob, 0)
+    pos = 24 + n_targets * (2 + n_params + 1) * 4
+    for _ in range(n_nodes):
+        op = struct.unpack_from("<I", blob, pos)[0]; pos += 4
+        if op == 0: pos += 8
+        elif op == 1: pos += 4
+        elif op == 18:
+            cnt = struct.unpack_from("<I", blob, pos + 8)[0]; pos += 12 + 4 * cnt
+        elif 8 <= op <= 17: pos += 4
+        else: pos += 8
+        yield (op,)
