@@ -817,3 +817,25 @@ def test_modelling_api_models_on_device():
     m = Model.observe([1.0, 2.0, 3.0], Normal(mu, sigma))
     x = R.Model(m.compile("fit_normal"), device=0, math_mode=_capi.MATH_STRICT).optimize()
     assert abs(float(m.predict(mu, x)) - 2.0) < 0.02 and 0.6 < float(m.predict(sigma, x)) < 0.75
+
+
+def test_cfg2_full_size_posterior_matches_least_squares():
+    # the bench configuration end to end (1e6 rows, HMC L=32, DualAvgTuner, tick engine, fast build): with N = 1e6 the
+    # posterior of (a, b) is the least-squares solution +- sigma/sqrt(N) and sigma's is the residual scale (SURVEY 8(d):
+    # "distributional parity via posterior means/variances within MCSE and R-hat")
+    spec = models.linreg(n=1_000_000, k=3)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    cfg = R.make_config(400, 200, R.HMCSampler(32), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    tr = m.sample(cfg, seeds=[1000 + c for c in range(128)])
+    y, X = spec.columns[0], np.stack([np.ones(1_000_000)] + list(spec.columns[1:]))
+    ols, res, _, _ = np.linalg.lstsq(X.T, y, rcond=None)
+    sigma = np.sqrt(res[0] / 1_000_000)
+    post = tr.chains.reshape(-1, 5)
+    se = sigma / 1e3                                            # posterior sd of each coefficient (X ~ N(0,1), N = 1e6)
+    assert np.all(np.abs(post[:, 1:].mean(axis=0) - ols) < 0.5 * se), (post[:, 1:].mean(axis=0), ols)
+    assert np.all(np.abs(post[:, 1:].std(axis=0) / se - 1.0) < 0.25)
+    assert abs(np.exp(post[:, 0]).mean() - sigma) < 3 * sigma / np.sqrt(2e6)
+    diag = tr.diagnostics()
+    assert all(r < 1.05 for r, _ in diag), diag
+    assert 0.6 < np.mean([st.meanAcceptProb for st in tr.stats]) < 0.95
+    assert all(0.3 < st.bfmi < 3.0 for st in tr.stats)
