@@ -152,7 +152,12 @@ struct rh_chain {
   double *ring;               // packed chains keep the ring buffer in their state image: entry i at ring[i]
 #endif
 #if RH_WITH_NUTS
-  wvec ckr[RH_NUTS_MAXD], ckrs[RH_NUTS_MAXD]; // NUTS momentum / momentum-sum checkpoints
+#if RH_BIGN
+  wvec ckr[RH_NUTS_MAXD], ckrs[RH_NUTS_MAXD]; // NUTS momentum / momentum-sum checkpoints (views on the state image)
+#else
+  rh_u64 *ck; // NUTS checkpoints stay in the chain's state image (word ((j * RH_SLOTS + k) * 2 + {0: r, 1: rsum}) * 64 + lane):
+              // they are touched once per leaf, and 24 register vectors behind a dynamic index cost ~50 VGPRs + select chains
+#endif
 #endif
 #if RH_WITH_DENSE
   // DenseMassMatrix (MassMatrix.scala:15-117), row i in lane i: Drow[j] = elements(i*n + j), Lrow[j] = Cholesky lower
@@ -240,11 +245,7 @@ RH_DEV void rh_chain_store(const rh_chain &c, rh_u64 *st, const int lane) {
   w += RH_RING_SLOTS;
 #endif
 #if RH_WITH_NUTS
-  for (int j = 0; j < RH_NUTS_MAXD; j++)
-    for (int k = 0; k < RH_SLOTS; k++) {
-      st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ckr[j].s[k]);
-      st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.ckrs[j].s[k]);
-    }
+  w += 2 * RH_NUTS_MAXD * RH_SLOTS;  // the checkpoints live in the image (c.ck)
 #endif
 #if RH_WITH_DENSE
   for (int j = 0; j < RH_NVARS; j++) st[(w++) * 64 + lane] = (rh_u64)__double_as_longlong(c.Drow[j]);
@@ -277,11 +278,7 @@ RH_DEV void rh_chain_load(rh_chain &c, rh_u64 *st, const int lane) {
   c.ring = (double *)(st + (size_t)w * 64); w += RH_RING_SLOTS;
 #endif
 #if RH_WITH_NUTS
-  for (int j = 0; j < RH_NUTS_MAXD; j++)
-    for (int k = 0; k < RH_SLOTS; k++) {
-      c.ckr[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
-      c.ckrs[j].s[k] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
-    }
+  c.ck = st + (size_t)w * 64; w += 2 * RH_NUTS_MAXD * RH_SLOTS;
 #endif
 #if RH_WITH_DENSE
   for (int j = 0; j < RH_NVARS; j++) c.Drow[j] = __longlong_as_double((rh_i64)st[(w++) * 64 + lane]);
@@ -780,16 +777,32 @@ RH_UNROLL_SLOTS
       const int idx_min = idx_max - nsub + 1;
       bool sub_turning = false;
       if ((c.n_leaf & 1) == 0) {
+#if RH_BIGN
 #pragma unroll
         for (int j = 0; j < RH_NUTS_MAXD; j++)
           if (j == idx_max) { c.ckr[j] = c.Bp; c.ckrs[j] = c.Sp; }
+#else
+RH_UNROLL_SLOTS
+        for (int s2 = 0; s2 < RH_SLOTS; s2++) {
+          c.ck[(size_t)((idx_max * RH_SLOTS + s2) * 2) * 64 + lane] = (rh_u64)__double_as_longlong(c.Bp.s[s2]);
+          c.ck[(size_t)((idx_max * RH_SLOTS + s2) * 2 + 1) * 64 + lane] = (rh_u64)__double_as_longlong(c.Sp.s[s2]);
+        }
+#endif
       } else {
         for (int k = idx_max; k >= idx_min && !sub_turning; k--) {
           RH_TMP(rk); RH_TMP(rsk);
+#if RH_BIGN
           wv_zero(rk); wv_zero(rsk);
 #pragma unroll
           for (int j = 0; j < RH_NUTS_MAXD; j++)
             if (j == k) { rk = c.ckr[j]; rsk = c.ckrs[j]; }
+#else
+RH_UNROLL_SLOTS
+          for (int s2 = 0; s2 < RH_SLOTS; s2++) {
+            rk.s[s2] = __longlong_as_double((rh_i64)c.ck[(size_t)((k * RH_SLOTS + s2) * 2) * 64 + lane]);
+            rsk.s[s2] = __longlong_as_double((rh_i64)c.ck[(size_t)((k * RH_SLOTS + s2) * 2 + 1) * 64 + lane]);
+          }
+#endif
           RH_TMP(sub);
 RH_UNROLL_SLOTS
           for (int s2 = 0; s2 < RH_SLOTS; s2++) sub.s[s2] = c.Sp.s[s2] - rsk.s[s2] + rk.s[s2];
