@@ -477,7 +477,8 @@ int orc_sample_chain_state(const orc_config *cfg, orc_density_fn f, void *ctx, i
     if (cfg->step_tuner == ORC_STEP_DUALAVG) { dualavg_update(&da, logAcceptProb); stepSize = jm_exp(cfg->math_mode, da.logStepSize); }
     memcpy(sample, params + n, sizeof(double) * n); /* lf.variables */
     if (masstuner_update(&mt, sample, massbuf)) {
-      mass = massbuf; /* DiagonalMassMatrix(variance) / DenseMassMatrix(covariance) -- require(!elements.contains(0.0)) not enforced here */
+      mass = massbuf; /* DiagonalMassMatrix(variance) / DenseMassMatrix(covariance): require(!elements.contains(0.0)) S/MassMatrix.scala:8,16 */
+      for (int e = 0; e < (cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED ? n * n : n); e++) if (massbuf[e] == 0.0) lf->density_error |= 2;
       if (cfg->mass_tuner == ORC_MASS_DENSE_WINDOWED) { lf->dense = massbuf; orc_cholesky_upper(massbuf, n, lf->chol_u); }
       if (cfg->step_tuner == ORC_STEP_DUALAVG) { /* DualAvgTuner.reset S/DualAvg.scala:17-21 */
         double ss = jm_exp(cfg->math_mode, da.logStepSizeBar);

@@ -445,7 +445,12 @@ RH_DEV bool rh_mass_update(rh_chain &c, const rh_cfg_dev &cfg, const int lane) {
     c.win_i = 0;
     c.win_size = (int)(c.win_size * cfg.mass_expansion);
     const double z = (double)(c.ve_samples - 1);          // covariance = cov / (samples - 1); reset() keeps `samples`
-    for (int k = 0; k < RH_NVARS; k++) { c.Drow[k] = c.Crow[k] / z; c.Crow[k] = 0.0; c.Lrow[k] = 0.0; }
+    double zeros = 0.0;                                   // DenseMassMatrix: require(!elements.contains(0.0)) (MassMatrix.scala:16)
+    for (int k = 0; k < RH_NVARS; k++) {
+      c.Drow[k] = c.Crow[k] / z; c.Crow[k] = 0.0; c.Lrow[k] = 0.0;
+      zeros += (lane < RH_NVARS && c.Drow[k] == 0.0) ? 1.0 : 0.0;
+    }
+    if (rh_wave_sum(zeros) > 0.0) c.err |= 2;
     c.ve_mean.s[0] = 0.0; c.ve_raw.s[0] = 0.0;
     // choleskyUpperTriangular (MassMatrix.scala:74-116): packed lower triangle, row by row
     for (int i = 0; i < RH_NVARS; i++)
@@ -487,6 +492,13 @@ RH_UNROLL_SLOTS
       c.SD.s[k] = live ? rh_strict_sqrt(c.M.s[k]) : 1.0;  // DiagonalMassMatrix.stdDevs
       c.ve_mean.s[k] = 0.0;                               // reset() zeroes mean and raw, NOT samples
       c.ve_raw.s[k] = 0.0;
+    }
+    { // DiagonalMassMatrix: require(!elements.contains(0.0)) (MassMatrix.scala:8) -- the reference throws; here the chain is
+      // flagged (rh_chain_stats.error = RH_E_INVALID) and the call returns that status
+      double zeros = 0.0;
+RH_UNROLL_SLOTS
+      for (int k = 0; k < RH_SLOTS; k++) zeros += ((k * 64 + lane < RH_NVARS) && c.M.s[k] == 0.0) ? 1.0 : 0.0;
+      if (rh_wave_sum(zeros) > 0.0) c.err |= 2;
     }
     c.mass_identity = 0;
     return true;

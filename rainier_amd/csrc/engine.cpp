@@ -892,18 +892,19 @@ extern "C" int rh_sampler_draws_device(rh_sampler *s, void **p) {
 extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *mass_diag) {
   if (!s) { g_err = "rh_sampler_stats: NULL"; return RH_E_INVALID; }
   std::lock_guard<std::mutex> lk(s->m->mu);
-  int any_lookup = 0;
+  int any_lookup = 0, any_zero_mass = 0;
   const int rc = guard(s->m, [&] {
     fetch_stats(s);
     for (int c = 0; c < s->chains; c++) {
       const rh_chain_stats_dev &d = s->last_stats[c];
-      if (d.error) any_lookup = 1;
+      if (d.error & 1) any_lookup = 1;
+      if (d.error & 2) any_zero_mass = 1;
       if (!stats) continue;
       rh_chain_stats &o = stats[c];
       o.leapfrog_steps = d.leapfrog_steps; o.warmup_leapfrog_steps = d.warmup_leapfrog_steps;
       o.gradient_evaluations = d.gradient_evaluations; o.accepted = d.accepted;
       o.mean_accept_prob = d.sampling_iterations ? d.sum_accept_prob / (double)d.sampling_iterations : 0.0;
-      o.step_size = d.step_size; o.error = d.error ? RH_E_LOOKUP : RH_OK; o.reserved = 0;
+      o.step_size = d.step_size; o.error = (d.error & 1) ? RH_E_LOOKUP : ((d.error & 2) ? RH_E_INVALID : RH_OK); o.reserved = 0;
       o.bfmi = s->cfg.sampler == RH_SAMPLER_NUTS ? std::nan("") : d.e_trans2 / d.e_raw;
     }
     if (mass_diag) {
@@ -918,6 +919,10 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
     }
   });
   if (rc == RH_OK && any_lookup) { s->m->err = g_err = "Lookup index out of range during sampling"; return RH_E_LOOKUP; }
+  if (rc == RH_OK && any_zero_mass) {
+    s->m->err = g_err = "requirement failed: an adapted mass matrix has a zero element (MassMatrix.scala:8,16) -- a chain did not move during a window";
+    return RH_E_INVALID;
+  }
   return rc;
 }
 extern "C" int rh_sampler_mass_dense(rh_sampler *s, double *out) {

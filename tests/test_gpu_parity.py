@@ -839,3 +839,22 @@ def test_cfg2_full_size_posterior_matches_least_squares():
     assert all(r < 1.05 for r, _ in diag), diag
     assert 0.6 < np.mean([st.meanAcceptProb for st in tr.stats]) < 0.95
     assert all(0.3 < st.bfmi < 3.0 for st in tr.stats)
+
+
+def test_zero_variance_window_is_the_reference_requirement_failure():
+    # a chain that never moves during an adaptation window yields DiagonalMassMatrix(0, ...): the reference throws
+    # "requirement failed" (MassMatrix.scala:8); here the chain is flagged and the call returns RH_E_INVALID
+    from rainier_amd.frontend import Graph
+    g = Graph(2, [0]); x, y = g.param(0), g.param(1)
+    spec = models.ModelSpec("stuck", g.compile([((x * x + y * y) * -1.0 - 1.0).log()]), [], [0], 2)   # log of a negative number: NaN energy, every proposal rejected
+    cfg = R.make_config(5, 30, R.HMCSampler(2), R.StaticStepSize(0.1), R.DiagonalMassMatrixTuner(5, 1.5, 0, 0))
+    ocfg = _oracle_cfg(cfg, O.JM_DET)
+    d = O.OracleDensity(spec, O.JM_DET)
+    _, _, _, rc = O.sample_chain(d.fn_ptr, d.handle, 2, ocfg, 7)
+    assert rc == 2
+    with pytest.raises(R.RainierHipError) as e:
+        R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(cfg, seeds=[7, 8])
+    assert e.value.code == _capi.RH_E_INVALID and "requirement failed" in str(e.value)
+    # the same chains without adaptation are fine: NaN energy is data, not an error (LeapFrog.scala:138-142)
+    ok = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT).sample(R.make_config(5, 30, R.HMCSampler(2), R.StaticStepSize(0.1), R.IdentityMassMatrixTuner()), seeds=[7])
+    assert np.all(ok.chains[0] == ok.chains[0][0])
