@@ -138,3 +138,33 @@ def test_jni_shim_typechecks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "tests", "stubs"),
                            "-I", os.path.join(root, "include"), os.path.join(root, "rainier_amd", "jni", "rainier_hip_jni.c")])
+
+
+def test_rir_parser_survives_mutated_blobs():
+    """Bit flips, truncations, random words and trailing bytes on valid programs: parse_rir + simplify must either accept
+    the blob or reject it with a status -- never crash (the JVM side hands this library bytes from another process space)."""
+    import random
+    seeds = [models.funnel().rir, models.eight_schools().rir, models.linreg(n=4).rir, models.logistic(n=4, k=8).rir,
+             models.hier_negbin(70, 2).rir]
+    rng = random.Random(2026)
+    accepted = rejected = 0
+    for _ in range(2500):
+        b = bytearray(rng.choice(seeds))
+        kind = rng.randrange(5)
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            del b[rng.randrange(len(b)):]
+        elif kind == 2:
+            i = rng.randrange(0, len(b) - 4, 4); b[i:i + 4] = rng.randrange(2 ** 32).to_bytes(4, "little")
+        elif kind == 3:
+            i = rng.randrange(0, len(b) - 4, 4); b[i:i + 4] = rng.choice([0, 1, 0xffffffff, 0x7fffffff, 18, 19, 20]).to_bytes(4, "little")
+        else:
+            b += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9)))
+        try:
+            _capi.simplify_rir(bytes(b)); accepted += 1
+        except _capi.RainierHipError as e:
+            assert e.code == _capi.RH_E_INVALID
+            rejected += 1
+    assert rejected > 1500 and accepted > 50
