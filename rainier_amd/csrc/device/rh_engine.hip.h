@@ -1839,3 +1839,11 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
 
 extern "C" __device__ __attribute__((used)) const int rh_state_words = RH_STATE_U64; // u64 words per chain image
 extern "C" __device__ __attribute__((used)) const int rh_state_dense_off = RH_STATE_DENSE_OFF;
+// position of the mass vector M among the state image's vectors (the host reads DiagonalMassMatrix.elements from there)
+enum {
+#define X(n) RH_VIDX_##n,
+  RH_STATE_VECS(X)
+#undef X
+  RH_VIDX_COUNT
+};
+extern "C" __device__ __attribute__((used)) const int rh_state_mass_vec = RH_VIDX_M;

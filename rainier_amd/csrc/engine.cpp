@@ -143,6 +143,7 @@ struct rh_model {
   rh::Program prog;
   rh::EmitOptions eopt;
   rh::EmitInfo info;
+  int mass_vec = 9;  // index of M in the state image (read back from the module: rh_state_mass_vec)
   std::string source, err, arch;
   std::vector<char> code;
   int device = 0;
@@ -284,6 +285,8 @@ void load_module(rh_model *m) {
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
   HIPCHK(hipMemcpy(&m->state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_mass_vec"));  // same position in every sampler-kernel variant
+  HIPCHK(hipMemcpy(&m->mass_vec, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   m->loaded = true;
 }
@@ -908,11 +911,11 @@ extern "C" int rh_sampler_stats(rh_sampler *s, rh_chain_stats *stats, double *ma
       o.bfmi = s->cfg.sampler == RH_SAMPLER_NUTS ? std::nan("") : d.e_trans2 / d.e_raw;
     }
     if (mass_diag) {
-      // M is the 10th vector of the state image (RH_STATE_VECS order in rh_engine.hip.h): Pp Pq Pg Bp Bq Bg Sp Sq Sg M
+      // M's position among the state image's vectors comes from the device code itself (rh_state_mass_vec)
       const int n = (int)s->m->prog.n_params, slots = (n + 63) / 64, W = s->state_words;
       const size_t width = (size_t)slots * 64 * sizeof(uint64_t);
       std::vector<uint64_t> img((size_t)slots * 64 * s->chains);
-      const char *base = (const char *)s->d_state + (size_t)9 * slots * 64 * sizeof(uint64_t);
+      const char *base = (const char *)s->d_state + (size_t)s->m->mass_vec * slots * 64 * sizeof(uint64_t);
       HIPCHK(hipMemcpy2D(img.data(), width, base, (size_t)W * sizeof(uint64_t), width, (size_t)s->chains, hipMemcpyDeviceToHost));
       for (int c = 0; c < s->chains; c++)
         for (int i = 0; i < n; i++) std::memcpy(&mass_diag[(size_t)c * n + i], &img[(size_t)c * slots * 64 + i], sizeof(double));
