@@ -15,6 +15,7 @@ Synthetic data (numpy default_rng(20260925)); inputs resident in HBM before the 
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -28,17 +29,25 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # MI355X public FP64 vector peak (not in the local guide)
+TRAFFIC_PROFILE = "r2_a_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
 
 
 def cpu_baseline(spec, L, seconds_budget=20.0):
-    """The oracle (oracle/: C restatement of the reference JVM path, kind = "port") timed on this box's host
+    """The oracle (oracle/: C restatement of the reference JVM path, kind = "port") timed on ALL of this box's host
     cores on a bounded sample of the same workload: one chain per thread, each running whole HMC iterations
-    (L=32) over the full data set with the reference's own 2L+1 gradient evaluations per trajectory."""
+    (L=32) over the full data set with the reference's own 2L+1 gradient evaluations per trajectory.
+    Two more figures beside it, each labelled: the same streamed gradient compiled by hand (upper bound for a JVM on the
+    streamed form), and the INLINED sufficient-statistics form -- what real Rainier runs for this model."""
     from tests import oracle_lib as O
     d0 = O.OracleDensity(spec)
     q = np.zeros(spec.n_params)
     t = time.perf_counter(); d0.update(q); per_grad = time.perf_counter() - t
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    nproc = os.cpu_count() or 1
+    try:
+        nproc_avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc_avail = nproc
+    cores = max(1, nproc_avail)
     iters = max(1, int(seconds_budget / (per_grad * (2 * L + 2))))
     cfg = O.make_config(sampler=O.HMC, n_steps=L, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
                         static_step=1e-3, math_mode=O.JM_LIBM)
@@ -64,7 +73,28 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
     closed = {"value": cores * reps / dt2, "unit": "leapfrog steps/s (1 gradient per step)", "cores": cores,
               "row_chain_evals_per_s": cores * reps * n / dt2,
               "sample": "%d threads x %d streamed gradients over %d rows, hand-written C, -O3 -mavx2 -mfma, %.1f s" % (cores, reps, n, dt2)}
-    return {"value": total / dt, "compiled_closed_form": closed, "unit": "leapfrog steps/s", "cores": cores, "kind": "port",
+    # third figure: the INLINED form.  TargetGroup.inlinable + PartialEvaluator.inline (compute/Target.scala:20-24,136-207,
+    # compute/PartialEvaluator.scala:90-97) fold the row sum of this model (3 covariates: 15 distributed terms < 20) into
+    # scalar coefficients at compile time, so the reference's compiled gradient is O(1) in the row count
+    # (rainier-benchmark/benchmarks.txt: Normal, 1 us per gradient at every N).  Here: one chain per thread doing leapfrog
+    # steps on that O(1) density, hand-written C over the 15 sufficient statistics (~2 s).
+    S = np.zeros(15)
+    lib.orc_linreg_suffstats(*[O._dp(c) for c in cols], C.c_long(n), O._dp(S))
+    lib.orc_linreg_inlined_leapfrog.restype = C.c_double
+    lib.orc_linreg_inlined_leapfrog.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_double]
+    t = time.perf_counter(); lib.orc_linreg_inlined_leapfrog(O._dp(S), 200000, 1e-6); per_step = (time.perf_counter() - t) / 200000
+    nsteps = max(1000, int(2.0 / per_step))
+    th3 = [threading.Thread(target=lambda: lib.orc_linreg_inlined_leapfrog(O._dp(S), nsteps, 1e-6)) for _ in range(cores)]
+    t = time.perf_counter(); [x.start() for x in th3]; [x.join() for x in th3]; dt3 = time.perf_counter() - t
+    inlined = {"value": cores * nsteps / dt3, "unit": "leapfrog steps/s (1 gradient per step)", "cores": cores,
+               "per_thread": nsteps / dt3,
+               "what": "the sufficient-statistics form PartialEvaluator.inline produces -- what real Rainier runs for cfg 2; "
+                       "O(1) per gradient, no rows streamed (so no row_chain_evals figure exists for it)",
+               "reference_published": "rainier-benchmark/benchmarks.txt: ~1 us per gradient on the JVM at any N => ~5e5 leapfrog "
+                                      "steps/s per thread at the reference's 2 gradients per step",
+               "sample": "%d threads x %d leapfrog steps on the inlined density, hand-written C -O3, %.1f s" % (cores, nsteps, dt3)}
+    return {"value": total / dt, "compiled_closed_form": closed, "inlined_sufficient_statistics": inlined,
+            "unit": "leapfrog steps/s", "cores": cores, "nproc": nproc, "kind": "port",
             "sample": "%d chains x %d HMC iterations (L=%d, %d rows), RIR interpreter, reference's 2L+1 gradient "
                       "evaluations per trajectory, %.1f s" % (cores, iters, L, spec.rows_streamed, dt),
             "row_chain_evals_per_s": total * spec.rows_streamed / dt}
@@ -98,15 +128,12 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     s.timing(reset=True)
     if dist is not None:
         import torch
-        hip = C.CDLL("libamdhip64.so")
-        local = torch.empty((cpg, a.steps, spec.n_params), dtype=torch.float64, device="cuda")
         dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     s.run(a.steps)
     gathered = None
     if dist is not None:
-        hip.hipMemcpy(C.c_void_p(local.data_ptr()), C.c_void_p(s.draws_device_ptr()), C.c_size_t(local.numel() * 8), 3)
-        gathered = D.gather_draws(local, world)
+        gathered = D.gather_draws_from_device(s.draws_device_ptr(), (cpg, a.steps, spec.n_params), world)
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stats, _ = s.stats()
@@ -194,36 +221,46 @@ def main():
     from rainier_amd import distributed as D
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
     engine = {"auto": 0, "chain": 1, "tick": 2}[a.engine]
-    cfg = R.make_config(K, W, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=engine,
-                        gradSplits=a.grad_splits)
-    s = R.Sampler(model, cfg, seeds)
-    s.warmup()                      # W untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
-    s.timing(reset=True)
 
-    gathered = None
-    if dist is not None:
-        import torch
-        hip = C.CDLL("libamdhip64.so")
-        local = torch.empty((cpg, K, spec.n_params), dtype=torch.float64, device="cuda")
-        dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s.run(K)                        # synchronises the engine stream
-    if dist is not None:
-        hip.hipMemcpy(C.c_void_p(local.data_ptr()), C.c_void_p(s.draws_device_ptr()), C.c_size_t(local.numel() * 8), 3)
-        gathered = D.gather_draws(local, world)        # the ONE collective: draws over xGMI (RCCL all-gather)
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def leg(iters, warm):
+        """One sampler run: `warm` untimed warm-up iterations, then `iters` timed ones + (N > 1) the ONE collective.
+        Returns (seconds [max over ranks], all draws on rank 0, stats, timing)."""
+        cfg = R.make_config(iters, warm, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=engine,
+                            gradSplits=a.grad_splits)
+        s = R.Sampler(model, cfg, seeds)
+        s.warmup()                      # untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
+        s.timing(reset=True)
+        gathered = None
+        if dist is not None:
+            import torch
+            dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.run(iters)                    # synchronises the engine stream
+        if dist is not None:
+            gathered = D.gather_draws_from_device(s.draws_device_ptr(), (cpg, iters, spec.n_params), world)   # RCCL all-gather over xGMI
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        tim = s.timing()
+        stats, _ = s.stats()
+        draws = (gathered.cpu().numpy() if rank == 0 else None) if gathered is not None else s.draws()
+        s.close()
+        return dt, draws, stats, tim
 
-    tim = s.timing()
-    stats, _ = s.stats()
+    dt, draws, stats, tim = leg(K, W)     # the timed region the contract defines: EXACTLY K steps after W warm-up steps
     steps_local = sum(st.leapfrogSteps for st in stats)
     assert steps_local == K * L * cpg, (steps_local, K, L, cpg)
     total_steps = steps_local * world
-    draws = gathered.cpu().numpy() if gathered is not None else s.draws()
+    # ESS/s leg, independent of the driver's --steps/--warmup: dual averaging needs ~100 iterations before the step size
+    # (and with it the autocorrelation) is meaningful, and Trace.diagnostics needs a few dozen draws per chain
+    ess_iters, ess_warm = max(K, 64), max(W, 128)
+    if (ess_iters, ess_warm) == (K, W):
+        ess_dt, ess_draws, ess_stats = dt, draws, stats
+    else:
+        ess_dt, ess_draws, ess_stats, _ = leg(ess_iters, ess_warm)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -232,14 +269,13 @@ def main():
     rows = spec.rows_streamed
     value = total_steps / dt
     rce = value * rows
-    ess_min = None
-    if K >= 4 and draws.shape[0] >= 2:
-        ess_min = min(e for _, e in R.diagnostics(draws))
+    ess_min = min(e for _, e in R.diagnostics(ess_draws)) if ess_draws.shape[0] >= 2 else None
     # dominant kernel, this rank: HIP events recorded on the engine's stream around each launch
     k_s = tim["kernel_ms"] / 1e3
     algo_bytes = tim["row_chain_evals"] * spec.bytes_per_row          # 8*(K+1) = 32 B per row-chain eval
     achieved = algo_bytes / k_s / 1e9
     flops = tim["row_chain_evals"] * spec.meta["flops_per_row"]       # 4K+4 = 16 flop per row-chain eval
+    src_sha = hashlib.sha256(model.hip_source.encode()).hexdigest()[:16]
     out = {
         "metric": "leapfrog steps/sec (all chains)", "value": value, "unit": "leapfrog steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -248,15 +284,19 @@ def main():
                                "%d chains/GPU, DualAvgTuner(0.8), identity mass" % (rows, L, cpg),
                    "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict, "factor_outputs": not (a.strict or a.no_factor),
                    "engine": tim["dominant_kernel"], "grad_chains": a.grad_chains, "grad_unroll": a.grad_unroll,
-                   "grad_splits": a.grad_splits},
+                   "grad_splits": a.grad_splits, "generated_source_sha16": src_sha},
         "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,
-        "ess_per_s": (ess_min / dt) if ess_min is not None else None,
+        "ess_per_s": (ess_min / ess_dt) if ess_min is not None else None,
+        "ess_leg": {"iterations": ess_iters, "warmup": ess_warm, "seconds": ess_dt, "ess_min": ess_min,
+                    "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in ess_stats])),
+                    "step_size_mean": float(np.mean([st.stepSize for st in ess_stats])),
+                    "note": "separate sampler run with >= 128 untimed adaptation iterations and >= 64 timed draws, so that "
+                            "ESS/s does not depend on --steps/--warmup; same chains, seeds and kernels as the timed region"},
         "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in stats])),
         # The kernel is fp64-compute-bound (the 32 MB data set is served from cache, HBM-side traffic is ~1e-3 of the
-        # algorithmic bytes), so the binding roofline is the fp64 pipe: 78.6 TFLOP/s, identical for v_fma_f64 and
-        # v_mfma_f64 on MI355X (the kernel issues v_fma_f64; "mfma" is the contract's name for the flop roofline).
+        # algorithmic bytes), so the binding roofline is the fp64 VALU pipe (the kernel issues v_fma_f64): 78.6 TFLOP/s.
         # 16 flop and 32 algorithmic bytes per row-chain eval; the HBM-equivalent figure is kept alongside.
-        "roofline": {"bound": "mfma", "kernel": tim["dominant_kernel"], "achieved": flops / k_s / 1e12, "peak": FP64_PEAK_TFLOPS,
+        "roofline": {"bound": "fp64_valu", "kernel": tim["dominant_kernel"], "achieved": flops / k_s / 1e12, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / k_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                      "launches": tim["launches"], "all_kernels_ms": tim["total_ms"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
                      "algorithmic_flops_per_launch": flops / max(1, tim["launches"]),
@@ -265,15 +305,25 @@ def main():
                                                 "source": "profiles/r1_d_fp64_ceiling: 0.23 DP instr/cycle/SIMD at the sustained 2.2 GHz, 16 flop per 9 instructions"},
                      "hbm_equivalent": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}},
     }
-    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this
-    # is the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this
-    # same command (profiles/r1_b_tick_engine/), reported as collected (KB -> bytes; the gfx950 x2 FETCH_SIZE
-    # correction is calibrated for 16 B/lane loads and these are 8 B/lane, so the read side is 1-2x this figure)
-    prof = os.path.join(ROOT, "profiles", "r1_b_tick_engine", "pmc_grad_kernel.json")
-    if tim["dominant_kernel"] == "rh_grad_kernel" and os.path.exists(prof) and rows == 1_000_000 and cpg == 1024:
-        pc = json.load(open(prof))["counters"]
-        out["roofline"]["traffic"] = (pc["FETCH_SIZE"]["mean_per_launch"] + pc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-        out["roofline"]["traffic_source"] = "profiles/r1_b_tick_engine/pmc_grad_kernel.json (separate rocprofv3 --pmc passes)"
+    # HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the process, so this is
+    # the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same
+    # command (tools/pmc_cfg2.sh -> profiles/<round>/pmc_grad_kernel.json).  It is reported ONLY when that profile was
+    # taken on byte-identical generated kernel source (sha of the model's HIP translation unit) and workload; otherwise
+    # traffic stays null.  KB -> bytes; FETCH_SIZE is reported as collected (the guide's gfx950 x2 correction is calibrated
+    # for 16 B/lane loads and these are 8 B/lane, so the read side is 1-2x this figure).
+    prof = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+    if os.path.exists(prof):
+        pj = json.load(open(prof))
+        same = pj.get("generated_source_sha16") == src_sha and pj.get("kernel") == tim["dominant_kernel"] and \
+            pj.get("rows") == rows and pj.get("chains_per_gpu") == cpg
+        if same:
+            pc = pj["counters"]
+            out["roofline"]["traffic"] = (pc["FETCH_SIZE"]["mean_per_launch"] + pc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+            out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc passes; git %s, generated source sha16 %s)" % (
+                TRAFFIC_PROFILE, pj.get("git_head", "?"), src_sha)
+        else:
+            out["roofline"]["traffic_source"] = "none: profiles/%s was taken on different kernel source or workload (sha16 %s vs %s)" % (
+                TRAFFIC_PROFILE, pj.get("generated_source_sha16"), src_sha)
     if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(spec, L)
     print(json.dumps(out))

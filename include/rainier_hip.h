@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 2  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense */
+#define RH_ABI_VERSION 3  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
+                             3: rh_density_eval_ex, rh_sample_multi, rh_compile_opts.reserved -> device-independent */
 
 enum rh_status {
   RH_OK = 0,
@@ -89,6 +90,16 @@ const char *rh_last_error(const rh_model *m);
  * q [chains][nvars] -> logp [chains], grad [chains][nvars] (host pointers).  Stateless, one call at a
  * time per model.  chains = 1 restores the reference trait exactly. */
 int rh_density_eval(rh_model *m, const double *q, int32_t chains, double *logp, double *grad);
+/* The same seam with the evaluation path chosen by the caller (rh_engine_kind, declared below):
+ *   RH_ENGINE_CHAIN : one chain per wavefront streams every row itself (rh_density_kernel; what rh_density_eval does for
+ *                     models without a parameter table)
+ *   RH_ENGINE_TICK  : the sampler's batched gradient path -- the row-streaming gradient kernel the model was lowered to
+ *                     (rh_grad_kernel | rh_grad_glm_kernel | rh_grad_gather_kernel) over `grad_splits` row splits (0 = the
+ *                     sampler's default) followed by the fixed-order combine of rh_tick_kernel
+ *   RH_ENGINE_AUTO  : rh_density_eval's choice.
+ * Results of the two paths agree to rounding (different summation order); both are DensityFunction.update batched. */
+int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, int32_t engine, int32_t grad_splits, double *logp,
+                       double *grad);
 
 /* ---- seam 3: SamplerConfig / Driver.sample ---------------------------------------------------- */
 
@@ -158,6 +169,16 @@ typedef struct rh_chain_stats {
  * pointers, caller-allocated; mass_diag and stats may be NULL. */
 int rh_sample(rh_model *m, const rh_config *cfg, const int64_t *seeds, int32_t chains, double *draws,
               double *mass_diag, rh_chain_stats *stats);
+
+/* Multi-GPU Model.sample: the chains are cut into n_models contiguous shards, shard g = global chains
+ * [g*chains/n_models, ...) runs on models[g] -- the SAME program and data compiled once per device (rh_model_create with
+ * rh_compile_opts.device = g), driven by one host thread per shard.  seeds / draws / mass_diag / stats are indexed by GLOBAL
+ * chain id exactly as in rh_sample, so the result is identical for every n_models (chains never interact:
+ * sampler/Driver.scala:13-17); there is no device-to-device traffic, the caller's host buffer is the gather.
+ * (bench.py's one-process-per-GPU launch uses rh_sampler_* per rank and one RCCL all-gather of the device-resident draws
+ * instead; both forms shard by global chain id.)  Replaces the loop  core/Model.scala:16-22. */
+int rh_sample_multi(rh_model *const *models, int32_t n_models, const rh_config *cfg, const int64_t *seeds, int32_t chains,
+                    double *draws, double *mass_diag, rh_chain_stats *stats);
 
 /* The same, split so that a caller can keep draws on the device, poll progress (sampler/Progress.scala)
  * and time phases.  Typical use: create -> warmup -> run(iterations) -> read stats -> destroy. */

@@ -210,6 +210,35 @@ static int update_impl(rir_density *d, const double *q, double *out, int acc_mod
   d->n_updates++;
   return d->lookup_error;
 }
+/* one pass, two results: the f64 sequential sums (DataFunction order) AND the sums of |term| that the parity bound is
+ * stated in -- halves the oracle's cost for the BASELINE-size parity tests */
+int rir_density_update_both(rir_density *d, const double *q, double *out, double *abs_out) {
+  const rir_prog *p = d->prog;
+  const uint32_t nout = p->n_params + 1;
+  double *in = calloc(p->n_inputs ? p->n_inputs : 1, sizeof(double));
+  memcpy(in, q, sizeof(double) * p->n_params);
+  for (uint32_t o = 0; o < nout; o++) { out[o] = 0.0; abs_out[o] = 0.0; }
+  d->lookup_error = 0;
+  size_t colbase = 0;
+  for (uint32_t t = 0; t < p->n_targets; t++) {
+    const rir_target *tg = &p->targets[t];
+    for (uint32_t i = 0; i < tg->n_once; i++) eval_node(d, tg->once_nodes[i], in);
+    int64_t rows = tg->n_cols ? d->nrows[t] : 1;
+    for (int64_t k = 0; k < rows; k++) {
+      for (uint32_t j = 0; j < tg->n_cols; j++) in[tg->input_start + j] = d->cols[colbase + j][k];
+      for (uint32_t i = 0; i < tg->n_row; i++) eval_node(d, tg->row_nodes[i], in);
+      for (uint32_t o = 0; o < nout; o++) {
+        const double c = d->val[tg->outputs[o]];
+        out[o] += c;
+        abs_out[o] += fabs(c);
+      }
+    }
+    colbase += tg->n_cols;
+  }
+  free(in);
+  d->n_updates++;
+  return d->lookup_error;
+}
 int rir_density_update(void *d, const double *q, double *out) { return update_impl((rir_density *)d, q, out, ACC_F64); }
 int rir_density_abs_sums(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_ABS); }
 int rir_density_update_ld(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_LD); }

@@ -68,6 +68,8 @@ void rir_density_free(rir_density *d);
 int rir_density_update(void *d, const double *q, double *out);
 /* sum over rows of |per-row contribution| per output (for condition-aware tolerances) */
 int rir_density_abs_sums(rir_density *d, const double *q, double *abs_out);
+/* both of the above in one pass over the rows */
+int rir_density_update_both(rir_density *d, const double *q, double *out, double *abs_out);
 /* long-double accumulation variant (which side is closer to the true sum) */
 int rir_density_update_ld(rir_density *d, const double *q, double *out);
 /* requirements program (header kind 1): out[t] = value of target t's outputs[0] at q */

@@ -8,4 +8,4 @@
 from .sampler import (DefaultConfig, DenseMassMatrixTuner, DensityFunction, DiagonalMassMatrix, DiagonalMassMatrixTuner,  # noqa: F401
                       DualAvgTuner, EHMC, EHMCSampler, HMC, HMCSampler, IdentityMassMatrixTuner, Model, NUTSSampler,
                       RainierHipError, Sampler, SamplerConfig, StaticMassMatrix, StaticStepSize, Trace,
-                      diagnostics, make_config, predict)
+                      diagnostics, make_config, predict, sample_multi)

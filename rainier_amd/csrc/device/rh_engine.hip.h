@@ -1783,10 +1783,15 @@ RH_UNROLL_SLOTS
 }
 
 #endif  // !RH_HAS_GATHER
-#if RH_HAS_GATHER
-// Seam 2 in gather mode: the gradient kernel fills `partial` / the scatter sums for q, this kernel finishes them
+#if RH_NROWTARGETS > 0
+// Seam 2 through the tick engine's gradient path (rh_density_eval_ex, RH_ENGINE_TICK; always in gather mode): the
+// gradient kernel has filled `partial` (and the scatter sums) for q, this kernel finishes them exactly like rh_tick_kernel
 extern "C" __global__ void __launch_bounds__(64)
-rh_density_fin_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
+rh_density_fin_kernel(const rh_model_data d,
+#if RH_HAS_GATHER
+                      const rh_gather_data gd,
+#endif
+                      const double *__restrict__ q,
                       const double *__restrict__ partial, double *__restrict__ logp, double *__restrict__ grad,
                       int *__restrict__ err_out, const int chains, const int nsplit) {
   const int chain = blockIdx.x;
@@ -1797,13 +1802,21 @@ rh_density_fin_kernel(const rh_model_data d, const rh_gather_data gd, const doub
   wvec qv, gv; // views on the caller's arrays (element i at [i])
   qv.s.p = const_cast<double *>(q) + (size_t)chain * RH_NVARS;
   gv.s.p = grad + (size_t)chain * RH_NVARS;
-  rh_combine_chain(qv, d, gd, partial, nsplit, chain, chains, lane, lp, gv, err);
+  rh_combine_chain(qv, d,
+#if RH_HAS_GATHER
+                   gd,
+#endif
+                   partial, nsplit, chain, chains, lane, lp, gv, err);
   if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
 #else
   wvec qv, gv;
 RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
-  rh_combine_chain(qv, d, gd, partial, nsplit, chain, chains, lane, lp, gv, err);
+  rh_combine_chain(qv, d,
+#if RH_HAS_GATHER
+                   gd,
+#endif
+                   partial, nsplit, chain, chains, lane, lp, gv, err);
   if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
 RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++)
@@ -1813,7 +1826,9 @@ RH_UNROLL_SLOTS
 #endif
 
 // Device self-test of the bit-exact pieces: mode 0 = n gaussians of ScalaRNG(seed), 1 = n uniforms,
-// 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75, 7 = fast-mode log
+// 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75, 7 = fast-mode log,
+// and of the functions generated model code calls for the remaining IR ops (ir/MethodGenerator.scala:66-93):
+// 8 = sin, 9 = cos, 10 = tan, 11 = asin, 12 = acos, 13 = atan, 14 = Math.pow (in[2i], in[2i+1]), 15 = abs, 16 = fast-mode exp
 extern "C" __global__ void __launch_bounds__(64)
 rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__ in, double *__restrict__ out, const int n) {
   const int lane = threadIdx.x;
@@ -1831,6 +1846,15 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
       else if (mode == 4) v = rh_strict_sqrt(in[i]);
       else if (mode == 5) v = in[2 * i] / in[2 * i + 1];
       else if (mode == 7) v = rh_fast_log(in[i]);
+      else if (mode == 8) v = sin(in[i]);
+      else if (mode == 9) v = cos(in[i]);
+      else if (mode == 10) v = tan(in[i]);
+      else if (mode == 11) v = asin(in[i]);
+      else if (mode == 12) v = acos(in[i]);
+      else if (mode == 13) v = atan(in[i]);
+      else if (mode == 14) v = rh_java_pow(in[2 * i], in[2 * i + 1]);
+      else if (mode == 15) v = __builtin_fabs(in[i]);
+      else if (mode == 16) v = exp(in[i]);
       else v = rh_pow_neg075(in[i]);
       out[i] = v;
     }

@@ -301,7 +301,9 @@ struct TargetEmitter {
          << R(nd.table[0]) << ");\n";
       return true;
     }
-    os << "    const int " << k << " = rh_d2i(" << R(nd.a) << ") - (" << nd.low << ");\n";
+    // unsigned difference: a saturated index (INT_MIN / INT_MAX) minus `low` must wrap, not overflow a signed int;
+    // every use below compares or indexes k as unsigned
+    os << "    const int " << k << " = (int)((unsigned)rh_d2i(" << R(nd.a) << ") - (unsigned)(" << nd.low << "));\n";
     if (nd.table.size() <= 64) {
       os << lhs;
       for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";

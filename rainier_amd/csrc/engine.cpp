@@ -16,6 +16,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -77,7 +78,7 @@ std::string lib_dir() {
 std::string cache_dir() {
   const char *env = std::getenv("RH_KERNEL_CACHE");
   std::string d = env && *env ? env : lib_dir() + "/kcache";
-  mkdir(d.c_str(), 0777);
+  mkdir(d.c_str(), 0700);
   return d;
 }
 bool read_file(const std::string &path, std::vector<char> &out) {
@@ -269,6 +270,7 @@ void load_module(rh_model *m) {
     HIPCHK(hipModuleGetFunction(&m->k_grad, m->module, "rh_grad_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_grad_lds, m->module, "rh_grad_lds_kernel"));
+    HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
   }
   m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
@@ -305,7 +307,8 @@ KSet &load_variant(rh_model *m, int v) {
   if (ks.loaded) return ks;
   HIPCHK(hipSetDevice(m->device));
   if (v == 0) { ks.module = m->module; ks.k_chain = m->k_chain; ks.k_tick = m->k_tick; ks.state_words = m->state_words; ks.loaded = true; return ks; }
-  const std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source);
+  const char *extra = std::getenv("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
+  const std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source, extra ? extra : "");
   HIPCHK(hipModuleLoadData(&ks.module, code.data()));
   if (!m->info.gather_mode) HIPCHK(hipModuleGetFunction(&ks.k_chain, ks.module, "rh_chain_kernel"));
   if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&ks.k_tick, ks.module, "rh_tick_kernel"));
@@ -326,6 +329,24 @@ int guard(rh_model *m, const std::function<void()> &fn) {
   catch (const std::exception &e) { g_err = e.what(); if (m) m->err = e.what(); return RH_E_INVALID; }
 }
 
+// rh_compile_opts -> emitter options, validated once for rh_model_create and rh_lower_only; returns the device ordinal
+int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
+  if (!opts) return -1;
+  if (opts->struct_size != (int32_t)sizeof(rh_compile_opts)) throw Fail{RH_E_INVALID, "rh_compile_opts.struct_size mismatch"};
+  if (opts->math_mode != RH_MATH_FAST && opts->math_mode != RH_MATH_STRICT) throw Fail{RH_E_INVALID, "unknown math_mode"};
+  m->eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
+  m->eopt.fp_contract = opts->fp_contract != 0;
+  if (opts->rows_unroll < 0 || opts->rows_unroll > 64) throw Fail{RH_E_INVALID, "rows_unroll out of range [0,64]"};
+  if (opts->rows_unroll > 0) m->eopt.rows_unroll = opts->rows_unroll;
+  if (opts->grad_chains < 0 || opts->grad_chains > 16 || opts->grad_unroll < 0 || opts->grad_unroll > 16)
+    throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
+  m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;
+  m->eopt.factor_outputs = opts->factor_outputs != 0;
+  if (opts->with_nuts < 0 || opts->with_nuts > 7) throw Fail{RH_E_INVALID, "with_nuts: unknown variant bits"};
+  m->want_nuts = opts->with_nuts != 0;
+  return opts->device;
+}
+
 void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void **args) {
   HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, s, args, nullptr));
 }
@@ -342,19 +363,8 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     std::string err;
     if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
     if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "rh_model_create needs a density program (header kind 0)"};
-    int dev = -1;
-    if (opts) {
-      if (opts->struct_size != (int32_t)sizeof(rh_compile_opts)) throw Fail{RH_E_INVALID, "rh_compile_opts.struct_size mismatch"};
-      m->eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
-      m->eopt.fp_contract = opts->fp_contract != 0;
-      if (opts->rows_unroll > 0) m->eopt.rows_unroll = opts->rows_unroll;
-      if (opts->grad_chains < 0 || opts->grad_chains > 16 || opts->grad_unroll < 0 || opts->grad_unroll > 16)
-        throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
-      m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;
-      m->eopt.factor_outputs = opts->factor_outputs != 0;
-      m->want_nuts = opts->with_nuts != 0;
-      dev = opts->device;
-    }
+    const int dev0 = apply_compile_opts(m, opts);
+    int dev = dev0;
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
       const auto &T = m->prog.targets[t];
       if (T.n_cols && (!nrows || nrows[t] < 0)) throw Fail{RH_E_INVALID, "negative or missing row count"};
@@ -447,13 +457,14 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
 
 extern "C" void rh_model_destroy(rh_model *m) {
   if (!m) return;
-  if (m->loaded) {
+  if (m->module || !m->dev_cols.empty()) {  // also after a failure half-way through load_module
     hipSetDevice(m->device);
     for (void *d : m->dev_cols) hipFree(d);
     for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
+    for (int v = 1; v < 8; v++)  // [0] aliases the base module
+      if (m->variants[v].module && m->variants[v].module != m->module) hipModuleUnload(m->variants[v].module);
     if (m->module) hipModuleUnload(m->module);
-    for (int v = 1; v < 4; v++) if (m->variants[v].module) hipModuleUnload(m->variants[v].module);
   }
   delete m;
 }
@@ -488,13 +499,7 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
     std::string err;
     if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
     if (m.prog.kind != 0) throw Fail{RH_E_INVALID, "rh_lower_only needs a density program (header kind 0)"};
-    if (opts) {
-      m.eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
-      m.eopt.fp_contract = opts->fp_contract != 0;
-      if (opts->rows_unroll > 0) m.eopt.rows_unroll = opts->rows_unroll;
-      m.eopt.grad_chains = opts->grad_chains; m.eopt.grad_unroll = opts->grad_unroll;
-      m.eopt.factor_outputs = opts->factor_outputs != 0;
-    }
+    (void)apply_compile_opts(&m, opts);
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
@@ -552,12 +557,62 @@ struct GatherBufs {
   }
   ~GatherBufs() { for (void *p : owned) (void)hipFree(p); }
 };
+
+// tick engine: row splits per chain group -- ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD
+// mapping applies, and >= 2048 rows per split
+int default_nsplit(const rh_model *m, int chains) {
+  const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+  int64_t max_rows = 1;
+  for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
+  int nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
+  if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
+  if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
+  if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
+  nsplit = ((nsplit + 7) / 8) * 8;
+  const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);
+  return (int)std::min<int64_t>(nsplit, cap);
+}
+
+// one batched gradient launch of the tick engine: whichever row-streaming kernel the model was lowered to
+// (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial
+void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d_partial, void *d_graderr, void *d_running,
+                 int chains, int nsplit, int xcd) {
+  const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+  if (m->info.gather_mode) {
+    void *ga[] = {&m->data, &gb->gd, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
+    launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
+    return;
+  }
+  void *args[] = {&m->data, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
+  if (m->k_grad_glm && m->glm_small) {
+    const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
+    launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
+  } else if (m->k_grad_glm) {
+    const int ctiles = (chains + 15) / 16;
+    const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
+    const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
+    HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
+  } else if (m->use_lds_grad) {
+    const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
+    const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
+    HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
+  } else
+    launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
+}
 }  // namespace
 
 // ---- seam 2 -----------------------------------------------------------------------------------------
 extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, double *logp, double *grad) {
+  return rh_density_eval_ex(m, q, chains, RH_ENGINE_AUTO, 0, logp, grad);
+}
+
+extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, int32_t engine, int32_t grad_splits,
+                                  double *logp, double *grad) {
   if (!m || !m->loaded) { g_err = "rh_density_eval: model not loaded"; return RH_E_INVALID; }
   if (!q || !logp || !grad || chains <= 0) { m->err = g_err = "rh_density_eval: bad arguments"; return RH_E_INVALID; }
+  if (engine < RH_ENGINE_AUTO || engine > RH_ENGINE_TICK || grad_splits < 0 || grad_splits > 65536) { m->err = g_err = "rh_density_eval_ex: unknown engine / bad grad_splits"; return RH_E_INVALID; }
+  if (engine == RH_ENGINE_TICK && m->n_row_targets == 0) { m->err = g_err = "the tick engine needs a model that streams rows"; return RH_E_INVALID; }
+  if (engine == RH_ENGINE_CHAIN && m->info.gather_mode) { m->err = g_err = "gather-mode models run on the tick engine only"; return RH_E_UNSUPPORTED; }
   std::lock_guard<std::mutex> lk(m->mu);
   int lookup_err = 0;
   const int rc = guard(m, [&] {
@@ -568,19 +623,29 @@ extern "C" int rh_density_eval(rh_model *m, const double *q, int32_t chains, dou
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(de, 0, sizeof(int), m->stream));
     int ch = chains;
-    if (m->info.gather_mode) {  // gradient kernel -> partial sums / scatter sums -> finish kernel
-      int nsplit = 64;
-      GatherBufs gb; gb.build(m, chains, nsplit);
-      const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
-      DevBuf bact(sizeof(int) * chains), bpart(sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max), brun(sizeof(int));
+    if (m->info.gather_mode || engine == RH_ENGINE_TICK) {
+      // the tick engine's gradient path exactly as the sampler drives it: the row-streaming gradient kernel fills the
+      // per-split partial sums (and, in gather mode, the scatter sums) for all chains, the finish kernel combines them in
+      // the same fixed order as rh_tick_kernel (rh_combine_chain) -- so parity tests reach the kernels the bench times
+      int nsplit = grad_splits > 0 ? grad_splits : (m->info.gather_mode ? 64 : default_nsplit(m, chains));
+      GatherBufs gb;
+      if (m->info.gather_mode) gb.build(m, chains, nsplit);
+      const size_t pbytes = sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max;
+      DevBuf bact(sizeof(int) * chains), bpart(pbytes), brun(sizeof(int));
       std::vector<int> ones((size_t)chains, 1);
       HIPCHK(hipMemcpyAsync(bact.p, ones.data(), sizeof(int) * chains, hipMemcpyHostToDevice, m->stream));
-      HIPCHK(hipMemsetAsync(bpart.p, 0, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max, m->stream));
-      void *dact = bact.p, *dpart = bpart.p, *drun = brun.p;
-      void *ga[] = {&m->data, &gb.gd, &dq, &dact, &dpart, &de, &drun, &ch, &nsplit};
-      launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
-      void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
-      launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
+      HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
+      int xcd = 1;
+      if (const char *e = std::getenv("RH_XCD_AWARE")) xcd = std::atoi(e);
+      launch_grad(m, &gb, dq, bact.p, bpart.p, de, brun.p, chains, nsplit, xcd);
+      void *dpart = bpart.p;
+      if (m->info.gather_mode) {
+        void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
+        launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
+      } else {
+        void *fa[] = {&m->data, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
+        launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
+      }
       HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
       HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * n * chains, hipMemcpyDeviceToHost, m->stream));
       HIPCHK(hipMemcpyAsync(&lookup_err, de, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -603,7 +668,7 @@ extern "C" int rh_selftest(rh_model *m, int32_t mode, int64_t seed, const double
   std::lock_guard<std::mutex> lk(m->mu);
   return guard(m, [&] {
     HIPCHK(hipSetDevice(m->device));
-    const size_t in_n = mode == 5 ? 2 * (size_t)n : (size_t)n;
+    const size_t in_n = (mode == 5 || mode == 14) ? 2 * (size_t)n : (size_t)n;
     DevBuf bin(sizeof(double) * in_n), bout(sizeof(double) * n);
     void *din = bin.p, *dout = bout.p;
     if (mode >= 2) HIPCHK(hipMemcpyAsync(din, in, sizeof(double) * in_n, hipMemcpyHostToDevice, m->stream));
@@ -656,6 +721,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       s->pack_l = m->info.pack_l;
       if (m->info.pack_l != 64 && cfg->sampler != RH_SAMPLER_HMC && chains < 4096) { v |= 4; s->pack_l = 64; }
       if ((v & 2) && (m->prog.n_params > 64 || m->info.bign)) throw Fail{RH_E_UNSUPPORTED, "DenseMassMatrixTuner supports at most 64 parameters"};
+      std::lock_guard<std::mutex> lk(m->mu);  // variants are built lazily: two samplers may be created concurrently
       KSet &ks = load_variant(m, v);
       s->k_chain = ks.k_chain; s->k_tick = ks.k_tick; s->state_words = ks.state_words; s->dense_off = ks.dense_off;
     }
@@ -697,19 +763,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     if (cfg->engine == RH_ENGINE_CHAIN && m->info.gather_mode) throw Fail{RH_E_UNSUPPORTED, "gather-mode models run on the tick engine only"};
     s->tick_engine = m->info.gather_mode || cfg->engine == RH_ENGINE_TICK || (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && m->rows_total >= 65536);
     if (s->tick_engine) {
-      const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
-      int64_t max_rows = 1;
-      for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
       int nsplit = cfg->grad_splits;
-      if (nsplit <= 0) {  // ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD mapping applies
-        nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
-        if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
-        if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
-        if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
-        nsplit = ((nsplit + 7) / 8) * 8;
-        const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);   // keep >= 2048 rows per split
-        nsplit = (int)std::min<int64_t>(nsplit, cap);
-      }
+      if (nsplit <= 0) nsplit = default_nsplit(m, chains);
       if (nsplit > 65536) throw Fail{RH_E_INVALID, "grad_splits too large"};
       s->nsplit = nsplit;
       if (const char *e = std::getenv("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
@@ -749,7 +804,6 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   rh_model *m = s->m;
   HIPCHK(hipSetDevice(m->device));
   int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
-  const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   auto tick = [&](int fresh, bool reset_counter) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     if (m->info.gather_mode) {
@@ -762,28 +816,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
                     &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
     launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
-  auto grad = [&]() {
-    if (m->info.gather_mode) {
-      void *ga[] = {&m->data, &s->gb->gd, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit};
-      launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
-      return;
-    }
-    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &chains, &nsplit, &xcd};
-    if (m->k_grad_glm && m->glm_small) {
-      const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
-      launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
-    } else if (m->k_grad_glm) {
-      const int ctiles = (chains + 15) / 16;
-      const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
-      const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
-      HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
-    } else if (m->use_lds_grad) {
-      const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
-      const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
-      HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
-    } else
-      launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
-  };
+  auto grad = [&]() { launch_grad(m, s->gb, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
   // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
   int remaining_hint = 32;
   if (s->cfg.sampler == RH_SAMPLER_HMC && s->warmed) {
@@ -977,6 +1010,40 @@ extern "C" int rh_sample(rh_model *m, const rh_config *cfg, const int64_t *seeds
   if (rc == RH_OK) rc = rh_sampler_stats(s, stats, mass_diag);
   rh_sampler_destroy(s);
   return rc;
+}
+
+// Model.sample's loop over chains (core/Model.scala:16-22) fanned out over several devices: one host thread per shard,
+// shard g owns the global chains [g*C/G, (g+1)*C/G) (remainder to the first shards), seeds / draws / stats / mass are
+// simply the caller's arrays at the shard's chain offset, so the result does not depend on how the chains were cut.
+// No device-to-device traffic: chains never interact (sampler/Driver.scala:13-17); the caller's host buffer is the gather.
+extern "C" int rh_sample_multi(rh_model *const *models, int32_t n_models, const rh_config *cfg, const int64_t *seeds,
+                               int32_t chains, double *draws, double *mass_diag, rh_chain_stats *stats) {
+  if (!models || n_models <= 0 || !cfg || !seeds || chains <= 0) { g_err = "rh_sample_multi: bad arguments"; return RH_E_INVALID; }
+  const int nv = models[0] ? rh_model_nvars(models[0]) : -1;
+  for (int g = 0; g < n_models; g++) {
+    if (!models[g] || !models[g]->loaded) { g_err = "rh_sample_multi: model " + std::to_string(g) + " not loaded"; return RH_E_INVALID; }
+    if (rh_model_nvars(models[g]) != nv) { g_err = "rh_sample_multi: the models differ (nvars)"; return RH_E_INVALID; }
+  }
+  const int G = std::min<int>(n_models, chains);
+  std::vector<int> first((size_t)G + 1, 0);
+  for (int g = 0; g < G; g++) first[(size_t)g + 1] = first[(size_t)g] + chains / G + (g < chains % G ? 1 : 0);
+  std::vector<int> rcs((size_t)G, RH_OK);
+  std::vector<std::string> errs((size_t)G);
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; g++)
+    th.emplace_back([&, g] {
+      const int c0 = first[(size_t)g], nc = first[(size_t)g + 1] - c0;
+      rh_config c = *cfg;
+      if (cfg->rng_next_gaussian) c.rng_next_gaussian = cfg->rng_next_gaussian + c0;
+      const size_t per_chain = (size_t)cfg->iterations * (size_t)nv;
+      rcs[(size_t)g] = rh_sample(models[g], &c, seeds + c0, nc, draws ? draws + (size_t)c0 * per_chain : nullptr,
+                                 mass_diag ? mass_diag + (size_t)c0 * nv : nullptr, stats ? stats + c0 : nullptr);
+      if (rcs[(size_t)g] != RH_OK) errs[(size_t)g] = rh_last_error(models[g]);
+    });
+  for (auto &t : th) t.join();
+  for (int g = 0; g < G; g++)
+    if (rcs[(size_t)g] != RH_OK) { g_err = "shard " + std::to_string(g) + ": " + errs[(size_t)g]; return rcs[(size_t)g]; }
+  return RH_OK;
 }
 
 // ---- Generator.prepare / Trace.predict: requirements evaluated for every draw on the device ---------------------------

@@ -34,6 +34,10 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
   if (P.kind > 1) { err = "RIR: unknown program kind"; return false; }
   if (P.n_params == 0 || n_targets == 0 || n_targets > (P.kind == 1 ? 4096u : (uint32_t)RH_MAX_TARGETS)) { err = "RIR: bad header (params/targets)"; return false; }
   if ((size_t)n_nodes * 8 > len) { err = "RIR: node count exceeds blob"; return false; }
+  // every target carries n_params + 1 output ids: a header whose target table cannot fit the blob is rejected before
+  // anything is sized from it (n_params = 0xFFFFFFFF would wrap n_params + 1 to 0, 2^31 would allocate gigabytes)
+  if (P.n_params > RH_RIR_MAX_PARAMS) { err = "RIR: n_params exceeds RH_RIR_MAX_PARAMS"; return false; }
+  if ((uint64_t)n_targets * ((uint64_t)P.n_params + 3) * 4 > (uint64_t)len) { err = "RIR: target table exceeds blob"; return false; }
   P.targets.resize(n_targets);
   uint32_t in = P.n_params, col = 0;
   for (auto &t : P.targets) {
@@ -41,7 +45,11 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
     t.input_start = in; t.col0 = col;
     in += t.n_cols; col += t.n_cols;
     t.outputs.resize(P.n_params + 1);
-    for (auto &o : t.outputs) { o = r.u32(); if (o >= n_nodes) { err = "RIR: output node id out of range"; return false; } }
+    for (auto &o : t.outputs) {
+      o = r.u32();
+      if (r.bad) { err = "RIR: truncated target table"; return false; }
+      if (o >= n_nodes) { err = "RIR: output node id out of range"; return false; }
+    }
     if (r.bad) { err = "RIR: truncated target table"; return false; }
   }
   if (col > RH_MAX_COLS) { err = "RIR: too many data columns"; return false; }

@@ -111,21 +111,37 @@ Program simplify(const Program &P, bool fast) {
         const Node na = B.Q.nodes[a], nb = B.Q.nodes[b];  // copies: the node vector grows below
         const bool la = na.op == RH_RIR_LOOKUP && B.all_const(na), lb = nb.op == RH_RIR_LOOKUP && B.all_const(nb);
         if (la && lb && na.a == nb.a && na.low == nb.low && na.table.size() == nb.table.size() && uses[n.a] == 1 && uses[n.b] == 1) {
-          std::vector<uint32_t> t;
-          for (size_t e = 0; e < na.table.size(); e++)
-            t.push_back(B.constant(fold(n.op, B.Q.nodes[na.table[e]].cval, B.Q.nodes[nb.table[e]].cval)));
-          const uint32_t idx = na.a; const int32_t low = na.low;
-          m[i] = B.lookup_raw(idx, low, t);
-          continue;
+          // a folded entry that is NaN (inf - inf, 0 * inf, 0 / 0) cannot be written as an RIR constant: leave the arithmetic
+          // to the device, which evaluates it to the same NaN the reference's bytecode would
+          std::vector<double> fv;
+          bool nan = false;
+          for (size_t e = 0; e < na.table.size(); e++) {
+            fv.push_back(fold(n.op, B.Q.nodes[na.table[e]].cval, B.Q.nodes[nb.table[e]].cval));
+            nan = nan || fv.back() != fv.back();
+          }
+          if (!nan) {
+            std::vector<uint32_t> t;
+            for (double v : fv) t.push_back(B.constant(v));
+            const uint32_t idx = na.a; const int32_t low = na.low;
+            m[i] = B.lookup_raw(idx, low, t);
+            continue;
+          }
         }
         if ((la && B.is_const(b) && uses[n.a] == 1) || (lb && B.is_const(a) && uses[n.b] == 1)) {
           const Node &lk = la ? na : nb;  // (na / nb are local copies)
-          std::vector<uint32_t> t;
-          for (uint32_t e : lk.table)
-            t.push_back(B.constant(la ? fold(n.op, B.Q.nodes[e].cval, nb.cval) : fold(n.op, na.cval, B.Q.nodes[e].cval)));
-          const uint32_t idx = lk.a; const int32_t low = lk.low;
-          m[i] = B.lookup_raw(idx, low, t);
-          continue;
+          std::vector<double> fv;
+          bool nan = false;
+          for (uint32_t e : lk.table) {
+            fv.push_back(la ? fold(n.op, B.Q.nodes[e].cval, nb.cval) : fold(n.op, na.cval, B.Q.nodes[e].cval));
+            nan = nan || fv.back() != fv.back();
+          }
+          if (!nan) {
+            std::vector<uint32_t> t;
+            for (double v : fv) t.push_back(B.constant(v));
+            const uint32_t idx = lk.a; const int32_t low = lk.low;
+            m[i] = B.lookup_raw(idx, low, t);
+            continue;
+          }
         }
       }
       // fast mode only (results may differ in the last place, like FMA contraction does): 1 / (1 / x) -> x

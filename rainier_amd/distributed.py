@@ -28,3 +28,22 @@ def gather_draws(local, world_size: int):
     out = torch.empty((world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out
+
+
+def gather_draws_from_device(dev_ptr: int, shape, world_size: int):
+    """The engine's device-resident draws (rh_sampler_draws_device: [chains_per_rank][iterations][nvars] fp64 on this
+    rank's GPU) -> all ranks' draws, without touching the host: one device-to-device copy into a torch tensor (the
+    engine's buffer belongs to the sampler handle) and ONE all-gather (RCCL over xGMI)."""
+    import ctypes as C
+    import torch
+    n = 1
+    for d in shape:
+        n *= int(d)
+    local = torch.empty(tuple(int(d) for d in shape), dtype=torch.float64, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    rc = hip.hipMemcpy(C.c_void_p(local.data_ptr()), C.c_void_p(int(dev_ptr)), C.c_size_t(n * 8), C.c_int(3))  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError("hipMemcpy(device draws -> torch tensor) failed: hipError %d" % rc)
+    return gather_draws(local, world_size)
+

@@ -298,6 +298,26 @@ class Sampler:
         except Exception: pass
 
 
+def sample_multi(models, config: SamplerConfig = None, seeds: Sequence[int] = None) -> "Trace":
+    """Model.sample fanned out over several devices behind the C ABI (rh_sample_multi): models[g] is the same program
+    compiled for device g; chains are cut into contiguous shards by GLOBAL chain id, so the trace does not depend on
+    len(models)."""
+    config = config or SamplerConfig()
+    nv = models[0].nVars
+    chains = len(seeds)
+    cfg, _keep = to_c_config(config, nv)
+    draws = np.zeros((chains, int(config.iterations), nv))
+    mass = np.zeros((chains, nv))
+    st = (_capi.ChainStats * chains)()
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    sd = (C.c_int64 * chains)(*[int(x) for x in seeds])
+    _capi.check(_capi.lib().rh_sample_multi(handles, len(models), C.byref(cfg), sd, chains, _capi.dptr(draws), _capi.dptr(mass), st),
+                models[0]._h)
+    stats = [Stats(s.leapfrog_steps, s.warmup_leapfrog_steps, s.gradient_evaluations, s.accepted, s.mean_accept_prob, s.step_size, s.bfmi)
+             for s in st]
+    return Trace(draws, mass, stats)
+
+
 class Model:
     """A compiled model: Compiler.compileTargets' replacement (compute/Compiler.scala:14-30) + Model.sample."""
 
@@ -321,11 +341,14 @@ class Model:
 
     def density(self) -> DensityFunction: return DensityFunction(self)
 
-    def density_batch(self, q: np.ndarray):
+    def density_batch(self, q: np.ndarray, engine: int = _capi.ENGINE_AUTO, grad_splits: int = 0):
+        """Batched DensityFunction.update.  engine = ENGINE_TICK evaluates through the sampler's batched gradient kernels
+        (rh_grad_kernel / rh_grad_glm_kernel / rh_grad_gather_kernel + the tick combine) instead of one chain per wavefront."""
         q = np.ascontiguousarray(q, dtype=np.float64)
         chains = q.shape[0]
         lp, g = np.zeros(chains), np.zeros((chains, self.nVars))
-        _capi.check(_capi.lib().rh_density_eval(self._h, _capi.dptr(q), chains, _capi.dptr(lp), _capi.dptr(g)), self._h)
+        _capi.check(_capi.lib().rh_density_eval_ex(self._h, _capi.dptr(q), chains, int(engine), int(grad_splits),
+                                                   _capi.dptr(lp), _capi.dptr(g)), self._h)
         return lp, g
 
     def sample(self, config: SamplerConfig = None, nChains: int = 4, seeds: Sequence[int] = None, rng_states=None) -> Trace:
@@ -360,7 +383,7 @@ class Model:
 
     def selftest(self, mode: int, seed: int = 0, x: np.ndarray = None, n: int = None) -> np.ndarray:
         x = np.zeros(1) if x is None else np.ascontiguousarray(x, dtype=np.float64)
-        n = (x.size // 2 if mode == 5 else x.size) if n is None else n
+        n = (x.size // 2 if mode in (5, 14) else x.size) if n is None else n
         out = np.zeros(n)
         _capi.check(_capi.lib().rh_selftest(self._h, mode, seed, _capi.dptr(x), _capi.dptr(out), n), self._h)
         return out

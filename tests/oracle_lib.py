@@ -146,6 +146,16 @@ class OracleDensity:
         return out
 
     def abs_sums(self, q): return self._call(self.lib.rir_density_abs_sums, q)[1]
+
+    def update_both(self, q):
+        """(sequential-sum outputs, sums of |term|) in one pass over the rows."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        out, ab = np.zeros(self.n + 1), np.zeros(self.n + 1)
+        self.lib.rir_density_update_both.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        if self.lib.rir_density_update_both(self.handle, _dp(q), _dp(out), _dp(ab)):
+            raise RuntimeError("lookup index out of range")
+        return out, ab
+
     def update_ld(self, q): return self._call(self.lib.rir_density_update_ld, q)[1]
 
     def __del__(self):

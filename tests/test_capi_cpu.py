@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rh_abi_version() == 2
+    assert lib.rh_abi_version() == 3
 
 
 def test_struct_layouts_match_header(lib):
@@ -123,7 +123,7 @@ def test_headers_are_c_and_library_links_from_c(tmp_path):
                            os.path.join(root, "tests", "stubs", "abi_check.c"), "-o", exe, "-L", os.path.join(root, "rainier_amd"),
                            "-lrainier_hip", "-Wl,-rpath," + os.path.join(root, "rainier_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([exe]).decode()
-    assert "abi 2 header 2" in out
+    assert "abi 3 header 3" in out
     assert "sizeof rh_config %d rh_chain_stats %d" % (C.sizeof(_capi.Config), C.sizeof(_capi.ChainStats)) in out
     assert "default 1000 1000 sampler 1 ehmc 1024 mass 1 50 1.5" in out          # DefaultConfig, sampler/Sampler.scala:17-27
     import torch
@@ -168,6 +168,22 @@ def test_rir_parser_survives_mutated_blobs():
             assert e.code == _capi.RH_E_INVALID
             rejected += 1
     assert rejected > 1500 and accepted > 50
+
+
+def test_rir_header_overflow_is_rejected_before_allocation():
+    """n_params is bounded against the blob before anything is sized from it -- 0xFFFFFFFF (n_params + 1 wraps to 0),
+    2^31 (gigabytes) and "large but plausible" values all come back as RH_E_INVALID, quickly, from every entry point."""
+    import struct, time
+    good = models.funnel().rir
+    for n_params in (0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 1 << 24, (1 << 24) + 1, 100000):
+        b = bytearray(good)
+        b[8:12] = struct.pack("<I", n_params)
+        t0 = time.time()
+        for fn in (lambda: _capi.simplify_rir(bytes(b)), lambda: _capi.lower_only(bytes(b))):
+            with pytest.raises(_capi.RainierHipError) as ei:
+                fn()
+            assert ei.value.code == _capi.RH_E_INVALID
+        assert time.time() - t0 < 2.0
 
 
 def test_committed_bench_line_honours_the_contract():

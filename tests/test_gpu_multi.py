@@ -1,0 +1,85 @@
+"""Multi-GPU path, as far as one MI355X can show it.
+
+  * rh_sample_multi (sharding behind the C ABI): the SAME chains cut into 1, 2, 3 and 5 shards -- every shard here runs on
+    device 0 -- give bit-identical draws, stats and mass matrices: the result is a function of the global chain id only.
+  * shard_seeds + per-rank samplers (what bench.py does per process) reproduce the unsharded run on real engine draws.
+  * the device-resident draws -> torch tensor -> RCCL all-gather path of bench.py (gather_draws_from_device), executed on
+    a world-size-1 NCCL(=RCCL) process group.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import rainier_amd as R
+from rainier_amd import _capi, models
+from rainier_amd import distributed as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(engine=_capi.ENGINE_AUTO):
+    return R.make_config(12, 30, R.EHMCSampler(64), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(10, 1.5, 5, 5), engine=engine)
+
+
+@pytest.mark.parametrize("builder,engine", [(lambda: models.eight_schools(), _capi.ENGINE_AUTO),
+                                            (lambda: models.linreg(n=70000, k=3), _capi.ENGINE_TICK)])
+def test_rh_sample_multi_is_independent_of_the_shard_count(builder, engine):
+    spec = builder()
+    strict = dict(math_mode=_capi.MATH_STRICT)
+    seeds = [7000 + c for c in range(11)]                 # 11 chains: uneven shards
+    m0 = R.Model(spec, device=0, **strict)
+    base = m0.sample(_cfg(engine), seeds=seeds)
+    for nshards in (1, 2, 3, 5, 16):
+        ms = [m0] + [R.Model(spec, device=0, **strict) for _ in range(min(nshards, 3) - 1)]
+        ms = (ms * nshards)[:nshards]                     # several shards may share a model handle (calls serialise on it)
+        tr = R.sample_multi(ms, _cfg(engine), seeds)
+        assert np.array_equal(tr.chains, base.chains), nshards
+        assert np.array_equal(tr.mass, base.mass)
+        assert [s.leapfrogSteps for s in tr.stats] == [s.leapfrogSteps for s in base.stats]
+        assert [s.stepSize for s in tr.stats] == [s.stepSize for s in base.stats]
+
+
+def test_rh_sample_multi_rejects_bad_arguments():
+    m = R.Model(models.funnel(10), device=0)
+    m2 = R.Model(models.eight_schools(), device=0)
+    m3 = R.Model(models.normal_1d(), device=0)
+    with pytest.raises(R.RainierHipError):
+        R.sample_multi([m, m3], R.HMC(5, 5, 2), [1, 2, 3])      # different programs (nvars differ)
+    tr = R.sample_multi([m, m], R.HMC(5, 5, 2), [1])            # more shards than chains: the surplus shards stay idle
+    assert tr.chains.shape == (1, 5, 10)
+    del m2
+
+
+def test_per_rank_samplers_with_global_seeds_match_the_unsharded_run():
+    """bench.py's protocol on real draws: rank r owns the global chains [r*cpr, (r+1)*cpr) with seeds base + global id."""
+    spec = models.linreg(n=70000, k=3)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True, grad_chains=8)
+    cpr, world = 6, 3
+    cfg = R.make_config(6, 10, R.HMCSampler(4), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    whole = m.sample(cfg, seeds=[1000 + g for g in range(cpr * world)]).chains
+    for rank in range(world):
+        part = m.sample(cfg, seeds=D.shard_seeds(1000, cpr, rank)).chains
+        assert np.array_equal(part, whole[rank * cpr:(rank + 1) * cpr])
+
+
+def test_device_draws_all_gather_over_rccl_world_size_one():
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec = models.linreg(n=70000, k=3)
+        m = R.Model(spec, device=0)
+        cfg = R.make_config(5, 5, R.HMCSampler(3), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+        s = R.Sampler(m, cfg, D.shard_seeds(1000, 4, 0))
+        s.warmup(); s.run(5)
+        out = D.gather_draws_from_device(s.draws_device_ptr(), (4, 5, spec.n_params), 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), s.draws())
+    finally:
+        dist.destroy_process_group()
