@@ -39,37 +39,49 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
     Two more figures beside it, each labelled: the same streamed gradient compiled by hand (upper bound for a JVM on the
     streamed form), and the INLINED sufficient-statistics form -- what real Rainier runs for this model."""
     from tests import oracle_lib as O
-    d0 = O.OracleDensity(spec)
-    q = np.zeros(spec.n_params)
-    t = time.perf_counter(); d0.update(q); per_grad = time.perf_counter() - t
+    from rainier_amd import models as _m
     nproc = os.cpu_count() or 1
     try:
         nproc_avail = len(os.sched_getaffinity(0))
     except AttributeError:
         nproc_avail = nproc
     cores = max(1, nproc_avail)
-    iters = max(1, int(seconds_budget / (per_grad * (2 * L + 2))))
-    cfg = O.make_config(sampler=O.HMC, n_steps=L, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
-                        static_step=1e-3, math_mode=O.JM_LIBM)
-    steps = [0] * cores
+    # BOUNDED sample: the interpreter costs ~80 ns per row and gradient, one HMC iteration is 2L+1 = 65 gradients, and every
+    # thread streams its own pass, so the sample is the first `n_s` rows of the same columns (cost is linear in the rows;
+    # the smaller working set can only flatter the CPU) and the iteration count is calibrated UNDER CONTENTION (all threads
+    # running) to ~12 s.  `value` is converted to full-size leapfrog steps/s (x n_s / N); `sample` says so.
+    N = spec.rows_streamed
+    n_s = min(N, 100_000)
+    spec_s = _m.linreg(n=n_s, k=len(spec.columns) - 1, columns=[np.ascontiguousarray(c[:n_s]) for c in spec.columns])
 
-    def work(i):
-        d = O.OracleDensity(spec)
-        _, _, st, _ = O.sample_chain(d.fn_ptr, d.handle, spec.n_params, cfg, 1000 + i)
-        steps[i] = st.leapfrog_steps
+    def run_all(iters):
+        cfg = O.make_config(sampler=O.HMC, n_steps=L, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
+                            static_step=1e-3, math_mode=O.JM_LIBM)
+        steps = [0] * cores
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t = time.perf_counter()
-    [x.start() for x in th]; [x.join() for x in th]
-    dt = time.perf_counter() - t
-    total = float(sum(steps))
+        def work(i):
+            d = O.OracleDensity(spec_s)
+            _, _, st, _ = O.sample_chain(d.fn_ptr, d.handle, spec_s.n_params, cfg, 1000 + i)
+            steps[i] = st.leapfrog_steps
+        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        t = time.perf_counter()
+        [x.start() for x in th]; [x.join() for x in th]
+        return time.perf_counter() - t, float(sum(steps))
+
+    t1, _ = run_all(1)                                   # calibration, all threads busy
+    iters = max(1, min(200, int(0.6 * seconds_budget / max(t1, 1e-3))))
+    dt, total = run_all(iters)
+    total_full = total * n_s / N                         # leapfrog steps over the FULL data set this corresponds to
     # second figure ("speed build", SURVEY 8(d)): the same streamed gradient written out by hand and compiled -O3 with
     # AVX2/FMA (oracle/closed_form.c) -- an upper bound for any JVM on these cores; one chain per thread, ~3 s
     lib = O.load(); cols = [np.ascontiguousarray(c) for c in spec.columns]; n = len(cols[0])
-    t = time.perf_counter(); lib.orc_linreg_streamed_reps(*[O._dp(c) for c in cols], n, 2); per = (time.perf_counter() - t) / 2
-    reps = max(2, int(3.0 / per))
-    th2 = [threading.Thread(target=lambda: lib.orc_linreg_streamed_reps(*[O._dp(c) for c in cols], n, reps)) for _ in range(cores)]
-    t = time.perf_counter(); [x.start() for x in th2]; [x.join() for x in th2]; dt2 = time.perf_counter() - t
+    def run_closed(reps):
+        th2 = [threading.Thread(target=lambda: lib.orc_linreg_streamed_reps(*[O._dp(c) for c in cols], n, reps)) for _ in range(cores)]
+        t = time.perf_counter(); [x.start() for x in th2]; [x.join() for x in th2]
+        return time.perf_counter() - t
+    per = run_closed(1)                                  # calibration with every core streaming (memory-bandwidth contention included)
+    reps = max(1, min(10000, int(3.0 / max(per, 1e-4))))
+    dt2 = run_closed(reps)
     closed = {"value": cores * reps / dt2, "unit": "leapfrog steps/s (1 gradient per step)", "cores": cores,
               "row_chain_evals_per_s": cores * reps * n / dt2,
               "sample": "%d threads x %d streamed gradients over %d rows, hand-written C, -O3 -mavx2 -mfma, %.1f s" % (cores, reps, n, dt2)}
@@ -93,11 +105,13 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
                "reference_published": "rainier-benchmark/benchmarks.txt: ~1 us per gradient on the JVM at any N => ~5e5 leapfrog "
                                       "steps/s per thread at the reference's 2 gradients per step",
                "sample": "%d threads x %d leapfrog steps on the inlined density, hand-written C -O3, %.1f s" % (cores, nsteps, dt3)}
-    return {"value": total / dt, "compiled_closed_form": closed, "inlined_sufficient_statistics": inlined,
+    return {"value": total_full / dt, "compiled_closed_form": closed, "inlined_sufficient_statistics": inlined,
             "unit": "leapfrog steps/s", "cores": cores, "nproc": nproc, "kind": "port",
-            "sample": "%d chains x %d HMC iterations (L=%d, %d rows), RIR interpreter, reference's 2L+1 gradient "
-                      "evaluations per trajectory, %.1f s" % (cores, iters, L, spec.rows_streamed, dt),
-            "row_chain_evals_per_s": total * spec.rows_streamed / dt}
+            "sample": "%d chains (one per core) x %d HMC iterations (L=%d) over the first %d of the %d rows, RIR interpreter, "
+                      "reference's 2L+1 gradient evaluations per trajectory, %.1f s; value = measured steps/s x %d/%d "
+                      "(full-size equivalent)" % (cores, iters, L, n_s, N, dt, n_s, N),
+            "measured_on_sample": {"leapfrog_steps_per_s": total / dt, "rows": n_s},
+            "row_chain_evals_per_s": total * n_s / dt}
 
 
 def side_workload(a, R, models, rank, local_rank, world, dist):

@@ -402,6 +402,87 @@ static double nuts_iteration(const orc_config *cfg, double *params, orc_leapfrog
   return jm_log(mode, mean_acc);
 }
 
+/* ---- NUTS, second statement: RECURSIVE tree building (cross-validation of the checkpoint bookkeeping above) ----------
+ * The same transition written the way Hoffman & Gelman (2014, Alg. 6) and Stan's multinomial variant are usually stated:
+ * build_tree(depth) = build_tree(depth-1) ++ build_tree(depth-1), every node keeps its first and last momentum and the
+ * sum of its momenta, the U-turn criterion of a node is evaluated from those three directly, a stopped child stops the
+ * parent.  There are NO checkpoints and no leaf-index arithmetic here -- that is the point: nuts_iteration's
+ * _leaf_idx_to_ckpt_idxs indexing (idx_max / idx_min / "sub = srsum - ckrs[k] + ckr[k]") must enumerate exactly the nodes
+ * this recursion visits, in the same (post-)order, and stop at the same leaf.  Leaves are visited left to right by both,
+ * so the per-leaf uniforms of the progressive sampling are consumed in the same order and the same leaf is selected.
+ * The node sums are formed as left + right here and as differences of running sums there: a U-turn decision can differ only
+ * when a dot product is within rounding of zero.  tests/test_oracle.py runs both over >= 1e4 trajectories (divergences,
+ * max-depth saturation, diagonal mass) and requires identical chains and identical leapfrog counts. */
+typedef struct {
+  double *r_first, *r_last, *rsum; /* [n] each */
+  int stopped;                     /* a sub-trajectory made a U-turn, or a leaf diverged */
+} nuts_node;
+typedef struct {
+  const orc_config *cfg; orc_leapfrog *lf; const double *mass; double eps, H0;
+  double sub_logw; long leaf_count; double *subprop; double sum_accept; long nleaf_total;
+} nuts_rec;
+static nuts_node nuts_node_new(int n) { nuts_node t; t.r_first = malloc(sizeof(double) * n); t.r_last = malloc(sizeof(double) * n); t.rsum = malloc(sizeof(double) * n); t.stopped = 0; return t; }
+static void nuts_node_free(nuts_node *t) { free(t->r_first); free(t->r_last); free(t->rsum); }
+static nuts_node nuts_build(nuts_rec *c, int depth) {
+  const int n = c->lf->n, mode = c->cfg->math_mode;
+  if (depth == 0) { /* one leaf = one leapfrog step */
+    nuts_node t = nuts_node_new(n);
+    orc_lf_take_steps(c->lf, 1, c->eps, c->mass);
+    double delta = energy(c->lf, c->lf->pqBuf, c->mass) - c->H0;
+    if (isnan(delta)) delta = INFINITY;
+    const double leaf_logw = -delta;
+    c->sum_accept += delta <= 0.0 ? 1.0 : jm_exp(mode, -delta); c->nleaf_total++;
+    const double new_logw = logaddexp_det(mode, c->sub_logw, leaf_logw);
+    const double u = rng_uniform(c->lf->rng);
+    if (c->leaf_count == 0 || u < jm_exp(mode, leaf_logw - new_logw)) lf_snapshot(c->lf, c->subprop);
+    c->sub_logw = new_logw; c->leaf_count++;
+    memcpy(t.r_first, c->lf->pqBuf, sizeof(double) * n); memcpy(t.r_last, c->lf->pqBuf, sizeof(double) * n);
+    memcpy(t.rsum, c->lf->pqBuf, sizeof(double) * n);
+    t.stopped = delta > 1000.0;
+    return t;
+  }
+  nuts_node a = nuts_build(c, depth - 1);
+  if (a.stopped) return a;
+  nuts_node b = nuts_build(c, depth - 1);
+  nuts_node t = nuts_node_new(n);
+  memcpy(t.r_first, a.r_first, sizeof(double) * n); memcpy(t.r_last, b.r_last, sizeof(double) * n);
+  for (int i = 0; i < n; i++) t.rsum[i] = a.rsum[i] + b.rsum[i];
+  t.stopped = b.stopped || nuts_is_turning(c->lf, n, c->mass, t.r_first, t.r_last, t.rsum);
+  nuts_node_free(&a); nuts_node_free(&b);
+  return t;
+}
+static double nuts_iteration_recursive(const orc_config *cfg, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
+  const int n = lf->n, mode = cfg->math_mode, sz = 2 * n + 1;
+  orc_lf_start_iteration(lf, params, mass);
+  nuts_rec c; c.cfg = cfg; c.lf = lf; c.mass = mass; c.H0 = energy(lf, params, mass); c.sum_accept = 0.0; c.nleaf_total = 0;
+  c.subprop = malloc(sizeof(double) * sz);
+  double *L = malloc(sizeof(double) * sz), *R = malloc(sizeof(double) * sz), *prop = malloc(sizeof(double) * sz), *rsum = malloc(sizeof(double) * n);
+  memcpy(L, params, sizeof(double) * sz); memcpy(R, params, sizeof(double) * sz); memcpy(prop, params, sizeof(double) * sz);
+  memcpy(rsum, params, sizeof(double) * n);
+  double tree_logw = 0.0;
+  for (int depth = 0; depth < cfg->nuts_max_depth; depth++) {
+    const int going_right = rng_uniform(lf->rng) > 0.5;
+    c.eps = going_right ? stepSize : -stepSize;
+    lf_restore(lf, going_right ? R : L);
+    c.sub_logw = -INFINITY; c.leaf_count = 0;
+    nuts_node t = nuts_build(&c, depth);
+    if (t.stopped) { nuts_node_free(&t); break; }
+    const double u = rng_uniform(lf->rng);
+    if (u < jm_exp(mode, c.sub_logw - tree_logw)) memcpy(prop, c.subprop, sizeof(double) * sz);
+    tree_logw = logaddexp_det(mode, tree_logw, c.sub_logw);
+    for (int i = 0; i < n; i++) rsum[i] += t.rsum[i];
+    lf_snapshot(lf, going_right ? R : L);
+    nuts_node_free(&t);
+    if (nuts_is_turning(lf, n, mass, L, R, rsum)) break;
+  }
+  memcpy(params + n, prop + n, sizeof(double) * (n + 1));
+  lf->iterations += 1; lf->accepted += 1;
+  const double mean_acc = c.nleaf_total ? c.sum_accept / (double)c.nleaf_total : 0.0;
+  lf->sumAccept += mean_acc;
+  free(L); free(R); free(prop); free(rsum); free(c.subprop);
+  return jm_log(mode, mean_acc);
+}
+
 /* ---- S/HMC.scala, S/EHMC.scala ----------------------------------------------------------- */
 typedef struct { const orc_config *cfg; ringbuf steps; double *snap; } samplerst;
 
@@ -418,6 +499,7 @@ static void ehmc_countSteps(samplerst *s, double *params, orc_leapfrog *lf, doub
 }
 static double sampler_warmup(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
   if (s->cfg->sampler == ORC_NUTS) return nuts_iteration(s->cfg, params, lf, stepSize, mass);
+  if (s->cfg->sampler == ORC_NUTS_RECURSIVE) return nuts_iteration_recursive(s->cfg, params, lf, stepSize, mass);
   orc_lf_start_iteration(lf, params, mass);
   if (s->cfg->sampler == ORC_HMC) { /* S/HMC.scala:6-13 */
     orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass);
@@ -430,6 +512,7 @@ static double sampler_warmup(samplerst *s, double *params, orc_leapfrog *lf, dou
 }
 static void sampler_run(samplerst *s, double *params, orc_leapfrog *lf, double stepSize, const double *mass) {
   if (s->cfg->sampler == ORC_NUTS) { (void)nuts_iteration(s->cfg, params, lf, stepSize, mass); return; }
+  if (s->cfg->sampler == ORC_NUTS_RECURSIVE) { (void)nuts_iteration_recursive(s->cfg, params, lf, stepSize, mass); return; }
   orc_lf_start_iteration(lf, params, mass);
   if (s->cfg->sampler == ORC_HMC) orc_lf_take_steps(lf, s->cfg->n_steps, stepSize, mass); /* S/HMC.scala:15-23 */
   else { int n = (int)ring_sample(&s->steps, lf->rng); orc_lf_take_steps(lf, n, stepSize, mass); } /* S/EHMC.scala:52-61 */

@@ -12,7 +12,8 @@
 /* S/DensityFunction.scala:3-8 folded into one call: out[0] = density, out[1+i] = gradient(i) */
 typedef int (*orc_density_fn)(void *ctx, const double *q, double *out);
 
-enum { ORC_HMC = 0, ORC_EHMC = 1, ORC_NUTS = 2 };
+enum { ORC_HMC = 0, ORC_EHMC = 1, ORC_NUTS = 2,
+       ORC_NUTS_RECURSIVE = 3 /* the same transition built recursively, without checkpoints: cross-validation only */ };
 enum { ORC_STEP_DUALAVG = 0, ORC_STEP_STATIC = 1 };
 enum { ORC_MASS_IDENTITY = 0, ORC_MASS_DIAG_WINDOWED = 1, ORC_MASS_STATIC_DIAG = 2, ORC_MASS_DENSE_WINDOWED = 3 };
 

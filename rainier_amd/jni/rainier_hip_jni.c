@@ -1,12 +1,18 @@
 /* rainier_hip_jni.c -- thin JNI shim over include/rainier_hip.h.
  *
- * NOT COMPILED IN THIS REPOSITORY'S BUILD: the build image has no JDK (no jni.h).  A Rainier maintainer builds it
- * next to librainier_hip.so with
+ * A Rainier maintainer builds it next to librainier_hip.so with
  *     cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
  *        rainier_hip_jni.c -L.. -lrainier_hip -o librainier_hip_jni.so
- * The Scala side that binds these functions is shown in INTEGRATION.md
- * (object com.stripe.rainier.hip.Native).  Every function pins/copies the Java arrays, calls the C ABI and maps a
- * non-zero status to RuntimeException -- no logic lives here.
+ * The build image of this repository has no JDK, so here the shim is compiled against tests/stubs/jni.h (the JNI
+ * specification's signatures for the calls it uses) and EXECUTED against tests/stubs/fake_jni.c, a function table that
+ * implements those calls over malloc'ed arrays with the JVM's copy-in / copy-back / JNI_ABORT semantics
+ * (tests/test_jni_shim.py: CPU argument marshalling, `-m gpu` end-to-end draws bit-identical to the ctypes path).
+ *
+ * The Scala side that binds these functions is integration/scala/Native.scala (object com.stripe.rainier.hip.Native).
+ * Every function pins/copies the Java arrays, calls the C ABI and maps a non-zero status to an exception -- no logic
+ * lives here.  The flat int/double arrays that carry rh_compile_opts and rh_config are described by the X-macro lists
+ * below; integration/scala/HipModel.scala builds them from locals with THE SAME NAMES IN THE SAME ORDER, which
+ * tests/test_jni_shim.py checks textually.
  */
 #include <jni.h>
 #include <stdlib.h>
@@ -14,17 +20,35 @@
 
 #include "rainier_hip.h"
 
-static void throw_rh(JNIEnv *env, rh_model *m, int rc) {
-  const char *msg = rh_last_error(m);
-  jclass cls = (*env)->FindClass(env, rc == RH_E_INVALID ? "java/lang/IllegalArgumentException" : "java/lang/RuntimeException");
+/* int[] copts -> rh_compile_opts (every field after struct_size, in declaration order) */
+#define RH_JNI_COPTS(X) X(device) X(math_mode) X(fp_contract) X(rows_unroll) X(grad_chains) X(grad_unroll) X(factor_outputs) X(with_nuts)
+/* int[] icfg / double[] dcfg -> rh_config (every scalar field; the two pointer fields travel as their own arrays) */
+#define RH_JNI_ICFG(X) \
+  X(iterations) X(warmup) X(sampler) X(hmc_steps) X(ehmc_max_steps) X(ehmc_min_steps) X(ehmc_buf_size) X(step_tuner) \
+  X(mass_tuner) X(mass_init_window) X(mass_skip_first) X(mass_skip_last) X(nuts_max_depth) X(engine) X(grad_splits)
+#define RH_JNI_DCFG(X) X(ehmc_p_count) X(dualavg_delta) X(static_step) X(mass_expansion)
+#define RH_JNI_COUNT(n) +1
+enum { RH_JNI_NCOPTS = 0 RH_JNI_COPTS(RH_JNI_COUNT), RH_JNI_NICFG = 0 RH_JNI_ICFG(RH_JNI_COUNT), RH_JNI_NDCFG = 0 RH_JNI_DCFG(RH_JNI_COUNT) };
+/* double[] stats: RH_JNI_NSTATS doubles per chain */
+#define RH_JNI_STATS(X) X(leapfrog_steps) X(warmup_leapfrog_steps) X(gradient_evaluations) X(accepted) X(mean_accept_prob) X(step_size) X(bfmi)
+enum { RH_JNI_NSTATS = 0 RH_JNI_STATS(RH_JNI_COUNT) };
+
+static void throw_msg(JNIEnv *env, int rc, const char *msg) {
+  jclass cls = (*env)->FindClass(env, rc == RH_E_INVALID ? "java/lang/IllegalArgumentException"
+                                      : rc == RH_E_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/RuntimeException");
   (*env)->ThrowNew(env, cls, msg && *msg ? msg : "rainier-hip error");
 }
+static void throw_rh(JNIEnv *env, rh_model *m, int rc) { throw_msg(env, rc, rh_last_error(m)); }
 
-/* long modelCreate(byte[] rir, double[][] columns, long[] nrows, int device, int mathMode, boolean fpContract) */
+/* int abiVersion() / int deviceCount() */
+JNIEXPORT jint JNICALL Java_com_stripe_rainier_hip_Native_00024_abiVersion(JNIEnv *env, jobject self) { (void)env; (void)self; return rh_abi_version(); }
+JNIEXPORT jint JNICALL Java_com_stripe_rainier_hip_Native_00024_deviceCount(JNIEnv *env, jobject self) { (void)env; (void)self; return rh_device_count(); }
+
+/* long modelCreate(byte[] rir, double[][] columns, long[] nrows, int[] copts) */
 JNIEXPORT jlong JNICALL Java_com_stripe_rainier_hip_Native_00024_modelCreate(
-    JNIEnv *env, jobject self, jbyteArray rir, jobjectArray columns, jlongArray nrows, jint device, jint mathMode,
-    jboolean fpContract) {
+    JNIEnv *env, jobject self, jbyteArray rir, jobjectArray columns, jlongArray nrows, jintArray copts) {
   (void)self;
+  if ((*env)->GetArrayLength(env, copts) != RH_JNI_NCOPTS) { throw_msg(env, RH_E_INVALID, "copts has the wrong length"); return 0; }
   const jsize ncols = (*env)->GetArrayLength(env, columns);
   const double **cols = (const double **)calloc(ncols ? ncols : 1, sizeof(double *));
   jdoubleArray *arrs = (jdoubleArray *)calloc(ncols ? ncols : 1, sizeof(jdoubleArray));
@@ -34,11 +58,18 @@ JNIEXPORT jlong JNICALL Java_com_stripe_rainier_hip_Native_00024_modelCreate(
   }
   jbyte *blob = (*env)->GetByteArrayElements(env, rir, NULL);
   jlong *rows = (*env)->GetLongArrayElements(env, nrows, NULL);
+  jint *co = (*env)->GetIntArrayElements(env, copts, NULL);
   rh_compile_opts opts;
   memset(&opts, 0, sizeof opts);
-  opts.struct_size = (int32_t)sizeof opts; opts.device = device; opts.math_mode = mathMode; opts.fp_contract = fpContract ? 1 : 0;
+  opts.struct_size = (int32_t)sizeof opts;
+  { int i = 0;
+#define X(f) opts.f = co[i++];
+    RH_JNI_COPTS(X)
+#undef X
+  }
   rh_model *m = NULL;
   const int rc = rh_model_create(blob, (size_t)(*env)->GetArrayLength(env, rir), cols, (const int64_t *)rows, &opts, &m);
+  (*env)->ReleaseIntArrayElements(env, copts, co, JNI_ABORT);
   (*env)->ReleaseLongArrayElements(env, nrows, rows, JNI_ABORT);
   (*env)->ReleaseByteArrayElements(env, rir, blob, JNI_ABORT);
   for (jsize i = 0; i < ncols; i++) (*env)->ReleaseDoubleArrayElements(env, arrs[i], (jdouble *)cols[i], JNI_ABORT);
@@ -52,15 +83,21 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_modelDestroy(JNI
   rh_model_destroy((rh_model *)(intptr_t)h);
 }
 
-/* void densityEval(long model, double[] q, int chains, double[] logp, double[] grad) */
+JNIEXPORT jint JNICALL Java_com_stripe_rainier_hip_Native_00024_modelNVars(JNIEnv *env, jobject self, jlong h) {
+  (void)env; (void)self;
+  return rh_model_nvars((const rh_model *)(intptr_t)h);
+}
+
+/* void densityEval(long model, double[] q, int chains, int engine, int gradSplits, double[] logp, double[] grad) */
 JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_densityEval(
-    JNIEnv *env, jobject self, jlong h, jdoubleArray q, jint chains, jdoubleArray logp, jdoubleArray grad) {
+    JNIEnv *env, jobject self, jlong h, jdoubleArray q, jint chains, jint engine, jint gradSplits, jdoubleArray logp,
+    jdoubleArray grad) {
   (void)self;
   rh_model *m = (rh_model *)(intptr_t)h;
   jdouble *qp = (*env)->GetDoubleArrayElements(env, q, NULL);
   jdouble *lp = (*env)->GetDoubleArrayElements(env, logp, NULL);
   jdouble *gp = (*env)->GetDoubleArrayElements(env, grad, NULL);
-  const int rc = rh_density_eval(m, qp, chains, lp, gp);
+  const int rc = rh_density_eval_ex(m, qp, chains, engine, gradSplits, lp, gp);
   (*env)->ReleaseDoubleArrayElements(env, q, qp, JNI_ABORT);
   (*env)->ReleaseDoubleArrayElements(env, logp, lp, 0);
   (*env)->ReleaseDoubleArrayElements(env, grad, gp, 0);
@@ -85,44 +122,106 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_optimize(
   if (rc != RH_OK) throw_rh(env, m, rc);
 }
 
-/* void sample(long model, int[] icfg, double[] dcfg, double[] staticMass, long[] seeds, double[] draws, double[] mass,
- *             double[] stats)   -- icfg/dcfg carry rh_config field by field (see Native.scala in INTEGRATION.md) */
+/* void sample(long[] models, int[] icfg, double[] dcfg, double[] staticMass (null), double[] rngNextGaussian (null),
+ *             long[] seeds, double[] draws, double[] mass, double[] stats (null))
+ * models: one handle per device (the same program compiled with copts.device = g); one handle = rh_sample, several =
+ * rh_sample_multi (chains cut into contiguous shards by global chain id; the result does not depend on the count). */
 JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_sample(
-    JNIEnv *env, jobject self, jlong h, jintArray icfg, jdoubleArray dcfg, jdoubleArray staticMass, jlongArray seeds,
-    jdoubleArray draws, jdoubleArray mass, jdoubleArray stats) {
+    JNIEnv *env, jobject self, jlongArray models, jintArray icfg, jdoubleArray dcfg, jdoubleArray staticMass,
+    jdoubleArray rngNextGaussian, jlongArray seeds, jdoubleArray draws, jdoubleArray mass, jdoubleArray stats) {
   (void)self;
-  rh_model *m = (rh_model *)(intptr_t)h;
+  const jsize nmodels = (*env)->GetArrayLength(env, models);
+  if (nmodels < 1 || (*env)->GetArrayLength(env, icfg) != RH_JNI_NICFG || (*env)->GetArrayLength(env, dcfg) != RH_JNI_NDCFG) {
+    throw_msg(env, RH_E_INVALID, "models / icfg / dcfg have the wrong length");
+    return;
+  }
+  const jsize chains = (*env)->GetArrayLength(env, seeds);
+  if (stats && (*env)->GetArrayLength(env, stats) != chains * RH_JNI_NSTATS) { throw_msg(env, RH_E_INVALID, "stats has the wrong length"); return; }
+  if (rngNextGaussian && (*env)->GetArrayLength(env, rngNextGaussian) != chains) { throw_msg(env, RH_E_INVALID, "rngNextGaussian has the wrong length"); return; }
+  jlong *mh = (*env)->GetLongArrayElements(env, models, NULL);
+  rh_model **ms = (rh_model **)calloc((size_t)nmodels, sizeof(rh_model *));
+  for (jsize g = 0; g < nmodels; g++) ms[g] = (rh_model *)(intptr_t)mh[g];
+  (*env)->ReleaseLongArrayElements(env, models, mh, JNI_ABORT);
   jint *ic = (*env)->GetIntArrayElements(env, icfg, NULL);
   jdouble *dc = (*env)->GetDoubleArrayElements(env, dcfg, NULL);
   rh_config cfg;
   rh_config_default(&cfg);
-  cfg.iterations = ic[0]; cfg.warmup = ic[1]; cfg.sampler = ic[2]; cfg.hmc_steps = ic[3];
-  cfg.ehmc_max_steps = ic[4]; cfg.ehmc_min_steps = ic[5]; cfg.ehmc_buf_size = ic[6]; cfg.step_tuner = ic[7];
-  cfg.mass_tuner = ic[8]; cfg.mass_init_window = ic[9]; cfg.mass_skip_first = ic[10]; cfg.mass_skip_last = ic[11];
-  cfg.ehmc_p_count = dc[0]; cfg.dualavg_delta = dc[1]; cfg.static_step = dc[2]; cfg.mass_expansion = dc[3];
+  { int i = 0;
+#define X(f) cfg.f = ic[i++];
+    RH_JNI_ICFG(X)
+#undef X
+    i = 0;
+#define X(f) cfg.f = dc[i++];
+    RH_JNI_DCFG(X)
+#undef X
+  }
   jdouble *sm = staticMass ? (*env)->GetDoubleArrayElements(env, staticMass, NULL) : NULL;
+  jdouble *nn = rngNextGaussian ? (*env)->GetDoubleArrayElements(env, rngNextGaussian, NULL) : NULL;
   cfg.static_mass = sm;
-  const jsize chains = (*env)->GetArrayLength(env, seeds);
+  cfg.rng_next_gaussian = nn;
   jlong *sd = (*env)->GetLongArrayElements(env, seeds, NULL);
   jdouble *dr = (*env)->GetDoubleArrayElements(env, draws, NULL);
-  jdouble *ms = (*env)->GetDoubleArrayElements(env, mass, NULL);
-  rh_chain_stats *st = (rh_chain_stats *)calloc(chains, sizeof(rh_chain_stats));
-  const int rc = rh_sample(m, &cfg, (const int64_t *)sd, chains, dr, ms, st);
-  if (rc == RH_OK && stats) { /* 7 doubles per chain: steps, warmupSteps, gradEvals, accepted, meanAccept, stepSize, bfmi */
+  jdouble *mp = (*env)->GetDoubleArrayElements(env, mass, NULL);
+  rh_chain_stats *st = (rh_chain_stats *)calloc(chains ? (size_t)chains : 1, sizeof(rh_chain_stats));
+  const int rc = nmodels == 1 ? rh_sample(ms[0], &cfg, (const int64_t *)sd, chains, dr, mp, st)
+                              : rh_sample_multi(ms, nmodels, &cfg, (const int64_t *)sd, chains, dr, mp, st);
+  if (rc == RH_OK && stats) {
     jdouble *sp = (*env)->GetDoubleArrayElements(env, stats, NULL);
     for (jsize c = 0; c < chains; c++) {
-      sp[7 * c + 0] = (double)st[c].leapfrog_steps; sp[7 * c + 1] = (double)st[c].warmup_leapfrog_steps;
-      sp[7 * c + 2] = (double)st[c].gradient_evaluations; sp[7 * c + 3] = (double)st[c].accepted;
-      sp[7 * c + 4] = st[c].mean_accept_prob; sp[7 * c + 5] = st[c].step_size; sp[7 * c + 6] = st[c].bfmi;
+      int i = 0;
+#define X(f) sp[RH_JNI_NSTATS * c + (i++)] = (double)st[c].f;
+      RH_JNI_STATS(X)
+#undef X
     }
     (*env)->ReleaseDoubleArrayElements(env, stats, sp, 0);
   }
   free(st);
-  (*env)->ReleaseDoubleArrayElements(env, mass, ms, 0);
-  (*env)->ReleaseDoubleArrayElements(env, draws, dr, 0);
+  (*env)->ReleaseDoubleArrayElements(env, mass, mp, rc == RH_OK ? 0 : JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, draws, dr, rc == RH_OK ? 0 : JNI_ABORT);
   (*env)->ReleaseLongArrayElements(env, seeds, sd, JNI_ABORT);
+  if (nn) (*env)->ReleaseDoubleArrayElements(env, rngNextGaussian, nn, JNI_ABORT);
   if (sm) (*env)->ReleaseDoubleArrayElements(env, staticMass, sm, JNI_ABORT);
   (*env)->ReleaseDoubleArrayElements(env, dcfg, dc, JNI_ABORT);
   (*env)->ReleaseIntArrayElements(env, icfg, ic, JNI_ABORT);
-  if (rc != RH_OK) throw_rh(env, m, rc);
+  if (rc != RH_OK) throw_rh(env, ms[0], rc);
+  free(ms);
+}
+
+/* void requirementsEval(byte[] rir, int[] copts, double[] draws, long ndraws, double[] out)   (Trace.predict's compiled part) */
+JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_requirementsEval(
+    JNIEnv *env, jobject self, jbyteArray rir, jintArray copts, jdoubleArray draws, jlong ndraws, jdoubleArray out) {
+  (void)self;
+  if ((*env)->GetArrayLength(env, copts) != RH_JNI_NCOPTS) { throw_msg(env, RH_E_INVALID, "copts has the wrong length"); return; }
+  jbyte *blob = (*env)->GetByteArrayElements(env, rir, NULL);
+  jint *co = (*env)->GetIntArrayElements(env, copts, NULL);
+  rh_compile_opts opts;
+  memset(&opts, 0, sizeof opts);
+  opts.struct_size = (int32_t)sizeof opts;
+  { int i = 0;
+#define X(f) opts.f = co[i++];
+    RH_JNI_COPTS(X)
+#undef X
+  }
+  jdouble *dp = (*env)->GetDoubleArrayElements(env, draws, NULL);
+  jdouble *op = (*env)->GetDoubleArrayElements(env, out, NULL);
+  const int rc = rh_requirements_eval(blob, (size_t)(*env)->GetArrayLength(env, rir), &opts, dp, ndraws, op);
+  (*env)->ReleaseDoubleArrayElements(env, out, op, rc == RH_OK ? 0 : JNI_ABORT);
+  (*env)->ReleaseDoubleArrayElements(env, draws, dp, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, copts, co, JNI_ABORT);
+  (*env)->ReleaseByteArrayElements(env, rir, blob, JNI_ABORT);
+  if (rc != RH_OK) throw_rh(env, NULL, rc);
+}
+
+/* void diagnostics(double[] draws, int chains, int iterations, int nvars, double[] rhat, double[] ess)   (Trace.diagnostics) */
+JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_diagnostics(
+    JNIEnv *env, jobject self, jdoubleArray draws, jint chains, jint iterations, jint nvars, jdoubleArray rhat, jdoubleArray ess) {
+  (void)self;
+  jdouble *dp = (*env)->GetDoubleArrayElements(env, draws, NULL);
+  jdouble *rp = (*env)->GetDoubleArrayElements(env, rhat, NULL);
+  jdouble *ep = (*env)->GetDoubleArrayElements(env, ess, NULL);
+  const int rc = rh_diagnostics(dp, chains, iterations, nvars, rp, ep);
+  (*env)->ReleaseDoubleArrayElements(env, ess, ep, 0);
+  (*env)->ReleaseDoubleArrayElements(env, rhat, rp, 0);
+  (*env)->ReleaseDoubleArrayElements(env, draws, dp, JNI_ABORT);
+  if (rc != RH_OK) throw_rh(env, NULL, rc);
 }

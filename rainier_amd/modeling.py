@@ -10,9 +10,10 @@ It mirrors, name for name, the pieces of rainier-core that sit in front of the h
   Uniform (core/Continuous.scala); Scale / Translate / Exp injections (core/Injection.scala); the Supports
   (core/Support.scala); Bernoulli, Geometric, NegativeBinomial, Poisson, Binomial (core/Discrete.scala, Multinomial.scala);
   Combinatorics (Nemes' log-Gamma); Model.observe (core/Model.scala:52-75); SBC.synthesize / fit (core/SBC.scala:61-69).
-`Real` here is a plain lazy expression tree; lowering to RIR goes through frontend.Graph (hash-consing + reverse-mode AD).
-Like the reference's PartialEvaluator, sub-expressions that depend on the observations but on no parameter are evaluated
-once on the host and become derived data columns; everything that involves a parameter stays un-inlined and is streamed.
+`Real` is rainier-compute's own algebra as restated in compute.py (Line / LogLine normal forms, Gradient on the Real DAG,
+TargetGroup.inlinable + PartialEvaluator.inline, Translator): `Model.compile()` produces the RIR that
+Compiler.compileTargets would hand to the reference's back end for the same model -- including the 8-way split of
+Model.observe (core/Model.scala:71-132) and the compile-time folding of inlinable likelihoods into O(1) targets.
 
 This is a TEST / AUTHORING aid (the product boundary is the C ABI; a JVM deployment keeps Rainier's own front-end).
 Generators take any object with `next_double()` / `next_gaussian()` (java.util.Random semantics): the tests pass the
@@ -25,123 +26,9 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-from .frontend import Graph
+from . import compute as _c
 from . import models as _models
-
-
-# ---------------------------------------------------------------------------------------------------- Real
-class Real:
-    __slots__ = ("op", "args", "val", "density", "_dep")
-
-    def __init__(self, op, args=(), val=None):
-        self.op, self.args, self.val, self.density, self._dep = op, tuple(args), val, None, None
-
-    # -- construction
-    @staticmethod
-    def of(x) -> "Real":
-        return x if isinstance(x, Real) else Real("const", (), float(x))
-
-    @staticmethod
-    def parameter(density: Callable[["Real"], "Real"] = None) -> "Real":
-        """Real.parameter { x => density(x) } (compute/Real.scala): a new sampled parameter and its log-density term."""
-        p = Real("param")
-        p.density = Real.of(density(p)) if density is not None else Real.of(0.0)
-        return p
-
-    @staticmethod
-    def column(values) -> "Real":
-        return Real("col", (), np.ascontiguousarray(values, dtype=np.float64))
-
-    def _b(self, op, o, swap=False):
-        o = Real.of(o)
-        l, r = (o, self) if swap else (self, o)
-        if l.op == "const" and r.op == "const" and op in ("add", "sub", "mul", "div"):   # constants fold (compute/RealOps.scala)
-            with np.errstate(all="ignore"):
-                v = float(_NP[op](np.float64(l.val), np.float64(r.val)))
-            if not math.isnan(v):
-                return Real("const", (), v)
-        return Real(op, (l, r))
-    def __add__(self, o): return self._b("add", o)
-    def __radd__(self, o): return self._b("add", o, True)
-    def __sub__(self, o): return self._b("sub", o)
-    def __rsub__(self, o): return self._b("sub", o, True)
-    def __mul__(self, o): return self._b("mul", o)
-    def __rmul__(self, o): return self._b("mul", o, True)
-    def __truediv__(self, o): return self._b("div", o)
-    def __rtruediv__(self, o): return self._b("div", o, True)
-    def __neg__(self): return self * -1.0
-    def pow(self, o): return self._b("pow", o)
-    def _u(self, op):
-        if self.op == "const":
-            with np.errstate(all="ignore"):
-                v = float(_NP[op](np.float64(self.val)))
-            if not math.isnan(v):
-                return Real("const", (), v)
-        return Real(op, (self,))
-    def exp(self): return self._u("exp")
-    def log(self): return self._u("log")
-    def abs(self): return self._u("abs")
-    @property
-    def logistic(self): return Real.of(1.0) / (Real.of(1.0) + (self * -1.0).exp())   # compute/Real.scala:42
-
-    # Real.eq / gt / gte / lt / lte (compute/Real.scala:83-115): Lookup(Compare(l, r), table, low = -1)
-    @staticmethod
-    def _cmp(l, r, table): return Real("lookup", (Real("cmp", (Real.of(l), Real.of(r))),) + tuple(Real.of(t) for t in table), -1)
-    @staticmethod
-    def eq(l, r, t, f): return Real._cmp(l, r, (f, t, f))
-    @staticmethod
-    def gt(l, r, t, f): return Real._cmp(l, r, (f, f, t))
-    @staticmethod
-    def gte(l, r, t, f): return Real._cmp(l, r, (f, t, t))
-    @staticmethod
-    def sum(xs):
-        xs = list(xs); acc = Real.of(xs[0])
-        for x in xs[1:]:
-            acc = acc + x
-        return acc
-
-    # -- analysis
-    def deps(self):
-        """(depends on a parameter, depends on a data column)"""
-        if self._dep is None:
-            if self.op == "param": self._dep = (True, False)
-            elif self.op == "col": self._dep = (False, True)
-            elif self.op == "const": self._dep = (False, False)
-            else:
-                ds = [a.deps() for a in self.args]
-                self._dep = (any(d[0] for d in ds), any(d[1] for d in ds))
-        return self._dep
-
-
-_NP = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "exp": np.exp, "log": np.log, "abs": np.abs}
-
-
-def evaluate(r: Real, params: Dict[int, object] = None, memo=None):
-    """Numeric value of a Real: floats / numpy arrays; `params` maps id(parameter) -> value (Evaluator, compute/Evaluator.scala)."""
-    memo = {} if memo is None else memo
-    k = id(r)
-    if k in memo:
-        return memo[k]
-    with np.errstate(all="ignore"):
-        if r.op == "const": v = np.float64(r.val)
-        elif r.op == "col": v = r.val
-        elif r.op == "param": v = params[id(r)]
-        elif r.op == "pow":
-            a, b = (evaluate(x, params, memo) for x in r.args); v = np.where(b == 0, 1.0, np.power(a, b))
-        elif r.op == "cmp":
-            a, b = (evaluate(x, params, memo) for x in r.args); v = np.where(a > b, 1.0, np.where(a == b, 0.0, -1.0))
-        elif r.op == "lookup":
-            idx = evaluate(r.args[0], params, memo); tab = [evaluate(x, params, memo) for x in r.args[1:]]
-            k0 = np.trunc(np.nan_to_num(idx)).astype(np.int64) - r.val
-            if np.any((k0 < 0) | (k0 >= len(tab))):
-                raise IndexError("Lookup index out of range")
-            v = tab[0]
-            for j in range(1, len(tab)):
-                v = np.where(k0 == j, tab[j], v)
-        else:
-            v = _NP[r.op](*[evaluate(x, params, memo) for x in r.args])
-    memo[k] = v
-    return v
+from .compute import Bounds, Real, evaluate  # noqa: F401  (Real is rainier-compute's algebra, restated in compute.py)
 
 
 # ---------------------------------------------------------------------------------------------------- RNG
@@ -178,8 +65,8 @@ class Combinatorics:
     @staticmethod
     def gamma(z):
         z = Real.of(z)
-        if z.op == "const" and z.val == 0.0: return Real.of(math.inf)
-        if z.op == "const" and z.val in (1.0, 2.0): return Real.of(0.0)
+        if z == Real.zero: return Real.infinity
+        if z == Real.one or z == Real.two: return Real.zero
         v = z + 1
         w = v + (Real.of(1.0) / ((12 * v) - (Real.of(1.0) / (10 * v))))
         return (Real.of(math.pi * 2).log() / 2) - (v.log() / 2) + (v * (w.log() - 1)) - z.log()
@@ -242,7 +129,7 @@ class _Exped(Continuous):              # Exp, core/Injection.scala:88-110
     def __init__(self, d): self.d = d
     def logDensity(self, y):
         y = Real.of(y)
-        return Real.gt(y, 0.0, self.d.logDensity(y.log()) + y.log() * -1, -math.inf)
+        return Real.gt(y, Real.zero, self.d.logDensity(y.log()) + y.log() * -1, Real.negInfinity)
     def generate(self, rng): return math.exp(self.d.generate(rng))
     @property
     def latent(self): return self.d.latent.exp()
@@ -276,7 +163,7 @@ class _GammaStandard(StandardContinuous):   # core/Continuous.scala:103-147
     def __init__(self, shape): self.shape = Real.of(shape)
     def logDensity(self, x):
         x = Real.of(x)
-        return (self.shape - 1) * x.log() - Combinatorics.gamma(self.shape) - x
+        return Bounds.positive(x, lambda: (self.shape - 1) * x.log() - Combinatorics.gamma(self.shape) - x)
     def generate(self, rng):
         a = _d(self.shape)
         if a < 1:
@@ -307,7 +194,7 @@ class Beta(StandardContinuous):            # :163-189
     def __init__(self, a, b): self.a, self.b = Real.of(a), Real.of(b)
     def logDensity(self, u):
         u = Real.of(u)
-        return (self.a - 1) * u.log() + (self.b - 1) * (1 - u).log() - Combinatorics.beta(self.a, self.b)
+        return Bounds.zeroToOne(u, lambda: (self.a - 1) * u.log() + (self.b - 1) * (1 - u).log() - Combinatorics.beta(self.a, self.b))
     def generate(self, rng):
         z1 = _GammaStandard(self.a).generate(rng); z2 = _GammaStandard(self.b).generate(rng)
         return z1 / (z1 + z2)
@@ -393,104 +280,69 @@ class Binomial(Discrete):                  # :196-232 + Multinomial.scala:17-29
 
 
 # ---------------------------------------------------------------------------------------------------- Model, SBC
-class Model:
-    """core/Model.scala:52-75: a list of (observations, distribution) likelihoods over shared parameters."""
+NumSplits = 8   # core/Model.scala:98
 
-    def __init__(self, likelihoods):
-        self.likelihoods = list(likelihoods)       # [(column Real, per-row log-density Real)]
+
+def _split(ts):
+    """Model.split (core/Model.scala:117-132): an initial chunk + NumSplits equal chunks"""
+    ts = list(ts)
+    splitSize = (len(ts) - 1) // NumSplits
+    initSize = len(ts) - splitSize * NumSplits
+    if splitSize == 0:
+        return ts[:initSize], []
+    return ts[:initSize], [ts[initSize + i * splitSize: initSize + (i + 1) * splitSize] for i in range(NumSplits)]
+
+
+def _column_density(dist, values) -> Real:
+    """Distribution.logDensity(seq) = Vec.from(seq).map(logDensity).columnize (core/Continuous.scala:14): the density of one
+    Column holding the observations"""
+    return dist.logDensity(Real.doubles(values))
+
+
+class Model:
+    """core/Model.scala:7-75: a list of likelihood Reals over shared parameters (+ tracked Reals)."""
+
+    def __init__(self, likelihoods, track=()):
+        self.likelihoods = list(likelihoods)
+        self.track = list(track)
+        self._group = {}
 
     @staticmethod
-    def observe(values: Sequence[float], dist) -> "Model":
-        col = Real.column(values)
-        return Model([(col, dist.logDensity(col))])
+    def observe(values: Sequence[float], dist, split: bool = True) -> "Model":
+        """Model.observe(ys, lh) (core/Model.scala:74-82): the observations are cut into an initial chunk and 8 equal chunks;
+        the model has the likelihoods [lh(init), sum of lh(chunk_i)] -- the second one reads 8 columns per row.
+        split = False: one likelihood over one column (the form the engine streams for the BASELINE configurations)."""
+        if not split:
+            return Model([_column_density(dist, values)])
+        init, splits = _split(values)
+        initReal = _column_density(dist, init)
+        if not splits:
+            return Model([initReal])
+        return Model([initReal, Real.sum([_column_density(dist, sp) for sp in splits])])
 
     def merge(self, other: "Model") -> "Model":
-        return Model(self.likelihoods + other.likelihoods)
+        return Model(self.likelihoods + other.likelihoods, self.track + other.track)
+
+    def targetGroup(self, inline: bool = True) -> "_c.TargetGroup":
+        if inline not in self._group:
+            self._group[inline] = _c.TargetGroup(self.likelihoods, self.track, inline)
+        return self._group[inline]
 
     def parameters(self) -> List[Real]:
-        seen, order = set(), []
-        def walk(r):
-            if id(r) in seen:
-                return
-            seen.add(id(r))
-            for a in r.args:
-                walk(a)
-            if r.op == "param":
-                order.append(r)
-                walk(r.density)
-        for _, e in self.likelihoods:
-            walk(e)
-        return order
+        return self.targetGroup().parameters
 
-    def compile(self, name: str = "model") -> "_models.ModelSpec":
-        """Lower to RIR: target 0 = prior (sum of the parameters' density terms), then one streamed target per likelihood.
-        Data-only sub-expressions become derived columns (what PartialEvaluator folds on the JVM)."""
-        params = self.parameters()
-        index = {id(p): i for i, p in enumerate(params)}
-        plans, columns, nrows = [], [], [0]
+    def compile(self, name: str = "model", inline: bool = True) -> "_models.ModelSpec":
+        """Model.dataFn = Compiler.default.compileTargets(targetGroup) (core/Model.scala:32-34), with the HIP serialiser in
+        place of the ASM back end: target 0 = "prior", then one target per likelihood, outputs = value :: gradient.
+        inline = False skips PartialEvaluator.inline so that every likelihood is streamed over its rows."""
+        rir, columns, rows, n = _c.to_rir(self.targetGroup(inline))
+        return _models.ModelSpec(name, rir, columns, rows, n, {"kind": "modeling", "inline": inline})
 
-        def make_derive(n):
-            cols: List[np.ndarray] = []
-            slot: Dict[int, int] = {}
-
-            def derive(r):
-                if id(r) not in slot:
-                    v = np.broadcast_to(np.asarray(evaluate(r), dtype=np.float64), (n,))
-                    slot[id(r)] = len(cols); cols.append(np.ascontiguousarray(v))
-                return slot[id(r)]
-            return derive, cols
-        for col, expr in self.likelihoods:
-            derive, cols = make_derive(len(col.val))
-            plans.append((expr, derive, cols)); nrows.append(len(col.val))
-        # first pass: find the derived columns of every target (needed before the Graph can be sized)
-        def scan(r, derive, seen):
-            if id(r) in seen:
-                return
-            seen.add(id(r))
-            hp, hd = r.deps()
-            if hd and not hp:
-                derive(r); return
-            for a in r.args:
-                scan(a, derive, seen)
-        for expr, derive, cols in plans:
-            scan(expr, derive, set())
-        g = Graph(len(params), [0] + [len(c) for _, _, c in plans])
-        memo: Dict[tuple, object] = {}
-        def lower(r, t, derive):
-            key = (id(r), t)
-            if key in memo:
-                return memo[key]
-            hp, hd = r.deps()
-            if hd and not hp:
-                e = g.col(t, derive(r))
-            elif r.op == "const": e = g.const(r.val)
-            elif r.op == "param": e = g.param(index[id(r)])
-            else:
-                a = [lower(x, t, derive) for x in r.args]
-                if r.op == "add": e = a[0] + a[1]
-                elif r.op == "sub": e = a[0] - a[1]
-                elif r.op == "mul": e = a[0] * a[1]
-                elif r.op == "div": e = a[0] / a[1]
-                elif r.op == "pow": e = a[0] ** a[1]
-                elif r.op == "cmp": e = a[0].compare(a[1])
-                elif r.op == "exp": e = a[0].exp()
-                elif r.op == "log": e = a[0].log()
-                elif r.op == "abs": e = a[0].abs()
-                elif r.op == "lookup": e = g.lookup(a[0], a[1:], r.val)
-                else: raise ValueError(r.op)
-            memo[key] = e
-            return e
-        prior = g.sum([lower(p.density, 0, None) for p in params]) if params else g.const(0.0)
-        targets = [prior] + [lower(expr, t + 1, derive) for t, (expr, derive, cols) in enumerate(plans)]
-        for _, _, cols in plans:
-            columns.extend(cols)
-        return _models.ModelSpec(name, g.compile(targets), columns, nrows, len(params), {"kind": "modeling"})
-
-    def predict(self, real: Real, draws: np.ndarray) -> np.ndarray:
+    def predict(self, real, draws: np.ndarray) -> np.ndarray:
         """Trace.predict(real) for draws [..., nVars] (host evaluation of the tracked Real)."""
         params = self.parameters()
         d = np.asarray(draws, dtype=np.float64)
-        return np.asarray(evaluate(Real.of(real), {id(p): d[..., i] for i, p in enumerate(params)}))
+        return np.asarray(evaluate(Real.of(real), {p: d[..., i] for i, p in enumerate(params)}))
 
 
 class SBC:
@@ -505,6 +357,6 @@ class SBC:
         dist = self.fn(*[Real.of(t) for t in truth])
         return [dist.generate(rng) for _ in range(samples)], truth[0]
 
-    def fit(self, values):
+    def fit(self, values, split: bool = True):
         latents = [p.latent for p in self.priors]
-        return Model.observe(values, self.fn(*latents)), latents[0]
+        return Model.observe(values, self.fn(*latents), split), latents[0]

@@ -1,6 +1,7 @@
-/* tests/stubs/jni.h -- NOT the JDK's jni.h: a declaration-only stand-in with exactly the JNI entry points that
- * rainier_amd/jni/rainier_hip_jni.c uses, so that the shim can be syntax- and type-checked in an image without a JDK
- * (tests/test_capi_cpu.py::test_jni_shim_typechecks).  Signatures follow the JNI specification (jni.h, JNINativeInterface_). */
+/* tests/stubs/jni.h -- NOT the JDK's jni.h: a stand-in with exactly the JNI entry points that
+ * rainier_amd/jni/rainier_hip_jni.c uses, so that the shim can be compiled in an image without a JDK and executed against
+ * tests/stubs/fake_jni.c (tests/test_jni_shim.py).  Signatures follow the JNI specification (jni.h, JNINativeInterface_);
+ * the real table has ~230 slots, the shim only ever reaches these through the JNIEnv, so the layout difference is moot here. */
 #ifndef RH_STUB_JNI_H
 #define RH_STUB_JNI_H
 #include <stdint.h>
@@ -10,6 +11,7 @@ typedef struct _jobject *jobject;
 typedef jobject jclass, jarray, jobjectArray, jbyteArray, jintArray, jlongArray, jdoubleArray, jthrowable;
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
+#define JNI_COMMIT 1
 #define JNI_ABORT 2
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_ *JNIEnv;

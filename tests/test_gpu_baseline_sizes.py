@@ -41,7 +41,8 @@ def _check_tiled(spec, model, distinct, chains, seed, tol, label):
         ref, ab = d.update_both(qq)
         bound = tol * ab + 1e-300
         rows = got[idx == j]
-        assert len(rows) > 0
+        if len(rows) == 0:          # fewer chains than distinct vectors
+            continue
         assert np.all(rows == rows[0]), (label, j, "chains with identical q disagree: the reduction is not fixed-order")
         err = np.abs(rows[0] - ref) / bound
         worst = max(worst, float(err.max()))

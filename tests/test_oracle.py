@@ -272,3 +272,54 @@ def test_closed_form_speed_build_matches_interpreter(oracle):
     th = np.array([-0.3, 0.5, 1.0, -2.0, 0.5]); out = np.zeros(6); c = spec.columns
     oracle.orc_linreg_streamed(O._dp(c[0]), O._dp(c[1]), O._dp(c[2]), O._dp(c[3]), len(c[0]), O._dp(th), O._dp(out))
     np.testing.assert_allclose(out, O.OracleDensity(spec).update(th), rtol=1e-11)
+
+
+def test_nuts_checkpoint_bookkeeping_equals_the_recursive_tree(oracle):
+    """f2 cross-validation.  NUTS does not exist in the reference, so the iterative multinomial NUTS
+    of oracle/sampler.c:nuts_iteration (and with it the device automaton, which is compared bit for bit with it on the
+    GPU) is pinned against a SECOND, independent statement of the transition: nuts_iteration_recursive builds the same
+    tree the Hoffman-Gelman / Stan way (recursive halves, node = (first r, last r, sum r), no checkpoints, no leaf-index
+    arithmetic).  Same uniforms, same leapfrog states => the same leaf must be selected and the trajectory must stop at
+    the same leaf: whole chains identical, leapfrog counts identical, over > 1e4 trajectories that include divergences,
+    max-depth saturation (depths 1..12), identity / adapted diagonal / static mass."""
+    NUTS_REC = 3
+    total = 0
+    cases = [
+        (models.funnel(10), dict(iterations=1500, warmup=300, nuts_max_depth=10), [1, 2]),
+        (models.eight_schools(), dict(iterations=1500, warmup=400, mass_tuner=O.MASS_DIAG_WINDOWED, nuts_max_depth=10), [3, 4]),
+        (models.normal_1d(), dict(iterations=800, warmup=100, nuts_max_depth=12), [5]),
+        # saturation: a tiny static step never turns -> every trajectory runs to max depth (2^d - 1 leaves)
+        (models.normal_1d(), dict(iterations=12, warmup=0, step_tuner=O.STEP_STATIC, static_step=1e-5, nuts_max_depth=12), [6]),
+        (models.funnel(10), dict(iterations=60, warmup=0, step_tuner=O.STEP_STATIC, static_step=1e-4, nuts_max_depth=7), [7]),
+        (models.eight_schools(), dict(iterations=300, warmup=0, step_tuner=O.STEP_STATIC, static_step=0.02, nuts_max_depth=1), [8]),
+        (models.eight_schools(), dict(iterations=300, warmup=0, step_tuner=O.STEP_STATIC, static_step=0.05, nuts_max_depth=3), [9]),
+        # divergences: a huge static step on the heavy-tailed eight-schools posterior / the 1-d normal
+        (models.eight_schools(), dict(iterations=600, warmup=0, step_tuner=O.STEP_STATIC, static_step=6.0, nuts_max_depth=10), [10, 11]),
+        (models.normal_1d(), dict(iterations=600, warmup=0, step_tuner=O.STEP_STATIC, static_step=60.0, nuts_max_depth=10), [12]),
+        (models.eight_schools(), dict(iterations=500, warmup=0, step_tuner=O.STEP_STATIC, static_step=0.3, nuts_max_depth=10,
+                                      mass_tuner=O.MASS_STATIC_DIAG, static_mass=np.linspace(0.3, 3.0, 10)), [13]),
+        (models.linreg(n=200, k=3), dict(iterations=600, warmup=300, mass_tuner=O.MASS_DIAG_WINDOWED, nuts_max_depth=10), [14]),
+    ]
+    depth_seen = set()
+    for spec, kw, seeds in cases:
+        for seed in seeds:
+            a = O.make_config(sampler=O.NUTS, math_mode=O.JM_DET, **kw)
+            b = O.make_config(sampler=NUTS_REC, math_mode=O.JM_DET, **kw)
+            da, ma, sa = O.sample_model(spec, a, seed)
+            db, mb, sb = O.sample_model(spec, b, seed)
+            assert np.array_equal(da, db, equal_nan=True), (spec.name, kw, seed)
+            assert np.array_equal(ma, mb)
+            assert sa.leapfrog_steps == sb.leapfrog_steps and sa.warmup_leapfrog_steps == sb.warmup_leapfrog_steps
+            assert sa.mean_accept_prob == sb.mean_accept_prob and sa.step_size == sb.step_size
+            total += kw["iterations"] + kw["warmup"]
+            if kw["iterations"]:
+                depth_seen.add(round(np.log2(sa.leapfrog_steps / kw["iterations"] + 1), 1))
+    assert total >= 10000
+    # the saturation cases really ran full trees (2^12 - 1 and 2^7 - 1 leaves per iteration) ...
+    a = O.make_config(sampler=O.NUTS, math_mode=O.JM_DET, iterations=12, warmup=0, step_tuner=O.STEP_STATIC, static_step=1e-5, nuts_max_depth=12)
+    _, _, st = O.sample_model(models.normal_1d(), a, 6)
+    assert st.leapfrog_steps == 12 * (2 ** 12 - 1)
+    # ... and the divergent ones really diverged early (mean acceptance far below the target, short trees)
+    a = O.make_config(sampler=O.NUTS, math_mode=O.JM_DET, iterations=600, warmup=0, step_tuner=O.STEP_STATIC, static_step=60.0, nuts_max_depth=10)
+    _, _, st = O.sample_model(models.normal_1d(), a, 12)
+    assert st.mean_accept_prob < 0.2 and st.leapfrog_steps < 600 * 8
