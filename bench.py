@@ -7,9 +7,11 @@
            1024 chains per GPU, DualAvgTuner(0.8), identity mass, chain seeds 1000 + global chain id.
   step   : one HMC iteration of every chain = 32 leapfrog steps x chains x 1e6 rows.
   --warmup W : W sampler warm-up iterations (step-size search + dual averaging), untimed.
-  N > 1  : one process per GPU (torch.distributed / RCCL); chains sharded by global id (weak scaling: 1024 per GPU),
-           data replicated, no collective on the data path; ONE all-gather of the draws over xGMI at the end,
-           inside the timed region.
+  N > 1  : one process per GPU (launched by torch.distributed.run); chains sharded by global id (weak scaling: 1024 per
+           GPU), data replicated, no collective on the data path; ONE RCCL all-gather of the device-resident draws over
+           xGMI at the end, inside the timed region, issued by the engine behind its C ABI (rh_comm_*).  torch.distributed is
+           used with the gloo (CPU) backend only: to hand rank 0's RCCL unique id to the other ranks and for the barriers --
+           torch never initialises its own bundled HIP runtime beside the engine's.
 
 Synthetic data (numpy default_rng(20260925)); inputs resident in HBM before the timed region starts.
 """
@@ -140,25 +142,25 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     s = R.Sampler(model, cfg, D.shard_seeds(2000, cpg, rank))
     t0 = time.perf_counter(); s.warmup(); tw = time.perf_counter() - t0
     s.timing(reset=True)
-    if dist is not None:
-        import torch
-        dist.barrier(); torch.cuda.synchronize()
+    comm = dist
+    if comm is not None:
+        comm.barrier(); D.device_synchronize(local_rank)
     t0 = time.perf_counter()
     s.run(a.steps)
     gathered = None
-    if dist is not None:
-        gathered = D.gather_draws_from_device(s.draws_device_ptr(), (cpg, a.steps, spec.n_params), world)
-        torch.cuda.synchronize()
+    if comm is not None:
+        gathered = comm.rccl.allgather_draws(s)          # RCCL all-gather over xGMI + copy to the host
+        D.device_synchronize(local_rank)
     dt = time.perf_counter() - t0
     stats, _ = s.stats()
     counts = [float(sum(st.leapfrogSteps for st in stats)), float(sum(st.warmupLeapfrogSteps for st in stats))]
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        cnt = torch.tensor(counts, dtype=torch.float64, device="cuda"); dist.all_reduce(cnt); counts = cnt.tolist()
+    if comm is not None:
+        dt = comm.rccl.allreduce_max(dt)
+        counts = comm.sum(counts)
     if rank != 0:
         return
     steps, wsteps = counts
-    draws = gathered.cpu().numpy() if gathered is not None else s.draws()
+    draws = gathered if gathered is not None else s.draws()
     nshow = min(spec.n_params, 16)
     ess = min(e for _, e in R.diagnostics(draws[:, :, :nshow])) if a.steps >= 4 and draws.shape[0] >= 2 else None
     tim = s.timing()
@@ -210,20 +212,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import rainier_amd as R
+    from rainier_amd import _capi, models
+    from rainier_amd import distributed as D
+    _capi.lib()                     # the engine (system ROCm runtime) is loaded BEFORE torch: one HIP runtime per process
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: exercise the RCCL path
-        os.environ["NCCL_DEBUG"] = "WARN"   # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import rainier_amd as R
-    from rainier_amd import models
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+        dist = HostGroup(rank, world, local_rank, D)
     if a.workload != "cfg2":
         side_workload(a, R, models, rank, local_rank, world, dist)
         if dist is not None:
-            dist.destroy_process_group()
+            dist.close()
         return
 
     K, W, L = a.steps, a.warmup, a.leapfrog
@@ -232,7 +232,6 @@ def main():
                     grad_chains=a.grad_chains, grad_unroll=a.grad_unroll,
                     factor_outputs=not (a.strict or a.no_factor))
     cpg = a.chains_per_gpu
-    from rainier_amd import distributed as D
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
     engine = {"auto": 0, "chain": 1, "tick": 2}[a.engine]
 
@@ -246,21 +245,18 @@ def main():
         s.timing(reset=True)
         gathered = None
         if dist is not None:
-            import torch
-            dist.barrier(); torch.cuda.synchronize()
+            dist.barrier(); D.device_synchronize(local_rank)
         t0 = time.perf_counter()
         s.run(iters)                    # synchronises the engine stream
         if dist is not None:
-            gathered = D.gather_draws_from_device(s.draws_device_ptr(), (cpg, iters, spec.n_params), world)   # RCCL all-gather over xGMI
-            torch.cuda.synchronize()
+            gathered = dist.rccl.allgather_draws(s)      # the ONE collective: RCCL all-gather over xGMI (+ copy to the host)
+            D.device_synchronize(local_rank)
         dt = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+            dt = dist.rccl.allreduce_max(dt)             # max over ranks
         tim = s.timing()
         stats, _ = s.stats()
-        draws = (gathered.cpu().numpy() if rank == 0 else None) if gathered is not None else s.draws()
+        draws = (gathered if rank == 0 else None) if gathered is not None else s.draws()
         s.close()
         return dt, draws, stats, tim
 
@@ -277,7 +273,7 @@ def main():
         ess_dt, ess_draws, ess_stats, _ = leg(ess_iters, ess_warm)
     if rank != 0:
         if dist is not None:
-            dist.destroy_process_group()
+            dist.close()
         return
 
     rows = spec.rows_streamed
@@ -342,7 +338,33 @@ def main():
         out["cpu_baseline"] = cpu_baseline(spec, L)
     print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.close()
+
+
+class HostGroup:
+    """The host side of an N > 1 run: a torch.distributed *gloo* group (CPU only) for the bootstrap of the engine's RCCL
+    communicator, the barriers and tiny host reductions; `rccl` is the engine's communicator (rh_comm)."""
+
+    def __init__(self, rank, world, local_rank, D):
+        mine = D.Comm.unique_id()       # every rank: loads the system RCCL now, BEFORE torch brings its bundled copy
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        dist.init_process_group("gloo")
+        uid = D.exchange_unique_id(dist, lambda: mine, rank)
+        self.rccl = D.Comm(uid, world, rank, local_rank)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def sum(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64)
+        self.dist.all_reduce(t)
+        return t.tolist()
+
+    def close(self):
+        self.rccl.close()
+        self.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define RH_ABI_VERSION 3  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
-                             3: rh_density_eval_ex, rh_sample_multi, rh_compile_opts.reserved -> device-independent */
+                             3: rh_density_eval_ex, rh_sample_multi, rh_comm_* (RCCL all-gather of the draws) */
 
 enum rh_status {
   RH_OK = 0,
@@ -179,6 +179,25 @@ int rh_sample(rh_model *m, const rh_config *cfg, const int64_t *seeds, int32_t c
  * instead; both forms shard by global chain id.)  Replaces the loop  core/Model.scala:16-22. */
 int rh_sample_multi(rh_model *const *models, int32_t n_models, const rh_config *cfg, const int64_t *seeds, int32_t chains,
                     double *draws, double *mass_diag, rh_chain_stats *stats);
+
+/* Multi-PROCESS multi-GPU (one process per device -- what `torch.distributed.run`, MPI or one JVM per GPU give): every
+ * rank samples its own shard of the chains (seeds by GLOBAL chain id; no collective on the data path) with rh_sampler_* and
+ * the device-resident draws are gathered ONCE with an RCCL all-gather over xGMI.  RCCL is loaded with dlopen on first use;
+ * without it these calls return RH_E_UNSUPPORTED.  Bootstrap: rank 0 calls rh_comm_unique_id and hands the 128 bytes to the
+ * other ranks by whatever channel the host program has; all ranks then call rh_comm_create (collective). */
+#define RH_COMM_ID_BYTES 128
+typedef struct rh_comm rh_comm;
+int rh_comm_unique_id(unsigned char id[RH_COMM_ID_BYTES]);
+int rh_comm_create(const unsigned char id[RH_COMM_ID_BYTES], int32_t world, int32_t rank, int32_t device, rh_comm **out);
+void rh_comm_destroy(rh_comm *c);
+/* collective: gathers every rank's draws ([chains][iterations][nvars], equal on all ranks) into [world * chains][...],
+ * rank-major == global chain id order.  host_out (may be NULL): caller-allocated host buffer; *dev_out (may be NULL): device
+ * pointer of the gathered buffer, owned by the communicator (valid until the next gather or rh_comm_destroy). */
+int rh_comm_allgather_draws(rh_comm *c, rh_sampler *s, double *host_out, void **dev_out);
+/* collective: *value = max over ranks (the timing reduction of a benchmark; doubles as a device-side barrier) */
+int rh_comm_allreduce_max(rh_comm *c, double *value);
+/* hipDeviceSynchronize on `device` (for hosts that never touch the HIP runtime themselves) */
+int rh_device_synchronize(int32_t device);
 
 /* The same, split so that a caller can keep draws on the device, poll progress (sampler/Progress.scala)
  * and time phases.  Typical use: create -> warmup -> run(iterations) -> read stats -> destroy. */

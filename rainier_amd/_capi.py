@@ -28,6 +28,7 @@ EXPORTS = [
     "rh_density_eval", "rh_density_eval_ex", "rh_config_default", "rh_sample", "rh_sample_multi", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
     "rh_sampler_timing", "rh_sampler_progress", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
+    "rh_comm_unique_id", "rh_comm_create", "rh_comm_destroy", "rh_comm_allgather_draws", "rh_comm_allreduce_max", "rh_device_synchronize",
 ]
 
 
@@ -102,6 +103,12 @@ def lib():
     L.rh_sampler_progress.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rh_diagnostics.argtypes = [dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
     L.rh_requirements_eval.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), dp, C.c_int64, dp]
+    L.rh_comm_unique_id.argtypes = [C.c_char_p]
+    L.rh_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.rh_comm_destroy.argtypes = [vp]
+    L.rh_comm_allgather_draws.argtypes = [vp, vp, dp, C.POINTER(vp)]
+    L.rh_comm_allreduce_max.argtypes = [vp, dp]
+    L.rh_device_synchronize.argtypes = [C.c_int32]
     L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.rh_free.argtypes = [vp]
     L.rh_simplify_rir.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]

@@ -1299,24 +1299,40 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #ifndef RH_GLM_ELEM_UNROLL
 #define RH_GLM_ELEM_UNROLL 4
 #endif
+        // full tiles of a wavefront whose 16 chains all exist need no validity masks (the common case by far)
+        const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 16 <= chains);
+        if (full) {
 #pragma unroll RH_GLM_ELEM_UNROLL
-        for (int r = 0; r < 4; r++) {
-          const int rrow = row0s + lg + 4 * r;
-          const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
-          double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-          GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
-          Wv[r] = valid ? w : 0.0;
+          for (int r = 0; r < 4; r++) {
+            const int rrow = row0s + lg + 4 * r;
+            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+            GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            Wv[r] = w;
 #pragma unroll
-          for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
+            for (int k = 0; k < GL::NOTHER; k++) oth[k] += o[k];
+          }
+        } else {
+#pragma unroll RH_GLM_ELEM_UNROLL
+          for (int r = 0; r < 4; r++) {
+            const int rrow = row0s + lg + 4 * r;
+            const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
+            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+            GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            Wv[r] = valid ? w : 0.0;
+#pragma unroll
+            for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
+          }
         }
 #pragma unroll
         for (int k = 0; k < RV; k++)
 #pragma unroll
           for (int r = 0; r < 4; r++) Gv[k] += xv[k][r] * Wv[r];
+        // backward: k-step outermost, so that consecutive MFMAs write DIFFERENT accumulator tiles (a dependent MFMA would wait
+        // for the previous one to drain)
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++)
+        for (int sstep = 0; sstep < 4; sstep++)
 #pragma unroll
-          for (int sstep = 0; sstep < 4; sstep++) {
+          for (int ct = 0; ct < CT; ct++) {
             const int rr = row0s + 4 * sstep + lg;
             const double a = bcol[ct] >= 0 ? tile[bcol[ct] * RH_GLM_TRP + rr] : (bcol[ct] == -1 ? 1.0 : 0.0);
             G[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Wv[sstep], G[ct], 0, 0, 0);
@@ -1828,7 +1844,7 @@ RH_UNROLL_SLOTS
 // Device self-test of the bit-exact pieces: mode 0 = n gaussians of ScalaRNG(seed), 1 = n uniforms,
 // 2 = strict log, 3 = strict exp, 4 = sqrt, 5 = a/b (in[2i], in[2i+1]), 6 = t^-0.75, 7 = fast-mode log,
 // and of the functions generated model code calls for the remaining IR ops (ir/MethodGenerator.scala:66-93):
-// 8 = sin, 9 = cos, 10 = tan, 11 = asin, 12 = acos, 13 = atan, 14 = Math.pow (in[2i], in[2i+1]), 15 = abs, 16 = fast-mode exp
+// 8 = sin, 9 = cos, 10 = tan, 11 = asin, 12 = acos, 13 = atan, 14 = Math.pow (in[2i], in[2i+1]), 15 = abs, 16 = fast-mode exp, 17 / 18 = rh_logit_link's softplus / sigmoid
 extern "C" __global__ void __launch_bounds__(64)
 rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__ in, double *__restrict__ out, const int n) {
   const int lane = threadIdx.x;
@@ -1855,6 +1871,7 @@ rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__
       else if (mode == 14) v = rh_java_pow(in[2 * i], in[2 * i + 1]);
       else if (mode == 15) v = __builtin_fabs(in[i]);
       else if (mode == 16) v = exp(in[i]);
+      else if (mode == 17 || mode == 18) { double sp, sg; rh_logit_link(in[i], sp, sg); v = mode == 17 ? sp : sg; }
       else v = rh_pow_neg075(in[i]);
       out[i] = v;
     }

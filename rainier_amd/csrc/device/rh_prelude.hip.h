@@ -149,6 +149,65 @@ RH_DEV double rh_strict_exp(double x) {
   return y * twom1000;
 }
 
+// ---- fast mode: softplus(t) = log(1 + e^t) and sigmoid(t) = 1 / (1 + e^-t) from ONE exponential ----------------------------
+// (the closed form of a Bernoulli-logit likelihood term and of its adjoint, see emit.cpp detect_logit).
+//   u = e^{-|t|} in (0, 1]   (never overflows; underflows to 0 for |t| > 745, where softplus = max(t, 0) and sigmoid = 0 / 1 exactly)
+//   d = 1 + u in (1, 2],  r = 1 / d
+//   sigmoid(t)  = t >= 0 ? r : u r
+//   softplus(t) = max(t, 0) + log1p(u),  log1p by fdlibm's log kernel on f = u (or (1 + u)/2 - 1 and + ln 2 when 1 + u > sqrt 2):
+//                 z = f / (2 + f), log(1 + f) = f - f^2/2 + z (f^2/2 + R(z^2))   (e_log.c, the Lg1..Lg7 minimax polynomial)
+// Both results are within 3 ulp of the exact values over the whole range (host model of this code: 2.1 / 2.7 ulp;
+// tests/test_gpu_parity.py asserts it on the device); the two divisions are v_rcp_f64 + two Newton steps (operands in [1, 3]:
+// no scaling, no special cases).
+RH_DEV double rh_rcp_1to4(double d) {          // 1/d for d in [1, 4]: reciprocal estimate + 2 Newton-Raphson steps
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
+RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
+  const double at = __builtin_fabs(t);
+  // e^{-|t|}: k = round(x / ln 2), r = x - k ln 2 in [-0.347, 0.347], degree-13 Taylor polynomial, scale by 2^k.
+  // x = max(-|t|, -800): e^{-800} is exactly 0 in fp64 (v_ldexp_f64 underflows gradually and correctly down to it)
+  const double x = __builtin_fmax(-at, -800.0);
+  const double kf = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, x);
+  r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);
+  double p = 0x1.6124613a86d09p-33;                       // 1/13!
+  p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);         // 1/12!
+  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);         // 1/11!
+  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);         // 1/10!
+  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);         // 1/9!
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);         // 1/8!
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);         // 1/7!
+  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);         // 1/6!
+  p = __builtin_fma(p, r, 0x1.1111111111111p-7);          // 1/5!
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);          // 1/4!
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);          // 1/3!
+  p = __builtin_fma(p, r, 0x1p-1);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const double u = __builtin_ldexp(p, (int)kf);            // v_ldexp_f64: correct gradual underflow
+  const double d = 1.0 + u;
+  const double rd = rh_rcp_1to4(d);
+  const double sg = t >= 0.0 ? rd : u * rd;
+  // log(1 + u) = log1p(u): f is taken from u itself, not from d - 1, so nothing is lost when u is tiny
+  const bool hi = u > 0x1.a827999fcef34p-2;                // 1 + u > sqrt 2: halve the argument, f = (1 + u) / 2 - 1
+  const double f = hi ? __builtin_fma(u, 0.5, -0.5) : u;
+  const double z = f * rh_rcp_1to4(2.0 + f);
+  const double z2 = z * z, z4 = z2 * z2;
+  const double t1 = z4 * __builtin_fma(z4, __builtin_fma(z4, 0x1.39a09d078c69fp-3, 0x1.c71c51d8e78afp-3), 0x1.999999997fa04p-2);
+  const double t2 = z2 * __builtin_fma(z4, __builtin_fma(z4, __builtin_fma(z4, 0x1.2f112df3e5244p-3, 0x1.7466496cb03dep-3), 0x1.2492494229359p-2),
+                                      0x1.5555555555593p-1);
+  const double R = t1 + t2, hfsq = 0.5 * f * f;
+  const double lg = (f - (hfsq - z * (hfsq + R))) + (hi ? 0x1.62e42fefa39efp-1 : 0.0);   // + ln 2 in the halved branch
+  // max(t, 0) as (t + |t|) / 2: exact for finite t and, unlike a max instruction, it propagates NaN
+  // A NaN t (a diverged chain) reaches the caller through softplus -- the VALUE, hence the energy, is NaN and the proposal is
+  // rejected (LeapFrog.scala:138-142); sigmoid is then finite garbage that is never used (the clamp above drops the NaN).
+  softplus = __builtin_fma(0.5, t + at, lg);
+  sigmoid = sg;
+}
+
 RH_DEV double rh_strict_sqrt(double x) { return __builtin_sqrt(x); } // IEEE correctly rounded (checked by tests)
 // Math.pow(t, -0.75) for the dual-averaging decay, t a positive integer: sqrt-composed, bit-reproducible
 RH_DEV double rh_pow_neg075(double t) { const double r = rh_strict_sqrt(t); return 1.0 / (r * rh_strict_sqrt(r)); }

@@ -474,6 +474,106 @@ struct TargetEmitter {
     glm.ok = true;
   }
 
+  // ---- fast mode: the scalar part of a Bernoulli-logit GLM in closed form ------------------------------------------------
+  // The reference writes the logistic likelihood naively -- p = 1 / (1 + exp(-eta)), Bernoulli.logDensity =
+  // Real.eq(y, 0, log(1 - p), log p) (core/Discrete.scala:38-52, compute/Real.scala:42) -- and differentiates it symbolically
+  // (compute/Gradient.scala), which leaves one exp, one log, three divisions and several selects per row-chain evaluation:
+  // ~190 VALU instructions, more than the two dense contractions around them.  Mathematically the pair is
+  //       value = -softplus(s * eta),   w = d value / d eta = -s * sigmoid(s * eta),   s = +1 if y == c else -1  (or the reverse)
+  // and in that form it costs one exp, one reciprocal and one short log series (rh_logit_link).  The rewrite is VERIFIED, not
+  // pattern-matched on the differentiated DAG: the shape requirements below make the scalar part a function of (eta, one data
+  // column) alone, the candidate is fixed by the value at two probe points, and both value AND w of the original DAG
+  // must agree with the closed form (1e-8 relative: the naive form itself loses digits through 1 - p) at 15 eta in [-12, 12]
+  // x 5 values of y, evaluated here on the host.  Anything that does not verify keeps its literal lowering.  Fast mode only:
+  // strict builds keep the reference's arithmetic operation for operation.
+  struct Logit { bool ok = false; int ycol = -1; double c = 0.0, s_hit = 1.0, s_miss = -1.0; } logit;
+
+  double host_eval(uint32_t id, double eta, int ycol, double yv, std::map<uint32_t, double> &memo, bool &bad) const {
+    if (id == glm.L) return eta;
+    auto it = memo.find(id);
+    if (it != memo.end()) return it->second;
+    const Node &nd = P.nodes[id];
+    auto E = [&](uint32_t x) { return host_eval(x, eta, ycol, yv, memo, bad); };
+    double v = 0.0;
+    switch (nd.op) {
+      case RH_RIR_CONST: v = nd.cval; break;
+      case RH_RIR_INPUT:
+        if (nd.input >= P.n_params && (int)(nd.input - P.targets[t].input_start) == ycol) v = yv; else { bad = true; v = 0.0; }
+        break;
+      case RH_RIR_ADD: v = E(nd.a) + E(nd.b); break;
+      case RH_RIR_SUB: v = E(nd.a) - E(nd.b); break;
+      case RH_RIR_MUL: v = E(nd.a) * E(nd.b); break;
+      case RH_RIR_DIV: v = E(nd.a) / E(nd.b); break;
+      case RH_RIR_POW: v = std::pow(E(nd.a), E(nd.b)); break;
+      case RH_RIR_COMPARE: { const double l = E(nd.a), r = E(nd.b); v = l > r ? 1.0 : (l == r ? 0.0 : -1.0); break; }
+      case RH_RIR_EXP: v = std::exp(E(nd.a)); break;
+      case RH_RIR_LOG: v = std::log(E(nd.a)); break;
+      case RH_RIR_ABS: v = std::fabs(E(nd.a)); break;
+      case RH_RIR_NOOP: v = E(nd.a); break;
+      case RH_RIR_SEQ: (void)E(nd.a); v = E(nd.b); break;
+      case RH_RIR_LOOKUP: {
+        const double ix = E(nd.a);
+        const long long k = (ix != ix ? 0LL : (long long)ix) - (long long)nd.low;
+        for (uint32_t e : nd.table) (void)E(e);
+        if (k < 0 || k >= (long long)nd.table.size()) { bad = true; v = 0.0; } else v = E(nd.table[(size_t)k]);
+        break;
+      }
+      default: bad = true;  // trigonometric nodes do not occur in a logit link
+    }
+    memo[id] = v;
+    return v;
+  }
+
+  void detect_logit() {
+    if (!glm.ok || !fast_div || !glm.thu.empty() || glm.others.size() != 1 || !glm.inv_nodes.empty()) return;
+    // the scalar part may read exactly one data column, and compares it with exactly one constant
+    int ycol = -1; double c = 0.0; bool have_c = false;
+    for (uint32_t n : glm.elem_nodes) {
+      const Node &nd = P.nodes[n];
+      std::vector<uint32_t> ops; operands(nd, ops);
+      for (uint32_t o : ops) {
+        const Node &on = P.nodes[o];
+        if (on.op == RH_RIR_INPUT && on.input >= P.n_params) {
+          const int col = (int)(on.input - P.targets[t].input_start);
+          if (ycol >= 0 && col != ycol) return;
+          ycol = col;
+          if (nd.op != RH_RIR_COMPARE || o != nd.a || P.nodes[nd.b].op != RH_RIR_CONST) return;  // the column only feeds compare(y, const)
+          if (have_c && P.nodes[nd.b].cval != c) return;
+          c = P.nodes[nd.b].cval; have_c = true;
+        }
+      }
+    }
+    if (ycol < 0 || !have_c || !std::isfinite(c)) return;
+    auto original = [&](double eta, double yv, double &val, double &w) -> bool {
+      std::map<uint32_t, double> memo; bool bad = false;
+      val = host_eval(glm.others[0].first, eta, ycol, yv, memo, bad);
+      w = host_eval(glm.w, eta, ycol, yv, memo, bad);
+      return !bad;
+    };
+    auto softplus = [](double x) { return x > 0 ? x + std::log1p(std::exp(-x)) : std::log1p(std::exp(x)); };
+    auto sigmoid = [](double x) { return x >= 0 ? 1.0 / (1.0 + std::exp(-x)) : std::exp(x) / (1.0 + std::exp(x)); };
+    // fix the signs from one probe per branch: value(eta = 1) is -softplus(1) = -1.3133 or -softplus(-1) = -0.3133
+    double s[2];
+    for (int b = 0; b < 2; b++) {
+      double val, w;
+      if (!original(1.0, b == 0 ? c : c + 1.0, val, w)) return;
+      if (std::fabs(val + softplus(1.0)) < 1e-9) s[b] = 1.0;
+      else if (std::fabs(val + softplus(-1.0)) < 1e-9) s[b] = -1.0;
+      else return;
+    }
+    static const double etas[] = {-12.0, -7.3, -3.1, -1.7, -0.9, -0.31, -1e-3, 0.0, 1e-3, 0.22, 0.8, 1.9, 3.7, 8.1, 12.0};
+    const double ys[] = {c, c + 1.0, c - 1.0, c + 0.5, c + 2.0};
+    for (double yv : ys)
+      for (double eta : etas) {
+        double val, w;
+        if (!original(eta, yv, val, w)) return;
+        const double sg = yv == c ? s[0] : s[1];
+        const double cv = -softplus(sg * eta), cw = -sg * sigmoid(sg * eta);
+        if (!(std::fabs(val - cv) <= 1e-8 * std::max(1.0, std::fabs(cv))) || !(std::fabs(w - cw) <= 1e-8)) return;
+      }
+    logit.ok = true; logit.ycol = ycol; logit.c = c; logit.s_hit = s[0]; logit.s_miss = s[1];
+  }
+
   std::string glm_ref(uint32_t id) const {
     if (id == glm.L) return "eta";
     const Node &nd = P.nodes[id];
@@ -505,6 +605,12 @@ struct TargetEmitter {
     // the scalar part; RH_GLM_COL(j) reads column j of the current row from the LDS tile
     os << "  template <class ColFn>\n  static RH_DEV void elem(const double *thu, const double eta, ColFn RH_GLM_COL, double &w, double *other, int &err) {\n"
           "    (void)thu; (void)eta; (void)other; (void)err;\n";
+    if (logit.ok) {  // verified closed form of the Bernoulli-logit scalar part (detect_logit)
+      os << "    const double s = (RH_GLM_COL(" << logit.ycol << ") == " << lit(logit.c) << ") ? " << lit(logit.s_hit) << " : " << lit(logit.s_miss) << ";\n"
+         << "    double sp, sg;\n    rh_logit_link(s * eta, sp, sg);\n"
+         << "    w = -(s * sg);\n    other[0] = -sp;\n  }\n};\n";
+      return true;
+    }
     // emit_node spells operands through ref(); the GLM scalar part needs its own spelling
     for (uint32_t n : glm.inv_nodes) if (!emit_glm_node(os, n, err)) return false;
     for (uint32_t n : glm.elem_nodes) if (!emit_glm_node(os, n, err)) return false;
@@ -650,6 +756,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
       ti.g_count = te.gather.count; ti.g_low = te.gather.low; I.targets.push_back(ti); }
     if (glm_target < 0 && o.glm_mfma && !gmode) {
       te.detect_glm();
+      if (o.logit_link) te.detect_logit();
       if (te.glm.ok) { if (!te.emit_glm(os, err)) return false; glm_target = (int)t; glm_small = te.glm.pred_param.size() <= 8; }
     }
     nacc_max = std::max(nacc_max, te.nacc());

@@ -206,6 +206,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_LOGIT_LINK")) m->eopt.logit_link = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
     int ncols_max = 1;
@@ -977,6 +978,16 @@ extern "C" int rh_sampler_mass_dense(rh_sampler *s, double *out) {
         for (int j = 0; j < n; j++) std::memcpy(&out[((size_t)c * n + i) * n + j], &img[((size_t)c * n + j) * 64 + i], sizeof(double));
   });
 }
+// comm.cpp: device, stream and size (in doubles) of a sampler's draws buffer; the calling thread's error string
+extern "C" int rh_sampler_geometry_(rh_sampler *s, int *device, void **stream, int64_t *doubles) {
+  if (!s || !s->m) return RH_E_INVALID;
+  if (device) *device = s->m->device;
+  if (stream) *stream = (void *)s->m->stream;
+  if (doubles) *doubles = (int64_t)s->chains * (int64_t)s->cfg.iterations * (int64_t)s->m->prog.n_params;
+  return RH_OK;
+}
+extern "C" void rh_set_thread_error_(const char *msg) { g_err = msg ? msg : ""; }
+
 extern "C" int rh_sampler_progress(const rh_sampler *s, int32_t *warmed, int32_t *iterations_done) {
   if (!s) { g_err = "rh_sampler_progress: NULL"; return RH_E_INVALID; }
   if (warmed) *warmed = s->warmed ? 1 : 0;

@@ -49,6 +49,7 @@ struct EmitOptions {
   bool force_bign = false;  // tests: HBM-resident chain vectors (big mode) even for small models
   int gather_min = 65;   // Lookup tables of at least this many trailing parameters switch the model to gather mode
   bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
+  bool logit_link = true;  // fast mode: a VERIFIED Bernoulli-logit scalar part is emitted in closed form (RH_LOGIT_LINK=0 switches it off)
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)

@@ -99,6 +99,7 @@ class Continuous:
     def generate(self, rng) -> float: raise NotImplementedError
     @property
     def latent(self) -> Real: raise NotImplementedError
+    def latentVec(self, k: int): return [self.latent for _ in range(k)]     # Vec.from(List.fill(k)(latent))
     def scale(self, a): return _Scaled(self, Real.of(a))
     def translate(self, b): return _Translated(self, Real.of(b))
     def exp(self): return _Exped(self)
@@ -319,6 +320,30 @@ class Model:
         if not splits:
             return Model([initReal])
         return Model([initReal, Real.sum([_column_density(dist, sp) for sp in splits])])
+
+    @staticmethod
+    def observe_vec(values: Sequence[float], covariates: Sequence[Sequence[float]], fn, split: bool = True) -> "Model":
+        """Model.observe(ys, lhs: Vec[D]) (core/Model.scala:84-96) for lhs = Vec.from(xs).map { case (u, v, ...) => dist }:
+        `columnize` turns every covariate into a Column (the index Lookup over constant tables folds, compute/Real.scala:310-325),
+        so each chunk is  fn(column_u, column_v, ...).logDensity(column_y)  -- the README regression's shape.
+        covariates: one sequence per covariate (column-major)."""
+        covs = [np.asarray(c, dtype=np.float64) for c in covariates]
+        ys = np.asarray(values, dtype=np.float64)
+        def chunk(idx):
+            return fn(*[Real.doubles(c[idx]) for c in covs]).logDensity(Real.doubles(ys[idx]))
+        n = len(ys)
+        if not split:
+            return Model([chunk(slice(0, n))])
+        init, splits = _split(range(n))
+        initReal = chunk(slice(0, len(init)))
+        if not splits:
+            return Model([initReal])
+        return Model([initReal, Real.sum([chunk(slice(sp[0], sp[-1] + 1)) for sp in splits])])
+
+    @staticmethod
+    def track(reals) -> "Model":
+        """Model.track(track) = new Model(List(Real.zero), track) (core/Model.scala:67)"""
+        return Model([Real.zero], list(reals))
 
     def merge(self, other: "Model") -> "Model":
         return Model(self.likelihoods + other.likelihoods, self.track + other.track)

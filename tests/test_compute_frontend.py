@@ -1,0 +1,222 @@
+"""rainier_amd/compute.py -- rainier-compute's front half restated: structure-level checks, each derived by
+hand from the reference source it cites, plus value/gradient checks against central differences (the recipe of
+rainier-test/.../compute/RealTest.scala:39-52) and against the hand-derived RIRs of models.py."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+from rainier_amd import compute as C
+from rainier_amd import models
+from rainier_amd.compute import Coefficients, Gradient, Line, LogLine, Real, Scalar, TargetGroup, Translator, Unary, to_rir
+from rainier_amd.modeling import Bernoulli, Exponential, Model, Normal, Uniform
+from tests import oracle_lib as O
+
+OPS = {0: "const", 1: "input", 2: "add", 3: "sub", 4: "mul", 5: "div", 6: "pow", 7: "compare", 8: "exp", 9: "log", 10: "abs", 11: "noop",
+       18: "lookup", 19: "seq"}
+
+
+def decode(rir: bytes):
+    """RIR blob -> (n_params, [(n_cols, outputs)], [node tuples]) (include/rainier_hip_rir.h)"""
+    w = struct.unpack("<%dI" % (len(rir) // 4), rir)
+    n_params, n_targets, n_nodes = w[2], w[3], w[4]
+    pos, targets = 6, []
+    for _ in range(n_targets):
+        targets.append((w[pos], list(w[pos + 2: pos + 3 + n_params]))); pos += 3 + n_params
+    nodes = []
+    for _ in range(n_nodes):
+        op = w[pos]
+        if op == 0: nodes.append(("const", struct.unpack("<d", struct.pack("<2I", w[pos + 1], w[pos + 2]))[0])); pos += 3
+        elif op == 1: nodes.append(("input", w[pos + 1])); pos += 2
+        elif op in (2, 3, 4, 5, 6, 7, 19): nodes.append((OPS[op], w[pos + 1], w[pos + 2])); pos += 3
+        elif op == 18:
+            cnt = w[pos + 3]; nodes.append(("lookup", w[pos + 1], struct.unpack("<i", struct.pack("<I", w[pos + 2]))[0], list(w[pos + 4: pos + 4 + cnt]))); pos += 4 + cnt
+        else: nodes.append((OPS.get(op, op), w[pos + 1])); pos += 2
+    assert pos == len(w)
+    return n_params, targets, nodes
+
+
+def lower(*reals, track=()):
+    g = TargetGroup(list(reals), track)
+    rir, cols, rows, n = to_rir(g)
+    return decode(rir), g
+
+
+# ---- the algebra (compute/RealOps.scala, LineOps.scala, LogLineOps.scala, Coefficients.scala) --------------------------
+def test_normal_forms():
+    x, y = Real.parameter(), Real.parameter()
+    assert (x + 0) is x and (x * 1) is x and (x * 0) == Real.zero                       # RealOps.add / multiply identities
+    l = x * 2 + y * 3 + 1
+    assert isinstance(l, Line) and l.b == Scalar(1.0)
+    assert [(t, a.value) for t, a in l.ax.toList()] == [(x, 2.0), (y, 3.0)]            # One.merge(other) = other + mine: Seq(mine, other) (Coefficients.scala:60-73)
+    l3 = l + Real.parameter() * 4
+    assert [a.value for _, a in l3.ax.toList()] == [4.0, 2.0, 3.0]                     # Many.+ PREPENDS a new term (Coefficients.scala:131)
+    assert (l - y * 3 - 1 - x * 2) == Real.zero                                        # coefficients cancel -> Empty -> the constant
+    assert ((x + y) + (x - y)).ax.toList() == [(x, Scalar(2.0))]                       # a cancelled term leaves One
+    p = x * y
+    assert isinstance(p, LogLine) and [(t, a.value) for t, a in p.ax.toList()] == [(x, 1.0), (y, 1.0)]
+    assert (x * x) == x.pow(2) and isinstance(x * x, LogLine)                           # case-class equality of LogLine
+    assert (x * x) / x == LogLine(Coefficients.pair(x, Scalar(1.0)))                    # exponents add: x^2 * x^-1 -> LogLine(x^1), NOT x (LogLineOps.multiply)
+    assert (x / x) == Real.one                                                          # merged.isEmpty -> Real.one
+    assert x.exp().log() is x and x.log().exp() is x                                    # RealOps.unary shortcuts
+    lg = (x * 3).log()                                                                  # LineOps.log: log(a x) = log x + log a (a > 0)
+    assert isinstance(lg, Line) and lg.ax.toList() == [(x.log(), Scalar(1.0))] and lg.b == Scalar(math.log(3))
+    assert isinstance((x * -3).log(), Unary)                                            # ... not for a < 0
+    sq = (x * 3).pow(2)                                                                 # LineOps.pow: (a x)^k = x^k * a^k
+    assert isinstance(sq, Line) and sq.ax.kind == 1 and sq.ax.coefficient == Scalar(9.0) and sq.ax.term == x.pow(2)
+    assert x.exp() == x.exp() and x.exp() is not x.exp()                                # Unary is a case class
+    assert (x + 1) != (x + 1)                                                           # Line is NOT (reference equality)
+    with pytest.raises(ArithmeticError):
+        Real.of(float("nan"))                                                           # ToReal.scala:16-17
+    with pytest.raises(ArithmeticError):
+        Real.zero / Real.zero                                                           # ConstantOps.divide
+    assert Real.eq(Real.of(2), 2, x, y) is x and Real.eq(Real.of(2), 3, x, y) is y      # Lookup.apply folds a scalar index
+    with pytest.raises(ArithmeticError):
+        C.Lookup.apply(Real.of(0.5), [x, y])
+
+
+def test_distribute_expands_small_squares_when_summed():
+    # LogLineOps.distribute (LogLineOps.scala:47-91): (x + y + 3)^2 has nTerms2 = 6 < 20 -> expanded when it meets a sum
+    x, y = Real.parameter(), Real.parameter()
+    z = x + y + 3
+    s = z * z + x
+    assert isinstance(s, Line)
+    terms = {repr(t): a.value for t, a in s.ax.toList()}
+    # x^2, y^2, x*y AND y*x (Many's equality includes the term ORDER, so the two products do not merge: footnote [0] #4 of
+    # compute/Real.scala), x, y ; constant 9
+    assert s.b == Scalar(9.0) and len(terms) == 6
+    xs = {t: a.value for t, a in s.ax.toList()}
+    assert xs[x] == 7.0 and xs[y] == 6.0 and xs[x * y] == 1.0 and xs[y * x] == 1.0 and xs[x.pow(2)] == 1.0 and xs[y.pow(2)] == 1.0
+    assert (x * y) != (y * x)
+    # 7 terms: nTerms2 = 28 >= 20 -> kept as a power
+    ps = [Real.parameter() for _ in range(7)]
+    w = Real.sum(ps)
+    assert [type(t) for t, _ in (w * w + x).ax.toList()] == [LogLine, C.Parameter]
+
+
+def test_gradient_is_symbolic_and_matches_central_differences():
+    rng = np.random.default_rng(0)
+    x, y, z = (Real.parameter() for _ in range(3))
+    exprs = [x * y + z.exp(), (x * x + 1).log() * y, Real.gt(x, y, x * z, y.abs()), (x + 2).pow(y), x.logistic * (y - z).pow(3) + (x * 4).sin(),
+             Real.eq(z, 0, 1.0, z) .log() if False else (z * z + 1).pow(0.5) / (y * y + 2), x.atan() + y.cos() * z.tan() + (x * 0.1).asin()]
+    for e in exprs:
+        g = Gradient.derive([x, y, z], e)
+        for _ in range(5):
+            q = rng.uniform(0.2, 0.9, 3)
+            env = {x: q[0], y: q[1], z: q[2]}
+            got = [float(C.evaluate(gi, env)) for gi in g]
+            for i in range(3):
+                h = 1e-6
+                qp, qm = q.copy(), q.copy(); qp[i] += h; qm[i] -= h
+                fd = (float(C.evaluate(e, dict(zip((x, y, z), qp)))) - float(C.evaluate(e, dict(zip((x, y, z), qm))))) / (2 * h)
+                assert abs(got[i] - fd) <= 1e-6 * max(1.0, abs(fd)), (e, i, got[i], fd)
+
+
+# ---- the Translator (compute/Translator.scala) -----------------------------------------------------------------------------
+def test_translator_line_is_a_left_fold_in_term_order_with_constant_first():
+    # makeLine: allTerms = (b, 1) :: terms; a = 1 -> x, a = 2 -> x + x, else x * a; combineTerms folds left (ring.useTree = false)
+    x, y, z = (Real.parameter() for _ in range(3))
+    (n, targets, nodes), g = lower(x * 2 + y * 3 + z + 5)
+    t = targets[1][1][0]                                   # value output of t_0
+    # terms in list order: z (prepended), then x (a=2), y (a=3); the constant goes first:  ((5 + z) + (x + x)) + y*3
+    def show(i):
+        nd = nodes[i]
+        if nd[0] == "const": return repr(nd[1])
+        if nd[0] == "input": return "p%d" % nd[1]
+        return "(%s %s %s)" % (show(nd[1]), {"add": "+", "mul": "*", "pow": "^"}[nd[0]], show(nd[2]))
+    assert show(t) == "(((5.0 + p2) + (p0 + p0)) + (p1 * 3.0))"
+    # gradient outputs are constants 2, 3, 1 in parameter order
+    assert [nodes[i] for i in targets[1][1][1:]] == [("const", 2.0), ("const", 3.0), ("const", 1.0)]
+
+
+def test_translator_logline_is_a_product_tree_with_x_times_x_and_pow():
+    x, y, z, w = (Real.parameter() for _ in range(4))
+    e = x.pow(2) * y.pow(-1) * z * w.pow(0.5)
+    (n, targets, nodes), g = lower(e)
+    def show(i):
+        nd = nodes[i]
+        if nd[0] == "const": return repr(nd[1])
+        if nd[0] == "input": return "p%d" % nd[1]
+        return "(%s %s %s)" % (show(nd[1]), {"add": "+", "mul": "*", "pow": "^"}[nd[0]], show(nd[2]))
+    # logLineExpr = makeLine(ax, Constant.One, powRing): `if (b.isZero) terms else (b, Const(1.0)) :: terms` tests the ADDITIVE
+    # zero, so every LogLine product starts with the factor 1.0 (Translator.scala:67-89).  Term list: w^0.5, z (prepended), then
+    # x^2, y^-1 ; grouped(2) tree over [1, w^0.5, z, x*x, y^-1]
+    assert show(targets[1][1][0]) == "(((1.0 * (p3 ^ 0.5)) * (p2 * (p0 * p0))) * (p1 ^ -1.0))"
+
+
+def test_translator_shares_subexpressions_across_outputs():
+    x, y = Real.parameter(), Real.parameter()
+    e = (x * y).exp() + (x * y).exp() * 2                    # equal Unary case-class instances merge in the Coefficients
+    (n, targets, nodes), g = lower(e)
+    assert sum(1 for nd in nodes if nd[0] == "exp") == 1     # one exp node for value AND both gradients
+    assert sum(1 for nd in nodes if nd[0] == "mul" and nodes[nd[1]] == ("const", 1.0) and nodes[nd[2]] == ("input", 0)) == 1   # the one x*y product
+    # Lookup lowers to SeqIR(defs :+ LookupIR) (Translator.scala:51-61): table entries are defined before the lookup
+    e2 = Real.gt(x, y, x.exp(), y.exp())
+    (n, targets, nodes), g = lower(e2)
+    val = nodes[targets[1][1][0]]
+    assert val[0] == "seq"
+    kinds = [nd[0] for nd in nodes]
+    # 1 compare for the select itself + 3 compares OF that compare against -1 / 0 / +1: LookupDiff = Real.eq(child.index, i, g, 0)
+    # per table entry (Gradient.scala:148-152) -- the selects-of-selects the engine's clean-up pass (simplify.cpp R1) re-indexes
+    assert kinds.index("exp") < kinds.index("lookup") and kinds.count("compare") == 4
+    lk = next(nd for nd in nodes if nd[0] == "lookup")
+    assert lk[2] == -1 and len(lk[3]) == 3 and nodes[lk[3][0]] == nodes[lk[3][1]]       # [lt, eq, gt] = [f, f, t]
+
+
+# ---- Target / TargetGroup / inlining (compute/Target.scala, PartialEvaluator.scala) ------------------------------------------
+def test_readme_regression_is_inlined_like_the_reference_and_k4_is_not():
+    cols = models.linreg_data(500, 4)
+    ys, xs = cols[0], cols[1:]
+
+    def build(k, **kw):
+        sigma = Exponential(1).latent; alpha = Normal(0, 1).latent; betas = Normal(0, 1).latentVec(k)
+        m = Model.observe_vec(ys, xs[:k], lambda *u: Normal(alpha + Real.sum([ui * bi for ui, bi in zip(u, betas)]), sigma), **kw)
+        return m
+    m3 = build(3)
+    spec = m3.compile("readme")
+    # 3 covariates: (y - a - b.x)^2 distributes into 15 products (< DistributeToMaxTerms), every term is a function of either
+    # the data or the parameters -> TargetGroup.inlinable -> PartialEvaluator.inline folds the 500 rows at compile time
+    assert spec.nrows == [0, 0, 0] and spec.columns == [] and spec.n_params == 5
+    ref = models.linreg(n=500, k=3, columns=cols[:4])
+    q = np.array([-0.3, 0.5, 1.0, -2.0, 0.5])
+    a, b = O.OracleDensity(spec).update(q), O.OracleDensity(ref).update(q)
+    np.testing.assert_allclose(a, b, rtol=1e-11)
+    # the same model kept un-inlined streams rows (4 + 8 x 62: Model.observe's split) and agrees
+    s2 = m3.compile("readme_streamed", inline=False)
+    assert s2.nrows == [0, 4, 62] and len(s2.columns) > 8
+    np.testing.assert_allclose(O.OracleDensity(s2).update(q), b, rtol=1e-11)
+    # 4 covariates: 21 >= 20 terms -> no distribution -> not inlinable -> streamed by the reference itself
+    s4 = build(4, split=False).compile("readme4")
+    assert s4.nrows == [0, 500]
+    q4 = np.array([-0.3, 0.5, 1.0, -2.0, 0.5, 0.25])
+    np.testing.assert_allclose(O.OracleDensity(s4).update(q4), O.OracleDensity(models.linreg(n=500, k=4, columns=cols)).update(q4), rtol=1e-11)
+
+
+def test_parameters_are_ordered_by_creation_and_priors_summed_once():
+    a = Normal(0, 1).latent
+    b = Uniform(0, 1).latent
+    m = Model.track([b, a])
+    g = m.targetGroup()
+    assert len(g.parameters) == 2 and g.parameters[0].sym < g.parameters[1].sym          # sortBy(_.param.sym.id)
+    spec = m.compile("two")
+    assert spec.nrows == [0, 0] and spec.n_params == 2
+    q = np.array([0.3, -0.4])
+    out = O.OracleDensity(spec).update(q)
+    sg = 1 / (1 + math.exp(0.4))
+    want = (-0.5 * 0.09 - 0.5 * math.log(2 * math.pi)) + (math.log(sg) + math.log(1 - sg))   # N(0,1) + logistic Jacobian (Uniform density = 0)
+    assert abs(out[0] - want) < 1e-14
+
+
+def test_logistic_regression_through_the_front_end_matches_the_hand_derived_rir():
+    k, n = 6, 400
+    cols = models.logistic_data(n, k)
+    a = Normal(0, 1).latent; bs = Normal(0, 1).latentVec(k)
+    m = Model.observe_vec(cols[0], cols[1:], lambda *u: Bernoulli((a + Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic), split=False)
+    spec = m.compile("logit")
+    assert spec.nrows == [0, n] and spec.n_params == k + 1
+    # the reference's algebra pushes every data-only factor into derived columns (gradientColumns, Target.scala:27-31)
+    assert len(spec.columns) > k + 1
+    ref = models.logistic(n=n, k=k, columns=cols)
+    for q in np.random.default_rng(3).normal(size=(4, k + 1)) * 0.5:
+        np.testing.assert_allclose(O.OracleDensity(spec).update(q), O.OracleDensity(ref).update(q), rtol=1e-10, atol=1e-10)

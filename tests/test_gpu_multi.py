@@ -64,22 +64,38 @@ def test_per_rank_samplers_with_global_seeds_match_the_unsharded_run():
         assert np.array_equal(part, whole[rank * cpr:(rank + 1) * cpr])
 
 
-def test_device_draws_all_gather_over_rccl_world_size_one():
-    import torch
-    import torch.distributed as dist
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        spec = models.linreg(n=70000, k=3)
-        m = R.Model(spec, device=0)
-        cfg = R.make_config(5, 5, R.HMCSampler(3), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
-        s = R.Sampler(m, cfg, D.shard_seeds(1000, 4, 0))
-        s.warmup(); s.run(5)
-        out = D.gather_draws_from_device(s.draws_device_ptr(), (4, 5, spec.n_params), 1)
-        torch.cuda.synchronize()
-        assert np.array_equal(out.cpu().numpy(), s.draws())
-    finally:
-        dist.destroy_process_group()
+def test_rccl_all_gather_of_device_draws_world_size_one():
+    """rh_comm_*: the engine's own RCCL communicator (dlopen librccl), one rank: unique id -> communicator -> all-gather of
+    the device-resident draws -> host, and the max-reduction used for the timing."""
+    spec = models.linreg(n=70000, k=3)
+    m = R.Model(spec, device=0)
+    cfg = R.make_config(5, 5, R.HMCSampler(3), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    s = R.Sampler(m, cfg, D.shard_seeds(1000, 4, 0))
+    s.warmup(); s.run(5)
+    comm = D.Comm(D.Comm.unique_id(), 1, 0, 0)
+    out = comm.allgather_draws(s)
+    assert out.shape == (4, 5, spec.n_params) and np.array_equal(out, s.draws())
+    assert comm.allgather_draws(s, to_host=False) != 0
+    assert comm.allreduce_max(3.25) == 3.25
+    D.device_synchronize(0)
+    comm.close()
+
+
+def test_bench_under_torch_distributed_run_one_rank():
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with one
+    rank: gloo bootstrap + the engine's RCCL all-gather inside the timed region; ONE JSON line on stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+           "--chains-per-gpu", "64", "--rows", "100000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["chains"] == 64

@@ -86,9 +86,9 @@ def copts(**kw):
                     dtype=np.int32)
 
 
-def flat_cfg(cfg):
+def flat_cfg(cfg, nvars=1):
     """sampler.py SamplerConfig -> (icfg, dcfg) in the shim's RH_JNI_ICFG / RH_JNI_DCFG order (what HipConfig.flatten builds)"""
-    c, _keep = R.sampler.to_c_config(cfg, 1)
+    c, _keep = R.sampler.to_c_config(cfg, nvars)
     ic = [c.iterations, c.warmup, c.sampler, c.hmc_steps, c.ehmc_max_steps, c.ehmc_min_steps, c.ehmc_buf_size, c.step_tuner,
           c.mass_tuner, c.mass_init_window, c.mass_skip_first, c.mass_skip_last, c.nuts_max_depth, c.engine, c.grad_splits]
     dc = [c.ehmc_p_count, c.dualavg_delta, c.static_step, c.mass_expansion]
@@ -191,7 +191,7 @@ def _create(fj, spec, **kw):
 
 
 def _sample(fj, handles, cfg, seeds, n, static_mass=None, nn=None):
-    ic, dc = flat_cfg(cfg)
+    ic, dc = flat_cfg(cfg, n)
     chains = len(seeds)
     draws, mass, stats = JArr(fj, np.zeros(chains * cfg.iterations * n)), JArr(fj, np.zeros(chains * n)), JArr(fj, np.zeros(chains * 7))
     call(fj, "sample", JArr(fj, np.array(handles, dtype=np.int64)), JArr(fj, ic), JArr(fj, dc),

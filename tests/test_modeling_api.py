@@ -1,5 +1,7 @@
 """The reference's test models written the way the reference writes them (rainier_amd/modeling.py), lowered
-to RIR and run end to end: the eleven SBC goldsets of core/SBCTest.scala:19-34 and OptimizerTest's "fit normal"."""
+through the restated rainier-compute front half (rainier_amd/compute.py: Real normal forms, Gradient, TargetGroup.inlinable +
+PartialEvaluator.inline, Translator) to the RIR Compiler.compileTargets would produce, and run end to end: the eleven SBC
+goldsets of core/SBCTest.scala:19-34 and OptimizerTest's "fit normal"."""
 import json
 import os
 
@@ -38,14 +40,27 @@ def test_sbc_goldset_through_the_modelling_api(oracle, name):
     values, truth = sbc.synthesize(ALL["synthetic_samples"], rng)
     model, real = sbc.fit(values)
     spec = model.compile(name)
-    assert spec.n_params == 1 and spec.nrows == [0, 1000]
+    # Model.observe cuts the 1000 points into 8 + 8 x 124 (core/Model.scala:98-132): two likelihood targets.  Nine of the
+    # eleven likelihoods are "inlinable" (Target.scala:136-207) and are folded into O(1) data-free targets at compile time,
+    # exactly what the reference runs; Gamma and Laplace stream their rows (the second target reads 8 columns per row).
+    assert spec.n_params == 1 and len(spec.nrows) == 3
+    assert spec.nrows == ([0, 8, 124] if name in ("SBCGamma", "SBCLaplace") else [0, 0, 0]), spec.nrows
     gold = np.array(ALL["models"][name]["goldset"])
     cfg = O.make_config(sampler=O.HMC, n_steps=1, iterations=len(gold), warmup=ALL["warmup"], step_tuner=O.STEP_DUALAVG,
                         delta=0.8, mass_tuner=O.MASS_IDENTITY, math_mode=O.JM_LIBM)
     d = O.OracleDensity(spec, O.JM_LIBM)
     draws, _, st, rc = O.sample_chain_state(d.fn_ptr, d.handle, 1, cfg, rng.r)
     got = model.predict(real, draws)
-    assert rc == 0 and np.abs((got - gold) / gold).max() < 1e-10, (name, got[:3], gold[:3])
+    assert rc == 0 and np.abs((got - gold) / gold).max() < 1e-12, (name, got[:3], gold[:3])
+    if name == "SBCGamma":            # no exp/log of a parameter-dependent quantity that glibc and HotSpot round differently:
+        assert np.array_equal(got, gold)   # the reference's recorded draws, reproduced bit for bit through the restated pipeline
+    # the same model with inlining switched off streams every row and lands on the same draws
+    spec2 = model.compile(name + "_streamed", inline=False)
+    assert spec2.nrows == [0, 8, 124]
+    rng2 = O.JavaRandom(ALL["seed"]); sbc.synthesize(ALL["synthetic_samples"], rng2)
+    d2 = O.OracleDensity(spec2, O.JM_LIBM)
+    draws2, _, _, rc2 = O.sample_chain_state(d2.fn_ptr, d2.handle, 1, cfg, rng2.r)
+    assert rc2 == 0 and np.abs((model.predict(real, draws2) - gold) / gold).max() < 1e-10, name
 
 
 def test_fit_normal_through_the_modelling_api(oracle):
