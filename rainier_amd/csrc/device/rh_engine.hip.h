@@ -1173,7 +1173,7 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
 // The G accumulators cost 4 VGPR pairs per 16 predictors for 16 chains -- the VALU path needs P+1 pairs per chain.
 #ifdef RH_GLM_TARGET
 #ifndef RH_GLM_W
-#define RH_GLM_W 8
+#define RH_GLM_W 4
 #endif
 #define RH_GLM_TRP 66
 typedef double rh_v4d __attribute__((ext_vector_type(4)));

@@ -201,10 +201,10 @@ RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
                                       0x1.5555555555593p-1);
   const double R = t1 + t2, hfsq = 0.5 * f * f;
   const double lg = (f - (hfsq - z * (hfsq + R))) + (hi ? 0x1.62e42fefa39efp-1 : 0.0);   // + ln 2 in the halved branch
-  // max(t, 0) as (t + |t|) / 2: exact for finite t and, unlike a max instruction, it propagates NaN
-  // A NaN t (a diverged chain) reaches the caller through softplus -- the VALUE, hence the energy, is NaN and the proposal is
-  // rejected (LeapFrog.scala:138-142); sigmoid is then finite garbage that is never used (the clamp above drops the NaN).
-  softplus = __builtin_fma(0.5, t + at, lg);
+  // max(t, 0) spelled as a select on (t <= 0): a NaN t (a diverged chain) fails the comparison and passes through, so the VALUE
+  // -- hence the energy -- is NaN and the proposal is rejected (LeapFrog.scala:138-142); a max instruction would drop it, and
+  // (t + |t|) / 2 would turn t = -inf into NaN.  sigmoid of a NaN t is finite garbage that is never used.
+  softplus = (t <= 0.0 ? 0.0 : t) + lg;
   sigmoid = sg;
 }
 
@@ -220,6 +220,8 @@ RH_DEV int rh_d2i(double x) { // D2I: NaN -> 0, saturating
   if (x <= -2147483648.0) return (-2147483647 - 1);
   return (int)x;
 }
+// fast mode: Math.pow(x, 0.5).  Differs from sqrt only at -0.0 (pow: +0.0) and -inf (pow: +inf); x + 0.0 turns -0.0 into +0.0.
+RH_DEV double rh_pow_half(double x) { return x == -RH_INF ? RH_INF : __builtin_sqrt(x + 0.0); }
 RH_DEV double rh_java_pow(double x, double y) { // java.lang.Math.pow = C99 pow + two Java-specific NaN cases
   if (y == 0.0) return 1.0;
   if (y != y) return RH_NAN;

@@ -73,6 +73,14 @@ struct TargetEmitter {
   }
 
   bool has_rows() const { return P.targets[t].n_cols > 0; }
+  // Math.pow; in fast mode x^0.5 / x^-0.5 (the Translator's sqrt spellings) become one v_sqrt_f64-based call
+  std::string pow_call(const std::string &x, uint32_t e_id, const std::string &e) const {
+    if (fast_div && P.nodes[e_id].op == RH_RIR_CONST) {
+      if (P.nodes[e_id].cval == 0.5) return "rh_pow_half(" + x + ")";
+      if (P.nodes[e_id].cval == -0.5) return "(0x1p+0 / rh_pow_half(" + x + "))";
+    }
+    return "rh_java_pow(" + x + ", " + e + ")";
+  }
   bool trivial(uint32_t id) const { return P.nodes[id].op == RH_RIR_CONST || P.nodes[id].op == RH_RIR_INPUT; }
   bool is_const(uint32_t id, double v) const { return id < P.nodes.size() && P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == v; }
 
@@ -349,7 +357,7 @@ struct TargetEmitter {
       case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
       case RH_RIR_MUL: os << lhs << R(nd.a) << " * " << R(nd.b) << ";\n"; break;
       case RH_RIR_DIV: { std::string rc; if (recip_const(nd.b, rc)) os << lhs << R(nd.a) << " * " << rc << ";\n"; else os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break; }
-      case RH_RIR_POW: os << lhs << "rh_java_pow(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
+      case RH_RIR_POW: os << lhs << pow_call(R(nd.a), nd.b, R(nd.b)) << ";\n"; break;
       case RH_RIR_COMPARE: os << lhs << "rh_compare(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_EXP: os << lhs << "RH_EXP(" << R(nd.a) << ");\n"; break;
       case RH_RIR_LOG: os << lhs << "RH_LOG(" << R(nd.a) << ");\n"; break;
@@ -628,7 +636,7 @@ struct TargetEmitter {
       case RH_RIR_SUB: os << lhs << R(nd.a) << " - " << R(nd.b) << ";\n"; break;
       case RH_RIR_MUL: os << lhs << R(nd.a) << " * " << R(nd.b) << ";\n"; break;
       case RH_RIR_DIV: { std::string rc; if (recip_const(nd.b, rc)) os << lhs << R(nd.a) << " * " << rc << ";\n"; else os << lhs << R(nd.a) << " / " << R(nd.b) << ";\n"; break; }
-      case RH_RIR_POW: os << lhs << "rh_java_pow(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
+      case RH_RIR_POW: os << lhs << pow_call(R(nd.a), nd.b, R(nd.b)) << ";\n"; break;
       case RH_RIR_COMPARE: os << lhs << "rh_compare(" << R(nd.a) << ", " << R(nd.b) << ");\n"; break;
       case RH_RIR_EXP: os << lhs << "RH_EXP(" << R(nd.a) << ");\n"; break;
       case RH_RIR_LOG: os << lhs << "RH_LOG(" << R(nd.a) << ");\n"; break;

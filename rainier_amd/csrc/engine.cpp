@@ -157,7 +157,7 @@ struct rh_model {
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
-  int glm_w = 8;
+  int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   // gather mode: per row target (ROWT order) the host copy of the group offsets (rows sorted by table index)
   hipFunction_t k_grad_gather = nullptr, k_density_fin = nullptr;

@@ -11,7 +11,9 @@
 //   R2  Lookup(Compare(..), [x, x, x]) (low = -1) -> x
 //   R3  Lookup(k, [f(a), f(b), ..])               -> f(Lookup(k, [a, b, ..]))    f one pure unary op, entries not used elsewhere
 //   R4  Lookup(k, C1) (+|-|*|/) Lookup(k, C2)     -> Lookup(k, C1 op C2)         all-constant tables; also against a constant
+//   E1  x * 1.0                                   -> x                           exact (the Translator's LogLine products start with 1.0)
 //   F1  1 / (1 / x)                               -> x                           fast mode only (<= 1 ulp apart)
+//   F2  pow(x, c), c in {-1, 2, -2, 3, -3, 4}     -> multiplications / one division   fast mode only (the Translator's x^c terms)
 //   CSE identical (op, a, b) nodes are built once (what VarDef/VarRef sharing already guarantees in the reference)
 #include "rir.hpp"
 #include "../../include/rainier_hip_rir.h"
@@ -143,6 +145,23 @@ Program simplify(const Program &P, bool fast) {
             continue;
           }
         }
+      }
+      // E1 (exact, both modes): x * 1.0 -> x.  IEEE multiplication by one returns its operand bit for bit (NaN payloads, signed
+      // zeros and infinities included).  The reference's Translator starts EVERY LogLine product with the factor 1.0
+      // (makeLine(ax, Constant.One, powRing): `if (b.isZero) terms else (b, Const(1.0)) :: terms`, compute/Translator.scala:67-89)
+      if (n.op == RH_RIR_MUL && B.is_const(a) && B.Q.nodes[a].cval == 1.0) { m[i] = b; continue; }
+      if (n.op == RH_RIR_MUL && B.is_const(b) && B.Q.nodes[b].cval == 1.0) { m[i] = a; continue; }
+      // F2 (fast mode only): Math.pow with the constant exponents the Translator emits for LogLine terms other than 1 and 2
+      // (compute/Translator.scala:101-114: x^-1 for every division, x^-2, x^3 ...) -> multiplications and ONE division; within
+      // 1-2 ulp of the correctly rounded power, against ~100 instructions for a general fp64 pow.  (+-0.5 -> sqrt at emission.)
+      if (fast && n.op == RH_RIR_POW && B.is_const(b)) {
+        const double e = B.Q.nodes[b].cval;
+        if (e == -1.0) { m[i] = B.op2(RH_RIR_DIV, B.constant(1.0), a); continue; }
+        if (e == 2.0) { m[i] = B.op2(RH_RIR_MUL, a, a); continue; }
+        if (e == -2.0) { m[i] = B.op2(RH_RIR_DIV, B.constant(1.0), B.op2(RH_RIR_MUL, a, a)); continue; }
+        if (e == 3.0) { m[i] = B.op2(RH_RIR_MUL, B.op2(RH_RIR_MUL, a, a), a); continue; }
+        if (e == -3.0) { m[i] = B.op2(RH_RIR_DIV, B.constant(1.0), B.op2(RH_RIR_MUL, B.op2(RH_RIR_MUL, a, a), a)); continue; }
+        if (e == 4.0) { const uint32_t sq = B.op2(RH_RIR_MUL, a, a); m[i] = B.op2(RH_RIR_MUL, sq, sq); continue; }
       }
       // fast mode only (results may differ in the last place, like FMA contraction does): 1 / (1 / x) -> x
       if (fast && n.op == RH_RIR_DIV && B.is_const(a) && B.Q.nodes[a].cval == 1.0 && B.Q.nodes[b].op == RH_RIR_DIV &&

@@ -46,7 +46,9 @@ def random_program(rng: random.Random, n_params=3, data=False):
         elif r < 0.75:
             (a, da), (b, db) = pick(), pick()
             e = rng.choice([lambda: a + b, lambda: a - b, lambda: a * b, lambda: a / (b.abs() + 0.25),
-                            lambda: 1.0 / (1.0 / (a.abs() + 0.5))])(), da or db
+                            lambda: 1.0 / (1.0 / (a.abs() + 0.5)),
+                            lambda: g.const(1.0) * a, lambda: a * g.const(1.0) + b,                      # E1: the Translator's leading 1.0
+                            lambda: (a.abs() + 0.5) ** g.const(rng.choice([-1.0, 2.0, -2.0, 3.0, -3.0, 4.0, 0.5, -0.5, 1.5]))])(), da or db
         else:
             a, da = pick()
             e = rng.choice([lambda: (a.abs() + 0.1).log(), lambda: (a * 0.3).exp(), lambda: a.abs(), lambda: a.sin(), lambda: a.atan()])(), da
