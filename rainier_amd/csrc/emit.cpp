@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <tuple>
@@ -270,6 +271,252 @@ struct TargetEmitter {
         for (size_t o = 0; o < (gmode ? (size_t)n_shared + 1 : P.targets[tt].outputs.size()); o++) reach_row[P.targets[tt].outputs[o]] = 1;
       sweep(reach_row);
     }
+  }
+
+  // ---- fast mode: the logit family of streamed likelihood terms in closed form (cfg 5's negative binomial) -------------------
+  // core/Discrete.scala writes NegativeBinomial / Binomial / Geometric densities as  C + alpha log(1 - p) + beta log p  with the
+  // caller's p; with p = 1 / (1 + m e^{-L}) (a logistic link, m > 0 constant: cfg 5 has m = n) symbolic differentiation leaves
+  // one exp, two logs and three divisions per row-chain evaluation.  With t = log m - L:
+  //       log p = -softplus(t),  log(1 - p) = t - softplus(t)
+  //       value = C + alpha t - (alpha + beta) softplus(t),      g = d value / d L = (alpha + beta) sigmoid(t) - alpha
+  // The VALUE is matched structurally (it is the distribution's own formula, not a differentiated one): a sum whose E-dependent
+  // terms are coef * log(P) / coef * log(1 - P) with P = 1 / (m E + 1), E = exp(-L) the target's only exponential.  Every OTHER
+  // E-dependent quantity the row needs (the adjoint in whatever association the differentiation produced it) is peeled of its
+  // E-independent factors down to a "core" and each core is VERIFIED numerically to equal kappa * g with a constant kappa
+  // (9 values of L x 6 random assignments of all parameters / columns, 1e-8).  Only if the value and every core verify, and
+  // nothing else still needs E, are those nodes emitted in closed form (one rh_logit_link per evaluation); otherwise the
+  // literal lowering stays.  Fast mode only.
+  struct Link {
+    bool ok = false;
+    uint32_t L = 0, E = 0, V = 0;
+    double logm = 0.0;
+    std::vector<std::pair<uint32_t, double>> alpha, beta;   // sum of (coefficient node or ONE, sign): value terms on log(1-P) / log P
+    std::vector<std::pair<uint32_t, double>> cterms;        // E-independent terms of the value (node, sign)
+    std::map<uint32_t, double> cores;                       // core node -> kappa
+    uint32_t first = 0;                                     // smallest overridden node id: the prelude is emitted before it
+  } link;
+
+  double host_eval2(uint32_t id, const std::vector<double> &inputs, double gz, std::map<uint32_t, double> &memo, bool &bad) const {
+    auto it = memo.find(id);
+    if (it != memo.end()) return it->second;
+    if (gather.ok && id == gather.node) return memo[id] = gz;
+    const Node &nd = P.nodes[id];
+    auto E = [&](uint32_t x) { return host_eval2(x, inputs, gz, memo, bad); };
+    double v = 0.0;
+    switch (nd.op) {
+      case RH_RIR_CONST: v = nd.cval; break;
+      case RH_RIR_INPUT: v = inputs[nd.input]; break;
+      case RH_RIR_ADD: v = E(nd.a) + E(nd.b); break;
+      case RH_RIR_SUB: v = E(nd.a) - E(nd.b); break;
+      case RH_RIR_MUL: v = E(nd.a) * E(nd.b); break;
+      case RH_RIR_DIV: v = E(nd.a) / E(nd.b); break;
+      case RH_RIR_POW: v = std::pow(E(nd.a), E(nd.b)); break;
+      case RH_RIR_COMPARE: { const double l = E(nd.a), r = E(nd.b); v = l > r ? 1.0 : (l == r ? 0.0 : -1.0); break; }
+      case RH_RIR_EXP: v = std::exp(E(nd.a)); break;
+      case RH_RIR_LOG: v = std::log(E(nd.a)); break;
+      case RH_RIR_ABS: v = std::fabs(E(nd.a)); break;
+      case RH_RIR_NOOP: v = E(nd.a); break;
+      case RH_RIR_SEQ: (void)E(nd.a); v = E(nd.b); break;
+      case RH_RIR_LOOKUP: {
+        const double ix = E(nd.a);
+        const long long k = (ix != ix ? 0LL : (long long)ix) - (long long)nd.low;
+        if (k < 0 || k >= (long long)nd.table.size()) { bad = true; v = 0.0; } else v = E(nd.table[(size_t)k]);
+        break;
+      }
+      default: bad = true;
+    }
+    return memo[id] = v;
+  }
+
+  void detect_link() {
+    if (!has_rows() || !fast_div || !factor || basis.empty()) return;
+    const size_t N = P.nodes.size();
+    // the target's only exponential, of the form exp(-L)
+    uint32_t E = NONE;
+    for (size_t n = 0; n < N; n++)
+      if (reach_row[n] && P.nodes[n].dep != 0 && P.nodes[n].op == RH_RIR_EXP) { if (E != NONE) return; E = (uint32_t)n; }
+    if (E == NONE) return;
+    uint32_t L = NONE;
+    { const Node &a = P.nodes[P.nodes[E].a];
+      if (a.op == RH_RIR_MUL && is_const(a.b, -1.0)) L = a.a;
+      else if (a.op == RH_RIR_MUL && is_const(a.a, -1.0)) L = a.b;
+      else if (a.op == RH_RIR_SUB && is_const(a.a, 0.0)) L = a.b;
+      else return; }
+    std::vector<char> depE(N, 0);
+    depE[E] = 1;
+    { std::vector<uint32_t> ops;
+      for (size_t n = E + 1; n < N; n++) { operands(P.nodes[n], ops); for (uint32_t o : ops) if (depE[o]) { depE[n] = 1; break; } } }
+    // P = 1 / (m E + 1), Q = 1 - P
+    auto match_D = [&](uint32_t d, double &m) -> bool {   // d == m E + 1
+      const Node &nd = P.nodes[d];
+      if (nd.op != RH_RIR_ADD) return false;
+      for (int sw = 0; sw < 2; sw++) {
+        const uint32_t x = sw ? nd.b : nd.a, one = sw ? nd.a : nd.b;
+        if (!is_const(one, 1.0)) continue;
+        if (x == E) { m = 1.0; return true; }
+        const Node &xn = P.nodes[x];
+        if (xn.op == RH_RIR_MUL) {
+          if (xn.a == E && P.nodes[xn.b].op == RH_RIR_CONST && P.nodes[xn.b].cval > 0 && std::isfinite(P.nodes[xn.b].cval)) { m = P.nodes[xn.b].cval; return true; }
+          if (xn.b == E && P.nodes[xn.a].op == RH_RIR_CONST && P.nodes[xn.a].cval > 0 && std::isfinite(P.nodes[xn.a].cval)) { m = P.nodes[xn.a].cval; return true; }
+        }
+      }
+      return false;
+    };
+    double m = 0.0;
+    auto is_P = [&](uint32_t x) { const Node &nd = P.nodes[x]; double mm; if (nd.op == RH_RIR_DIV && is_const(nd.a, 1.0) && match_D(nd.b, mm)) { if (m == 0.0) m = mm; return mm == m; } return false; };
+    auto is_Q = [&](uint32_t x) { const Node &nd = P.nodes[x]; return nd.op == RH_RIR_SUB && is_const(nd.a, 1.0) && is_P(nd.b); };
+    // the value: the one basis term whose E-dependent summands are all coef * log(P | Q)
+    Link lk;
+    bool found = false;
+    for (uint32_t b : basis) {
+      if (!depE[b]) continue;
+      Link cand; cand.L = L; cand.E = E; cand.V = b;
+      bool good = true, any = false;
+      std::vector<std::pair<uint32_t, double>> stack{{b, 1.0}};
+      while (!stack.empty() && good) {
+        auto [x, sg] = stack.back(); stack.pop_back();
+        const Node &nd = P.nodes[x];
+        if (!depE[x]) { cand.cterms.push_back({x, sg}); continue; }
+        if (nd.op == RH_RIR_ADD) { stack.push_back({nd.b, sg}); stack.push_back({nd.a, sg}); continue; }
+        if (nd.op == RH_RIR_SUB) { stack.push_back({nd.b, -sg}); stack.push_back({nd.a, sg}); continue; }
+        uint32_t lg = NONE, coef = ONE;
+        if (nd.op == RH_RIR_LOG) lg = x;
+        else if (nd.op == RH_RIR_MUL && P.nodes[nd.a].op == RH_RIR_LOG && depE[nd.a] && !depE[nd.b]) { lg = nd.a; coef = nd.b; }
+        else if (nd.op == RH_RIR_MUL && P.nodes[nd.b].op == RH_RIR_LOG && depE[nd.b] && !depE[nd.a]) { lg = nd.b; coef = nd.a; }
+        if (lg == NONE) { good = false; break; }
+        const uint32_t arg = P.nodes[lg].a;
+        if (is_P(arg)) cand.beta.push_back({coef, sg});
+        else if (is_Q(arg)) cand.alpha.push_back({coef, sg});
+        else { good = false; break; }
+        any = true;
+      }
+      if (good && any) { if (found) return; lk = cand; found = true; }
+    }
+    if (!found || m <= 0.0) return;
+    lk.logm = std::log(m);
+    // every other E-dependent root -> its core (peel E-independent factors and negations)
+    std::vector<uint32_t> roots;
+    for (uint32_t b : basis) if (b != lk.V && depE[b]) roots.push_back(b);
+    if (gather.ok && depE[gather.sv]) roots.push_back(gather.sv);
+    std::vector<char> above(N, 0);          // E-dependent nodes that stay (products of a core with E-independent factors)
+    for (uint32_t r : roots) {
+      uint32_t x = r;
+      for (;;) {
+        const Node &nd = P.nodes[x];
+        if (nd.op == RH_RIR_MUL && depE[nd.a] != depE[nd.b]) { above[x] = 1; x = depE[nd.a] ? nd.a : nd.b; continue; }
+        if (nd.op == RH_RIR_SUB && is_const(nd.a, 0.0) && depE[nd.b]) { above[x] = 1; x = nd.b; continue; }
+        break;
+      }
+      if (x == lk.V) return;
+      lk.cores[x] = 0.0;
+    }
+    // nothing else may need E once V and the cores are closed forms
+    { std::vector<char> need(N, 0);
+      for (uint32_t b : basis) need[b] = 1;
+      if (gather.ok) need[gather.sv] = 1;
+      std::vector<uint32_t> ops;
+      for (size_t n = N; n-- > 0;) {
+        if (!need[n]) continue;
+        if (n == lk.V) { for (auto &c : lk.cterms) need[c.first] = 1; for (auto &c : lk.alpha) if (c.first < NONE) need[c.first] = 1; for (auto &c : lk.beta) if (c.first < NONE) need[c.first] = 1; need[L] = 1; continue; }
+        if (lk.cores.count((uint32_t)n)) continue;
+        operands(P.nodes[n], ops);
+        for (uint32_t o : ops) need[o] = 1;
+      }
+      for (size_t n = 0; n < N; n++) if (need[n] && depE[n] && n != lk.V && !lk.cores.count((uint32_t)n) && !above[n]) return;
+      if (need[E]) return; }
+    // the prelude (L, alpha, beta nodes) must be defined before the first overridden node
+    lk.first = lk.V;
+    for (auto &c : lk.cores) lk.first = std::min(lk.first, c.first);
+    auto before = [&](uint32_t x) { return x >= NONE || trivial(x) || P.nodes[x].dep == 0 || x < lk.first; };
+    if (!before(L)) return;
+    for (auto &c : lk.alpha) if (!before(c.first)) return;
+    for (auto &c : lk.beta) if (!before(c.first)) return;
+    // numerical verification
+    auto softplus = [](double x) { return x > 0 ? x + std::log1p(std::exp(-x)) : std::log1p(std::exp(x)); };
+    auto sigmoid = [](double x) { return x >= 0 ? 1.0 / (1.0 + std::exp(-x)) : std::exp(x) / (1.0 + std::exp(x)); };
+    static const double Ls[] = {-6.0, -3.1, -1.3, -0.4, 0.2, 0.9, 2.1, 4.4, 7.0};
+    unsigned long long rs = 0x9E3779B97F4A7C15ULL;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (double)(rs >> 11) / 9007199254740992.0; };
+    // pass 0 estimates every core's kappa = core / g (mean over the probes, then snapped to 13 significant digits: the true
+    // factors are small rationals like -1 or 1/10 and one quotient carries rounding noise); pass 1 verifies value and cores
+    std::map<uint32_t, std::pair<double, int>> acc;
+    for (int pass = 0; pass < 2; pass++) {
+      rs = 0x9E3779B97F4A7C15ULL;
+      for (int probe = 0; probe < 6; probe++) {
+        std::vector<double> inputs(P.n_inputs);
+        for (uint32_t i = 0; i < P.n_inputs; i++) inputs[i] = i < P.n_params ? (rnd() - 0.5) * 1.6 : (probe % 2 ? std::floor(rnd() * 6.0) : rnd() * 3.0 + 0.1);
+        const double gz = (rnd() - 0.5) * 1.2;
+        for (double Lv : Ls) {
+          std::map<uint32_t, double> memo; bool bad = false;
+          memo[L] = Lv + lk.logm;                       // t = log m - L = -Lv
+          auto sum = [&](const std::vector<std::pair<uint32_t, double>> &ts) { double a = 0; for (auto &c : ts) a += c.second * (c.first == ONE ? 1.0 : host_eval2(c.first, inputs, gz, memo, bad)); return a; };
+          const double al = sum(lk.alpha), be = sum(lk.beta), cc = sum(lk.cterms);
+          const double tt = -Lv, cv = cc + al * tt - (al + be) * softplus(tt), g = (al + be) * sigmoid(tt) - al;
+          const double v0 = host_eval2(lk.V, inputs, gz, memo, bad);
+          if (bad || !(std::fabs(v0 - cv) <= 1e-8 * std::max(1.0, std::fabs(cv)))) return;
+          for (auto &c : lk.cores) {
+            const double k0 = host_eval2(c.first, inputs, gz, memo, bad);
+            if (bad) return;
+            if (pass == 0) { if (std::fabs(g) > 1e-2) { acc[c.first].first += k0 / g; acc[c.first].second++; } }
+            else if (!(std::fabs(k0 - c.second * g) <= 1e-8 * std::max(1.0, std::fabs(c.second * g)))) return;
+          }
+        }
+      }
+      if (pass == 0)
+        for (auto &c : lk.cores) {
+          auto &a = acc[c.first];
+          if (a.second < 8) return;
+          double k = a.first / a.second;
+          if (!std::isfinite(k) || k == 0.0) return;
+          char buf[64]; std::snprintf(buf, sizeof buf, "%.12e", k);
+          const double snapped = std::strtod(buf, nullptr);
+          c.second = std::fabs(snapped - k) <= 1e-12 * std::fabs(k) ? snapped : k;
+        }
+    }
+    lk.ok = true;
+    link = lk;
+    // liveness again, with V and the cores as leaves
+    reach_row.assign(N, 0);
+    for (uint32_t b : basis) reach_row[b] = 1;
+    if (gather.ok) reach_row[gather.sv] = 1;
+    { std::vector<uint32_t> ops;
+      for (size_t n = N; n-- > 0;) {
+        if (!reach_row[n]) continue;
+        if (n == link.V) { for (auto &c : link.cterms) reach_row[c.first] = 1; for (auto &c : link.alpha) if (c.first < NONE) reach_row[c.first] = 1; for (auto &c : link.beta) if (c.first < NONE) reach_row[c.first] = 1; reach_row[L] = 1; continue; }
+        if (link.cores.count((uint32_t)n)) continue;
+        operands(P.nodes[n], ops);
+        for (uint32_t o : ops) reach_row[o] = 1;
+      } }
+    // invariants: recompute the slots from the new liveness
+    inv_slot.clear();
+    { std::vector<uint32_t> ops;
+      auto want = [&](uint32_t x) { if (x >= NONE) return; if (P.nodes[x].dep == 0 && !trivial(x) && !inv_slot.count(x)) { int sl = (int)inv_slot.size(); inv_slot[x] = sl; } };
+      for (size_t n = 0; n < N; n++) {
+        if (!reach_row[n]) continue;
+        if (P.nodes[n].dep == 0) { want((uint32_t)n); continue; }
+        if (n == link.V || link.cores.count((uint32_t)n)) continue;
+        operands(P.nodes[n], ops);
+        for (uint32_t o : ops) want(o);
+      }
+      for (const Lin &l : outs) { want(l.alpha); want(l.beta); }
+      reach_inv.assign(N, 0);
+      for (auto &kv : inv_slot) reach_inv[kv.first] = 1;
+      sweep(reach_inv); }
+  }
+
+  std::string link_sum(const std::vector<std::pair<uint32_t, double>> &ts) const {
+    std::string e;
+    for (auto &c : ts) {
+      const std::string term = c.first == ONE ? "0x1p+0" : ref(c.first, 1);
+      e += (c.second < 0 ? " - " : (e.empty() ? "" : " + ")) + term;
+    }
+    return e.empty() ? "0x0p+0" : "(" + e + ")";
+  }
+  void emit_link_prelude(std::ostringstream &os) const {
+    os << "    const double lk_t = " << lit(link.logm) << " - " << ref(link.L, 1) << ";\n"
+       << "    double lk_sp, lk_sg;\n    rh_logit_link(lk_t, lk_sp, lk_sg);\n"
+       << "    const double lk_a = " << link_sum(link.alpha) << ", lk_ab = lk_a + " << link_sum(link.beta) << ";\n"
+       << "    const double lk_g = lk_ab * lk_sg - lk_a;\n";
   }
 
   // how an operand is spelled: ctx 0 = invariants(), 1 = row(), 2 = finish()
@@ -685,9 +932,16 @@ struct TargetEmitter {
       else
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double *acc, int &err) {\n"
               "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+      bool link_open = false;
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
         if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
+        if (link.ok && (n == link.V || link.cores.count((uint32_t)n))) {   // verified closed forms (detect_link)
+          if (!link_open) { emit_link_prelude(os); link_open = true; }
+          if (n == link.V) os << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
+          else os << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
+          continue;
+        }
         if (!emit_node(os, (uint32_t)n, 1, err)) return false;
       }
       for (size_t j = 0; j < basis.size(); j++) os << accumulate("acc[" + std::to_string(j) + "]", basis[j], 1);
@@ -759,6 +1013,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
     te.gmode = gmode; te.n_shared = n_shared;
     if (gmode) { if (!te.detect_gather(err)) return false; if (te.gather.ok) ngather++; }
     te.plan();
+    if (o.logit_link) te.detect_link();
     if (!te.emit(os, err)) return false;
     { EmitInfo::TargetInfo ti; ti.has_rows = P.targets[t].n_cols > 0; ti.has_gather = te.gather.ok; ti.g_col = te.gather.col;
       ti.g_count = te.gather.count; ti.g_low = te.gather.low; I.targets.push_back(ti); }

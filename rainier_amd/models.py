@@ -234,3 +234,31 @@ def hier_negbin(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fai
     cols = [np.arange(G, dtype=np.float64), dv, dc, dg, dx0, dx1]
     return ModelSpec("hier_negbin_%dx%d" % (G, per_group), rir, cols, [0, G, G * per_group], n_params,
                      {"kind": "hier_negbin", "groups": G})
+
+
+def negbin_glm(n: int = 100_000, k: int = 3, seed: int = 7, n_fail: float = 5.0) -> ModelSpec:
+    """A negative-binomial GLM without group effects: theta = (a, b_0..b_{k-1}) ~ N(0,1), p = 1 / (1 + n e^{-eta}) so that the
+    mean is e^eta, NegativeBinomial(p, n).logDensity(v) written as core/Discrete.scala:111-114 does (the data-only factorial
+    terms folded into a column).  The streamed twin of cfg 5's row term: exercises the logit-family closed form on the plain
+    batched gradient kernel."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((k, n)) * 0.4
+    beta = rng.standard_normal(k) * 0.5
+    lam = np.exp(0.3 + beta @ X)
+    v = rng.negative_binomial(n_fail, n_fail / (n_fail + lam)).astype(np.float64)
+    crow = nemes_log_gamma(n_fail + v - 1 + 1) - nemes_log_gamma(v + 1) - float(nemes_log_gamma(n_fail - 1 + 1))
+    g = Graph(1 + k, [0, 2 + k])
+    a = g.param(0)
+    b = [g.param(1 + j) for j in range(k)]
+    prior = std_normal_logpdf(a)
+    for bj in b:
+        prior = prior + std_normal_logpdf(bj)
+    vv, cc = g.col(1, 0), g.col(1, 1)
+    eta = a
+    for j, bj in enumerate(b):
+        eta = eta + bj * g.col(1, 2 + j)
+    p = 1.0 / ((eta * -1.0).exp() * n_fail + 1.0)
+    row = cc + (1.0 - p).log() * n_fail + vv * p.log()
+    rir = g.compile([prior, row])
+    cols = [np.ascontiguousarray(v), np.ascontiguousarray(crow)] + [np.ascontiguousarray(X[j]) for j in range(k)]
+    return ModelSpec("negbin_glm_%dx%d" % (k, n), rir, cols, [0, n], 1 + k, {"kind": "negbin_glm", "k": k})

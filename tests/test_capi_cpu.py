@@ -187,11 +187,11 @@ def test_rir_header_overflow_is_rejected_before_allocation():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r1_e_final/bench_cfg2.json is the output of `python bench.py` on an MI355X: one JSON line with the keys the
+    """profiles/r2_a_cfg2/bench_default.json is the output of `python bench.py` on an MI355X: one JSON line with the keys the
     driver and the judge read (metric/value/...; roofline{bound, achieved, peak, unit, frac, traffic}; cpu_baseline{...})."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lines = [l for l in open(os.path.join(root, "profiles", "r1_e_final", "bench_cfg2.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(root, "profiles", "r2_a_cfg2", "bench_default.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -201,8 +201,46 @@ def test_committed_bench_line_honours_the_contract():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "cfg2" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "mfma", "fp64_valu") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert c["inlined_sufficient_statistics"]["value"] > 0 and c["nproc"] >= c["cores"]
+    assert d["ess_leg"]["warmup"] >= 128 and d["ess_leg"]["iterations"] >= 64 and 0.6 < d["ess_leg"]["mean_accept_prob"] < 0.99
     assert abs(d["value"] - d["config"]["chains"] * d["config"]["leapfrog_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_logit_family_links_are_lowered_in_closed_form_only_when_verified():
+    """emit.cpp detect_logit / detect_link: fast builds of cfg 4 (Bernoulli-logit, MFMA GLM kernel), cfg 5 (negative binomial in
+    gather mode) and a plain negative-binomial GLM call rh_logit_link once per evaluation; strict builds and RH_LOGIT_LINK=0
+    keep the literal lowering; a model whose adjoint does NOT match the closed form (a gradient output scaled by hand) is left
+    alone -- the rewrite is verified numerically, never assumed."""
+    fast = _capi.compile_opts(fp_contract=True, factor_outputs=True)
+    gen = lambda src: src.split("// ---- generated from RIR")[1].split("// rh_engine.hip.h")[0]   # the per-model part only
+    for spec in (models.logistic(n=8, k=50), models.hier_negbin(200, 2), models.negbin_glm(n=8, k=3)):
+        src, _ = _capi.lower_only(spec.rir, fast)
+        assert "rh_logit_link(" in gen(src), spec.name
+        src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
+        assert "rh_logit_link(" not in gen(src), spec.name
+    os.environ["RH_LOGIT_LINK"] = "0"
+    try:
+        src, _ = _capi.lower_only(models.hier_negbin(200, 2).rir, fast)
+        assert "rh_logit_link(" not in gen(src)
+    finally:
+        del os.environ["RH_LOGIT_LINK"]
+    # a wrong adjoint: the same value, but "d/d a" replaced by its square -> that core is not kappa * g -> literal lowering
+    # (a constant factor would not do: output factoring peels it off and the row-level core still verifies, correctly)
+    from rainier_amd.frontend import Graph
+    import numpy as np
+    g = Graph(2, [0, 3])
+    a, b = g.param(0), g.param(1)
+    eta = a + b * g.col(1, 2)
+    p = 1.0 / ((eta * -1.0).exp() * 5.0 + 1.0)
+    row = g.col(1, 1) + (1.0 - p).log() * 5.0 + g.col(1, 0) * p.log()
+    good = g.compile([a * a * -0.5, row])
+    src, _ = _capi.lower_only(good, fast)
+    assert "rh_logit_link(" in gen(src)
+    gr = g.gradient(row)
+    bad = g.compile([a * a * -0.5, row], gradients=[g.gradient(a * a * -0.5), [gr[0] * gr[0], gr[1]]])
+    src, _ = _capi.lower_only(bad, fast)
+    assert "rh_logit_link(" not in gen(src)
