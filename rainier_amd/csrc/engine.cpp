@@ -191,11 +191,6 @@ struct rh_sampler {
   int nsplit = 0, xcd_aware = 1;
   void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
   std::vector<hipEvent_t> ev;
-  // tick engine, >= 2 x 256 chains: the chains are driven as two half-batches so that one half's latency-bound tick kernel runs
-  // (on its own stream) underneath the other half's gradient kernel; gradient launches stay strictly serial on the main stream
-  int nbatch = 1;
-  hipStream_t tstream = nullptr;
-  hipEvent_t evg[2] = {nullptr, nullptr}, evt[2] = {nullptr, nullptr};
   GatherBufs *gb = nullptr;
   std::vector<rh_chain_stats_dev> last_stats;
   int64_t grads_at_reset = 0;
@@ -567,8 +562,7 @@ struct GatherBufs {
 // tick engine: row splits per chain group -- ~4 wavefronts per SIMD (256 CUs x 4 SIMDs), a multiple of 8 so that the XCD
 // mapping applies, and >= 2048 rows per split
 int default_nsplit(const rh_model *m, int chains) {
-  int ngroups = (chains + m->grad_k - 1) / m->grad_k;
-  if (!m->info.gather_mode && chains >= 512 && !std::getenv("RH_TICK_BATCHES")) ngroups = (ngroups + 1) / 2;  // two half-batches per tick: size each launch
+  const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   int64_t max_rows = 1;
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
   int nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
@@ -583,28 +577,28 @@ int default_nsplit(const rh_model *m, int chains) {
 // one batched gradient launch of the tick engine: whichever row-streaming kernel the model was lowered to
 // (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial
 void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d_partial, void *d_graderr, void *d_running,
-                 int chains, int nsplit, int xcd, hipStream_t stream) {
+                 int chains, int nsplit, int xcd) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   if (m->info.gather_mode) {
     void *ga[] = {&m->data, &gb->gd, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
-    launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, stream, ga);
+    launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
     return;
   }
   void *args[] = {&m->data, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
   if (m->k_grad_glm && m->glm_small) {
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
-    launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, stream, args);
+    launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
     const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
-    HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, stream, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else if (m->use_lds_grad) {
     const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
     const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
-    HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, stream, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
   } else
-    launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, stream, args);
+    launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
 }
 }  // namespace
 
@@ -644,7 +638,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
       int xcd = 1;
       if (const char *e = std::getenv("RH_XCD_AWARE")) xcd = std::atoi(e);
-      launch_grad(m, &gb, dq, bact.p, bpart.p, de, brun.p, chains, nsplit, xcd, m->stream);
+      launch_grad(m, &gb, dq, bact.p, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
         void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
@@ -748,8 +742,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     const size_t draws_bytes = (size_t)chains * (size_t)(cfg->iterations ? cfg->iterations : 1) * n * sizeof(double);
     HIPCHK(hipMalloc(&s->d_draws, draws_bytes));
     HIPCHK(hipMalloc(&s->d_stats, sizeof(rh_chain_stats_dev) * chains));
-    HIPCHK(hipMalloc(&s->d_running, 2 * sizeof(int)));
-    HIPCHK(hipMemset(s->d_running, 0, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&s->d_running, sizeof(int)));
     {
       std::vector<int64_t> rec((size_t)2 * chains);
       for (int c = 0; c < chains; c++) {
@@ -780,15 +773,6 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       HIPCHK(hipMalloc(&s->d_active, sizeof(int) * chains));
       HIPCHK(hipMalloc(&s->d_partial, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
       HIPCHK(hipMalloc(&s->d_graderr, sizeof(int)));
-      {
-        int want = (!m->info.gather_mode && chains >= 512) ? 2 : 1;
-        if (const char *e = std::getenv("RH_TICK_BATCHES")) want = std::atoi(e) >= 2 && !m->info.gather_mode && chains >= 128 ? 2 : 1;
-        s->nbatch = want;
-        if (want == 2) {
-          HIPCHK(hipStreamCreateWithFlags(&s->tstream, hipStreamNonBlocking));
-          for (int b = 0; b < 2; b++) { HIPCHK(hipEventCreateWithFlags(&s->evg[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->evt[b], hipEventDisableTiming)); }
-        }
-      }
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
       HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
@@ -809,8 +793,6 @@ extern "C" void rh_sampler_destroy(rh_sampler *s) {
   for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr})
     if (p) hipFree(p);
   for (hipEvent_t e : s->ev) hipEventDestroy(e);
-  for (int b = 0; b < 2; b++) { if (s->evg[b]) hipEventDestroy(s->evg[b]); if (s->evt[b]) hipEventDestroy(s->evt[b]); }
-  if (s->tstream) hipStreamDestroy(s->tstream);
   delete s->gb;
   if (s->e0) hipEventDestroy(s->e0);
   if (s->e1) hipEventDestroy(s->e1);
@@ -819,45 +801,23 @@ extern "C" void rh_sampler_destroy(rh_sampler *s) {
 
 namespace {
 // tick engine: [tick] then repeat { [grad] [tick] } until no chain asks for a gradient any more.
-// With two half-batches (s->nbatch == 2) the launches are   main stream:  gradA gradB gradA gradB ...   (strictly serial)
-//                                                            tick stream:       tickA tickB tickA ...   tick X waits for grad X,
-// the next grad X waits for tick X: each tick runs underneath the other half's gradient kernel.  A chain's arithmetic does
-// not depend on the batching (the batch boundary is a multiple of 64 chains, the row splits come from the total chain count).
 void advance_to_ticks(rh_sampler *s, int it_stop) {
   rh_model *m = s->m;
   HIPCHK(hipSetDevice(m->device));
-  int nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
-  const int n = (int)m->prog.n_params, nb = s->nbatch;
-  int off[3] = {0, s->chains, s->chains};
-  if (nb == 2) off[1] = ((s->chains / 2 + 63) / 64) * 64;
-  struct View { void *state, *seeds, *draws, *stats, *running, *qbuf, *active, *partial; int chains; };
-  View vw[2];
-  for (int b = 0; b < nb; b++) {
-    const size_t o = (size_t)off[b];
-    vw[b].chains = off[b + 1] - off[b];
-    vw[b].state = (char *)s->d_state + o * s->state_words * sizeof(uint64_t);
-    vw[b].seeds = (char *)s->d_seeds + o * 2 * sizeof(int64_t);
-    vw[b].draws = (char *)s->d_draws + o * (size_t)s->cfg.iterations * n * sizeof(double);
-    vw[b].stats = (char *)s->d_stats + o * sizeof(rh_chain_stats_dev);
-    vw[b].running = (char *)s->d_running + b * sizeof(int);
-    vw[b].qbuf = (char *)s->d_qbuf + o * n * sizeof(double);
-    vw[b].active = (char *)s->d_active + o * sizeof(int);
-    vw[b].partial = (char *)s->d_partial + o * (size_t)m->n_row_targets * nsplit * m->nacc_max * sizeof(double);
-  }
-  auto tick = [&](int b, int fresh, bool reset_counter, hipStream_t st) {
-    View &v = vw[b];
-    if (reset_counter) HIPCHK(hipMemsetAsync(v.running, 0, sizeof(int), st));
+  int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
+  auto tick = [&](int fresh, bool reset_counter) {
+    if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     if (m->info.gather_mode) {
-      void *args[] = {&m->data, &s->gb->gd, &s->cfg, &v.state, &v.seeds, &s->d_mass, &v.draws, &v.stats, &v.running, &v.qbuf,
-                      &v.active, &v.partial, &s->d_graderr, &v.chains, &nsplit, &stop, &fresh};
-      launch(s->k_tick, (unsigned)v.chains, 64, st, args);
+      void *args[] = {&m->data, &s->gb->gd, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+                      &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+      launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
       return;
     }
-    void *args[] = {&m->data, &s->cfg, &v.state, &v.seeds, &s->d_mass, &v.draws, &v.stats, &v.running, &v.qbuf,
-                    &v.active, &v.partial, &s->d_graderr, &v.chains, &nsplit, &stop, &fresh};
-    launch(s->k_tick, (unsigned)v.chains, 64, st, args);
+    void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+                    &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+    launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
-  auto grad = [&](int b) { View &v = vw[b]; launch_grad(m, s->gb, v.qbuf, v.active, v.partial, s->d_graderr, v.running, v.chains, nsplit, xcd, m->stream); };
+  auto grad = [&]() { launch_grad(m, s->gb, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
   // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
   int remaining_hint = 32;
   if (s->cfg.sampler == RH_SAMPLER_HMC && s->warmed) {
@@ -865,49 +825,34 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     remaining_hint = std::max(1, iters * std::max(1, s->cfg.hmc_steps));
   }
   HIPCHK(hipEventRecord(s->e0, m->stream));
-  for (int b = 0; b < nb; b++) tick(b, s->started ? 0 : 1, true, m->stream);
+  tick(s->started ? 0 : 1, true);
   s->started = true;
   HIPCHK(hipEventRecord(s->e1, m->stream));
   for (;;) {
-    int running[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(running, s->d_running, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    int running = 0;
+    HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s->e0, s->e1));
     s->total_ms += ms;
-    if (running[0] + (nb == 2 ? running[1] : 0) == 0) break;
+    if (running == 0) break;
     const int B = std::min(remaining_hint, 256);
-    while ((int)s->ev.size() < 2 * B * nb) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev.push_back(e); }
+    while ((int)s->ev.size() < 2 * B) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev.push_back(e); }
     HIPCHK(hipEventRecord(s->e0, m->stream));
-    if (nb == 1) {
-      for (int i = 0; i < B; i++) {
-        HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
-        grad(0);
-        HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
-        tick(0, 0, false, m->stream);
-      }
-    } else {
-      for (int i = 0; i < B; i++)
-        for (int b = 0; b < 2; b++) {
-          if (i > 0) HIPCHK(hipStreamWaitEvent(m->stream, s->evt[b], 0));       // grad X(i) after tick X(i-1)
-          HIPCHK(hipEventRecord(s->ev[2 * (2 * i + b)], m->stream));
-          grad(b);
-          HIPCHK(hipEventRecord(s->ev[2 * (2 * i + b) + 1], m->stream));
-          HIPCHK(hipEventRecord(s->evg[b], m->stream));
-          HIPCHK(hipStreamWaitEvent(s->tstream, s->evg[b], 0));                 // tick X(i) after grad X(i)
-          tick(b, 0, false, s->tstream);
-          HIPCHK(hipEventRecord(s->evt[b], s->tstream));
-        }
-      for (int b = 0; b < 2; b++) HIPCHK(hipStreamWaitEvent(m->stream, s->evt[b], 0));   // join: the main stream ends after both last ticks
+    for (int i = 0; i < B; i++) {
+      HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
+      grad();
+      HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
+      tick(0, false);
     }
     HIPCHK(hipEventRecord(s->e1, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    for (int i = 0; i < B * nb; i++) {
+    for (int i = 0; i < B; i++) {
       float g = 0;
       HIPCHK(hipEventElapsedTime(&g, s->ev[2 * i], s->ev[2 * i + 1]));
       s->kernel_ms += g;
     }
-    s->launches += B * nb;
+    s->launches += B;
     remaining_hint = std::max(32, remaining_hint - B);
   }
 }

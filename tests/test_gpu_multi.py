@@ -101,23 +101,3 @@ def test_bench_under_torch_distributed_run_one_rank():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["chains"] == 64
-
-
-@pytest.mark.parametrize("sampler", ["hmc", "ehmc", "nuts"])
-def test_half_batched_ticks_do_not_change_a_single_draw(sampler, monkeypatch):
-    """tick engine, >= 512 chains (forced here from 128 with RH_TICK_BATCHES=2): the chains are driven as two half-batches so that
-    one half's tick kernel runs underneath the other half's gradient kernel.  Same row splits, same chain groups => every draw,
-    mass matrix and statistic is bit-identical to the single-batch schedule."""
-    spec = models.linreg(n=70000, k=3)
-    smp = {"hmc": R.HMCSampler(5), "ehmc": R.EHMCSampler(64), "nuts": R.NUTSSampler(5)}[sampler]
-    cfg = R.make_config(10, 25, smp, R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(8, 1.5, 4, 4), engine=_capi.ENGINE_TICK, gradSplits=16)
-    seeds = [300 + c for c in range(200)]                  # 200 chains: halves of 128 and 72 (ragged second half)
-    out = {}
-    for nb in ("1", "2"):
-        monkeypatch.setenv("RH_TICK_BATCHES", nb)
-        m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True, grad_chains=8)
-        out[nb] = m.sample(cfg, seeds=seeds)
-        m.close()
-    assert np.array_equal(out["1"].chains, out["2"].chains)
-    assert np.array_equal(out["1"].mass, out["2"].mass)
-    assert [s.leapfrogSteps for s in out["1"].stats] == [s.leapfrogSteps for s in out["2"].stats]
