@@ -262,3 +262,56 @@ def negbin_glm(n: int = 100_000, k: int = 3, seed: int = 7, n_fail: float = 5.0)
     rir = g.compile([prior, row])
     cols = [np.ascontiguousarray(v), np.ascontiguousarray(crow)] + [np.ascontiguousarray(X[j]) for j in range(k)]
     return ModelSpec("negbin_glm_%dx%d" % (k, n), rir, cols, [0, n], 1 + k, {"kind": "negbin_glm", "k": k})
+
+
+# ---- the same configurations written the way the REFERENCE writes them, lowered by its own front end ------------------------
+# (rainier_amd/modeling.py + compute.py: rainier-core's distributions and Model.observe, rainier-compute's Real algebra,
+#  Gradient, PartialEvaluator.inline and Translator, restated).  The RIR of these builders is what Compiler.compileTargets
+#  would hand to the back end; the hand-derived builders above are the natural streamed forms SURVEY 8(d) sizes.
+def eight_schools_reference() -> ModelSpec:
+    """cfg 3 as rainier-benchmark/.../bench/stan/EightSchools.scala:9-20 writes it.  Every single-observation likelihood is
+    inlinable, so all ten targets come out data-free, exactly as in the reference."""
+    from . import modeling as M
+    mu = M.Normal(0, 5).latent
+    tau = M.Cauchy(0, 5).latent.abs()
+    thetas = M.Normal(mu, tau).latentVec(len(EIGHT_SCHOOLS_SIGMA))
+    m = M.Model([M.Real.zero])                                         # Model.empty
+    for theta, y, sg in zip(thetas, EIGHT_SCHOOLS_Y, EIGHT_SCHOOLS_SIGMA):
+        m = M.Model.observe([float(y)], M.Normal(theta, sg)).merge(m)   # foldLeft(Model.empty) { observe(...).merge(m) }
+    spec = m.compile("eight_schools_reference")
+    spec.meta["kind"] = "eight_schools"
+    return spec
+
+
+def funnel_reference(dim: int = 10) -> ModelSpec:
+    """cfg 1: y = Normal(0, 3).latent, x_i = Normal(0, exp(y / 2)).latent, tracked (Model.track: the likelihood is Real.zero)."""
+    from . import modeling as M
+    y = M.Normal(0, 3).latent
+    xs = [M.Normal(0, (y / 2).exp()).latent for _ in range(dim - 1)]
+    spec = M.Model.track([y] + xs).compile("funnel%d_reference" % dim)
+    spec.meta["kind"] = "funnel"
+    return spec
+
+
+def linreg_reference(n: int = 1000, k: int = 3, seed: int = 20260925, columns=None, inline: bool = True, split: bool = True) -> ModelSpec:
+    """cfg 2 as the reference's README writes it (README.md:19-32): sigma = Exponential(1).latent, alpha = Normal(0,1).latent,
+    betas = Normal(0,1).latentVec(k), Model.observe(ys, Vec.from(xs).map { x => Normal(alpha + x.dot(betas), sigma) }).
+    With k <= 3 the reference INLINES the likelihood (15 distributed terms < 20): the spec has no data columns at all."""
+    from . import modeling as M
+    cols = linreg_data(n, k, seed) if columns is None else columns
+    sigma = M.Exponential(1).latent
+    alpha = M.Normal(0, 1).latent
+    betas = M.Normal(0, 1).latentVec(k)
+    m = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Normal(alpha + M.Real.sum([ui * bi for ui, bi in zip(u, betas)]), sigma), split=split)
+    return m.compile("linreg_reference_%dx%d" % (k, n), inline=inline)
+
+
+def logistic_reference(n: int = 1000, k: int = 8, seed: int = 4, columns=None) -> ModelSpec:
+    """cfg 4's model text: Bernoulli((a + x.dot(b)).logistic) observed row by row.  Not inlinable (the link is non-linear); the
+    reference's algebra pushes every data-only factor into derived columns (gradientColumns): 5 (k + 1) columns."""
+    from . import modeling as M
+    cols = logistic_data(n, k, seed) if columns is None else columns
+    a = M.Normal(0, 1).latent
+    bs = M.Normal(0, 1).latentVec(k)
+    m = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic), split=False)
+    return m.compile("logistic_reference_%dx%d" % (k, n))

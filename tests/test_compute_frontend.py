@@ -220,3 +220,27 @@ def test_logistic_regression_through_the_front_end_matches_the_hand_derived_rir(
     ref = models.logistic(n=n, k=k, columns=cols)
     for q in np.random.default_rng(3).normal(size=(4, k + 1)) * 0.5:
         np.testing.assert_allclose(O.OracleDensity(spec).update(q), O.OracleDensity(ref).update(q), rtol=1e-10, atol=1e-10)
+
+
+def test_baseline_models_in_reference_text_match_the_hand_derived_rirs():
+    """models.*_reference(): the BASELINE configurations written as the reference writes them and lowered by the restated front
+    end agree with the hand-derived streamed RIRs of models.py (value and full gradient, oracle interpreter)."""
+    rng = np.random.default_rng(5)
+    a, b = models.eight_schools_reference(), models.eight_schools()
+    assert a.nrows == [0] * 10 and a.n_params == 10 and a.columns == []        # prior + Model.empty + 8 inlined observations
+    for q in rng.normal(size=(5, 10)) * 0.8:
+        np.testing.assert_allclose(O.OracleDensity(a).update(q), O.OracleDensity(b).update(q), rtol=1e-13, atol=1e-13)
+    a, b = models.funnel_reference(10), models.funnel(10)
+    assert a.nrows == [0, 0]
+    for q in rng.normal(size=(5, 10)):
+        np.testing.assert_allclose(O.OracleDensity(a).update(q), O.OracleDensity(b).update(q), rtol=1e-13, atol=1e-13)
+    cols = models.linreg_data(700, 3)
+    a, b = models.linreg_reference(columns=cols), models.linreg(n=700, k=3, columns=cols)
+    assert a.columns == [] and a.nrows == [0, 0, 0]                             # the reference inlines cfg 2
+    for q in rng.normal(size=(4, 5)) * 0.5:
+        np.testing.assert_allclose(O.OracleDensity(a).update(q), O.OracleDensity(b).update(q), rtol=1e-10, atol=1e-10)
+    cols = models.logistic_data(300, 8)
+    a, b = models.logistic_reference(columns=cols), models.logistic(n=300, k=8, columns=cols)
+    assert a.nrows == [0, 300] and len(a.columns) == 5 * 9
+    for q in rng.normal(size=(4, 9)) * 0.5:
+        np.testing.assert_allclose(O.OracleDensity(a).update(q), O.OracleDensity(b).update(q), rtol=1e-10, atol=1e-10)
