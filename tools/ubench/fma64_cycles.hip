@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(64) k(double *out, unsigned long long *cyc, co
   const double a = in[0];
   const double one = in[3000];
   const double va = in[2 + threadIdx.x];
+  const double vb = in[130 + threadIdx.x];
 #pragma unroll
   for (int i = 0; i < NACC; i++) acc[i] = in[threadIdx.x + i];
   __builtin_amdgcn_s_barrier();
@@ -23,6 +24,12 @@ __global__ void __launch_bounds__(64) k(double *out, unsigned long long *cyc, co
       if (MODE == 0) acc[i] = __builtin_fma(va, a, acc[i]);                                   // accumulate-form FMA
       else if (MODE == 1) acc[i] = (i % 9 < 7) ? __builtin_fma(va, a, acc[i]) : acc[i] + va;  // 7 fma : 2 add
       else if (MODE == 2) acc[i] = (i % 9 < 7) ? __builtin_fma(va, a, acc[i]) : __builtin_fma(va, one, acc[i]);
+      else if (MODE == 4) {   // v_fmac_f64 with a DPP row_newbcast source: the lane-per-chain GLM formulation's broadcast FMA
+        if (i % 4 == 0) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(va), "v"(vb));
+        else if (i % 4 == 1) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(va), "v"(vb));
+        else if (i % 4 == 2) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:10 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(va), "v"(vb));
+        else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(va), "v"(vb));
+      }
       else acc[i] = acc[i] + va;
     }
   }
@@ -114,11 +121,19 @@ void run(const char *name, int w, double *out, unsigned long long *cyc, double *
   printf("\n");
 }
 
-int main() {
+int main(int argc, char **argv) {
   double *in, *out; unsigned long long *cyc;
   hipMalloc(&in, 4096 * 8); hipMalloc(&out, 256 * 4 * 8 * 64 * 8); hipMalloc(&cyc, 256 * 4 * 8 * 4 * 8);
   std::vector<double> h(4096, 1.0000001); h[3000] = 1.0;
   hipMemcpy(in, h.data(), 4096 * 8, hipMemcpyHostToDevice);
+  if (argc > 1) {   // `fma64_cycles dpp`: only the DPP-broadcast FMA against the plain one
+    for (int w = 1; w <= 2; w++) {
+      run<16, 0>("fma(v, s, acc)", w, out, cyc, in);
+      run<16, 4>("fmac_dpp row_newbcast", w, out, cyc, in);
+      run<40, 4>("fmac_dpp row_newbcast", w, out, cyc, in);
+    }
+    return 0;
+  }
   for (int w = 1; w <= 4; w++) {
     run<16, 0>("fma(v, s, acc)", w, out, cyc, in);
     run<40, 0>("fma(v, s, acc)", w, out, cyc, in);
