@@ -149,7 +149,7 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     s.run(a.steps)
     gathered = None
     if comm is not None:
-        gathered = comm.rccl.allgather_draws(s)          # RCCL all-gather over xGMI + copy to the host
+        gathered = comm.rccl.allgather_draws(s, to_host=(rank == 0))     # RCCL all-gather over xGMI (rank 0: + copy to the host)
         D.device_synchronize(local_rank)
     dt = time.perf_counter() - t0
     stats, _ = s.stats()
@@ -160,7 +160,7 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     if rank != 0:
         return
     steps, wsteps = counts
-    draws = gathered if gathered is not None else s.draws()
+    draws = gathered if comm is not None else s.draws()
     nshow = min(spec.n_params, 16)
     ess = min(e for _, e in R.diagnostics(draws[:, :, :nshow])) if a.steps >= 4 and draws.shape[0] >= 2 else None
     tim = s.timing()
@@ -249,14 +249,15 @@ def main():
         t0 = time.perf_counter()
         s.run(iters)                    # synchronises the engine stream
         if dist is not None:
-            gathered = dist.rccl.allgather_draws(s)      # the ONE collective: RCCL all-gather over xGMI (+ copy to the host)
+            # the ONE collective: RCCL all-gather over xGMI; rank 0 also copies the gathered draws to the host (diagnostics)
+            gathered = dist.rccl.allgather_draws(s, to_host=(rank == 0))
             D.device_synchronize(local_rank)
         dt = time.perf_counter() - t0
         if dist is not None:
             dt = dist.rccl.allreduce_max(dt)             # max over ranks
         tim = s.timing()
         stats, _ = s.stats()
-        draws = (gathered if rank == 0 else None) if gathered is not None else s.draws()
+        draws = (gathered if rank == 0 else None) if dist is not None else s.draws()
         s.close()
         return dt, draws, stats, tim
 
@@ -346,6 +347,7 @@ class HostGroup:
     communicator, the barriers and tiny host reductions; `rccl` is the engine's communicator (rh_comm)."""
 
     def __init__(self, rank, world, local_rank, D):
+        D.device_synchronize(local_rank)   # this rank's device becomes the thread's current device before RCCL sees it
         mine = D.Comm.unique_id()       # every rank: loads the system RCCL now, BEFORE torch brings its bundled copy
         import torch
         import torch.distributed as dist
