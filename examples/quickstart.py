@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rainier_amd as R
-from rainier_amd import models
+from rainier_amd import _capi, models
 from rainier_amd.modeling import Model as RainierModel, Normal, Uniform
 
 m = R.Model(models.linreg(n=1_000_000, k=3), fp_contract=True, factor_outputs=True)
@@ -18,3 +18,13 @@ mu, sigma = Normal(0, 10).latent, Uniform(0, 1).latent
 fit = RainierModel.observe([1.0, 2.0, 3.0], Normal(mu, sigma))
 tr = R.Model(fit.compile()).sample(R.make_config(500, 500), seeds=[1, 2, 3, 4])
 print("fit normal: mu", fit.predict(mu, tr.chains).mean(), "sigma", fit.predict(sigma, tr.chains).mean())
+
+# the BASELINE models in the reference's own model text, lowered by the restated front end (compute.py): cfg 3 ...
+es = R.Model(models.eight_schools_reference(), math_mode=_capi.MATH_STRICT)
+tr = es.sample(R.make_config(500, 500), seeds=range(64))          # DefaultConfig: EHMC + DualAvg + windowed diagonal mass
+print("eight schools (EightSchools.scala text): rhat max", max(r for r, _ in tr.diagnostics()))
+
+# ... and Model.sample over several devices in ONE native call (here: two shards on device 0; the trace does not depend on it)
+m2 = R.Model(models.linreg(n=1_000_000, k=3), fp_contract=True, factor_outputs=True)
+t2 = R.sample_multi([m, m2], cfg, range(1024))
+print("two shards == one:", np.array_equal(t2.chains, trace.chains))
