@@ -26,6 +26,9 @@ struct _jobject {
 static const size_t fj_elem[] = {0, 1, 4, 8, 8, sizeof(jobject), 0};
 
 static int g_outstanding = 0, g_bad_release = 0, g_gets = 0, g_copybacks = 0;
+static int g_pinning = 0;   /* 0: a copying JVM (Get returns a copy, isCopy = JNI_TRUE); 1: a pinning JVM (Get returns the array's own
+                               storage, isCopy = JNI_FALSE, Release modes do not move data) -- the JNI specification allows both */
+void fj_set_pinning(int on) { g_pinning = on; }
 static char g_exc_class[128], g_exc_msg[1024];
 static struct { void *buf; jobject arr; } g_live[256];
 
@@ -73,9 +76,9 @@ static jobject f_GetObjectArrayElement(JNIEnv *env, jobjectArray a, jsize i) {
 static void *get_elems(jarray a, int kind, jboolean *is_copy) {
   if (!a || a->kind != kind) { g_bad_release++; return NULL; }
   const size_t bytes = (size_t)a->len * fj_elem[kind];
-  void *buf = malloc(bytes ? bytes : 1);
-  memcpy(buf, a->data, bytes);
-  if (is_copy) *is_copy = 1;
+  void *buf;
+  if (g_pinning) { buf = a->data; if (is_copy) *is_copy = 0; }
+  else { buf = malloc(bytes ? bytes : 1); memcpy(buf, a->data, bytes); if (is_copy) *is_copy = 1; }
   for (int i = 0; i < 256; i++) if (!g_live[i].buf) { g_live[i].buf = buf; g_live[i].arr = a; break; }
   g_outstanding++; g_gets++;
   return buf;
@@ -84,9 +87,11 @@ static void release_elems(jarray a, int kind, void *buf, jint mode) {
   int found = 0;
   for (int i = 0; i < 256; i++) if (g_live[i].buf == buf && buf) { found = g_live[i].arr == a; g_live[i].buf = NULL; break; }
   if (!found || !a || a->kind != kind) { g_bad_release++; return; }
-  if (mode == 0) { memcpy(a->data, buf, (size_t)a->len * fj_elem[kind]); g_copybacks++; }
-  else if (mode != JNI_ABORT) g_bad_release++;   /* JNI_COMMIT is never right for the shim */
-  free(buf);
+  if (mode != 0 && mode != JNI_ABORT) g_bad_release++;   /* JNI_COMMIT is never right for the shim */
+  if (buf != a->data) {
+    if (mode == 0) { memcpy(a->data, buf, (size_t)a->len * fj_elem[kind]); g_copybacks++; }
+    free(buf);
+  }
   g_outstanding--;
 }
 static jbyte *f_GetByte(JNIEnv *e, jbyteArray a, jboolean *c) { (void)e; return (jbyte *)get_elems(a, FJ_BYTE, c); }

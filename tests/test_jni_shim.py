@@ -39,6 +39,7 @@ def fj(tmp_path_factory):
     L.fj_array_data.restype = vp; L.fj_array_data.argtypes = [vp]
     L.fj_free.argtypes = [vp]
     L.fj_exception_class.restype = C.c_char_p; L.fj_exception_message.restype = C.c_char_p
+    L.fj_set_pinning.argtypes = [C.c_int]
     for name, res, args in [
             ("abiVersion", C.c_int32, []), ("deviceCount", C.c_int32, []),
             ("modelCreate", C.c_int64, [vp, vp, vp, vp]), ("modelDestroy", None, [C.c_int64]), ("modelNVars", C.c_int32, [C.c_int64]),
@@ -140,7 +141,17 @@ def test_scala_flat_array_layouts_match_the_shim():
 
 
 # ---- CPU: executed marshalling ------------------------------------------------------------------------------------------
-def test_shim_runs_without_a_jvm_diagnostics_end_to_end(fj):
+@pytest.fixture(params=["copying", "pinning"])
+def jvm(fj, request):
+    """both array-access behaviours the JNI specification allows: a JVM that copies (isCopy = JNI_TRUE, Release(0) copies back,
+    JNI_ABORT discards) and one that pins (the native code works on the array's own storage)"""
+    fj.fj_set_pinning(1 if request.param == "pinning" else 0)
+    yield fj
+    fj.fj_set_pinning(0)
+
+
+def test_shim_runs_without_a_jvm_diagnostics_end_to_end(jvm):
+    fj = jvm
     assert call(fj, "abiVersion") == _capi.lib().rh_abi_version()
     rng = np.random.default_rng(0)
     draws = rng.normal(size=(4, 50, 3)).cumsum(axis=1) * 0.1
@@ -201,7 +212,8 @@ def _sample(fj, handles, cfg, seeds, n, static_mass=None, nn=None):
 
 
 @pytest.mark.gpu
-def test_shim_sample_is_bit_identical_to_the_ctypes_path(fj):
+def test_shim_sample_is_bit_identical_to_the_ctypes_path(jvm):
+    fj = jvm
     spec = models.eight_schools()
     seeds = [11, 12, 13, 14, 15]
     for cfg, kw in [(R.make_config(20, 60), dict(math_mode=1)),                                        # DefaultConfig: EHMC + DualAvg + diag mass
