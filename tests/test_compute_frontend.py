@@ -244,3 +244,57 @@ def test_baseline_models_in_reference_text_match_the_hand_derived_rirs():
     assert a.nrows == [0, 300] and len(a.columns) == 5 * 9
     for q in rng.normal(size=(4, 9)) * 0.5:
         np.testing.assert_allclose(O.OracleDensity(a).update(q), O.OracleDensity(b).update(q), rtol=1e-10, atol=1e-10)
+
+
+def test_inlined_regression_has_the_shape_of_the_papers_appendix_a_listing():
+    """The paper (website/static/img/rainier.pdf, Appendix A) decompiles "a portion of the bytecode generated for a linear
+    regression model": a fragment without its data or model text, produced by an EARLIER compiler revision than the one under
+    /root/reference (it memoises into a second array `g[]` and divides by sigma^2, whereas the Translator this package
+    restates never uses its ring's `minus` operator -- Translator.scala:92-99,104-115 -- and builds product TREES,
+    :117-141), so node-sequence equality with it is not defined.  What the listing shares with today's algebra IS checkable on
+    a regression of its shape (one scale, three location parameters, likelihood folded over the rows at compile time):
+      (1) the sum is a left fold that starts from the constant;
+      (2) squares are x*x, not pow(x, 2);
+      (3) every cross product appears TWICE, as b_i*b_j/s^2 and b_j*b_i/s^2 with bit-equal coefficients -- the listing's g[1]
+          / g[3] pair -- because LogLine equality includes term order (Coefficients.scala) and nothing merges the two;
+      (4) the precision factor is shared by every likelihood term (the listing's g[2])."""
+    rng = np.random.default_rng(1)
+    x1, x3, ys = rng.normal(size=19), rng.normal(size=19), rng.normal(size=19)
+    sigma = Exponential(1).latent; b1 = Normal(0, 1).latent; b2 = Normal(0, 1).latent; b3 = Normal(0, 1).latent
+    spec = Model.observe_vec(ys, [x1, x3], lambda u, v: Normal(b1 * u + b2 + b3 * v, sigma)).compile("appendix_a")
+    assert spec.nrows == [0, 0, 0] and spec.columns == []
+    n, targets, nodes = decode(spec.rir)
+    like = max(targets, key=lambda t: sum(1 for _ in _walk(nodes, t[1][0])))[1][0]      # the folded likelihood target
+    # (1) peel the left fold
+    terms, i = [], like
+    while nodes[i][0] == "add":
+        terms.append(nodes[i][2]); i = nodes[i][1]
+    assert nodes[i][0] == "const"
+    terms.reverse()
+    assert len(terms) == 14                    # 1 + 3 linear + 9 ordered products (3 squares, 3 x 2 cross) + the log-sigma term
+    # (2)+(3): classify the parameter products inside every term
+    pairs, prec = {}, set()
+    for t in terms:
+        if nodes[t][0] != "mul" or nodes[nodes[t][2]][0] != "const": continue
+        coef = nodes[nodes[t][2]][1]
+        for j in _walk(nodes, nodes[t][1]):
+            nd = nodes[j]
+            if nd[0] == "pow" and nodes[nd[2]] == ("const", -2.0): prec.add(j)
+            if nd[0] == "mul" and nodes[nd[1]][0] == "input" and nodes[nd[2]][0] == "input":
+                pairs[(nodes[nd[1]][1], nodes[nd[2]][1])] = coef
+    assert not any(nd[0] == "pow" and nodes[nd[2]] == ("const", 2.0) for nd in nodes)
+    assert set(pairs) == {(a, b) for a in (1, 2, 3) for b in (1, 2, 3)}
+    for a in (1, 2, 3):
+        for b in (1, 2, 3):
+            assert pairs[(a, b)] == pairs[(b, a)]                                   # bit-equal, never merged
+    assert len(prec) == 1                                                            # (4) one shared sigma^-2 node
+
+
+def _walk(nodes, i, seen=None):
+    seen = set() if seen is None else seen
+    if i in seen: return
+    seen.add(i); yield i
+    nd = nodes[i]
+    for c in nd[1:]:
+        if nd[0] in ("const", "input"): break
+        if isinstance(c, int) and not (nd[0] == "lookup" and c is nd[2]): yield from _walk(nodes, c, seen)
