@@ -110,8 +110,12 @@ def lib():
     L.rh_comm_allreduce_max.argtypes = [vp, dp]
     L.rh_device_synchronize.argtypes = [C.c_int32]
     L.rh_lower_only.argtypes = [vp, C.c_size_t, C.POINTER(CompileOpts), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.rh_lower_only_data.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.POINTER(CompileOpts), C.c_char_p,
+                                     C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.rh_free.argtypes = [vp]
     L.rh_simplify_rir.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rh_canonicalize_rir.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]
     _lib = L
     return L
@@ -137,6 +141,25 @@ def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=
     return o
 
 
+def canonicalize_rir(rir: bytes, columns, nrows, fast: bool = False, refactor: bool = False):
+    """Column canonicalisation (csrc/columns.cpp; with refactor also csrc/refactor.cpp + the clean-up pass) applied to an RIR
+    blob and its data, returned as (RIR, kept) with kept[j] = index into `columns` of the j-th column the rewritten program
+    reads (test hook, no device needed)."""
+    L = lib()
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
+    arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
+    nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
+    kept = (C.c_uint32 * max(1, len(cols)))()
+    nk = C.c_uint32(0)
+    out, n = C.c_void_p(), C.c_size_t(0)
+    buf = C.create_string_buffer(rir, len(rir))
+    check(L.rh_canonicalize_rir(buf, len(rir), arr, nr, int(fast), int(refactor), C.byref(out), C.byref(n), kept, C.byref(nk)))
+    try:
+        return C.string_at(out, n.value), [int(kept[i]) for i in range(nk.value)]
+    finally:
+        L.rh_free(out)
+
+
 def simplify_rir(rir: bytes, fast: bool = False) -> bytes:
     """The emitter's clean-up pass (csrc/simplify.cpp) applied to an RIR blob, returned as RIR (test hook)."""
     L = lib()
@@ -149,14 +172,21 @@ def simplify_rir(rir: bytes, fast: bool = False) -> bytes:
         L.rh_free(out)
 
 
-def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950"):
-    """RIR -> HIP source -> gfx950 code object, without a device.  Returns (source, code_size)."""
+def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", columns=None, nrows=None):
+    """RIR -> HIP source -> gfx950 code object, without a device.  Returns (source, code_size).  With columns / nrows the
+    data-dependent passes of rh_model_create (column canonicalisation) run as well."""
     L = lib()
     src = C.c_char_p()
     size = C.c_size_t(0)
     buf = C.create_string_buffer(rir, len(rir))
     o = opts if opts is not None else compile_opts()
-    rc = L.rh_lower_only(buf, len(rir), C.byref(o), arch.encode(), C.byref(src), C.byref(size))
+    if columns is not None:
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
+        arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
+        nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
+        rc = L.rh_lower_only_data(buf, len(rir), arr, nr, C.byref(o), arch.encode(), C.byref(src), C.byref(size))
+    else:
+        rc = L.rh_lower_only(buf, len(rir), C.byref(o), arch.encode(), C.byref(src), C.byref(size))
     text = src.value.decode() if src.value else ""
     if src:
         L.rh_free(src)

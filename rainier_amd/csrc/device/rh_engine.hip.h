@@ -1221,13 +1221,13 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
   for (int ks = 0; ks < PT; ks++) {
     const int pred = 4 * ks + lg;
-    Bf[ks] = (pred < PM) ? q[(size_t)cl * RH_NVARS + GL::pred_param[pred < PM ? pred : 0]] : 0.0;
+    Bf[ks] = (pred < PM) ? GL::pred_scale[pred < PM ? pred : 0] * q[(size_t)cl * RH_NVARS + GL::pred_param[pred < PM ? pred : 0]] : 0.0;
     acol[ks] = (pred < PM) ? GL::pred_col[pred < PM ? pred : 0] : -2;
   }
   double thv[RV > 0 ? RV : 1], Gv[RV > 0 ? RV : 1];  // VALU remainder: this lane's chain's coefficients and gradient sums
   int vcol[RV > 0 ? RV : 1];
 #pragma unroll
-  for (int k = 0; k < RV; k++) { thv[k] = q[(size_t)cl * RH_NVARS + GL::pred_param[PM + k]]; vcol[k] = GL::pred_col[PM + k]; Gv[k] = 0.0; }
+  for (int k = 0; k < RV; k++) { thv[k] = GL::pred_scale[PM + k] * q[(size_t)cl * RH_NVARS + GL::pred_param[PM + k]]; vcol[k] = GL::pred_col[PM + k]; Gv[k] = 0.0; }
   int bcol[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ct++) {
@@ -1468,7 +1468,7 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
 #pragma unroll
     for (int ks = 0; ks < PT; ks++) {
       const int pred = 4 * ks + lg;
-      Bf[t][ks] = (pred < P) ? q[(size_t)cl[t] * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
+      Bf[t][ks] = (pred < P) ? GL::pred_scale[pred < P ? pred : 0] * q[(size_t)cl[t] * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < GL::NTHU; k++) thu[t][k] = q[(size_t)cl[t] * RH_NVARS + GL::thu_param[k]];

@@ -4,7 +4,6 @@
 #define RH_SHARED_H
 
 #define RH_MAX_TARGETS 64
-#define RH_MAX_COLS 128
 #define RH_RING_SLOTS 4  /* EHMC step-count ring buffer: <= 256 entries, lane-distributed */
 #define RH_NUTS_MAXD 12  /* NUTS: deepest tree (2^12 leaves); momentum checkpoints per chain */
 
@@ -25,9 +24,11 @@ typedef struct rh_cfg_dev {
   int nuts_max_depth, reserved;
 } rh_cfg_dev;
 
-/* observation columns resident in HBM: flattened target-major, then column */
+/* observation columns resident in HBM: `cols` is a device-resident table of column pointers (flattened target-major, then
+ * column), so the number of columns is not bounded by the kernel-argument segment; a kernel reads the few pointers it
+ * needs with wave-uniform scalar loads */
 typedef struct rh_model_data {
-  const double *cols[RH_MAX_COLS];
+  const double *const *cols;
   long long nrows[RH_MAX_TARGETS];
 } rh_model_data;
 

@@ -634,24 +634,35 @@ struct TargetEmitter {
     bool ok = false;
     uint32_t L = 0, w = 0;
     std::vector<int> pred_param, pred_col, pred_acc;  // pred_col = -1: the constant 1 column (bare intercept)
+    std::vector<double> pred_scale;                   // eta = sum_k pred_scale[k] * theta[pred_param[k]] * x[pred_col[k]]
     std::vector<std::pair<uint32_t, int>> others;     // (node, accumulator index)
     std::vector<uint32_t> thu;                        // parameters the scalar part reads (compact order)
     std::vector<uint32_t> elem_nodes;                 // row nodes of the scalar part, ascending
     std::vector<uint32_t> inv_nodes;                  // invariant nodes of the scalar part, ascending
   } glm;
 
-  bool lincomb(uint32_t id, std::vector<std::pair<int, int>> &out) const {
+  // leaf := [const *] param [* column] in any association;  tree := leaf | tree + tree | tree - tree.  A term is (parameter,
+  // column or -1 for the bare intercept, scale): eta = sum scale * theta_param * x_column
+  struct LinTerm { int param, col; double scale; };
+  bool linleaf(uint32_t id, LinTerm &lt) const {
     const Node &nd = P.nodes[id];
-    auto is_param = [&](uint32_t x) { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input < P.n_params; };
-    auto is_col = [&](uint32_t x) { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input >= P.n_params; };
-    if (is_param(id)) { out.push_back({(int)nd.input, -1}); return true; }
-    if (nd.op == RH_RIR_MUL) {
-      if (is_param(nd.a) && is_col(nd.b)) { out.push_back({(int)P.nodes[nd.a].input, (int)(P.nodes[nd.b].input - P.targets[t].input_start)}); return true; }
-      if (is_param(nd.b) && is_col(nd.a)) { out.push_back({(int)P.nodes[nd.b].input, (int)(P.nodes[nd.a].input - P.targets[t].input_start)}); return true; }
-      return false;
+    if (nd.op == RH_RIR_CONST) { lt.scale *= nd.cval; return std::isfinite(lt.scale) && lt.scale != 0.0; }
+    if (nd.op == RH_RIR_INPUT) {
+      if (nd.input < P.n_params) { if (lt.param >= 0) return false; lt.param = (int)nd.input; }
+      else { if (lt.col >= 0) return false; lt.col = (int)(nd.input - P.targets[t].input_start); }
+      return true;
     }
-    if (nd.op == RH_RIR_ADD) return lincomb(nd.a, out) && lincomb(nd.b, out);
+    if (nd.op == RH_RIR_MUL) return linleaf(nd.a, lt) && linleaf(nd.b, lt);
     return false;
+  }
+  bool lincomb(uint32_t id, double sign, std::vector<LinTerm> &out) const {
+    const Node &nd = P.nodes[id];
+    if (nd.op == RH_RIR_ADD) return lincomb(nd.a, sign, out) && lincomb(nd.b, sign, out);
+    if (nd.op == RH_RIR_SUB) return lincomb(nd.a, sign, out) && lincomb(nd.b, -sign, out);
+    LinTerm lt{-1, -1, sign};
+    if (!linleaf(id, lt) || lt.param < 0) return false;
+    out.push_back(lt);
+    return true;
   }
 
   void detect_glm() {
@@ -659,20 +670,21 @@ struct TargetEmitter {
     // the widest linear predictor among the row nodes
     size_t best = 0;
     for (size_t n = 0; n < P.nodes.size(); n++) {
-      if (!reach_row[n] || P.nodes[n].dep == 0 || P.nodes[n].op != RH_RIR_ADD) continue;
-      std::vector<std::pair<int, int>> terms;
-      if (lincomb((uint32_t)n, terms) && terms.size() >= 2 && terms.size() > best) { best = terms.size(); glm.L = (uint32_t)n; }
+      if (!reach_row[n] || P.nodes[n].dep == 0 || (P.nodes[n].op != RH_RIR_ADD && P.nodes[n].op != RH_RIR_SUB)) continue;
+      std::vector<LinTerm> terms;
+      if (lincomb((uint32_t)n, 1.0, terms) && terms.size() >= 2 && terms.size() > best) { best = terms.size(); glm.L = (uint32_t)n; }
     }
     if (!best) return;
-    std::vector<std::pair<int, int>> terms;
-    lincomb(glm.L, terms);
+    std::vector<LinTerm> terms;
+    lincomb(glm.L, 1.0, terms);
     std::map<int, int> col_pred;
     int bare = -1;
     for (auto &pc : terms) {
-      if (pc.second < 0) { if (bare >= 0) return; bare = (int)glm.pred_param.size(); }
-      else if (col_pred.count(pc.second)) return;
-      else col_pred[pc.second] = (int)glm.pred_param.size();
-      glm.pred_param.push_back(pc.first); glm.pred_col.push_back(pc.second); glm.pred_acc.push_back(-1);
+      if (pc.col < 0) { if (bare >= 0) return; bare = (int)glm.pred_param.size(); }
+      else if (col_pred.count(pc.col)) return;
+      else col_pred[pc.col] = (int)glm.pred_param.size();
+      for (int pp : glm.pred_param) if (pp == pc.param) return;   // one coefficient per predictor
+      glm.pred_param.push_back(pc.param); glm.pred_col.push_back(pc.col); glm.pred_acc.push_back(-1); glm.pred_scale.push_back(pc.scale);
     }
     auto col_of = [&](uint32_t x) -> int {
       const Node &nd = P.nodes[x];
@@ -741,7 +753,7 @@ struct TargetEmitter {
   // must agree with the closed form (1e-8 relative: the naive form itself loses digits through 1 - p) at 15 eta in [-12, 12]
   // x 5 values of y, evaluated here on the host.  Anything that does not verify keeps its literal lowering.  Fast mode only:
   // strict builds keep the reference's arithmetic operation for operation.
-  struct Logit { bool ok = false; int ycol = -1; double c = 0.0, s_hit = 1.0, s_miss = -1.0; } logit;
+  struct Logit { bool ok = false; int ycol = -1; double c = 0.0, s_hit = 1.0, s_miss = -1.0, kappa = 1.0; } logit;
 
   double host_eval(uint32_t id, double eta, int ycol, double yv, std::map<uint32_t, double> &memo, bool &bad) const {
     if (id == glm.L) return eta;
@@ -781,8 +793,11 @@ struct TargetEmitter {
 
   void detect_logit() {
     if (!glm.ok || !fast_div || !glm.thu.empty() || glm.others.size() != 1 || !glm.inv_nodes.empty()) return;
-    // the scalar part may read exactly one data column, and compares it with exactly one constant
-    int ycol = -1; double c = 0.0; bool have_c = false;
+    // the scalar part may read exactly one data column.  Either that column only feeds compare(y, c) with one constant c -- then
+    // the closed form is checked for y = c and four other values -- or (the reference's own lowering: y indexes a Lookup and
+    // multiplies masked terms) the column's distinct values are known from the data (Program::col_domain, at most two of
+    // them) and the closed form is checked on exactly those.
+    int ycol = -1; double c = 0.0; bool have_c = false, only_compare = true;
     for (uint32_t n : glm.elem_nodes) {
       const Node &nd = P.nodes[n];
       std::vector<uint32_t> ops; operands(nd, ops);
@@ -792,13 +807,21 @@ struct TargetEmitter {
           const int col = (int)(on.input - P.targets[t].input_start);
           if (ycol >= 0 && col != ycol) return;
           ycol = col;
-          if (nd.op != RH_RIR_COMPARE || o != nd.a || P.nodes[nd.b].op != RH_RIR_CONST) return;  // the column only feeds compare(y, const)
-          if (have_c && P.nodes[nd.b].cval != c) return;
+          if (nd.op != RH_RIR_COMPARE || o != nd.a || P.nodes[nd.b].op != RH_RIR_CONST) { only_compare = false; continue; }
+          if (have_c && P.nodes[nd.b].cval != c) only_compare = false;
           c = P.nodes[nd.b].cval; have_c = true;
         }
       }
     }
-    if (ycol < 0 || !have_c || !std::isfinite(c)) return;
+    if (ycol < 0) return;
+    std::vector<double> ys;
+    if (only_compare && have_c && std::isfinite(c)) ys = {c, c + 1.0, c - 1.0, c + 0.5, c + 2.0};
+    else {
+      const size_t g = (size_t)P.targets[t].col0 + (size_t)ycol;
+      if (g >= P.col_domain.size() || P.col_domain[g].empty() || P.col_domain[g].size() > 2) return;
+      ys = P.col_domain[g];
+      c = ys[0];
+    }
     auto original = [&](double eta, double yv, double &val, double &w) -> bool {
       std::map<uint32_t, double> memo; bool bad = false;
       val = host_eval(glm.others[0].first, eta, ycol, yv, memo, bad);
@@ -808,25 +831,32 @@ struct TargetEmitter {
     auto softplus = [](double x) { return x > 0 ? x + std::log1p(std::exp(-x)) : std::log1p(std::exp(x)); };
     auto sigmoid = [](double x) { return x >= 0 ? 1.0 / (1.0 + std::exp(-x)) : std::exp(x) / (1.0 + std::exp(x)); };
     // fix the signs from one probe per branch: value(eta = 1) is -softplus(1) = -1.3133 or -softplus(-1) = -0.3133
-    double s[2];
-    for (int b = 0; b < 2; b++) {
+    double s[2] = {1.0, 1.0};
+    for (int b = 0; b < 2 && b < (int)ys.size(); b++) {
       double val, w;
-      if (!original(1.0, b == 0 ? c : c + 1.0, val, w)) return;
+      if (!original(1.0, ys[(size_t)b], val, w)) return;
       if (std::fabs(val + softplus(1.0)) < 1e-9) s[b] = 1.0;
       else if (std::fabs(val + softplus(-1.0)) < 1e-9) s[b] = -1.0;
       else return;
     }
+    if (ys.size() == 1) s[1] = s[0];
+    // the adjoint basis term may carry a constant factor (the output factoring peels signs into alpha): w = kappa * d value / d eta
+    double kappa = 1.0;
+    { double val, w;
+      if (!original(1.0, ys[0], val, w)) return;
+      kappa = w / (-s[0] * sigmoid(s[0] * 1.0));
+      if (!std::isfinite(kappa) || kappa == 0.0) return;
+      if (std::fabs(kappa - std::nearbyint(kappa)) < 1e-9) kappa = std::nearbyint(kappa); }
     static const double etas[] = {-12.0, -7.3, -3.1, -1.7, -0.9, -0.31, -1e-3, 0.0, 1e-3, 0.22, 0.8, 1.9, 3.7, 8.1, 12.0};
-    const double ys[] = {c, c + 1.0, c - 1.0, c + 0.5, c + 2.0};
     for (double yv : ys)
       for (double eta : etas) {
         double val, w;
         if (!original(eta, yv, val, w)) return;
         const double sg = yv == c ? s[0] : s[1];
-        const double cv = -softplus(sg * eta), cw = -sg * sigmoid(sg * eta);
-        if (!(std::fabs(val - cv) <= 1e-8 * std::max(1.0, std::fabs(cv))) || !(std::fabs(w - cw) <= 1e-8)) return;
+        const double cv = -softplus(sg * eta), cw = kappa * (-sg * sigmoid(sg * eta));
+        if (!(std::fabs(val - cv) <= 1e-8 * std::max(1.0, std::fabs(cv))) || !(std::fabs(w - cw) <= 1e-8 * std::max(1.0, std::fabs(kappa)))) return;
       }
-    logit.ok = true; logit.ycol = ycol; logit.c = c; logit.s_hit = s[0]; logit.s_miss = s[1];
+    logit.ok = true; logit.ycol = ycol; logit.c = c; logit.s_hit = s[0]; logit.s_miss = s[1]; logit.kappa = kappa;
   }
 
   std::string glm_ref(uint32_t id) const {
@@ -853,6 +883,9 @@ struct TargetEmitter {
       os << "};\n";
     };
     arr("pred_param", glm.pred_param); arr("pred_col", glm.pred_col); arr("pred_acc", glm.pred_acc);
+    os << "  static constexpr double pred_scale[" << Pn << "] = {";
+    for (size_t i = 0; i < Pn; i++) os << (i ? "," : "") << lit(glm.pred_scale[i]);
+    os << "};\n";
     std::vector<int> oacc, thu;
     for (auto &o : glm.others) oacc.push_back(o.second);
     for (uint32_t x : glm.thu) thu.push_back((int)x);
@@ -863,7 +896,7 @@ struct TargetEmitter {
     if (logit.ok) {  // verified closed form of the Bernoulli-logit scalar part (detect_logit)
       os << "    const double s = (RH_GLM_COL(" << logit.ycol << ") == " << lit(logit.c) << ") ? " << lit(logit.s_hit) << " : " << lit(logit.s_miss) << ";\n"
          << "    double sp, sg;\n    rh_logit_link(s * eta, sp, sg);\n"
-         << "    w = -(s * sg);\n    other[0] = -sp;\n  }\n};\n";
+         << (logit.kappa == 1.0 ? std::string("    w = -(s * sg);\n") : "    w = " + lit(-logit.kappa) + " * (s * sg);\n") << "    other[0] = -sp;\n  }\n};\n";
       return true;
     }
     // emit_node spells operands through ref(); the GLM scalar part needs its own spelling
@@ -1058,7 +1091,9 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
               EmitInfo *info) {
   if (!o.simplify) return emit_hip_impl(P, o, defines, targets, err, info);
-  return emit_hip_impl(simplify(P, o.fp_contract), o, defines, targets, err, info);
+  Program Q = simplify(P, o.fp_contract);
+  if (o.refactor && o.fp_contract) Q = simplify(refactor(Q), true);
+  return emit_hip_impl(Q, o, defines, targets, err, info);
 }
 static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {

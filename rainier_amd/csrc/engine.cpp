@@ -167,6 +167,8 @@ struct rh_model {
   int state_words = 0;
   rh_model_data data{};
   std::vector<void *> dev_cols;
+  void *d_coltab = nullptr;                  // device table of the column pointers (rh_model_data.cols)
+  std::vector<uint32_t> col_map;             // engine column -> caller's column (base columns kept by canonicalize_columns)
   int64_t rows_total = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -348,6 +350,23 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
   return opts->device;
 }
 
+// derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
+// fills m->col_map (engine column -> caller's column) and the per-target row counts
+void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t) {
+  std::string err;
+  nrows_t.assign(m->prog.targets.size(), 0);
+  for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) nrows_t[t] = nrows[t];
+  m->col_map.clear();
+  for (uint32_t c = 0; c < m->prog.n_cols_total; c++) {
+    if (!columns[c]) throw Fail{RH_E_INVALID, "a column pointer is NULL"};
+    m->col_map.push_back(c);
+  }
+  bool canon = m->prog.n_cols_total > 0;
+  if (const char *e = std::getenv("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
+  if (canon && rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, m->col_map, err)) m->eopt.refactor = true;
+  if (const char *e = std::getenv("RH_REFACTOR")) m->eopt.refactor = m->eopt.refactor && std::atoi(e) != 0;
+}
+
 void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void **args) {
   HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, s, args, nullptr));
 }
@@ -371,6 +390,8 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
       if (T.n_cols && (!nrows || nrows[t] < 0)) throw Fail{RH_E_INVALID, "negative or missing row count"};
       if (T.n_cols && !columns) throw Fail{RH_E_INVALID, "columns is NULL but the model has data columns"};
     }
+    std::vector<int64_t> nrows_t;
+    canonicalize(m, columns, nrows, nrows_t);
     assemble_source(m);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -392,17 +413,17 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     // group g = rows whose table index is low + g.  Row targets without a gather are cut into pseudo-groups of 4096 rows.
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
       const auto &T = m->prog.targets[t];
-      m->data.nrows[t] = T.n_cols ? nrows[t] : 0;
+      m->data.nrows[t] = T.n_cols ? nrows_t[t] : 0;
       if (!T.n_cols) continue;
-      m->rows_total += nrows[t];
-      const int64_t nr = nrows[t];
+      m->rows_total += nrows_t[t];
+      const int64_t nr = nrows_t[t];
       std::vector<int64_t> perm;  // empty = identity
       if (m->info.gather_mode) {
         const auto &ti = m->info.targets[t];
         if (nr >= (int64_t)1 << 31) throw Fail{RH_E_UNSUPPORTED, "gather mode: more than 2^31 rows in one target"};
         std::vector<int> off;
         if (ti.has_gather) {
-          const double *idx = columns[T.col0 + ti.g_col];
+          const double *idx = columns[m->col_map[T.col0 + ti.g_col]];
           off.assign((size_t)ti.g_count + 1, 0);
           bool sorted = true;
           int64_t prev = 0;
@@ -440,16 +461,19 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
         const size_t bytes = (size_t)nr * sizeof(double);
         HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
         m->dev_cols.push_back(d);
-        const double *src = columns[T.col0 + j];
+        const double *src = columns[m->col_map[T.col0 + j]];
         if (!perm.empty()) {
           tmp.resize((size_t)nr);
           for (int64_t r = 0; r < nr; r++) tmp[(size_t)r] = src[perm[(size_t)r]];
           src = tmp.data();
         }
         if (bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-        m->data.cols[T.col0 + j] = (const double *)d;
       }
     }
+    // the pointer table itself (dev_cols is in flattened column order: targets ascending, then column)
+    HIPCHK(hipMalloc(&m->d_coltab, std::max<size_t>(1, m->dev_cols.size()) * sizeof(void *)));
+    if (!m->dev_cols.empty()) HIPCHK(hipMemcpy(m->d_coltab, m->dev_cols.data(), m->dev_cols.size() * sizeof(void *), hipMemcpyHostToDevice));
+    m->data.cols = (const double *const *)m->d_coltab;
   });
   if (rc != RH_OK) { rh_model_destroy(m); return rc; }
   *out = m;
@@ -461,6 +485,7 @@ extern "C" void rh_model_destroy(rh_model *m) {
   if (m->module || !m->dev_cols.empty()) {  // also after a failure half-way through load_module
     hipSetDevice(m->device);
     for (void *d : m->dev_cols) hipFree(d);
+    if (m->d_coltab) hipFree(m->d_coltab);
     for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     for (int v = 1; v < 8; v++)  // [0] aliases the base module
@@ -493,14 +518,17 @@ extern "C" int rh_device_count(void) {
 
 // Lower + cross-compile only (no device needed): used by build()/CPU tests.  Returns the generated source
 // through *src_out (malloc'ed, caller frees with rh_free) and the code-object size.
-extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_opts *opts, const char *arch,
-                             char **src_out, size_t *code_size) {
+// rh_lower_only_data: the same with the observation columns in hand, i.e. exactly the lowering rh_model_create performs
+// (column canonicalisation and what follows from it included); columns == NULL skips the data-dependent passes.
+extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
+                                  const rh_compile_opts *opts, const char *arch, char **src_out, size_t *code_size) {
   rh_model m;
   const int rc = guard(nullptr, [&] {
     std::string err;
     if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
     if (m.prog.kind != 0) throw Fail{RH_E_INVALID, "rh_lower_only needs a density program (header kind 0)"};
     (void)apply_compile_opts(&m, opts);
+    if (columns && nrows) { std::vector<int64_t> nrows_t; canonicalize(&m, columns, nrows, nrows_t); }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
@@ -509,6 +537,10 @@ extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_o
     if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 7) + m.source);
   });
   return rc;
+}
+extern "C" int rh_lower_only(const void *rir, size_t rir_len, const rh_compile_opts *opts, const char *arch,
+                             char **src_out, size_t *code_size) {
+  return rh_lower_only_data(rir, rir_len, nullptr, nullptr, opts, arch, src_out, code_size);
 }
 extern "C" void rh_free(void *p) { std::free(p); }
 // Test hook (no device needed): the program after the emitter's clean-up pass, as RIR again, so that the CPU suite can
@@ -519,6 +551,27 @@ extern "C" int rh_simplify_rir(const void *rir, size_t rir_len, int fast, void *
     if (!rh::parse_rir(rir, rir_len, P, err)) throw Fail{RH_E_INVALID, err};
     const std::vector<unsigned char> b = rh::write_rir(rh::simplify(P, fast != 0));
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
+  });
+}
+
+// Test hook (no device needed): the program after column canonicalisation (and, with refactor != 0, after the fast-mode
+// re-association and clean-up) as RIR again, plus the caller's column index of every column the program still reads, so that
+// the CPU suite can check on the oracle's interpreter that the rewrite preserves values.  kept must hold one entry per
+// original column; returns RH_OK also when nothing was rewritten (identity map).
+extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows, int fast,
+                                   int refactor, void **out, size_t *out_len, uint32_t *kept, uint32_t *n_kept) {
+  return guard(nullptr, [&] {
+    rh::Program P; std::string err;
+    if (!rh::parse_rir(rir, rir_len, P, err)) throw Fail{RH_E_INVALID, err};
+    std::vector<int64_t> nr(P.targets.size(), 0);
+    for (size_t t = 0; t < P.targets.size(); t++) if (P.targets[t].n_cols) nr[t] = nrows[t];
+    std::vector<uint32_t> k;
+    const bool changed = rh::canonicalize_columns(P, columns, nr.data(), fast != 0, k, err);
+    if (changed && refactor) P = rh::simplify(rh::refactor(rh::simplify(P, fast != 0)), fast != 0);
+    const std::vector<unsigned char> b = rh::write_rir(P);
+    *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
+    for (size_t i = 0; i < k.size(); i++) kept[i] = k[i];
+    *n_kept = (uint32_t)k.size();
   });
 }
 

@@ -1,0 +1,425 @@
+// refactor.cpp -- fast-mode re-association of the row targets of a program whose derived columns were just folded back
+// into products of base columns (columns.cpp).
+//
+// The reference differentiates symbolically and distributes every data-only factor into its own column, so a GLM's gradient
+// arrives as  out_k = A*(x_k*y) + B*(x_k*y) + C*(-x_k*(y-1))  instead of  x_k * w.  After canonicalize_columns the x_k are
+// visible again, but they sit inside separate product terms.  This pass brings every row-dependent node into a normal form
+//        sum of  coefficient * monomial,   monomial = product of atoms with integer exponents
+// (atoms: inputs, and every non-polynomial node -- exp, log, general pow, compare, lookup, NOOP-wrapped affine columns, and
+// "sum atoms" for sums that are multiplied by other sums or raised to a power: SUM x SUM IS NEVER EXPANDED, only
+// monomial x sum distributes), and rebuilds it as
+//        s * F * (plain sum of the remaining monomials)
+// with F the monomial common to ALL terms and s a common coefficient.  Nothing is factored partially (no Horner splitting):
+// masked terms such as S*(y-1) stay separate products, so a branch that is switched off by a 0 mask never meets a large
+// term of the other branch in a subtraction.  Equal sums are built once (hash-consed on the normal form, sign-normalised), so
+// the residual / linear predictor shared by the value and all gradients is computed once per row.
+//
+// Rounding changes (products are re-associated, x/y becomes x*y^-1 grouped into one division per monomial), exactly like FMA
+// contraction or output factoring: fast mode only, and only for programs that arrived with derived columns.  If the
+// rebuilt row code of a target is not cheaper than the original, the original is kept for that target.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <tuple>
+
+#include "../../include/rainier_hip_rir.h"
+#include "rir.hpp"
+
+namespace rh {
+namespace {
+
+typedef std::vector<std::pair<uint32_t, int>> Mono;   // (atom id, exponent != 0), ascending atom id
+typedef std::vector<std::pair<Mono, double>> Poly;    // (monomial, coefficient != 0), ascending monomial
+
+constexpr size_t CAP = 512;  // monomials per polynomial; above it a product keeps its operands as sum atoms
+
+struct Atom {
+  uint32_t op = 0;                 // RH_RIR_INPUT, a unary op, POW, COMPARE, LOOKUP, or 0xFFFFFFFF = a sum atom
+  uint32_t input = 0;
+  int32_t low = 0;
+  std::vector<uint32_t> kids;      // polynomial ids
+  uint8_t dep = 0;
+  bool operator<(const Atom &o) const { return std::tie(op, input, low, kids) < std::tie(o.op, o.input, o.low, o.kids); }
+};
+constexpr uint32_t SUM_ATOM = 0xFFFFFFFFu;
+
+struct Refactor {
+  const Program &P;
+  std::vector<Atom> atoms;
+  std::map<Atom, uint32_t> atom_ids;
+  std::vector<Poly> polys;
+  std::map<Poly, uint32_t> poly_ids;
+  std::vector<int> node_poly;  // per input node: polynomial id (-1 = not yet)
+
+  explicit Refactor(const Program &p) : P(p), node_poly(p.nodes.size(), -1) {}
+
+  uint32_t intern(const Poly &p) {
+    auto it = poly_ids.find(p);
+    if (it != poly_ids.end()) return it->second;
+    polys.push_back(p);
+    return poly_ids[p] = (uint32_t)polys.size() - 1;
+  }
+  uint32_t atom(const Atom &a) {
+    auto it = atom_ids.find(a);
+    if (it != atom_ids.end()) return it->second;
+    atoms.push_back(a);
+    return atom_ids[a] = (uint32_t)atoms.size() - 1;
+  }
+  uint8_t poly_dep(const Poly &p) const {
+    for (auto &t : p) for (auto &f : t.first) if (atoms[f.first].dep) return atoms[f.first].dep;
+    return 0;
+  }
+  static Poly constant(double v) { Poly p; if (v != 0.0) p.push_back({Mono(), v}); return p; }
+  Poly of_atom(uint32_t a, int e = 1) const { Poly p; p.push_back({Mono{{a, e}}, 1.0}); return p; }
+
+  static void normalize(Poly &p) {
+    std::sort(p.begin(), p.end(), [](const std::pair<Mono, double> &x, const std::pair<Mono, double> &y) { return x.first < y.first; });
+    Poly q;
+    for (auto &t : p) {
+      if (!q.empty() && q.back().first == t.first) q.back().second += t.second; else q.push_back(t);
+    }
+    p.clear();
+    for (auto &t : q) if (t.second != 0.0) p.push_back(t);
+  }
+  static Poly add(const Poly &a, const Poly &b, double sb) {
+    Poly r = a;
+    for (auto &t : b) r.push_back({t.first, sb * t.second});
+    normalize(r);
+    return r;
+  }
+  static Mono mono_mul(const Mono &a, const Mono &b) {
+    Mono r;
+    size_t i = 0, j = 0;
+    while (i < a.size() || j < b.size()) {
+      if (j == b.size() || (i < a.size() && a[i].first < b[j].first)) r.push_back(a[i++]);
+      else if (i == a.size() || b[j].first < a[i].first) r.push_back(b[j++]);
+      else { const int e = a[i].second + b[j].second; if (e) r.push_back({a[i].first, e}); i++; j++; }
+    }
+    return r;
+  }
+  // P = s * Q with Q sign-/scale-normalised: leading coefficient +1 when all |coefficients| agree, else positive
+  static double content_scale(Poly &p) {
+    if (p.empty()) return 1.0;
+    bool equal = true;
+    const double c0 = p[0].second;
+    for (auto &t : p) if (std::fabs(t.second) != std::fabs(c0)) equal = false;
+    const double s = equal ? c0 : (c0 < 0 ? -1.0 : 1.0);
+    if (s != 1.0) for (auto &t : p) t.second = equal ? (t.second == c0 ? 1.0 : -1.0) : -t.second;
+    return s;
+  }
+  // a multi-term polynomial as ONE atom (sign-normalised): returns the polynomial  s * atom^e
+  Poly sum_atom(Poly p, int e) {
+    const double s = content_scale(p);
+    Atom a; a.op = SUM_ATOM; a.kids.push_back(intern(p)); a.dep = poly_dep(p);
+    Poly r = of_atom(atom(a), e);
+    double se = 1.0;
+    for (int i = 0; i < std::abs(e); i++) se *= s;
+    r[0].second = e >= 0 ? se : 1.0 / se;
+    return r;
+  }
+  Poly as_factor(const Poly &p, int e) {  // p^e as a polynomial without expanding a sum (callers exclude 0^negative)
+    if (p.empty()) return Poly();
+    if (p.size() == 1) {
+      Mono m;
+      for (auto &f : p[0].first) m.push_back({f.first, f.second * e});
+      double c = 1.0;
+      for (int i = 0; i < std::abs(e); i++) c *= p[0].second;
+      Poly r; r.push_back({m, e >= 0 ? c : 1.0 / c});
+      return r;
+    }
+    return sum_atom(p, e);
+  }
+  Poly mul(const Poly &a, const Poly &b) {
+    if (a.empty() || b.empty()) return Poly();
+    if (a.size() > 1 && b.size() > 1) {  // sum x sum: never expanded
+      const Poly fa = sum_atom(a, 1), fb = sum_atom(b, 1);
+      Poly r; r.push_back({mono_mul(fa[0].first, fb[0].first), fa[0].second * fb[0].second});
+      return r;
+    }
+    if (a.size() * b.size() > CAP) return mul(sum_atom(a, 1), b);
+    Poly r;
+    for (auto &x : a) for (auto &y : b) r.push_back({mono_mul(x.first, y.first), x.second * y.second});
+    normalize(r);
+    return r;
+  }
+
+  // operands first: nodes are in topological order and compute_polys() walks them ascending, so no recursion happens here
+  Poly poly_of(uint32_t id) {
+    if (node_poly[id] >= 0) return polys[(size_t)node_poly[id]];
+    const Node &nd = P.nodes[id];
+    Poly r;
+    switch (nd.op) {
+      case RH_RIR_CONST: r = constant(nd.cval); break;
+      case RH_RIR_INPUT: { Atom a; a.op = RH_RIR_INPUT; a.input = nd.input; a.dep = nd.dep; r = of_atom(atom(a)); break; }
+      case RH_RIR_ADD: r = add(poly_of(nd.a), poly_of(nd.b), 1.0); break;
+      case RH_RIR_SUB: r = add(poly_of(nd.a), poly_of(nd.b), -1.0); break;
+      case RH_RIR_MUL: { const Poly a = poly_of(nd.a), b = poly_of(nd.b); r = mul(a, b); break; }
+      case RH_RIR_DIV: {
+        const Poly a = poly_of(nd.a), b = poly_of(nd.b);
+        if (b.empty()) r = opaque2(nd); else r = mul(a, as_factor(b, -1));
+        break;
+      }
+      case RH_RIR_POW: {
+        const Node &e = P.nodes[nd.b];
+        const double ev = e.cval;
+        if (e.op == RH_RIR_CONST && ev == std::floor(ev) && std::fabs(ev) <= 8.0 && ev != 0.0 && !poly_of(nd.a).empty()) {
+          const Poly a = poly_of(nd.a);
+          r = as_factor(a, (int)ev);
+        } else r = opaque2(nd);
+        break;
+      }
+      case RH_RIR_SEQ: r = poly_of(nd.b); break;   // the VarDef side is ordinary sharing in a DAG
+      case RH_RIR_COMPARE: r = opaque2(nd); break;
+      case RH_RIR_LOOKUP: {
+        Atom a; a.op = RH_RIR_LOOKUP; a.low = nd.low;
+        { const Poly k = poly_of(nd.a); a.kids.push_back(intern(k)); a.dep = poly_dep(k); }
+        for (uint32_t e : nd.table) { const Poly k = poly_of(e); a.kids.push_back(intern(k)); if (poly_dep(k)) a.dep = poly_dep(k); }
+        r = of_atom(atom(a));
+        break;
+      }
+      default: {  // unary ops, NOOP included (an affine column image stays atomic)
+        Atom a; a.op = nd.op;
+        const Poly k = poly_of(nd.a);
+        a.kids.push_back(intern(k)); a.dep = poly_dep(k);
+        r = of_atom(atom(a));
+      }
+    }
+    for (auto &t : r) if (!std::isfinite(t.second)) bad = true;
+    node_poly[id] = (int)intern(r);
+    return r;
+  }
+  bool bad = false;  // a folded coefficient overflowed / became NaN: the caller keeps the original program
+  void compute_polys(const std::vector<char> &live) {
+    for (uint32_t i = 0; i < P.nodes.size(); i++) if (live[i]) (void)poly_of(i);
+  }
+  Poly opaque2(const Node &nd) {
+    Atom a; a.op = nd.op;
+    const Poly x = poly_of(nd.a), y = poly_of(nd.b);
+    a.kids.push_back(intern(x)); a.kids.push_back(intern(y));
+    a.dep = poly_dep(x) ? poly_dep(x) : poly_dep(y);
+    return of_atom(atom(a));
+  }
+
+  // ---- rebuilding -------------------------------------------------------------------------------------------------------
+  Program Q;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;
+  std::map<uint64_t, uint32_t> consts;
+  std::map<uint32_t, uint32_t> inputs;
+  std::map<uint32_t, uint32_t> built_poly, built_atom;
+
+  uint32_t push(const Node &n) { Q.nodes.push_back(n); return (uint32_t)Q.nodes.size() - 1; }
+  uint32_t k(double v) {
+    uint64_t b; std::memcpy(&b, &v, 8);
+    auto it = consts.find(b);
+    if (it != consts.end()) return it->second;
+    Node n; n.op = RH_RIR_CONST; n.cval = v;
+    return consts[b] = push(n);
+  }
+  uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
+    auto key = std::make_tuple(op, a, b);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.b = b; n.dep = Q.nodes[a].dep ? Q.nodes[a].dep : Q.nodes[b].dep;
+    return cons[key] = push(n);
+  }
+  uint32_t op1(uint32_t op, uint32_t a) {
+    auto key = std::make_tuple(op, a, 0xffffffffu);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.dep = Q.nodes[a].dep;
+    return cons[key] = push(n);
+  }
+  uint32_t build_atom(uint32_t ai) {
+    auto it = built_atom.find(ai);
+    if (it != built_atom.end()) return it->second;
+    const Atom a = atoms[ai];
+    uint32_t id;
+    if (a.op == RH_RIR_INPUT) {
+      auto ii = inputs.find(a.input);
+      if (ii != inputs.end()) id = ii->second;
+      else { Node n; n.op = RH_RIR_INPUT; n.input = a.input; n.dep = a.dep; id = inputs[a.input] = push(n); }
+    } else if (a.op == SUM_ATOM) id = build_poly(a.kids[0]);
+    else if (a.op == RH_RIR_LOOKUP) {
+      Node n; n.op = RH_RIR_LOOKUP; n.low = a.low;
+      std::vector<uint32_t> ks;
+      for (uint32_t kid : a.kids) ks.push_back(build_poly(kid));
+      n.a = ks[0]; n.table.assign(ks.begin() + 1, ks.end());
+      n.dep = 0;
+      for (uint32_t x : ks) if (Q.nodes[x].dep) n.dep = Q.nodes[x].dep;
+      id = push(n);
+    } else if (a.kids.size() == 2) { const uint32_t x = build_poly(a.kids[0]), y = build_poly(a.kids[1]); id = op2(a.op, x, y); }
+    else id = op1(a.op, build_poly(a.kids[0]));
+    return built_atom[ai] = id;
+  }
+  uint32_t power(uint32_t x, int e) {  // e >= 1
+    uint32_t r = x;
+    if (e == 2) return op2(RH_RIR_MUL, x, x);
+    if (e == 4) { const uint32_t sq = op2(RH_RIR_MUL, x, x); return op2(RH_RIR_MUL, sq, sq); }
+    for (int i = 1; i < e; i++) r = op2(RH_RIR_MUL, r, x);
+    return r;
+  }
+  // product of the atoms of m selected by (row-dependent?, positive exponent?); 0xFFFFFFFF = empty product
+  uint32_t part(const Mono &m, bool row, bool pos) {
+    uint32_t r = 0xFFFFFFFFu;
+    for (auto &f : m) {
+      if ((atoms[f.first].dep != 0) != row || (f.second > 0) != pos) continue;
+      const uint32_t x = power(build_atom(f.first), std::abs(f.second));
+      r = r == 0xFFFFFFFFu ? x : op2(RH_RIR_MUL, r, x);
+    }
+    return r;
+  }
+  uint32_t build_mono(double coef, const Mono &m) {
+    uint32_t grp[2];
+    for (int row = 0; row < 2; row++) {
+      const uint32_t num = part(m, row != 0, true), den = part(m, row != 0, false);
+      if (den == 0xFFFFFFFFu) grp[row] = num;
+      else grp[row] = op2(RH_RIR_DIV, num == 0xFFFFFFFFu ? k(1.0) : num, den);
+    }
+    uint32_t r = grp[0];
+    if (coef != 1.0) r = r == 0xFFFFFFFFu ? k(coef) : op2(RH_RIR_MUL, k(coef), r);
+    if (grp[1] != 0xFFFFFFFFu) r = r == 0xFFFFFFFFu ? grp[1] : op2(RH_RIR_MUL, r, grp[1]);
+    return r == 0xFFFFFFFFu ? k(1.0) : r;
+  }
+  uint32_t build_poly(uint32_t pi) {
+    auto it = built_poly.find(pi);
+    if (it != built_poly.end()) return it->second;
+    Poly p = polys[pi];
+    uint32_t id;
+    if (p.empty()) id = k(0.0);
+    else if (p.size() == 1) id = build_mono(p[0].second, p[0].first);
+    else {
+      // the monomial common to every term: atoms present everywhere with exponents of one sign, the smallest magnitude
+      Mono F;
+      for (auto &f : p[0].first) {
+        int e = f.second;
+        bool all = true;
+        for (size_t t = 1; t < p.size() && all; t++) {
+          int et = 0;
+          for (auto &g : p[t].first) if (g.first == f.first) et = g.second;
+          if (et == 0 || (et > 0) != (e > 0)) all = false; else if (std::abs(et) < std::abs(e)) e = et;
+        }
+        if (all) F.push_back({f.first, e});
+      }
+      if (!F.empty()) {
+        Mono Finv;
+        for (auto &f : F) Finv.push_back({f.first, -f.second});
+        for (auto &t : p) t.first = mono_mul(t.first, Finv);
+        normalize(p);
+      }
+      const double s = content_scale(p);
+      if (!F.empty() || s != 1.0) {
+        const uint32_t body = build_poly(intern(p));
+        // data columns outermost, then the invariants, then the other row-level factors:  c_k * (alpha * (f * body)) -- the output
+        // factoring peels alpha, and the x_k * w shape of a GLM gradient (w = f * body, the same node for every k) is in the open
+        Mono Finvar, Fcol, Frow;
+        for (auto &f : F) {
+          const Atom &a = atoms[f.first];
+          (a.dep == 0 ? Finvar : (a.op == RH_RIR_INPUT && f.second > 0 ? Fcol : Frow)).push_back(f);
+        }
+        uint32_t r = body;
+        if (!Frow.empty()) r = op2(RH_RIR_MUL, build_mono(1.0, Frow), r);
+        if (!Finvar.empty() || s != 1.0) r = op2(RH_RIR_MUL, build_mono(s, Finvar), r);
+        if (!Fcol.empty()) r = op2(RH_RIR_MUL, build_mono(1.0, Fcol), r);
+        id = r;
+      } else {
+        // plain sum in normal-form order, positive terms first so that the fold never starts with a negation
+        std::vector<size_t> order;
+        for (size_t t = 0; t < p.size(); t++) if (p[t].second > 0) order.push_back(t);
+        for (size_t t = 0; t < p.size(); t++) if (!(p[t].second > 0)) order.push_back(t);
+        uint32_t acc = 0xFFFFFFFFu;
+        for (size_t t : order) {
+          const double c = p[t].second;
+          if (acc == 0xFFFFFFFFu) acc = build_mono(c, p[t].first);
+          else if (c < 0) acc = op2(RH_RIR_SUB, acc, build_mono(-c, p[t].first));
+          else acc = op2(RH_RIR_ADD, acc, build_mono(c, p[t].first));
+        }
+        id = acc;
+      }
+    }
+    return built_poly[pi] = id;
+  }
+};
+
+void mark_live(const Program &P, const std::vector<uint32_t> &roots, std::vector<char> &live) {
+  live.assign(P.nodes.size(), 0);
+  for (uint32_t o : roots) live[o] = 1;
+  for (size_t i = P.nodes.size(); i-- > 0;) {
+    if (!live[i]) continue;
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+    live[n.a] = 1;
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) live[e] = 1; }
+    else if ((n.op >= RH_RIR_ADD && n.op <= RH_RIR_COMPARE) || n.op == RH_RIR_SEQ) live[n.b] = 1;
+  }
+}
+double row_cost(const Program &P, const Target &T) {
+  std::vector<char> live;
+  mark_live(P, T.outputs, live);
+  double c = 0;
+  for (size_t i = 0; i < P.nodes.size(); i++) {
+    if (!live[i] || P.nodes[i].dep == 0) continue;
+    switch (P.nodes[i].op) {
+      case RH_RIR_CONST: case RH_RIR_INPUT: case RH_RIR_NOOP: case RH_RIR_SEQ: break;
+      case RH_RIR_DIV: c += 8; break;
+      case RH_RIR_POW: c += 60; break;
+      case RH_RIR_EXP: case RH_RIR_LOG: c += 30; break;
+      case RH_RIR_LOOKUP: c += (double)P.nodes[i].table.size(); break;
+      default: c += (P.nodes[i].op >= RH_RIR_SIN) ? 60 : 1;
+    }
+  }
+  return c;
+}
+
+}  // namespace
+
+Program refactor(const Program &P) {
+  Refactor R(P);
+  R.Q.n_params = P.n_params; R.Q.n_inputs = P.n_inputs; R.Q.n_cols_total = P.n_cols_total; R.Q.kind = P.kind;
+  R.Q.targets = P.targets; R.Q.col_domain = P.col_domain;
+  // 1) every node of the input program is copied (so that data-free targets and fall-backs keep their exact structure) ...
+  std::vector<uint32_t> m(P.nodes.size());
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    switch (n.op) {
+      case RH_RIR_CONST: m[i] = R.k(n.cval); break;
+      case RH_RIR_INPUT: {
+        auto it = R.inputs.find(n.input);
+        if (it != R.inputs.end()) m[i] = it->second;
+        else { Node q; q.op = RH_RIR_INPUT; q.input = n.input; q.dep = n.dep; m[i] = R.inputs[n.input] = R.push(q); }
+        break;
+      }
+      case RH_RIR_LOOKUP: {
+        Node q = n; q.a = m[n.a];
+        for (uint32_t &e : q.table) e = m[e];
+        m[i] = R.push(q);
+        break;
+      }
+      case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_POW: case RH_RIR_COMPARE: case RH_RIR_SEQ:
+        m[i] = R.op2(n.op, m[n.a], m[n.b]); break;
+      default: m[i] = R.op1(n.op, m[n.a]);
+    }
+  }
+  // 2) ... and the row targets are rebuilt from their normal forms behind them
+  {
+    std::vector<uint32_t> roots;
+    for (const Target &T : P.targets) if (T.n_cols) for (uint32_t o : T.outputs) roots.push_back(o);
+    std::vector<char> live;
+    mark_live(P, roots, live);
+    R.compute_polys(live);
+    if (R.bad) return P;
+  }
+  for (size_t t = 0; t < P.targets.size(); t++) {
+    Target &T = R.Q.targets[t];
+    for (uint32_t &o : T.outputs) o = m[o];
+    if (!T.n_cols) continue;
+    std::vector<uint32_t> rebuilt;
+    for (uint32_t o : P.targets[t].outputs) rebuilt.push_back(R.build_poly(R.intern(R.poly_of(o))));
+    Target cand = T; cand.outputs = rebuilt;
+    if (row_cost(R.Q, cand) <= row_cost(R.Q, T)) T.outputs = rebuilt;
+  }
+  return R.Q;
+}
+
+}  // namespace rh

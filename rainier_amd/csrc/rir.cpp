@@ -52,7 +52,7 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
     }
     if (r.bad) { err = "RIR: truncated target table"; return false; }
   }
-  if (col > RH_MAX_COLS) { err = "RIR: too many data columns"; return false; }
+  if (col > RH_RIR_MAX_COLS) { err = "RIR: too many data columns"; return false; }
   if (P.kind == 1 && col != 0) { err = "RIR: a requirements program cannot have data columns"; return false; }
   P.n_inputs = in; P.n_cols_total = col;
   P.nodes.resize(n_nodes);

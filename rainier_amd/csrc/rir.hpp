@@ -26,12 +26,25 @@ struct Program {
   uint32_t n_params = 0, n_inputs = 0, n_cols_total = 0, kind = 0;  // kind 1 = requirements program
   std::vector<Target> targets;
   std::vector<Node> nodes;
+  // per data column (flattened order): its distinct values when there are at most 8 of them, else empty; empty vector = not
+  // analysed.  Filled by canonicalize_columns from the data the model is created with.
+  std::vector<std::vector<double>> col_domain;
 };
 
 // Parses and validates a blob; returns false and sets err on malformed input.
 bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 
 std::vector<unsigned char> write_rir(const Program &p);
+
+// Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
+// constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns
+// true when the program was rewritten.
+bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,
+                          std::string &err);
+
+// Fast-mode re-association of row targets after canonicalize_columns (refactor.cpp): products are merged into monomials
+// and the factor common to every term of an output is pulled out, so that x_k * w shapes reappear.
+Program refactor(const Program &p);
 
 // Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
 Program simplify(const Program &p, bool fast = false);
@@ -40,6 +53,7 @@ struct EmitOptions {
   bool fast_log = true;      // fast mode: rh_fast_log (<= 1 ulp, ~40 instructions) instead of the device library's log (RH_FAST_LOG=0)
   bool pack = true;          // data-free models with <= 32 parameters: several chains per wavefront (RH_PACK=0 switches it off)
   bool simplify = true;      // run simplify() before lowering (RH_SIMPLIFY=0 switches it off)
+  bool refactor = false;     // fast mode, set when canonicalize_columns rewrote derived columns: run refactor() as well (RH_REFACTOR=0)
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
   int rows_unroll = 4;

@@ -100,7 +100,7 @@ Program simplify(const Program &P, bool fast) {
 
   Builder B;
   B.Q.n_params = P.n_params; B.Q.n_inputs = P.n_inputs; B.Q.n_cols_total = P.n_cols_total; B.Q.kind = P.kind;
-  B.Q.targets = P.targets;
+  B.Q.targets = P.targets; B.Q.col_domain = P.col_domain;
   std::vector<uint32_t> m(P.nodes.size(), 0);
   for (uint32_t i = 0; i < P.nodes.size(); i++) {
     const Node &n = P.nodes[i];
