@@ -9,7 +9,8 @@
 //      a constant                   (every row the same value)
 //      +-c_a                        (a copy / negated copy)
 //      +-(c_a * c_b)                (an elementwise product of two earlier columns)
-//      c_a + alpha, alpha - c_a, beta * c_a   (an affine image; kept atomic -- wrapped in NOOP -- so that later algebra never
+//      c_a + alpha, alpha - c_a, beta * c_a   (an affine image -- beta = -0.0 is how the signed zeros of x_k * (-0.0) survive
+//                                              strict mode --; kept atomic -- wrapped in NOOP -- so that later algebra never
 //                                              distributes over it: (y - 1) * S must stay a masked term, not S*y - S)
 // its INPUT node is replaced by that expression over the BASE columns, which alone are uploaded.  Every relation is
 // verified on ALL rows (candidates are pre-filtered on 32 sample rows).  In strict mode "equal" means bit-identical, so the
@@ -99,7 +100,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
         for (int64_t r : sr)
           if (ca[r] != 0.0 && std::isfinite(ca[r])) {
             const double be = c[r] / ca[r];
-            if (be == be && std::isfinite(be) && be != 0.0 && be != 1.0 && be != -1.0 && verify(j, [&](int64_t q) { return be * ca[q]; })) { e.kind = CExpr::MULC; e.a = a; e.c = be; found = true; }
+            if (be == be && std::isfinite(be) && be != 1.0 && be != -1.0 && verify(j, [&](int64_t q) { return be * ca[q]; })) { e.kind = CExpr::MULC; e.a = a; e.c = be; found = true; }
             break;
           }
       }

@@ -1199,6 +1199,9 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   constexpr int PT = (PM + 3) / 4;    // forward k-steps (4 predictors each)
   constexpr int CT = (PM + 15) / 16;  // backward predictor tiles
   constexpr int MYC = (NC + W - 1) / W;
+  // row tiles are double-buffered in LDS while two of them fit the 160 KB of a CU (<= 155 columns); wider models (<= 310
+  // columns) keep one tile and pay a second barrier per tile.  The host sizes the dynamic LDS with the same rule.
+  constexpr int NBUF = (2 * NC * RH_GLM_TRP * 8 <= 160 * 1024) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -1271,7 +1274,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   if (ntiles > 0) { fetch(0); park(0); }
   __syncthreads();
   for (long long t = 0; t < ntiles; t++) {
-    const int buf = (int)(t & 1);
+    const int buf = NBUF == 2 ? (int)(t & 1) : 0;
     if (t + 1 < ntiles) fetch(t + 1);
     if (compute) {
       const double *tile = rh_lds + (size_t)buf * NC * RH_GLM_TRP;
@@ -1339,7 +1342,8 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
           }
       }
     }
-    if (t + 1 < ntiles) park(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // every wave is done with the only tile before it is overwritten
+    if (t + 1 < ntiles) park(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
   if (compute) {

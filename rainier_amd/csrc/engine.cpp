@@ -151,7 +151,7 @@ struct rh_model {
   bool loaded = false;
   hipModule_t module = nullptr;
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
-  int grad_w = 8, ncols_max = 0;
+  int grad_w = 8, ncols_max = 0, glm_ncols = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
@@ -286,6 +286,9 @@ void load_module(rh_model *m) {
   const bool small_mfma = std::getenv("RH_GLM_SMALL_MFMA") && std::atoi(std::getenv("RH_GLM_SMALL_MFMA")) != 0;
   if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
+  if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
+  // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
+  if (!m->glm_small && (size_t)m->glm_ncols * 66u * sizeof(double) > 160u * 1024u) m->k_grad_glm = nullptr;
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
@@ -644,7 +647,8 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
-    const unsigned lds = 2u * (unsigned)m->ncols_max * 66u * sizeof(double);
+    const unsigned tile = (unsigned)m->glm_ncols * 66u * sizeof(double);  // rh_grad_glm_kernel's NBUF rule: two tiles while they fit
+    const unsigned lds = (2u * tile <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else if (m->use_lds_grad) {
     const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);

@@ -1,0 +1,137 @@
+"""csrc/columns.cpp + csrc/refactor.cpp on the CPU: the reference's derived-column lowerings (compute/Target.scala:27-31
+`gradientColumns`) fold back to their base columns, values are preserved (bit for bit in strict mode, to rounding in fast
+mode -- checked on the oracle's RIR interpreter), and the lowering that follows finds the GLM / closed-form link in them."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from rainier_amd import _capi, models
+from rainier_amd.frontend import Graph
+from rainier_amd.models import ModelSpec
+from rainier_amd import modeling as M
+from tests import oracle_lib as O
+
+
+def _rewritten(spec, fast, refactor):
+    rir, kept = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=refactor)
+    # the rewritten program keeps the target table; row counts hang on the targets, not on the columns
+    return dataclasses.replace(spec, rir=rir, columns=[spec.columns[j] for j in kept]), kept
+
+
+def _linreg_reference(n, k):
+    cols = models.linreg_data(n, k)
+    sigma = M.Exponential(1).latent; alpha = M.Normal(0, 1).latent; betas = M.Normal(0, 1).latentVec(k)
+    m = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Normal(alpha + M.Real.sum([ui * bi for ui, bi in zip(u, betas)]), sigma), split=False)
+    return m.compile("linreg_ref_%d" % k, inline=False), cols
+
+
+def test_logistic_reference_lowering_folds_to_its_base_columns():
+    k, n = 6, 400
+    spec = models.logistic_reference(n=n, k=k)
+    assert len(spec.columns) == 5 * (k + 1)
+    # strict: only bit-identical relations (y - 1 has a -0.0 where the reference's column has it the other way round, so that
+    # column stays a base) and the rewritten program reproduces the original bit for bit
+    s2, kept = _rewritten(spec, fast=False, refactor=False)
+    assert len(kept) == k + 2 and kept[:k + 1] == list(range(k + 1))
+    for q in np.random.default_rng(0).normal(size=(4, k + 1)) * 0.7:
+        assert np.array_equal(O.OracleDensity(spec).update(q), O.OracleDensity(s2).update(q))
+    # fast: value equality (+0 == -0) folds everything onto y and the k covariate columns; re-association changes rounding only
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    assert kept == list(range(k + 1))
+    for q in np.random.default_rng(1).normal(size=(4, k + 1)) * 0.7:
+        a, b = O.OracleDensity(spec).update(q), O.OracleDensity(s3).update(q)
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-12 * n)
+    assert len(s3.rir) < len(spec.rir) / 2
+
+
+def test_masked_branches_keep_their_accuracy_at_extreme_predictors():
+    """No partial factoring: S * (y - 1) stays a masked product.  With |eta| up to ~25 the switched-off branch of the reference's
+    gradient is ~1e10 times the live one; had (y - 1) been distributed (S*y - S) the live branch would lose those digits.
+    (Beyond that the reference's own formula overflows to NaN.)"""
+    k, n = 3, 64
+    spec = models.logistic_reference(n=n, k=k)
+    s3, _ = _rewritten(spec, fast=True, refactor=True)
+    for scale in (5.0, 8.0):
+        q = np.array([scale, -scale, scale, 0.5 * scale])
+        a, b = O.OracleDensity(spec).update(q), O.OracleDensity(s3).update(q)
+        ok = np.isfinite(a)
+        assert ok.all()
+        np.testing.assert_allclose(b[ok], a[ok], rtol=1e-13)
+
+
+def test_linear_regression_reference_lowering():
+    spec, cols = _linreg_reference(500, 4)          # 4 covariates: not inlined by the reference (21 >= 20 distributed terms)
+    assert spec.nrows == [0, 500] and len(spec.columns) == 38
+    s2, kept = _rewritten(spec, fast=False, refactor=False)
+    assert len(kept) == 5
+    q = np.array([-0.3, 0.5, 1.0, -2.0, 0.5, 0.25])
+    assert np.array_equal(O.OracleDensity(spec).update(q), O.OracleDensity(s2).update(q))
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    a, b = O.OracleDensity(spec).update(q), O.OracleDensity(s3).update(q)
+    np.testing.assert_allclose(b, a, rtol=1e-11)
+    # ... and agrees with the natural form (y, x_1..x_4 streamed, residual computed once)
+    nat = O.OracleDensity(models.linreg(n=500, k=4, columns=cols)).update(q)
+    np.testing.assert_allclose(b, nat, rtol=1e-10)
+
+
+def test_natural_forms_are_left_alone():
+    for spec in (models.linreg(n=300, k=3), models.logistic(n=300, k=5), models.hier_negbin(20, 30)):
+        rir, kept = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=True, refactor=True)
+        assert kept == list(range(len(spec.columns))) and rir == spec.rir
+
+
+def test_random_derived_columns_round_trip_bit_exactly():
+    """Property test of the relations themselves: random base columns, derived columns of every kind the pass knows, a program
+    that mixes them; strict-mode rewriting must be invisible to the interpreter."""
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        n = int(rng.integers(40, 200))
+        base = [rng.normal(size=n) for _ in range(3)] + [rng.integers(0, 2, size=n).astype(float)]
+        derived = [-base[0], base[1] * base[2], -(base[0] * base[3]), base[3] - 1.0, 1.0 - base[3], 2.5 * base[1], base[2].copy(),
+                   np.full(n, 3.25), base[1] * base[1], (base[1] * base[2]) * base[3]]
+        cols = base + derived
+        order = list(range(len(base))) + list(len(base) + rng.permutation(len(derived)))
+        # products of derived columns must come after their factors: keep the construction order for those two
+        order = [j for j in order if j not in (len(cols) - 1,)] + [len(cols) - 1]
+        cols = [cols[j] for j in order]
+        g = Graph(3, [len(cols)])
+        th = [g.param(i) for i in range(3)]
+        c = [g.col(0, j) for j in range(len(cols))]
+        eta = th[0]
+        for j, cj in enumerate(c):
+            eta = eta + (th[j % 3] * cj) * (0.1 * (j + 1))
+        val = (eta * 0.05).exp() + c[1] * c[len(base)]
+        spec = ModelSpec("derived_%d" % trial, g.compile([val]), cols, [n], 3, {})
+        s2, kept = _rewritten(spec, fast=False, refactor=False)
+        assert len(kept) <= 5, kept          # the four bases (+ at most one signed-zero casualty)
+        for q in rng.normal(size=(3, 3)):
+            assert np.array_equal(O.OracleDensity(spec).update(q), O.OracleDensity(s2).update(q))
+        s3, _ = _rewritten(spec, fast=True, refactor=True)
+        for q in rng.normal(size=(3, 3)):
+            np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
+
+
+def test_reference_lowering_reaches_the_glm_kernel_and_the_closed_form_link():
+    """What rh_model_create does with the reference's 50-covariate logistic lowering (255 columns): 51 columns are kept, the
+    linear predictor goes to rh_grad_glm_kernel (with the reference's negated intercept as a scaled predictor) and the scalar
+    part is the verified closed form -- the same code path as the hand-derived natural form."""
+    k, n = 50, 600
+    spec = models.logistic_reference(n=n, k=k)
+    assert len(spec.columns) == 255
+    opts = _capi.compile_opts(fp_contract=True, factor_outputs=True)
+    src, size = _capi.lower_only(spec.rir, opts, columns=spec.columns, nrows=spec.nrows)
+    assert size > 0
+    assert "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in src
+    assert "rh_logit_link(s * eta, sp, sg);" in src and "pred_scale[51]" in src and "(-0x1p+0)" in src.split("pred_scale[51]")[1].split(";")[0]
+    # strict builds keep the literal arithmetic, but still stream the base columns only
+    src2, _ = _capi.lower_only(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), columns=spec.columns, nrows=spec.nrows)
+    assert "NCOLS = 52" in src2 and "rh_logit_link(s * eta" not in src2
+
+
+def test_more_than_128_columns_parse():
+    k = 200
+    spec = models.logistic(n=64, k=k)
+    assert len(spec.columns) == k + 1
+    src, size = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True))
+    assert size > 0 and "static constexpr int P = 201" in src

@@ -1,0 +1,106 @@
+"""What the reference's own front end emits for streamed models -- derived `gradientColumns` (compute/Target.scala:27-31) --
+through rh_model_create on the device: column canonicalisation (csrc/columns.cpp), the fast-mode re-association
+(csrc/refactor.cpp), then the same kernels as the hand-derived natural forms.  Parity is always against the oracle's
+interpreter evaluating the ORIGINAL program on ALL its original columns."""
+import numpy as np
+import pytest
+
+import rainier_amd as R
+from rainier_amd import _capi, models
+from rainier_amd import modeling as M
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(spec, model, qs, tol, math_mode=O.JM_LIBM, engine=None):
+    d = O.OracleDensity(spec, math_mode)
+    lp, g = model.density_batch(qs) if engine is None else model.density_batch(qs, engine=engine)
+    for c, q in enumerate(qs):
+        ref, ab = d.update_both(q)
+        got = np.concatenate([[lp[c]], g[c]])
+        bound = tol * ab + 1e-300
+        assert np.all(np.abs(got - ref) <= bound), (spec.name, c, np.max(np.abs(got - ref) / bound))
+
+
+def test_logistic_reference_lowering_strict_and_fast():
+    k, n = 8, 5000
+    spec = models.logistic_reference(n=n, k=k)
+    assert len(spec.columns) == 5 * (k + 1)
+    qs = np.random.default_rng(11).normal(size=(7, k + 1)) * 0.5
+    # strict: the literal arithmetic, on the base columns only (bit-identical relations; y - 1 differs in a signed zero and stays)
+    ms = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "NCOLS = %d, COL0 = 0" % (k + 2) in ms.hip_source
+    _check(spec, ms, qs, 1e-12, O.JM_DET)
+    _check(spec, ms, qs, 1e-12, O.JM_DET, engine=_capi.ENGINE_TICK)
+    # fast: y and the k covariates; linear predictor on the narrow GLM path or the VALU kernel, scalar part in closed form
+    mf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "NCOLS = %d, COL0 = 0" % (k + 1) in mf.hip_source and "rh_logit_link(s * eta, sp, sg);" in mf.hip_source
+    _check(spec, mf, qs, 1e-12)
+    _check(spec, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
+    # the same chains as the hand-derived natural form on the same data, to rounding
+    nat = R.Model(models.logistic(n=n, k=k, columns=models.logistic_data(n, k)), device=0, fp_contract=True, factor_outputs=True)
+    cfg = R.make_config(4, 0, R.HMCSampler(3), R.StaticStepSize(2e-3), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    # parameter order: the reference numbers parameters by creation (a, then b_k), models.logistic uses the same order
+    np.testing.assert_allclose(mf.sample(cfg, seeds=range(5)).chains, nat.sample(cfg, seeds=range(5)).chains, rtol=1e-7, atol=1e-9)
+
+
+def test_cfg4_shape_reference_lowering_255_columns_on_the_mfma_kernel():
+    """50 covariates: 255 columns arrive, 51 are uploaded, rh_grad_glm_kernel + closed-form link run -- the reference's negated
+    intercept (`a * -1.0` in its Line) as a scaled predictor."""
+    k, n, chains = 50, 20000, 48
+    spec = models.logistic_reference(n=n, k=k)
+    assert len(spec.columns) == 255
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in m.hip_source
+    qs = np.random.default_rng(12).normal(size=(3, k + 1)) * 0.25
+    _check(spec, m, qs, 1e-12)
+    _check(spec, m, qs, 1e-12, engine=_capi.ENGINE_TICK)
+    cfg = R.make_config(3, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    s = R.Sampler(m, cfg, list(range(chains))); s.warmup(); s.run(3)
+    assert s.timing()["dominant_kernel"] == "rh_grad_glm_kernel"
+    a = s.draws(); s.close()
+    nat = R.Model(models.logistic(n=n, k=k, columns=models.logistic_data(n, k)), device=0, fp_contract=True, factor_outputs=True)
+    np.testing.assert_allclose(a, nat.sample(cfg, seeds=range(chains)).chains, rtol=1e-7, atol=1e-9)
+
+
+def test_linear_regression_reference_lowering_38_columns():
+    n, k = 6000, 4
+    cols = models.linreg_data(n, k)
+    sigma = M.Exponential(1).latent; alpha = M.Normal(0, 1).latent; betas = M.Normal(0, 1).latentVec(k)
+    spec = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Normal(alpha + M.Real.sum([ui * bi for ui, bi in zip(u, betas)]), sigma),
+                               split=False).compile("linreg_ref_4", inline=False)
+    assert len(spec.columns) == 38
+    qs = np.random.default_rng(13).normal(size=(6, k + 2)) * 0.5
+    ms = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "NCOLS = 5, COL0 = 0" in ms.hip_source
+    _check(spec, ms, qs, 1e-12, O.JM_DET)
+    mf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "NCOLS = 5, COL0 = 0" in mf.hip_source
+    _check(spec, mf, qs, 1e-12)
+    _check(spec, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
+    # the residual is computed once per row again: the row code is as short as the natural form's (5 basis sums + k + 1 FMAs)
+    nat = R.Model(models.linreg(n=n, k=k, columns=cols), device=0, fp_contract=True, factor_outputs=True)
+    row = lambda src: src.split("static RH_DEV void row(")[2].split("static RH_DEV void finish(")[0].count("const double n")
+    assert row(mf.hip_source) <= row(nat.hip_source) + 4, (row(mf.hip_source), row(nat.hip_source))
+
+
+def test_more_than_128_columns():
+    """The column pointers live in a device table (rh_model_data.cols): a 200-covariate logistic regression (201 columns) runs on
+    the MFMA GLM kernel and on the chain engine."""
+    k, n, chains = 200, 3000, 20
+    spec = models.logistic(n=n, k=k)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    qs = np.random.default_rng(14).normal(size=(3, k + 1)) * 0.1
+    _check(spec, m, qs, 1e-12)
+    _check(spec, m, qs, 1e-12, engine=_capi.ENGINE_TICK)
+
+
+def test_canonicalisation_can_be_switched_off(monkeypatch):
+    k, n = 4, 2000
+    spec = models.logistic_reference(n=n, k=k)
+    monkeypatch.setenv("RH_CANON_COLUMNS", "0")
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "NCOLS = 25, COL0 = 0" in m.hip_source
+    qs = np.random.default_rng(15).normal(size=(4, k + 1)) * 0.5
+    _check(spec, m, qs, 1e-12)
