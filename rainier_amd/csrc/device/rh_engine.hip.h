@@ -171,6 +171,20 @@ struct rh_chain {
 #define RH_STATE_NCK 0
 #endif
 
+// positions inside the state image (small-vector layout): vector n starts at slot RH_VI_n * RH_SLOTS, scalar n is word RH_SI_n of
+// the scalar block -- the order rh_chain_store / rh_chain_load walk
+enum {
+#define X(n) RH_VI_##n,
+  RH_STATE_VECS(X)
+#undef X
+  RH_VI_COUNT
+};
+enum {
+#define X(n) RH_SI_##n,
+  RH_STATE_F64(X) RH_STATE_INT(X) RH_STATE_I64(X)
+#undef X
+  RH_SI_COUNT
+};
 #define RH_CNT(n) +1
 #define RH_STATE_NVEC (0 RH_STATE_VECS(RH_CNT))
 #define RH_STATE_NSCALAR ((0 RH_STATE_F64(RH_CNT)) + (0 RH_STATE_INT(RH_CNT)) + (0 RH_STATE_I64(RH_CNT)))
@@ -1731,6 +1745,9 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 #endif
 }
 
+#ifndef RH_TICK_FAST
+#define RH_TICK_FAST 1
+#endif
 extern "C" __global__ void __launch_bounds__(64)
 rh_tick_kernel(const rh_model_data d,
 #if RH_HAS_GATHER
@@ -1745,6 +1762,57 @@ rh_tick_kernel(const rh_model_data d,
   const int lane = threadIdx.x;
   if (chain >= chains) return;
   rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
+#if RH_TICK_FAST && !RH_BIGN && !RH_WITH_DENSE && !RH_HAS_GATHER && RH_PACK_L == 64
+  // Fast path for the tick that follows a mid-trajectory gradient (all but one of the L ticks of an HMC / EHMC trajectory):
+  // `twoFullSteps` (LeapFrog.scala:175-184) is  p += eps * grad;  q += eps * velocity(p)  and touches three vectors and a
+  // handful of scalars of the ~20-vector state image.  Only those are loaded and stored here, with the same functions the
+  // automaton's RH_S_TS_MID case applies to them, so the chains are bit-identical to the general path below -- which costs
+  // ~13 us per wavefront in state traffic and instruction fetch for the same arithmetic.
+  if (!fresh) {
+    rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+    const int pc = rh_uniform_i((int)(rh_i64)sc[RH_SI_pc]), need = rh_uniform_i((int)(rh_i64)sc[RH_SI_need_eval]);
+    const int ts_i = rh_uniform_i((int)(rh_i64)sc[RH_SI_ts_i]), ts_l = rh_uniform_i((int)(rh_i64)sc[RH_SI_ts_l]);
+    if (pc == RH_S_TS_MID && need != 0 && ts_i < ts_l) {
+      rh_chain c;  // only the fields read below are filled
+      c.mass_identity = rh_uniform_i((int)(rh_i64)sc[RH_SI_mass_identity]);
+      c.sampling_started = rh_uniform_i((int)(rh_i64)sc[RH_SI_sampling_started]);
+      c.err = rh_uniform_i((int)(rh_i64)sc[RH_SI_err]);
+      c.eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
+      c.n_grad = (rh_i64)sc[RH_SI_n_grad]; c.n_leapfrog = (rh_i64)sc[RH_SI_n_leapfrog]; c.n_warm_leapfrog = (rh_i64)sc[RH_SI_n_warm_leapfrog];
+RH_UNROLL_SLOTS
+      for (int k = 0; k < RH_SLOTS; k++) {
+        c.Bq.s[k] = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS + k) * 64 + lane]);
+        c.Bp.s[k] = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS + k) * 64 + lane]);
+        c.M.s[k] = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS + k) * 64 + lane]);
+      }
+      int err = grad_err[0];
+      rh_combine_chain(c.Bq, d, partial, nsplit, chain, chains, lane, c.pend_logp, c.pend_g, err);
+      c.err |= err;
+      c.BU = c.pend_logp * -1; c.Bg = c.pend_g;          // RH_S_TS_MID, ts_i < ts_l
+      wv_axpy(c.Bp, c.eps, c.Bg);
+      rh_new_qs(c, c.mass_identity != 0);
+RH_UNROLL_SLOTS
+      for (int k = 0; k < RH_SLOTS; k++) {
+        if (k * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + k * 64 + lane] = c.Bq.s[k];
+        st[(size_t)(RH_VI_Bq * RH_SLOTS + k) * 64 + lane] = (rh_u64)__double_as_longlong(c.Bq.s[k]);
+        st[(size_t)(RH_VI_Bp * RH_SLOTS + k) * 64 + lane] = (rh_u64)__double_as_longlong(c.Bp.s[k]);
+        st[(size_t)(RH_VI_Bg * RH_SLOTS + k) * 64 + lane] = (rh_u64)__double_as_longlong(c.Bg.s[k]);
+        st[(size_t)(RH_VI_pend_g * RH_SLOTS + k) * 64 + lane] = (rh_u64)__double_as_longlong(c.pend_g.s[k]);
+      }
+      if (lane == 0) {
+        sc[RH_SI_BU] = (rh_u64)__double_as_longlong(c.BU); sc[RH_SI_pend_logp] = (rh_u64)__double_as_longlong(c.pend_logp);
+        sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)c.err;
+        sc[RH_SI_n_grad] = (rh_u64)(c.n_grad + 1); sc[RH_SI_n_leapfrog] = (rh_u64)c.n_leapfrog; sc[RH_SI_n_warm_leapfrog] = (rh_u64)c.n_warm_leapfrog;
+        rh_chain_stats_dev *out = stats + chain;
+        out->leapfrog_steps = c.n_leapfrog; out->warmup_leapfrog_steps = c.n_warm_leapfrog; out->gradient_evaluations = c.n_grad + 1;
+        out->error = c.err; out->status = RH_ADV_NEED_GRAD;
+        active[chain] = 1;
+        atomicAdd(n_running, 1);
+      }
+      return;
+    }
+  }
+#endif
   rh_chain c;
   if (fresh) rh_chain_zero(st, lane);
   rh_chain_load(c, st, lane);

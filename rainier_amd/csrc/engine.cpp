@@ -228,6 +228,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_CHAIN_WAVES")) defines += "#define RH_CHAIN_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
