@@ -104,7 +104,8 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
             break;
           }
       }
-      for (int a = 0; a < j && !found; a++) {
+      // (quadratic in the number of earlier columns: bounded, so that a model with thousands of columns is not held up here)
+      for (int a = 0; a < j && !found && (int64_t)j * j <= 4000000; a++) {
         if (ex[(size_t)a].kind == CExpr::CONST) continue;
         const double *ca = col[(size_t)a];
         for (int b = a; b < j && !found; b++) {
