@@ -115,7 +115,7 @@ def lib():
     L.rh_free.argtypes = [vp]
     L.rh_simplify_rir.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rh_canonicalize_rir.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_void_p),
-                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
     L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]
     _lib = L
     return L
@@ -142,20 +142,25 @@ def compile_opts(device=-1, math_mode=MATH_FAST, fp_contract=False, rows_unroll=
 
 
 def canonicalize_rir(rir: bytes, columns, nrows, fast: bool = False, refactor: bool = False):
-    """Column canonicalisation (csrc/columns.cpp; with refactor also csrc/refactor.cpp + the clean-up pass) applied to an RIR
-    blob and its data, returned as (RIR, kept) with kept[j] = index into `columns` of the j-th column the rewritten program
-    reads (test hook, no device needed)."""
+    """What rh_model_create does to a program and its data before lowering (csrc/columns.cpp; with refactor -- fast builds --
+    also csrc/refactor.cpp: re-association and Model.observe's 8-way split rolled back into rows), returned as
+    (RIR, parts, nrows): parts[j] = [(index into `columns` or 0xFFFFFFFF for zeros, block length), ...] whose data,
+    concatenated, is column j of the rewritten program; nrows = its row count per target (test hook, no device needed)."""
     L = lib()
     cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
     arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
     nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
-    kept = (C.c_uint32 * max(1, len(cols)))()
-    nk = C.c_uint32(0)
+    words = (C.c_uint32 * max(3, 3 * len(cols)))()
+    nw = C.c_uint32(0)
+    nr_out = (C.c_int64 * max(1, len(nrows)))()
     out, n = C.c_void_p(), C.c_size_t(0)
     buf = C.create_string_buffer(rir, len(rir))
-    check(L.rh_canonicalize_rir(buf, len(rir), arr, nr, int(fast), int(refactor), C.byref(out), C.byref(n), kept, C.byref(nk)))
+    check(L.rh_canonicalize_rir(buf, len(rir), arr, nr, int(fast), int(refactor), C.byref(out), C.byref(n), words, C.byref(nw), nr_out))
     try:
-        return C.string_at(out, n.value), [int(kept[i]) for i in range(nk.value)]
+        parts, i = [], 0
+        while i < nw.value:
+            k = words[i]; parts.append([(int(words[i + 1 + 2 * j]), int(words[i + 2 + 2 * j])) for j in range(k)]); i += 1 + 2 * k
+        return C.string_at(out, n.value), parts, [int(nr_out[t]) for t in range(len(nrows))]
     finally:
         L.rh_free(out)
 

@@ -118,6 +118,16 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       if (found) { ex[(size_t)j] = e; changed = true; }
     }
   }
+  // Model.observe's initial chunk (core/Model.scala:84-96): a row target with at most 8 rows next to a big one.  Its rows are
+  // substituted as constants and summed in row order (the order the reference's row loop adds them): a data-free target, so that
+  // the model keeps ONE streamed target for the row kernels.
+  std::vector<char> unroll(P.targets.size(), 0);
+  {
+    bool big = false;
+    for (size_t t = 0; t < P.targets.size(); t++) big = big || (P.targets[t].n_cols && nrows[t] >= 16);
+    for (size_t t = 0; t < P.targets.size() && big; t++)
+      if (P.targets[t].n_cols && nrows[t] >= 1 && nrows[t] <= 8) { unroll[t] = 1; changed = true; }
+  }
   // new column numbering: base columns only, original order
   std::vector<Target> nt = P.targets;
   uint32_t in = P.n_params, colc = 0;
@@ -128,7 +138,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     base_new[t].assign(T.n_cols, -1);
     uint32_t nb = 0;
     for (uint32_t j = 0; j < T.n_cols; j++) {
-      const bool base = exprs[t].empty() || exprs[t][j].kind == CExpr::BASE;
+      const bool base = !unroll[t] && (exprs[t].empty() || exprs[t][j].kind == CExpr::BASE);
       if (!base) continue;
       base_new[t][j] = (int)nb++;
       kept.push_back(T.col0 + j);
@@ -149,7 +159,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     }
     // a row target keeps at least one column (its row count hangs on it): all-derived cannot happen (column 0 is never derived
     // unless constant) -- keep column 0 as a base then
-    if (T.n_cols && nb == 0) {
+    if (T.n_cols && nb == 0 && !unroll[t]) {
       base_new[t][0] = 0; nb = 1; kept.push_back(T.col0); P.col_domain.push_back({});
       exprs[t][0] = CExpr();
     }
@@ -218,6 +228,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
   std::vector<uint32_t> m(P.nodes.size(), 0);
   for (uint32_t i = 0; i < P.nodes.size(); i++) {
     const Node &n = P.nodes[i];
+    if (n.dep && unroll[(size_t)n.dep - 1]) { m[i] = constant(0.0); continue; }   // rebuilt per row below
     switch (n.op) {
       case RH_RIR_CONST: m[i] = constant(n.cval); break;
       case RH_RIR_INPUT:
@@ -242,7 +253,62 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       default: m[i] = op1(n.op, m[n.a], Q.nodes[m[n.a]].dep);
     }
   }
-  for (Target &t : Q.targets) for (uint32_t &o : t.outputs) o = m[o];
+  for (size_t t = 0; t < Q.targets.size(); t++) if (!unroll[t]) for (uint32_t &o : Q.targets[t].outputs) o = m[o];
+  // the unrolled targets: per row, the target's nodes again with the row's values as constants (exact folding of + - * /,
+  // compares and constant-index lookups only: transcendental nodes stay for the device)
+  auto cval = [&](uint32_t id, double &v) { if (Q.nodes[id].op != RH_RIR_CONST) return false; v = Q.nodes[id].cval; return true; };
+  for (size_t t = 0; t < P.targets.size(); t++) {
+    if (!unroll[t]) continue;
+    const Target &T = P.targets[t];
+    std::vector<char> live(P.nodes.size(), 0);
+    for (uint32_t o : T.outputs) live[o] = 1;
+    for (size_t i = P.nodes.size(); i-- > 0;) {
+      if (!live[i]) continue;
+      const Node &n = P.nodes[i];
+      if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+      live[n.a] = 1;
+      if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) live[e] = 1; }
+      else if ((n.op >= RH_RIR_ADD && n.op <= RH_RIR_COMPARE) || n.op == RH_RIR_SEQ) live[n.b] = 1;
+    }
+    std::vector<uint32_t> acc(T.outputs.size(), 0);
+    for (int64_t r = 0; r < nrows[t]; r++) {
+      std::vector<uint32_t> mr(P.nodes.size(), 0);
+      for (uint32_t i = 0; i < P.nodes.size(); i++) {
+        if (!live[i]) continue;
+        const Node &n = P.nodes[i];
+        if (n.dep != t + 1) { mr[i] = m[i]; continue; }
+        double x, y;
+        switch (n.op) {
+          case RH_RIR_INPUT: mr[i] = constant(columns[T.col0 + (n.input - T.input_start)][r]); break;
+          case RH_RIR_LOOKUP: {
+            const uint32_t ix = mr[n.a];
+            if (cval(ix, x)) {
+              const long long k = (x != x ? 0LL : (long long)x) - (long long)n.low;
+              if (k >= 0 && k < (long long)n.table.size()) { mr[i] = mr[n.table[(size_t)k]]; break; }
+            }
+            Node q; q.op = RH_RIR_LOOKUP; q.a = ix; q.low = n.low;
+            for (uint32_t e : n.table) q.table.push_back(mr[e]);
+            mr[i] = push(q);
+            break;
+          }
+          case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_COMPARE: {
+            const uint32_t a = mr[n.a], b = mr[n.b];
+            if (cval(a, x) && cval(b, y)) {
+              const double v = n.op == RH_RIR_ADD ? x + y : n.op == RH_RIR_SUB ? x - y : n.op == RH_RIR_MUL ? x * y : n.op == RH_RIR_DIV ? x / y
+                                                          : (x > y ? 1.0 : (x == y ? 0.0 : -1.0));
+              if (v == v) { mr[i] = constant(v); break; }
+            }
+            mr[i] = op2(n.op, a, b, 0);
+            break;
+          }
+          case RH_RIR_POW: case RH_RIR_SEQ: mr[i] = op2(n.op, mr[n.a], mr[n.b], 0); break;
+          default: mr[i] = op1(n.op, mr[n.a], 0);
+        }
+      }
+      for (size_t o = 0; o < T.outputs.size(); o++) acc[o] = r == 0 ? mr[T.outputs[o]] : op2(RH_RIR_ADD, acc[o], mr[T.outputs[o]], 0);
+    }
+    Q.targets[t].outputs = acc;
+  }
   P = std::move(Q);
   return true;
 }

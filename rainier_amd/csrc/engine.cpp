@@ -168,7 +168,9 @@ struct rh_model {
   rh_model_data data{};
   std::vector<void *> dev_cols;
   void *d_coltab = nullptr;                  // device table of the column pointers (rh_model_data.cols)
-  std::vector<uint32_t> col_map;             // engine column -> caller's column (base columns kept by canonicalize_columns)
+  std::vector<std::vector<int64_t>> col_len; // ... and the length of every block (0xFFFFFFFF in col_src = a block of zeros)
+  std::vector<std::vector<uint32_t>> col_src; // engine column -> the caller's columns concatenated into it (one, unless the
+                                             // target was rolled back from Model.observe's 8-way split: refactor.cpp)
   int64_t rows_total = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
@@ -355,20 +357,66 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
 }
 
 // derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
-// fills m->col_map (engine column -> caller's column) and the per-target row counts
+// fills m->col_src (engine column -> the caller's columns it is made of) and the per-target row counts
 void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t) {
   std::string err;
   nrows_t.assign(m->prog.targets.size(), 0);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) nrows_t[t] = nrows[t];
-  m->col_map.clear();
+  std::vector<uint32_t> kept;
   for (uint32_t c = 0; c < m->prog.n_cols_total; c++) {
     if (!columns[c]) throw Fail{RH_E_INVALID, "a column pointer is NULL"};
-    m->col_map.push_back(c);
+    kept.push_back(c);
   }
-  bool canon = m->prog.n_cols_total > 0;
+  bool canon = m->prog.n_cols_total > 0, changed = false;
   if (const char *e = std::getenv("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
-  if (canon && rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, m->col_map, err)) m->eopt.refactor = true;
-  if (const char *e = std::getenv("RH_REFACTOR")) m->eopt.refactor = m->eopt.refactor && std::atoi(e) != 0;
+  if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err);
+  bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
+  if (const char *e = std::getenv("RH_REFACTOR")) re = re && std::atoi(e) != 0;
+  m->col_src.clear(); m->col_len.clear();
+  {
+    size_t g = 0;
+    for (size_t t = 0; t < m->prog.targets.size(); t++)
+      for (uint32_t j = 0; j < m->prog.targets[t].n_cols; j++, g++) { m->col_src.push_back({kept[g]}); m->col_len.push_back({nrows_t[t]}); }
+  }
+  if (!re) return;
+  // fast builds: re-association, and Model.observe's 8-way split rolled back into rows (refactor.cpp); the row counts follow
+  std::vector<int> owner;  // column (before rolling) -> its target
+  for (size_t t = 0; t < m->prog.targets.size(); t++) for (uint32_t j = 0; j < m->prog.targets[t].n_cols; j++) owner.push_back((int)t);
+  std::vector<std::vector<uint32_t>> parts;
+  rh::Program Q = rh::simplify(m->prog, true);
+  bool rederive = true;
+  if (const char *e = std::getenv("RH_REDERIVE")) rederive = std::atoi(e) != 0;
+  if (rederive) {  // the gradient in its natural form, from the value output (verified against the supplied one): rederive.cpp
+    std::vector<const double *> cp;
+    for (uint32_t c : kept) cp.push_back(columns[c]);
+    Q = rh::simplify(rh::rederive_gradients(Q, cp, nrows_t.data()), true);
+  }
+  m->prog = rh::simplify(rh::refactor(Q, &parts), true);
+  std::vector<std::vector<uint32_t>> src;
+  std::vector<std::vector<int64_t>> len;
+  std::vector<int64_t> nr(m->prog.targets.size(), 0);
+  for (size_t t = 0; t < m->prog.targets.size(); t++) {
+    const auto &T = m->prog.targets[t];
+    for (uint32_t j = 0; j < T.n_cols; j++) {
+      std::vector<uint32_t> cs;
+      std::vector<int64_t> ls;
+      int64_t rows = 0;
+      const auto &pj = parts[T.col0 + j];
+      for (size_t b = 0; b < pj.size(); b++) {
+        const uint32_t g = pj[b];
+        if (g == 0xFFFFFFFFu) {   // zeros, as long as block b of the target's first column
+          if (j == 0 || b >= len[T.col0].size()) throw Fail{RH_E_INVALID, "internal: zero block without a reference column"};
+          cs.push_back(g); ls.push_back(len[T.col0][b]);
+        } else { cs.push_back(kept[g]); ls.push_back(nrows_t[(size_t)owner[g]]); }
+        rows += ls.back();
+      }
+      if (j == 0) nr[t] = rows;
+      else if (rows != nr[t]) throw Fail{RH_E_INVALID, "internal: rolled columns of one target disagree on the row count"};
+      src.push_back(cs); len.push_back(ls);
+    }
+  }
+  m->col_src = src; m->col_len = len;
+  nrows_t = nr;
 }
 
 void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void **args) {
@@ -421,13 +469,28 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
       if (!T.n_cols) continue;
       m->rows_total += nrows_t[t];
       const int64_t nr = nrows_t[t];
+      std::vector<double> joined;
+      auto column = [&](uint32_t ec) -> const double * {   // engine column ec on the host: the caller's array, or its parts joined
+        const auto &cs = m->col_src[ec];
+        if (cs.size() == 1) return columns[cs[0]];
+        joined.clear();
+        for (size_t b = 0; b < cs.size(); b++) {
+          const int64_t L = m->col_len[ec][b];
+          if (cs[b] == 0xFFFFFFFFu) joined.insert(joined.end(), (size_t)L, 0.0);
+          else joined.insert(joined.end(), columns[cs[b]], columns[cs[b]] + L);
+        }
+        if ((int64_t)joined.size() != nr) throw Fail{RH_E_INVALID, "internal: joined column length"};
+        return joined.data();
+      };
       std::vector<int64_t> perm;  // empty = identity
       if (m->info.gather_mode) {
         const auto &ti = m->info.targets[t];
         if (nr >= (int64_t)1 << 31) throw Fail{RH_E_UNSUPPORTED, "gather mode: more than 2^31 rows in one target"};
         std::vector<int> off;
         if (ti.has_gather) {
-          const double *idx = columns[m->col_map[T.col0 + ti.g_col]];
+          std::vector<double> idx_store;
+          const double *idx = column(T.col0 + ti.g_col);
+          if (idx == joined.data()) { idx_store = joined; idx = idx_store.data(); }
           off.assign((size_t)ti.g_count + 1, 0);
           bool sorted = true;
           int64_t prev = 0;
@@ -465,7 +528,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
         const size_t bytes = (size_t)nr * sizeof(double);
         HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
         m->dev_cols.push_back(d);
-        const double *src = columns[m->col_map[T.col0 + j]];
+        const double *src = column(T.col0 + j);
         if (!perm.empty()) {
           tmp.resize((size_t)nr);
           for (int64_t r = 0; r < nr; r++) tmp[(size_t)r] = src[perm[(size_t)r]];
@@ -559,23 +622,31 @@ extern "C" int rh_simplify_rir(const void *rir, size_t rir_len, int fast, void *
 }
 
 // Test hook (no device needed): the program after column canonicalisation (and, with refactor != 0, after the fast-mode
-// re-association and clean-up) as RIR again, plus the caller's column index of every column the program still reads, so that
-// the CPU suite can check on the oracle's interpreter that the rewrite preserves values.  kept must hold one entry per
-// original column; returns RH_OK also when nothing was rewritten (identity map).
+// re-association / slot rolling and clean-up) as RIR again, so that the CPU suite can check on the oracle's interpreter that
+// the rewrite preserves values.  parts_out receives, per column the rewritten program reads, a count followed by that many
+// (caller column index | 0xFFFFFFFF = zeros, block length) pairs: the data concatenated into it, in order -- at most
+// 3 * original columns words; nrows_out the row
+// count of every target.  Returns RH_OK also when nothing was rewritten.
 extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows, int fast,
-                                   int refactor, void **out, size_t *out_len, uint32_t *kept, uint32_t *n_kept) {
+                                   int refactor, void **out, size_t *out_len, uint32_t *parts_out, uint32_t *n_parts_words,
+                                   int64_t *nrows_out) {
+  rh_model m;
   return guard(nullptr, [&] {
-    rh::Program P; std::string err;
-    if (!rh::parse_rir(rir, rir_len, P, err)) throw Fail{RH_E_INVALID, err};
-    std::vector<int64_t> nr(P.targets.size(), 0);
-    for (size_t t = 0; t < P.targets.size(); t++) if (P.targets[t].n_cols) nr[t] = nrows[t];
-    std::vector<uint32_t> k;
-    const bool changed = rh::canonicalize_columns(P, columns, nr.data(), fast != 0, k, err);
-    if (changed && refactor) P = rh::simplify(rh::refactor(rh::simplify(P, fast != 0)), fast != 0);
-    const std::vector<unsigned char> b = rh::write_rir(P);
+    std::string err;
+    if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
+    m.eopt.fp_contract = fast != 0;
+    m.eopt.simplify = refactor != 0;   // canonicalize() re-associates only when the clean-up pass is on
+    std::vector<int64_t> nr;
+    canonicalize(&m, columns, nrows, nr);
+    const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
-    for (size_t i = 0; i < k.size(); i++) kept[i] = k[i];
-    *n_kept = (uint32_t)k.size();
+    uint32_t w = 0;
+    for (size_t c = 0; c < m.col_src.size(); c++) {
+      parts_out[w++] = (uint32_t)m.col_src[c].size();
+      for (size_t b = 0; b < m.col_src[c].size(); b++) { parts_out[w++] = m.col_src[c][b]; parts_out[w++] = (uint32_t)m.col_len[c][b]; }
+    }
+    *n_parts_words = w;
+    for (size_t t = 0; t < nr.size(); t++) nrows_out[t] = nr[t];
   });
 }
 

@@ -19,6 +19,8 @@
 // rebuilt row code of a target is not cheaper than the original, the original is kept for that target.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -33,7 +35,6 @@ namespace {
 typedef std::vector<std::pair<uint32_t, int>> Mono;   // (atom id, exponent != 0), ascending atom id
 typedef std::vector<std::pair<Mono, double>> Poly;    // (monomial, coefficient != 0), ascending monomial
 
-constexpr size_t CAP = 512;  // monomials per polynomial; above it a product keeps its operands as sum atoms
 
 struct Atom {
   uint32_t op = 0;                 // RH_RIR_INPUT, a unary op, POW, COMPARE, LOOKUP, or 0xFFFFFFFF = a sum atom
@@ -44,6 +45,7 @@ struct Atom {
   bool operator<(const Atom &o) const { return std::tie(op, input, low, kids) < std::tie(o.op, o.input, o.low, o.kids); }
 };
 constexpr uint32_t SUM_ATOM = 0xFFFFFFFFu;
+constexpr uint32_t ZERO_PART = 0xFFFFFFFFu;  // in a column's part list: a block of zeros as long as the same block of the target's first column
 
 struct Refactor {
   const Program &P;
@@ -133,12 +135,15 @@ struct Refactor {
   }
   Poly mul(const Poly &a, const Poly &b) {
     if (a.empty() || b.empty()) return Poly();
-    if (a.size() > 1 && b.size() > 1) {  // sum x sum: never expanded
+    if (a.size() > 1 && b.size() > 1) {  // sum x sum: never expanded ...
+      // ... except a parameter-only sum against a row-level one: the invariant becomes ONE atom and multiplies every row term
+      // (the common-factor extraction pulls it out again; the row terms -- e.g. the 8 slots of Model.observe -- stay apart)
+      const bool ra = poly_dep(a) != 0, rb = poly_dep(b) != 0;
+      if (ra != rb) return ra ? mul(a, sum_atom(b, 1)) : mul(sum_atom(a, 1), b);
       const Poly fa = sum_atom(a, 1), fb = sum_atom(b, 1);
       Poly r; r.push_back({mono_mul(fa[0].first, fb[0].first), fa[0].second * fb[0].second});
       return r;
     }
-    if (a.size() * b.size() > CAP) return mul(sum_atom(a, 1), b);
     Poly r;
     for (auto &x : a) for (auto &y : b) r.push_back({mono_mul(x.first, y.first), x.second * y.second});
     normalize(r);
@@ -200,6 +205,213 @@ struct Refactor {
     a.kids.push_back(intern(x)); a.kids.push_back(intern(y));
     a.dep = poly_dep(x) ? poly_dep(x) : poly_dep(y);
     return of_atom(atom(a));
+  }
+
+  // ---- slot rolling ----------------------------------------------------------------------------------------------------
+  // Model.observe cuts the observations into an initial chunk and 8 contiguous splits and sums the splits' log-densities as
+  // ONE expression (core/Model.scala:71-132): a "row" of that target carries the columns of 8 observations, and the
+  // reference's Line algebra has merged the parameter-only terms of the 8 copies (8 * log sigma ...).  In normal form the
+  // structure is plain to see: the monomials of every output fall into S groups that touch disjoint column sets of equal
+  // size, plus column-free ("shared") monomials.  If renaming group s's columns onto group 1's (in column order) turns
+  // every output's group-s part into its group-1 part, the target is rolled back:  S times the rows, 1/S of the columns,
+  //      out = shared / S + part_1          (S = 8: the division is exact)
+  // and an initial-chunk target whose outputs are that same function of its own columns is appended as further rows.
+  std::map<uint32_t, std::vector<uint32_t>> acols;   // atom -> the column inputs it reaches (sorted)
+  const std::vector<uint32_t> &atom_cols(uint32_t a) {
+    auto it = acols.find(a);
+    if (it != acols.end()) return it->second;
+    std::vector<uint32_t> r;
+    const Atom A = atoms[a];
+    if (A.op == RH_RIR_INPUT) { if (A.input >= P.n_params) r.push_back(A.input); }
+    else for (uint32_t kid : A.kids) { const std::vector<uint32_t> v = poly_cols(polys[kid]); r.insert(r.end(), v.begin(), v.end()); }
+    std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end());
+    return acols[a] = r;
+  }
+  std::vector<uint32_t> mono_cols(const Mono &m) {
+    std::vector<uint32_t> r;
+    for (auto &f : m) if (atoms[f.first].dep) { const std::vector<uint32_t> &v = atom_cols(f.first); r.insert(r.end(), v.begin(), v.end()); }
+    std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end());
+    return r;
+  }
+  std::vector<uint32_t> poly_cols(const Poly p) {
+    std::vector<uint32_t> r;
+    for (auto &t : p) { const std::vector<uint32_t> v = mono_cols(t.first); r.insert(r.end(), v.begin(), v.end()); }
+    std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end());
+    return r;
+  }
+  std::map<uint32_t, bool> aparam;   // atom -> does it read a parameter
+  bool atom_has_param(uint32_t a) {
+    auto it = aparam.find(a);
+    if (it != aparam.end()) return it->second;
+    const Atom A = atoms[a];
+    bool r = false;
+    if (A.op == RH_RIR_INPUT) r = A.input < P.n_params;
+    else for (uint32_t kid : A.kids) { const Poly kp = polys[kid]; for (auto &t : kp) for (auto &f : t.first) if (atom_has_param(f.first)) r = true; }
+    return aparam[a] = r;
+  }
+  bool mono_has_param(const Mono &m) { for (auto &f : m) if (atom_has_param(f.first)) return true; return false; }
+  // column-blind structural hashes (every data column hashes alike): they order a slot's monomials and atoms the same way in
+  // every slot, so that a walk in that order meets corresponding columns in the same sequence
+  std::map<uint32_t, uint64_t> hatom;
+  static uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xBF58476D1CE4E5B9ull; }
+  uint64_t h_atom(uint32_t a) {
+    auto it = hatom.find(a);
+    if (it != hatom.end()) return it->second;
+    const Atom A = atoms[a];
+    uint64_t h = mix(0x1234, A.op);
+    if (A.op == RH_RIR_INPUT) h = A.input >= P.n_params ? mix(h, 0xC01) : mix(mix(h, 0x9A7), A.input);
+    else { h = mix(h, (uint64_t)(int64_t)A.low); for (uint32_t kid : A.kids) h = mix(h, h_poly(polys[kid])); }
+    return hatom[a] = h;
+  }
+  uint64_t h_mono(const Mono &m) {
+    std::vector<uint64_t> v;
+    for (auto &f : m) v.push_back(mix(h_atom(f.first), (uint64_t)(int64_t)f.second));
+    std::sort(v.begin(), v.end());
+    uint64_t h = 0x77;
+    for (uint64_t x : v) h = mix(h, x);
+    return h;
+  }
+  uint64_t h_poly(const Poly p) {
+    std::vector<uint64_t> v;
+    for (auto &t : p) { uint64_t b; std::memcpy(&b, &t.second, 8); v.push_back(mix(h_mono(t.first), b)); }
+    std::sort(v.begin(), v.end());
+    uint64_t h = 0x99;
+    for (uint64_t x : v) h = mix(h, x);
+    return h;
+  }
+  void walk_atom(uint32_t a, std::vector<uint32_t> &order, std::map<uint32_t, char> &seen) {
+    const Atom A = atoms[a];
+    if (A.op == RH_RIR_INPUT) { if (A.input >= P.n_params && !seen.count(A.input)) { seen[A.input] = 1; order.push_back(A.input); } return; }
+    if (A.dep == 0) return;
+    for (uint32_t kid : A.kids) walk_poly(polys[kid], order, seen);
+  }
+  void walk_poly(const Poly p, std::vector<uint32_t> &order, std::map<uint32_t, char> &seen) {
+    std::vector<std::pair<uint64_t, size_t>> ms;
+    for (size_t i = 0; i < p.size(); i++) ms.push_back({h_mono(p[i].first), i});
+    std::sort(ms.begin(), ms.end());
+    for (auto &mi : ms) {
+      std::vector<std::pair<uint64_t, uint32_t>> as;
+      for (auto &f : p[mi.second].first) as.push_back({h_atom(f.first), f.first});
+      std::sort(as.begin(), as.end());
+      for (auto &x : as) walk_atom(x.second, order, seen);
+    }
+  }
+  typedef std::map<uint32_t, uint32_t> ColMap;
+  uint32_t rename_atom(uint32_t a, const ColMap &cmap, std::map<uint32_t, uint32_t> &memo) {
+    auto it = memo.find(a);
+    if (it != memo.end()) return it->second;
+    Atom A = atoms[a];
+    if (A.dep == 0) return a;
+    if (A.op == RH_RIR_INPUT) { auto c = cmap.find(A.input); if (c != cmap.end()) A.input = c->second; }
+    else for (uint32_t &kid : A.kids) kid = intern(rename_poly(polys[kid], cmap, memo));
+    const uint32_t r = atom(A);
+    return memo[a] = r;
+  }
+  Poly rename_poly(const Poly p, const ColMap &cmap, std::map<uint32_t, uint32_t> &memo) {
+    Poly r;
+    for (auto &t : p) {
+      Mono m;
+      for (auto &f : t.first) m.push_back({rename_atom(f.first, cmap, memo), f.second});
+      std::sort(m.begin(), m.end());
+      r.push_back({m, t.second});
+    }
+    normalize(r);
+    return r;
+  }
+  static bool approx_equal(const Poly &a, const Poly &b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++)
+      if (a[i].first != b[i].first || std::fabs(a[i].second - b[i].second) > 1e-13 * std::fabs(b[i].second)) return false;
+    return true;
+  }
+  struct Rolled {
+    bool ok = false;
+    std::vector<std::vector<uint32_t>> slots;   // [slot][i]: column input ids, position i corresponds across slots
+    std::vector<Poly> outs;                     // per output: shared / S + part_1 + loose data terms
+    std::vector<uint32_t> loose;                // columns of parameter-free terms outside every slot (the reference's Line keeps the
+                                                // sum of all data-only terms as ONE column): kept, padded with zeros for the other slots
+    int init_target = -1;
+    std::vector<uint32_t> init_cols;            // the initial chunk's columns, same positions
+  };
+  Rolled try_roll(size_t t, const std::vector<char> &taken) {
+    Rolled R;
+    const Target &T = P.targets[t];
+    const size_t no = T.outputs.size();
+    std::vector<Poly> po(no);
+    for (size_t o = 0; o < no; o++) po[o] = poly_of(T.outputs[o]);
+    // union-find over the target's columns
+    std::map<uint32_t, uint32_t> parent;
+    std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { auto it = parent.find(x); if (it == parent.end()) { parent[x] = x; return x; } if (it->second == x) return x; const uint32_t r = find(it->second); parent[x] = r; return r; };
+    for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); for (size_t i = 1; i < c.size(); i++) parent[find(c[i])] = find(c[0]); if (!c.empty()) find(c[0]); }
+    if (std::getenv("RH_DEBUG_ROLL"))
+      for (size_t o = 0; o < no; o++) for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (c.size() > 4) { std::fprintf(stderr, "  output %zu: monomial with %zu columns, atoms:", o, c.size()); for (auto &f : m.first) std::fprintf(stderr, " [op %u kids %zu cols %zu]^%d", atoms[f.first].op, atoms[f.first].kids.size(), atom_cols(f.first).size(), f.second); std::fprintf(stderr, "\n"); break; } }
+    std::map<uint32_t, std::vector<uint32_t>> comp;
+    for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
+    // components that only occur in parameter-free monomials are loose data terms, not slots
+    std::map<uint32_t, char> has_param_comp;
+    for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && mono_has_param(m.first)) has_param_comp[find(c[0])] = 1; }
+    std::map<uint32_t, char> is_loose;
+    for (auto &kv : comp) {
+      std::sort(kv.second.begin(), kv.second.end());
+      if (has_param_comp.count(kv.first)) R.slots.push_back(kv.second);
+      else for (uint32_t c : kv.second) { R.loose.push_back(c); is_loose[c] = 1; }
+    }
+    if (std::getenv("RH_DEBUG_ROLL")) { std::fprintf(stderr, "roll t=%zu: %zu slot components, %zu loose columns; sizes", t, R.slots.size(), R.loose.size()); for (auto &sl : R.slots) std::fprintf(stderr, " %zu", sl.size()); std::fprintf(stderr, "\n"); }
+    if (std::getenv("RH_DEBUG_ROLL")) for (auto &sl : R.slots) { std::fprintf(stderr, "   slot:"); for (uint32_t c : sl) std::fprintf(stderr, " %u", c - P.n_params); std::fprintf(stderr, "\n"); }
+    if (R.slots.size() < 2) return R;
+    std::sort(R.slots.begin(), R.slots.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+    std::sort(R.loose.begin(), R.loose.end());
+    const size_t S = R.slots.size(), mcols = R.slots[0].size();
+    for (auto &sl : R.slots) if (sl.size() != mcols) return R;
+    std::map<uint32_t, size_t> slot_of;
+    for (size_t s = 0; s < S; s++) for (uint32_t c : R.slots[s]) slot_of[c] = s;
+    {  // corresponding columns by structure, not by position in the column list
+      std::vector<std::vector<uint32_t>> order(S);
+      std::vector<std::map<uint32_t, char>> seen(S);
+      for (size_t o = 0; o < no; o++) {
+        std::vector<Poly> part(S);
+        for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && !is_loose.count(c[0])) part[slot_of[c[0]]].push_back(m); }
+        for (size_t s = 0; s < S; s++) walk_poly(part[s], order[s], seen[s]);
+      }
+      for (size_t s = 0; s < S; s++) if (order[s].size() != mcols) return R;
+      R.slots = order;
+    }
+    std::vector<ColMap> cmap(S);
+    for (size_t s = 1; s < S; s++) for (size_t i = 0; i < mcols; i++) cmap[s][R.slots[s][i]] = R.slots[0][i];
+    std::vector<std::map<uint32_t, uint32_t>> memo(S);
+    for (size_t o = 0; o < no; o++) {
+      Poly shared, loose; std::vector<Poly> part(S);
+      for (auto &m : po[o]) {
+        const std::vector<uint32_t> c = mono_cols(m.first);
+        if (c.empty()) shared.push_back(m); else if (is_loose.count(c[0])) loose.push_back(m); else part[slot_of[c[0]]].push_back(m);
+      }
+      for (size_t s = 1; s < S; s++) if (!approx_equal(rename_poly(part[s], cmap[s], memo[s]), part[0])) { if (std::getenv("RH_DEBUG_ROLL")) { std::fprintf(stderr, "roll t=%zu: output %zu, slot %zu differs from slot 0 (%zu vs %zu monomials)\n", t, o, s, part[s].size(), part[0].size());
+          const Poly rn = rename_poly(part[s], cmap[s], memo[s]);
+          for (int w = 0; w < 2; w++) for (auto &mm : (w ? rn : part[0])) { std::fprintf(stderr, "   %s coef %.17g:", w ? "slot s" : "slot 0", mm.second); for (auto &f : mm.first) { const Atom &A = atoms[f.first]; std::fprintf(stderr, " a%u[op %u low %d kids", f.first, A.op, A.low); for (size_t q = 0; q < A.kids.size() && q < 4; q++) std::fprintf(stderr, " %u", A.kids[q]); std::fprintf(stderr, " (n=%zu)]^%d", A.kids.size(), f.second); } std::fprintf(stderr, "\n"); } }
+          return R; }
+      Poly out = part[0];
+      for (auto &m : shared) out.push_back({m.first, m.second / (double)S});
+      for (auto &m : loose) out.push_back(m);
+      normalize(out);
+      R.outs.push_back(out);
+    }
+    // an initial chunk: another row target whose outputs are the same function of its own columns
+    for (size_t t0 = 0; t0 < P.targets.size() && R.init_target < 0 && R.loose.empty(); t0++) {
+      const Target &T0 = P.targets[t0];
+      if (t0 == t || !T0.n_cols || taken[t0] || T0.outputs.size() != no) continue;
+      std::vector<Poly> p0(no);
+      std::vector<uint32_t> used;
+      for (size_t o = 0; o < no; o++) { p0[o] = poly_of(T0.outputs[o]); const std::vector<uint32_t> v = poly_cols(p0[o]); used.insert(used.end(), v.begin(), v.end()); }
+      std::sort(used.begin(), used.end()); used.erase(std::unique(used.begin(), used.end()), used.end());
+      if (used.size() != mcols) continue;
+      ColMap c0; for (size_t i = 0; i < mcols; i++) c0[used[i]] = R.slots[0][i];
+      std::map<uint32_t, uint32_t> mm;
+      bool same = true;
+      for (size_t o = 0; o < no && same; o++) same = approx_equal(rename_poly(p0[o], c0, mm), R.outs[o]);
+      if (same) { R.init_target = (int)t0; R.init_cols = used; }
+    }
+    R.ok = true;
+    return R;
   }
 
   // ---- rebuilding -------------------------------------------------------------------------------------------------------
@@ -374,10 +586,11 @@ double row_cost(const Program &P, const Target &T) {
 
 }  // namespace
 
-Program refactor(const Program &P) {
+Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
   Refactor R(P);
   R.Q.n_params = P.n_params; R.Q.n_inputs = P.n_inputs; R.Q.n_cols_total = P.n_cols_total; R.Q.kind = P.kind;
   R.Q.targets = P.targets; R.Q.col_domain = P.col_domain;
+  if (parts) { parts->clear(); for (uint32_t c = 0; c < P.n_cols_total; c++) parts->push_back({c}); }
   // 1) every node of the input program is copied (so that data-free targets and fall-backs keep their exact structure) ...
   std::vector<uint32_t> m(P.nodes.size());
   for (uint32_t i = 0; i < P.nodes.size(); i++) {
@@ -410,16 +623,98 @@ Program refactor(const Program &P) {
     R.compute_polys(live);
     if (R.bad) return P;
   }
-  for (size_t t = 0; t < P.targets.size(); t++) {
+  const size_t NT = P.targets.size();
+  std::vector<char> merged(NT, 0);                                 // initial-chunk targets appended to a rolled target
+  std::vector<std::vector<uint32_t>> keep_cols(NT);                // per target: the old input ids it keeps, in order
+  std::vector<std::vector<std::vector<uint32_t>>> col_src(NT);     // per kept column: the old input ids concatenated into it
+  for (size_t t = 0; t < NT; t++) {
     Target &T = R.Q.targets[t];
     for (uint32_t &o : T.outputs) o = m[o];
-    if (!T.n_cols) continue;
+    for (uint32_t j = 0; j < P.targets[t].n_cols; j++) { keep_cols[t].push_back(P.targets[t].input_start + j); col_src[t].push_back({P.targets[t].input_start + j}); }
+  }
+  for (size_t t = 0; t < NT; t++) {
+    Target &T = R.Q.targets[t];
+    if (!T.n_cols || merged[t]) continue;
+    if (parts) {
+      const Refactor::Rolled rr = R.try_roll(t, merged);
+      if (rr.ok) {
+        std::vector<uint32_t> rebuilt;
+        for (const Poly &p : rr.outs) rebuilt.push_back(R.build_poly(R.intern(p)));
+        T.outputs = rebuilt;
+        keep_cols[t] = rr.slots[0];
+        col_src[t].assign(rr.slots[0].size(), {});
+        for (size_t i = 0; i < rr.slots[0].size(); i++) {
+          if (rr.init_target >= 0) col_src[t][i].push_back(rr.init_cols[i]);
+          for (auto &sl : rr.slots) col_src[t][i].push_back(sl[i]);
+        }
+        for (uint32_t c : rr.loose) {   // [its data, zeros for the rows of the other slots]
+          keep_cols[t].push_back(c);
+          std::vector<uint32_t> cs{c};
+          for (size_t sl = 1; sl < rr.slots.size(); sl++) cs.push_back(ZERO_PART);
+          col_src[t].push_back(cs);
+        }
+        if (rr.init_target >= 0) {
+          const size_t t0 = (size_t)rr.init_target;
+          merged[t0] = 1; keep_cols[t0].clear(); col_src[t0].clear();
+          for (uint32_t &o : R.Q.targets[t0].outputs) o = R.k(0.0);
+        }
+        continue;
+      }
+    }
     std::vector<uint32_t> rebuilt;
     for (uint32_t o : P.targets[t].outputs) rebuilt.push_back(R.build_poly(R.intern(R.poly_of(o))));
     Target cand = T; cand.outputs = rebuilt;
     if (row_cost(R.Q, cand) <= row_cost(R.Q, T)) T.outputs = rebuilt;
   }
-  return R.Q;
+  if (!parts) return R.Q;
+  // 3) renumber the columns that are left (dropped ones only survive in dead nodes, which the clean-up pass sweeps); columns no
+  //    output reads any more (the reference's gradient-only columns after re-derivation) go as well
+  Program &Q = R.Q;
+  {
+    std::vector<uint32_t> roots;
+    for (const Target &T : Q.targets) for (uint32_t o : T.outputs) roots.push_back(o);
+    std::vector<char> live;
+    mark_live(Q, roots, live);
+    std::vector<char> used(P.n_inputs, 0);
+    for (size_t i = 0; i < Q.nodes.size(); i++) if (live[i] && Q.nodes[i].op == RH_RIR_INPUT && Q.nodes[i].input < P.n_inputs) used[Q.nodes[i].input] = 1;
+    for (size_t t = 0; t < NT; t++) {
+      if (keep_cols[t].empty()) continue;
+      std::vector<uint32_t> kc; std::vector<std::vector<uint32_t>> cs;
+      for (size_t i = 0; i < keep_cols[t].size(); i++) if (used[keep_cols[t][i]]) { kc.push_back(keep_cols[t][i]); cs.push_back(col_src[t][i]); }
+      if (kc.empty()) { kc.push_back(keep_cols[t][0]); cs.push_back(col_src[t][0]); }   // the row count hangs on a column
+      keep_cols[t] = kc; col_src[t] = cs;
+    }
+  }
+  std::map<uint32_t, uint32_t> renum;
+  std::vector<std::vector<double>> dom;
+  uint32_t in = P.n_params, colc = 0;
+  parts->clear();
+  for (size_t t = 0; t < NT; t++) {
+    Q.targets[t].input_start = in; Q.targets[t].col0 = colc; Q.targets[t].n_cols = (uint32_t)keep_cols[t].size();
+    for (size_t i = 0; i < keep_cols[t].size(); i++) {
+      renum[keep_cols[t][i]] = in + (uint32_t)i;
+      std::vector<uint32_t> src; std::vector<double> d; bool known = !P.col_domain.empty();
+      for (uint32_t old : col_src[t][i]) {
+        if (old == ZERO_PART) { src.push_back(ZERO_PART); if (std::find(d.begin(), d.end(), 0.0) == d.end()) d.push_back(0.0); continue; }
+        const uint32_t g = old - P.n_params;
+        src.push_back(g);
+        if (known && g < P.col_domain.size() && !P.col_domain[g].empty()) { for (double v : P.col_domain[g]) if (std::find(d.begin(), d.end(), v) == d.end()) d.push_back(v); } else known = false;
+      }
+      if (!known || d.size() > 8) d.clear();
+      std::sort(d.begin(), d.end());
+      parts->push_back(src); dom.push_back(d);
+    }
+    in += Q.targets[t].n_cols; colc += Q.targets[t].n_cols;
+  }
+  Q.n_inputs = in; Q.n_cols_total = colc;
+  if (!P.col_domain.empty()) Q.col_domain = dom;
+  for (Node &n : Q.nodes)
+    if (n.op == RH_RIR_INPUT && n.input >= P.n_params) {
+      auto it = renum.find(n.input);
+      if (it != renum.end()) n.input = it->second;
+      else { n.op = RH_RIR_CONST; n.cval = 0.0; n.input = 0; n.dep = 0; }   // a dropped column: only dead nodes still name it
+    }
+  return Q;
 }
 
 }  // namespace rh

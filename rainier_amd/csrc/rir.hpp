@@ -44,7 +44,15 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
 
 // Fast-mode re-association of row targets after canonicalize_columns (refactor.cpp): products are merged into monomials
 // and the factor common to every term of an output is pulled out, so that x_k * w shapes reappear.
-Program refactor(const Program &p);
+// With `parts`, targets written by Model.observe's 8-way split are also rolled back into rows: parts[new column] = the old
+// columns (flattened index) whose data is concatenated into it, in order (0xFFFFFFFF = a block of zeros as long as the same
+// block of the target's first column); a target's row count is the sum of its parts'.
+Program refactor(const Program &p, std::vector<std::vector<uint32_t>> *parts = nullptr);
+
+// Fast mode (rederive.cpp): the gradient outputs of every streamed target re-derived from its value output by reverse-mode
+// differentiation and VERIFIED against the supplied ones on sample rows (cols[c] = host data of column c, nrows per target);
+// targets that do not verify keep their outputs.
+Program rederive_gradients(const Program &p, const std::vector<const double *> &cols, const int64_t *nrows, bool *changed = nullptr);
 
 // Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
 Program simplify(const Program &p, bool fast = false);

