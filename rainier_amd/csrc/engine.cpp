@@ -370,6 +370,7 @@ void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrow
   bool canon = m->prog.n_cols_total > 0, changed = false;
   if (const char *e = std::getenv("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
   if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err);
+  for (size_t t = 0; t < m->prog.targets.size(); t++) if (!m->prog.targets[t].n_cols) nrows_t[t] = 0;   // an unrolled initial chunk
   bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
   if (const char *e = std::getenv("RH_REFACTOR")) re = re && std::atoi(e) != 0;
   m->col_src.clear(); m->col_len.clear();

@@ -136,3 +136,79 @@ def test_more_than_128_columns_parse():
     assert len(spec.columns) == k + 1
     src, size = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True))
     assert size > 0 and "static constexpr int P = 201" in src
+
+
+# ---- what Model.observe really produces: an initial chunk + ONE expression over 8 slots (core/Model.scala:71-132) ------------
+def _logistic_split(n, k):
+    cols = models.logistic_data(n, k)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k)
+    m = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic), split=True)
+    return m.compile("logistic_split_%dx%d" % (k, n)), cols
+
+
+def test_eight_way_split_is_rolled_back_into_rows():
+    k, n = 6, 1000
+    spec, cols = _logistic_split(n, k)
+    assert spec.nrows == [0, 8, 124] and len(spec.columns) == 273           # 8 + 8 x 124 observations, 35 + 8 x ~30 columns
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    # initial chunk unrolled into a data-free target; the 8 slots are rows again; y and the k covariates are all that is read
+    assert s3.nrows == [0, 0, 992] and len(s3.columns) == k + 1 and all(len(p) == 8 for p in kept)
+    for q in np.random.default_rng(2).normal(size=(4, k + 1)) * 0.6:
+        np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-12, atol=1e-12 * n)
+    # ... and it is the natural form's function of the same data
+    nat = models.logistic(n=n, k=k, columns=cols)
+    q = np.array([0.2, -0.4, 0.3, 0.1, -0.2, 0.5, 0.05])
+    np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(nat).update(q), rtol=1e-11)
+    # strict builds: columns folded, initial chunk unrolled, the 8 slots stay one expression; values to the last bits
+    s2, _ = _rewritten(spec, fast=False, refactor=False)
+    assert s2.nrows == [0, 0, 124] and 8 * (k + 1) <= len(s2.columns) <= 8 * (k + 2) + 2
+    np.testing.assert_allclose(O.OracleDensity(s2).update(q), O.OracleDensity(spec).update(q), rtol=1e-14)
+
+
+def test_cfg4_as_the_reference_hands_it_over():
+    """50 covariates through Model.observe: 1945 columns in two row targets -> one streamed target of 51 columns on the MFMA GLM
+    kernel with the closed-form link (fast build)."""
+    k, n = 50, 2000
+    spec, _ = _logistic_split(n, k)
+    assert len(spec.columns) == 1945 and spec.nrows == [0, 8, 249]
+    src, size = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True), columns=spec.columns, nrows=spec.nrows)
+    assert size > 0 and "#define RH_NROWTARGETS 1\n" in src
+    assert "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in src and "rh_logit_link(s * eta, sp, sg);" in src
+
+
+def _glmm():
+    import json, os
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glmm_poisson2.json")))
+    return models.glmm_poisson2_reference(100, 40, data)
+
+
+def test_glmm_poisson2_reference_benchmark_model():
+    """bench/stan/GLMMPoisson2.scala in the reference's model text (146 parameters; alphas(site) and yearBetas(year) are Lookups
+    over index COLUMNS): 493 columns arrive -- the reference's gradient carries one mask column per (slot, table entry) -- and
+    4 are left: count, year, site, and the Line's summed data-only term (log-factorials), zero-padded for the other slots."""
+    spec = _glmm()
+    assert spec.nrows == [0, 8, 499] and len(spec.columns) == 493 and spec.n_params == 146
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    assert s3.nrows == [0, 0, 3992] and len(s3.columns) == 4
+    assert sum(1 for p in kept if isinstance(p, tuple) and 0xFFFFFFFF in p) == 1
+    for q in np.random.default_rng(3).normal(size=(3, 146)) * 0.3:
+        a, b = O.OracleDensity(spec).update(q), O.OracleDensity(s3).update(q)
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-9)
+
+
+def test_a_gradient_that_is_not_the_derivative_is_kept():
+    """The re-derivation is verified against the supplied outputs: swap two of them and the program must come back computing the
+    SWAPPED outputs (its own, wrong, gradient), not the true one."""
+    import struct
+    k, n = 4, 300
+    spec = models.logistic_reference(n=n, k=k)
+    w = list(struct.unpack("<%dI" % (len(spec.rir) // 4), spec.rir))
+    n_params, pos = w[2], 6 + (3 + w[2])        # target 1's table starts after target 0's: {n_cols, 0, outputs[n_params + 1]}
+    out = pos + 2
+    w[out + 2], w[out + 3] = w[out + 3], w[out + 2]          # d/d theta_1 <-> d/d theta_2
+    bad = dataclasses.replace(spec, rir=struct.pack("<%dI" % len(w), *w))
+    s3, _ = _rewritten(bad, fast=True, refactor=True)
+    q = np.array([0.3, -0.2, 0.4, 0.1, -0.5])
+    a, b, good = O.OracleDensity(bad).update(q), O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q)
+    np.testing.assert_allclose(b, a, rtol=1e-11)
+    assert abs(good[2] - a[2]) > 1e-3 and n_params == k + 1

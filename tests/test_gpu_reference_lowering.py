@@ -104,3 +104,67 @@ def test_canonicalisation_can_be_switched_off(monkeypatch):
     assert "NCOLS = 25, COL0 = 0" in m.hip_source
     qs = np.random.default_rng(15).normal(size=(4, k + 1)) * 0.5
     _check(spec, m, qs, 1e-12)
+
+
+# ---- with Model.observe's 8-way split, i.e. exactly the TargetGroup the JVM would hand over --------------------------------
+def _logistic_split(n, k):
+    cols = models.logistic_data(n, k)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k)
+    m = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic), split=True)
+    return m.compile("logistic_split_%dx%d" % (k, n)), cols
+
+
+def test_split_logistic_strict_and_fast():
+    k, n = 8, 5000
+    spec, cols = _logistic_split(n, k)
+    assert spec.nrows == [0, 8, 624] and len(spec.columns) > 300
+    qs = np.random.default_rng(21).normal(size=(6, k + 1)) * 0.5
+    ms = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)         # literal arithmetic; initial chunk unrolled, columns folded
+    assert "#define RH_NROWTARGETS 1\n" in ms.hip_source
+    _check(spec, ms, qs, 1e-12, O.JM_DET)
+    _check(spec, ms, qs, 1e-12, O.JM_DET, engine=_capi.ENGINE_TICK)
+    mf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)   # gradient re-derived, 8 slots rolled back into rows
+    assert "#define RH_NROWTARGETS 1\n" in mf.hip_source and "NCOLS = %d, COL0 = 0" % (k + 1) in mf.hip_source
+    assert "rh_logit_link(s * eta, sp, sg);" in mf.hip_source
+    _check(spec, mf, qs, 1e-12)
+    _check(spec, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
+    nat = R.Model(models.logistic(n=n, k=k, columns=cols), device=0, fp_contract=True, factor_outputs=True)
+    cfg = R.make_config(4, 0, R.HMCSampler(3), R.StaticStepSize(2e-3), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    np.testing.assert_allclose(mf.sample(cfg, seeds=range(5)).chains, nat.sample(cfg, seeds=range(5)).chains, rtol=1e-7, atol=1e-9)
+
+
+def test_cfg4_shape_as_the_reference_hands_it_over_1945_columns():
+    k, n, chains = 50, 20000, 48
+    spec, cols = _logistic_split(n, k)
+    assert len(spec.columns) == 1945 and spec.nrows == [0, 8, 2499]
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "#define RH_NROWTARGETS 1\n" in m.hip_source and "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in m.hip_source
+    qs = np.random.default_rng(22).normal(size=(3, k + 1)) * 0.25
+    _check(spec, m, qs, 1e-12)
+    _check(spec, m, qs, 1e-12, engine=_capi.ENGINE_TICK)
+    cfg = R.make_config(3, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    s = R.Sampler(m, cfg, list(range(chains))); s.warmup(); s.run(3)
+    assert s.timing()["dominant_kernel"] == "rh_grad_glm_kernel"
+    a = s.draws(); s.close()
+    # the natural form streams the rows in their original order, this one slot-major: the same sums in a different order
+    nat = R.Model(models.logistic(n=n, k=k, columns=cols), device=0, fp_contract=True, factor_outputs=True)
+    np.testing.assert_allclose(a, nat.sample(cfg, seeds=range(chains)).chains, rtol=1e-7, atol=1e-9)
+
+
+def test_glmm_poisson2_reference_benchmark_model_on_the_device():
+    """bench/stan/GLMMPoisson2.scala (100 sites x 40 years, 146 parameters, two Lookups over index columns) in the reference's
+    model text: 493 columns -> 4; density and gradient against the oracle on the original program, and a short adaptive run."""
+    import json, os
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glmm_poisson2.json")))
+    spec = models.glmm_poisson2_reference(100, 40, data)
+    assert len(spec.columns) == 493
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "NCOLS = 4, COL0 = 0" in m.hip_source and "#define RH_NROWTARGETS 1\n" in m.hip_source
+    qs = np.random.default_rng(23).normal(size=(4, 146)) * 0.3
+    _check(spec, m, qs, 1e-11)
+    _check(spec, m, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    tr = m.sample(R.make_config(20, 60), seeds=range(8))          # DefaultConfig: EHMC, dual averaging, windowed diagonal mass
+    assert np.all(np.isfinite(tr.chains)) and all(st.leapfrog_steps > 0 for st in tr.stats)
+    # the posterior means of the site effects move towards the log of the site's mean count: a sanity check of the sampler on
+    # this model, not a parity statement (20 draws)
+    assert tr.chains.shape == (8, 20, 146)
