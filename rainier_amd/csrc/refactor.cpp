@@ -19,8 +19,6 @@
 // rebuilt row code of a target is not cheaper than the original, the original is kept for that target.
 #include <algorithm>
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -60,6 +58,8 @@ struct Refactor {
   uint32_t intern(const Poly &p) {
     auto it = poly_ids.find(p);
     if (it != poly_ids.end()) return it->second;
+    work += p.size() + 1;
+    if (work > (size_t)1 << 24) bad = true;   // a budget, so that no program can hold model creation up: the caller keeps its input
     polys.push_back(p);
     return poly_ids[p] = (uint32_t)polys.size() - 1;
   }
@@ -195,7 +195,8 @@ struct Refactor {
     node_poly[id] = (int)intern(r);
     return r;
   }
-  bool bad = false;  // a folded coefficient overflowed / became NaN: the caller keeps the original program
+  bool bad = false;  // a folded coefficient overflowed / became NaN, or the work budget ran out: the caller keeps the original program
+  size_t work = 0;
   void compute_polys(const std::vector<char> &live) {
     for (uint32_t i = 0; i < P.nodes.size(); i++) if (live[i]) (void)poly_of(i);
   }
@@ -283,6 +284,9 @@ struct Refactor {
     const Atom A = atoms[a];
     if (A.op == RH_RIR_INPUT) { if (A.input >= P.n_params && !seen.count(A.input)) { seen[A.input] = 1; order.push_back(A.input); } return; }
     if (A.dep == 0) return;
+    const uint32_t key = 0x80000000u | a;            // atoms are visited once per walk (shared sub-atoms would be re-walked 2^depth times)
+    if (seen.count(key)) return;
+    seen[key] = 1;
     for (uint32_t kid : A.kids) walk_poly(polys[kid], order, seen);
   }
   void walk_poly(const Poly p, std::vector<uint32_t> &order, std::map<uint32_t, char> &seen) {
@@ -343,21 +347,39 @@ struct Refactor {
     std::map<uint32_t, uint32_t> parent;
     std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { auto it = parent.find(x); if (it == parent.end()) { parent[x] = x; return x; } if (it->second == x) return x; const uint32_t r = find(it->second); parent[x] = r; return r; };
     for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); for (size_t i = 1; i < c.size(); i++) parent[find(c[i])] = find(c[0]); if (!c.empty()) find(c[0]); }
-    if (std::getenv("RH_DEBUG_ROLL"))
-      for (size_t o = 0; o < no; o++) for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (c.size() > 4) { std::fprintf(stderr, "  output %zu: monomial with %zu columns, atoms:", o, c.size()); for (auto &f : m.first) std::fprintf(stderr, " [op %u kids %zu cols %zu]^%d", atoms[f.first].op, atoms[f.first].kids.size(), atom_cols(f.first).size(), f.second); std::fprintf(stderr, "\n"); break; } }
     std::map<uint32_t, std::vector<uint32_t>> comp;
     for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
     // components that only occur in parameter-free monomials are loose data terms, not slots
     std::map<uint32_t, char> has_param_comp;
     for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && mono_has_param(m.first)) has_param_comp[find(c[0])] = 1; }
     std::map<uint32_t, char> is_loose;
+    std::vector<std::vector<uint32_t>> comps;   // the components that parameters reach
     for (auto &kv : comp) {
       std::sort(kv.second.begin(), kv.second.end());
-      if (has_param_comp.count(kv.first)) R.slots.push_back(kv.second);
+      if (has_param_comp.count(kv.first)) comps.push_back(kv.second);
       else for (uint32_t c : kv.second) { R.loose.push_back(c); is_loose[c] = 1; }
     }
-    if (std::getenv("RH_DEBUG_ROLL")) { std::fprintf(stderr, "roll t=%zu: %zu slot components, %zu loose columns; sizes", t, R.slots.size(), R.loose.size()); for (auto &sl : R.slots) std::fprintf(stderr, " %zu", sl.size()); std::fprintf(stderr, "\n"); }
-    if (std::getenv("RH_DEBUG_ROLL")) for (auto &sl : R.slots) { std::fprintf(stderr, "   slot:"); for (uint32_t c : sl) std::fprintf(stderr, " %u", c - P.n_params); std::fprintf(stderr, "\n"); }
+    std::sort(comps.begin(), comps.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+    {
+      // a slot is one connected component when the observation's density ties its columns together (the usual case), or one
+      // component of every structural class when it is additively separable (sum_s A(x_s) + B(z_s): any pairing of the A and
+      // B terms into rows gives the same sum; the s-th of each class, in column order, is taken)
+      std::map<uint32_t, size_t> comp_of;
+      for (size_t c = 0; c < comps.size(); c++) for (uint32_t col : comps[c]) comp_of[col] = c;
+      std::vector<uint64_t> ch(comps.size(), 0x5107);
+      for (size_t o = 0; o < no; o++) {
+        std::vector<Poly> part(comps.size());
+        for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && !is_loose.count(c[0])) part[comp_of[c[0]]].push_back(m); }
+        for (size_t c = 0; c < comps.size(); c++) ch[c] = mix(mix(ch[c], o), h_poly(part[c]));
+      }
+      std::map<uint64_t, std::vector<size_t>> classes;
+      for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
+      size_t S0 = 0;
+      for (auto &kv : classes) { if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return R; }
+      if (S0 < 2) return R;
+      R.slots.assign(S0, {});
+      for (auto &kv : classes) for (size_t s = 0; s < S0; s++) for (uint32_t col : comps[kv.second[s]]) R.slots[s].push_back(col);
+    }
     if (R.slots.size() < 2) return R;
     std::sort(R.slots.begin(), R.slots.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
     std::sort(R.loose.begin(), R.loose.end());
@@ -385,10 +407,7 @@ struct Refactor {
         const std::vector<uint32_t> c = mono_cols(m.first);
         if (c.empty()) shared.push_back(m); else if (is_loose.count(c[0])) loose.push_back(m); else part[slot_of[c[0]]].push_back(m);
       }
-      for (size_t s = 1; s < S; s++) if (!approx_equal(rename_poly(part[s], cmap[s], memo[s]), part[0])) { if (std::getenv("RH_DEBUG_ROLL")) { std::fprintf(stderr, "roll t=%zu: output %zu, slot %zu differs from slot 0 (%zu vs %zu monomials)\n", t, o, s, part[s].size(), part[0].size());
-          const Poly rn = rename_poly(part[s], cmap[s], memo[s]);
-          for (int w = 0; w < 2; w++) for (auto &mm : (w ? rn : part[0])) { std::fprintf(stderr, "   %s coef %.17g:", w ? "slot s" : "slot 0", mm.second); for (auto &f : mm.first) { const Atom &A = atoms[f.first]; std::fprintf(stderr, " a%u[op %u low %d kids", f.first, A.op, A.low); for (size_t q = 0; q < A.kids.size() && q < 4; q++) std::fprintf(stderr, " %u", A.kids[q]); std::fprintf(stderr, " (n=%zu)]^%d", A.kids.size(), f.second); } std::fprintf(stderr, "\n"); } }
-          return R; }
+      for (size_t s = 1; s < S; s++) if (!approx_equal(rename_poly(part[s], cmap[s], memo[s]), part[0])) return R;
       Poly out = part[0];
       for (auto &m : shared) out.push_back({m.first, m.second / (double)S});
       for (auto &m : loose) out.push_back(m);
@@ -666,6 +685,7 @@ Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
     Target cand = T; cand.outputs = rebuilt;
     if (row_cost(R.Q, cand) <= row_cost(R.Q, T)) T.outputs = rebuilt;
   }
+  if (R.bad) return P;     // (parts still holds the identity)
   if (!parts) return R.Q;
   // 3) renumber the columns that are left (dropped ones only survive in dead nodes, which the clean-up pass sweeps); columns no
   //    output reads any more (the reference's gradient-only columns after re-derivation) go as well

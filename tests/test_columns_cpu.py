@@ -212,3 +212,44 @@ def test_a_gradient_that_is_not_the_derivative_is_kept():
     a, b, good = O.OracleDensity(bad).update(q), O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q)
     np.testing.assert_allclose(b, a, rtol=1e-11)
     assert abs(good[2] - a[2]) > 1e-3 and n_params == k + 1
+
+
+# ---- property test: the reference's RealTest expressions as streamed row terms, through every data-dependent pass -----------
+from tests.realtest_cases import CASES, Alg  # noqa: E402
+
+_SKIP = {"lookup", "cancelling x^2 then distributing", "tanh at infty"}   # need integral / infinite arguments
+
+
+@pytest.mark.parametrize("name,fn", [(c[0], c[1]) for c in CASES if c[0] not in _SKIP])
+def test_realtest_expressions_survive_rederivation_and_rolling(name, fn):
+    """value = sum over 8 slots of f(theta_0 * x_s + theta_1) + theta_2 * z_s, written the way Model.observe writes a split
+    target (one expression, 8 x 3 columns, the third column of every slot a derived one: -x_s), gradient by the authoring DSL.
+    Fast-mode passes must fold the derived columns, re-derive the gradient, roll the slots (24 -> 2 columns, 8 x the rows) and
+    keep value and gradient to rounding wherever the original is finite."""
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    n, S = 40, 8
+    xs = [rng.uniform(-0.45, 0.45, n) for _ in range(S)]
+    zs = [rng.normal(size=n) for _ in range(S)]
+    cols = []
+    for s in range(S): cols += [xs[s], zs[s], -xs[s]]
+    g = Graph(3, [3 * S])
+    A = Alg(g)
+    th = [g.param(i) for i in range(3)]
+    val = None
+    for s in range(S):
+        x, z, mx = g.col(0, 3 * s), g.col(0, 3 * s + 1), g.col(0, 3 * s + 2)
+        term = fn(A, th[0] * x + th[1]) + th[2] * z + (mx * th[0]) * 0.25
+        val = term if val is None else val + term
+    spec = ModelSpec("realtest_" + name, g.compile([val]), cols, [n], 3, {})
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    assert s3.nrows == [S * n] and len(s3.columns) == 2, (s3.nrows, len(s3.columns))
+    checked = 0
+    for q in ([0.7, 0.3, -0.4], [-0.9, -0.2, 0.8], [0.4, 0.45, 0.1]):
+        a, b = O.OracleDensity(spec).update(np.array(q)), O.OracleDensity(s3).update(np.array(q))
+        ok = np.isfinite(a)
+        if not ok[0]:
+            continue                      # outside the expression's domain (x^x for x < 0, ...)
+        checked += 1
+        assert np.all(np.isfinite(b[ok]))
+        np.testing.assert_allclose(b[ok], a[ok], rtol=1e-9, atol=1e-9)
+    assert checked >= 1
