@@ -46,7 +46,7 @@ struct Same {
 }  // namespace
 
 bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,
-                          std::string &err) {
+                          std::string &err, bool allow_unroll) {
   (void)err;
   kept.clear();
   P.col_domain.clear();
@@ -123,8 +123,11 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
   // the model keeps ONE streamed target for the row kernels.
   std::vector<char> unroll(P.targets.size(), 0);
   {
+    // only for programs that are recognisably the reference's lowering (derived columns were found) and not in gather mode,
+    // whose data-free targets may not read the parameter table
     bool big = false;
     for (size_t t = 0; t < P.targets.size(); t++) big = big || (P.targets[t].n_cols && nrows[t] >= 16);
+    big = big && changed && allow_unroll;
     for (size_t t = 0; t < P.targets.size() && big; t++)
       if (P.targets[t].n_cols && nrows[t] >= 1 && nrows[t] <= 8) { unroll[t] = 1; changed = true; }
   }

@@ -24,6 +24,7 @@
 #include <unistd.h>
 
 #include "../../include/rainier_hip.h"
+#include "../../include/rainier_hip_rir.h"
 #include "device/rh_shared.h"
 #include "rir.hpp"
 #include "optimize.hpp"
@@ -369,7 +370,20 @@ void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrow
   }
   bool canon = m->prog.n_cols_total > 0, changed = false;
   if (const char *e = std::getenv("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
-  if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err);
+  // gather mode (a Lookup over a long run of trailing parameters indexed by a column: emit.cpp) keeps its targets as they are
+  bool gather = false;
+  {
+    int gmin = m->eopt.gather_min;
+    if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
+    const rh::Program &P = m->prog;
+    for (const rh::Node &nd : P.nodes) {
+      if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < gmin) continue;
+      const rh::Node &ix = P.nodes[nd.a], &t0 = P.nodes[nd.table[0]];
+      if (ix.op == RH_RIR_INPUT && ix.input >= P.n_params && t0.op == RH_RIR_INPUT && t0.input < P.n_params &&
+          t0.input + nd.table.size() == P.n_params) gather = true;
+    }
+  }
+  if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, !gather);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (!m->prog.targets[t].n_cols) nrows_t[t] = 0;   // an unrolled initial chunk
   bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
   if (const char *e = std::getenv("RH_REFACTOR")) re = re && std::atoi(e) != 0;

@@ -40,7 +40,7 @@ std::vector<unsigned char> write_rir(const Program &p);
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns
 // true when the program was rewritten.
 bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,
-                          std::string &err);
+                          std::string &err, bool allow_unroll = true);
 
 // Fast-mode re-association of row targets after canonicalize_columns (refactor.cpp): products are merged into monomials
 // and the factor common to every term of an output is pulled out, so that x_k * w shapes reappear.
