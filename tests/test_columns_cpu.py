@@ -253,3 +253,24 @@ def test_realtest_expressions_survive_rederivation_and_rolling(name, fn):
         assert np.all(np.isfinite(b[ok]))
         np.testing.assert_allclose(b[ok], a[ok], rtol=1e-9, atol=1e-9)
     assert checked >= 1
+
+
+def test_split_linear_regression_rolls_back_to_the_natural_row():
+    """4 covariates through Model.observe (not inlinable: 21 distributed terms): 8 + 8 x 124 observations, 111 columns ->
+    one streamed target of 5 columns and 992 rows whose row code is the natural form's (residual once, 5 basis sums)."""
+    n, k = 1000, 4
+    cols = models.linreg_data(n, k)
+    sigma = M.Exponential(1).latent; alpha = M.Normal(0, 1).latent; betas = M.Normal(0, 1).latentVec(k)
+    spec = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Normal(alpha + M.Real.sum([ui * bi for ui, bi in zip(u, betas)]), sigma),
+                               split=True).compile("linreg_split_4", inline=False)
+    assert spec.nrows == [0, 8, 124] and len(spec.columns) > 100
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    assert s3.nrows == [0, 0, 992] and len(s3.columns) == k + 1
+    q = np.array([-0.3, 0.5, 1.0, -2.0, 0.5, 0.25])
+    np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
+    np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(models.linreg(n=n, k=k, columns=cols)).update(q), rtol=1e-10)
+    src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True), columns=spec.columns, nrows=spec.nrows)
+    nat, _ = _capi.lower_only(models.linreg(n=n, k=k, columns=cols).rir, _capi.compile_opts(fp_contract=True, factor_outputs=True))
+    assert "#define RH_NROWTARGETS 1\n" in src
+    nacc = lambda text: int(text.split("#define RH_NACC_MAX ")[1].split("\n")[0])
+    assert nacc(src) == nacc(nat)
