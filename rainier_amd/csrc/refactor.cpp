@@ -19,6 +19,8 @@
 // rebuilt row code of a target is not cheaper than the original, the original is kept for that target.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -179,8 +181,30 @@ struct Refactor {
       case RH_RIR_COMPARE: r = opaque2(nd); break;
       case RH_RIR_LOOKUP: {
         Atom a; a.op = RH_RIR_LOOKUP; a.low = nd.low;
-        { const Poly k = poly_of(nd.a); a.kids.push_back(intern(k)); a.dep = poly_dep(k); }
-        for (uint32_t e : nd.table) { const Poly k = poly_of(e); a.kids.push_back(intern(k)); if (poly_dep(k)) a.dep = poly_dep(k); }
+        const Poly ix = poly_of(nd.a);
+        a.kids.push_back(intern(ix)); a.dep = poly_dep(ix);
+        std::vector<Poly> ent;
+        bool row_entries = false;
+        for (uint32_t e : nd.table) { ent.push_back(poly_of(e)); row_entries = row_entries || poly_dep(ent.back()) != 0; }
+        if (a.dep == 0 && row_entries) {
+          // a select on a parameter-only index between row-level sums (what differentiating |sigma| or a bound check leaves:
+          // eq(sigma, 0, 0, sum over all slots ...)) is the sum of its terms, each times a select between CONSTANTS:
+          //     select(k, [sum_m c_0m m, sum_m c_1m m, ...]) = sum_m m * select(k, [c_0m, c_1m, ...])
+          // -- exact, and the row terms of different slots stay apart instead of being locked into one atom
+          std::map<Mono, std::vector<double>> coef;
+          for (size_t j = 0; j < ent.size(); j++) for (auto &t : ent[j]) { auto &v = coef[t.first]; v.resize(ent.size(), 0.0); v[j] = t.second; }
+          for (auto &kv : coef) {
+            bool same = true;
+            for (double c : kv.second) same = same && c == kv.second[0];
+            if (same) { r.push_back({kv.first, kv.second[0]}); continue; }
+            Atom sel = a;
+            for (double c : kv.second) sel.kids.push_back(intern(constant(c)));
+            r.push_back({mono_mul(kv.first, Mono{{atom(sel), 1}}), 1.0});
+          }
+          normalize(r);
+          break;
+        }
+        for (const Poly &k : ent) { a.kids.push_back(intern(k)); if (poly_dep(k)) a.dep = poly_dep(k); }
         r = of_atom(atom(a));
         break;
       }
@@ -337,6 +361,11 @@ struct Refactor {
     int init_target = -1;
     std::vector<uint32_t> init_cols;            // the initial chunk's columns, same positions
   };
+  // RH_ROLL_WHY=1: say on stderr why a target with several column groups was not rolled
+  static Rolled why(Rolled R, const char *reason) {
+    if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: target not rolled back into rows: %s\n", reason);
+    return R;
+  }
   Rolled try_roll(size_t t, const std::vector<char> &taken) {
     Rolled R;
     const Target &T = P.targets[t];
@@ -375,16 +404,16 @@ struct Refactor {
       std::map<uint64_t, std::vector<size_t>> classes;
       for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
       size_t S0 = 0;
-      for (auto &kv : classes) { if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return R; }
-      if (S0 < 2) return R;
+      for (auto &kv : classes) { if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return why(R, "structural classes of unequal size"); }
+      if (S0 < 2) return why(R, "fewer than two structurally equal components");
       R.slots.assign(S0, {});
       for (auto &kv : classes) for (size_t s = 0; s < S0; s++) for (uint32_t col : comps[kv.second[s]]) R.slots[s].push_back(col);
     }
-    if (R.slots.size() < 2) return R;
+    if (R.slots.size() < 2) return why(R, "fewer than two slots");
     std::sort(R.slots.begin(), R.slots.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
     std::sort(R.loose.begin(), R.loose.end());
     const size_t S = R.slots.size(), mcols = R.slots[0].size();
-    for (auto &sl : R.slots) if (sl.size() != mcols) return R;
+    for (auto &sl : R.slots) if (sl.size() != mcols) return why(R, "slots of unequal width");
     std::map<uint32_t, size_t> slot_of;
     for (size_t s = 0; s < S; s++) for (uint32_t c : R.slots[s]) slot_of[c] = s;
     {  // corresponding columns by structure, not by position in the column list
@@ -395,7 +424,7 @@ struct Refactor {
         for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && !is_loose.count(c[0])) part[slot_of[c[0]]].push_back(m); }
         for (size_t s = 0; s < S; s++) walk_poly(part[s], order[s], seen[s]);
       }
-      for (size_t s = 0; s < S; s++) if (order[s].size() != mcols) return R;
+      for (size_t s = 0; s < S; s++) if (order[s].size() != mcols) return why(R, "the structural walk did not reach every column of a slot");
       R.slots = order;
     }
     std::vector<ColMap> cmap(S);
@@ -407,7 +436,7 @@ struct Refactor {
         const std::vector<uint32_t> c = mono_cols(m.first);
         if (c.empty()) shared.push_back(m); else if (is_loose.count(c[0])) loose.push_back(m); else part[slot_of[c[0]]].push_back(m);
       }
-      for (size_t s = 1; s < S; s++) if (!approx_equal(rename_poly(part[s], cmap[s], memo[s]), part[0])) return R;
+      for (size_t s = 1; s < S; s++) if (!approx_equal(rename_poly(part[s], cmap[s], memo[s]), part[0])) return why(R, "an output's part of one slot is not the renamed part of the first slot");
       Poly out = part[0];
       for (auto &m : shared) out.push_back({m.first, m.second / (double)S});
       for (auto &m : loose) out.push_back(m);

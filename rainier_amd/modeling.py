@@ -200,6 +200,13 @@ class Beta(StandardContinuous):            # :163-189
         z1 = _GammaStandard(self.a).generate(rng); z2 = _GammaStandard(self.b).generate(rng)
         return z1 / (z1 + z2)
 
+class Mixture(Continuous):                 # core/Continuous.scala:218-248 (logDensity; components: list of (dist, weight))
+    def __init__(self, components): self.components = [(d, Real.of(w)) for d, w in components]
+    def logDensity(self, x):
+        x = Real.of(x)
+        return Real.logSumExp([d.logDensity(x) + w.log() for d, w in self.components])
+
+
 class _UniformStandard(StandardContinuous):  # :202-213
     support = BoundedSupport(0.0, 1.0)
     def logDensity(self, x): return Beta(1, 1).logDensity(x)

@@ -327,6 +327,19 @@ def glmm_poisson2_reference(n_sites: int = 100, n_years: int = 40, data=None) ->
     return m.compile("glmm_poisson2_reference_%dx%d" % (n_sites, n_years))
 
 
+def lowdim_gaussmix_reference(data) -> ModelSpec:
+    """bench/stan/LowDimGaussMix.scala:9-24 in the reference's model text: a two-component normal mixture over 1000 observations,
+    `Model.observe(ys, mix)` (8 + 8 x 124 split); logDensity = Real.logSumExp (a max through Real.gt selects, two exps, a log).
+    data = {"ys": 1000 floats} (tests/golden/lowdim_gaussmix.json)."""
+    from . import modeling as M
+    def mu_sigma(): return M.Normal(0, 2).latent, M.Normal(0, 2).latent.abs()
+    mu1, sigma1 = mu_sigma()
+    mu2, sigma2 = mu_sigma()
+    theta = M.Beta(5, 5).latent
+    mix = M.Mixture([(M.Normal(mu1, sigma1), theta), (M.Normal(mu2, sigma2), M.Real.one - theta)])
+    return M.Model.observe(list(data["ys"]), mix).compile("lowdim_gaussmix_reference")
+
+
 def logistic_reference(n: int = 1000, k: int = 8, seed: int = 4, columns=None) -> ModelSpec:
     """cfg 4's model text: Bernoulli((a + x.dot(b)).logistic) observed row by row.  Not inlinable (the link is non-linear); the
     reference's algebra pushes every data-only factor into derived columns (gradientColumns): 5 (k + 1) columns."""

@@ -274,3 +274,17 @@ def test_split_linear_regression_rolls_back_to_the_natural_row():
     assert "#define RH_NROWTARGETS 1\n" in src
     nacc = lambda text: int(text.split("#define RH_NACC_MAX ")[1].split("\n")[0])
     assert nacc(src) == nacc(nat)
+
+
+def test_lowdim_gaussmix_reference_benchmark_model():
+    """bench/stan/LowDimGaussMix.scala in the reference's model text: Mixture.logDensity = Real.logSumExp (a max through Real.gt
+    selects), sigma = |latent| (whose derivative is a select on a parameter between row-level sums).  174 columns -> 2, the 8
+    slots rolled back: 992 rows."""
+    import json, os
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lowdim_gaussmix.json")))
+    spec = models.lowdim_gaussmix_reference(data)
+    assert spec.nrows == [0, 8, 124] and spec.n_params == 5 and len(spec.columns) == 174
+    s3, kept = _rewritten(spec, fast=True, refactor=True)
+    assert s3.nrows == [0, 0, 992] and len(s3.columns) == 2
+    for q in np.random.default_rng(5).normal(size=(4, 5)) * 0.7:
+        np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)

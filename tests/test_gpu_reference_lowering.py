@@ -170,3 +170,23 @@ def test_glmm_poisson2_reference_benchmark_model_on_the_device():
     assert tr.chains.shape == (8, 10, 146) and np.all(np.isfinite(tr.chains)) and all(st.leapfrogSteps > 0 for st in tr.stats)
     grads = sum(st.gradientEvaluations for st in tr.stats) / 8
     print("GLMMPoisson2 (reference lowering, generic Lookup path): %.1f s for ~%d gradients per chain, 8 chains" % (dt, grads))
+
+
+def test_lowdim_gaussmix_reference_benchmark_model_on_the_device():
+    """bench/stan/LowDimGaussMix.scala (two-component normal mixture, 1000 observations, 5 parameters) in the reference's model
+    text: logSumExp with its Real.gt max, |sigma|; 174 columns -> 2, 992 + 8 observations.  Density and gradient against the
+    oracle on the original program (both math modes), and the two modes of the posterior are found."""
+    import json, os
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lowdim_gaussmix.json")))
+    spec = models.lowdim_gaussmix_reference(data)
+    qs = np.random.default_rng(24).normal(size=(6, 5)) * 0.7
+    ms = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    _check(spec, ms, qs, 1e-12, O.JM_DET)
+    mf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "NCOLS = 2, COL0 = 0" in mf.hip_source and "#define RH_NROWTARGETS 1\n" in mf.hip_source
+    _check(spec, mf, qs, 1e-11)
+    _check(spec, mf, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    tr = mf.sample(R.make_config(100, 300), seeds=range(16))
+    mu = np.sort(tr.chains[:, :, [0, 2]], axis=2).mean(axis=1)                    # per chain (mu1, mu2) up to label switching
+    good = (np.abs(mu[:, 0] + 2.75) < 0.5) & (np.abs(mu[:, 1] - 2.85) < 0.5)      # the data sit around -2.75 and +2.85
+    assert good.sum() >= 12, mu
