@@ -357,6 +357,20 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
   return opts->device;
 }
 
+// parse + (when there are more targets than the engine holds) merge the runs of data-free targets; the caller's per-target row
+// counts are re-indexed to the targets that are left
+void load_program(rh_model *m, const void *rir, size_t rir_len, const int64_t *nrows, std::vector<int64_t> &nrows_m) {
+  std::string err;
+  if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
+  if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "a density program (header kind 0) is needed"};
+  std::vector<uint32_t> oldt;
+  rh::merge_data_free_targets(m->prog, oldt);
+  if (m->prog.targets.size() > RH_MAX_TARGETS)
+    throw Fail{RH_E_UNSUPPORTED, "more than 64 targets are left after merging the data-free ones (RH_MAX_TARGETS)"};
+  nrows_m.assign(m->prog.targets.size(), 0);
+  for (size_t t = 0; t < m->prog.targets.size(); t++) if (nrows && m->prog.targets[t].n_cols) nrows_m[t] = nrows[oldt[t]];
+}
+
 // derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
 // fills m->col_src (engine column -> the caller's columns it is made of) and the per-target row counts
 void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t) {
@@ -447,18 +461,17 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
   *out = nullptr;
   rh_model *m = new rh_model();
   const int rc = guard(m, [&] {
-    std::string err;
-    if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
-    if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "rh_model_create needs a density program (header kind 0)"};
+    std::vector<int64_t> nrows_in;
+    load_program(m, rir, rir_len, nrows, nrows_in);
     const int dev0 = apply_compile_opts(m, opts);
     int dev = dev0;
     for (size_t t = 0; t < m->prog.targets.size(); t++) {
       const auto &T = m->prog.targets[t];
-      if (T.n_cols && (!nrows || nrows[t] < 0)) throw Fail{RH_E_INVALID, "negative or missing row count"};
+      if (T.n_cols && (!nrows || nrows_in[t] < 0)) throw Fail{RH_E_INVALID, "negative or missing row count"};
       if (T.n_cols && !columns) throw Fail{RH_E_INVALID, "columns is NULL but the model has data columns"};
     }
     std::vector<int64_t> nrows_t;
-    canonicalize(m, columns, nrows, nrows_t);
+    canonicalize(m, columns, nrows_in.data(), nrows_t);
     assemble_source(m);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -606,11 +619,10 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
                                   const rh_compile_opts *opts, const char *arch, char **src_out, size_t *code_size) {
   rh_model m;
   const int rc = guard(nullptr, [&] {
-    std::string err;
-    if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
-    if (m.prog.kind != 0) throw Fail{RH_E_INVALID, "rh_lower_only needs a density program (header kind 0)"};
+    std::vector<int64_t> nrows_in;
+    load_program(&m, rir, rir_len, nrows, nrows_in);
     (void)apply_compile_opts(&m, opts);
-    if (columns && nrows) { std::vector<int64_t> nrows_t; canonicalize(&m, columns, nrows, nrows_t); }
+    if (columns && nrows) { std::vector<int64_t> nrows_t; canonicalize(&m, columns, nrows_in.data(), nrows_t); }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }

@@ -32,7 +32,7 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
   const uint32_t n_targets = r.u32(), n_nodes = r.u32();
   P.kind = r.u32();
   if (P.kind > 1) { err = "RIR: unknown program kind"; return false; }
-  if (P.n_params == 0 || n_targets == 0 || n_targets > (P.kind == 1 ? 4096u : (uint32_t)RH_MAX_TARGETS)) { err = "RIR: bad header (params/targets)"; return false; }
+  if (P.n_params == 0 || n_targets == 0 || n_targets > (P.kind == 1 ? 4096u : RH_RIR_MAX_TARGETS)) { err = "RIR: bad header (params/targets)"; return false; }
   if ((size_t)n_nodes * 8 > len) { err = "RIR: node count exceeds blob"; return false; }
   // every target carries n_params + 1 output ids: a header whose target table cannot fit the blob is rejected before
   // anything is sized from it (n_params = 0xFFFFFFFF would wrap n_params + 1 to 0, 2^31 would allocate gigabytes)
@@ -111,6 +111,32 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
     }
   return true;
 }
+// More targets than the engine holds (RH_MAX_TARGETS): every run of consecutive data-free targets becomes one target whose
+// outputs are the left-fold sums of the run's outputs in target order -- the order in which the kernels add the targets up, so
+// the model's values do not change by a bit.  (A model that observes one value at a time -- the reference's ARK benchmark:
+// `Model.observe(ys(t), ...)` merged 195 times -- arrives with one data-free target per observation.)
+bool merge_data_free_targets(Program &P, std::vector<uint32_t> &old_target_of) {
+  old_target_of.clear();
+  for (uint32_t t = 0; t < P.targets.size(); t++) old_target_of.push_back(t);
+  if (P.kind != 0 || P.targets.size() <= RH_MAX_TARGETS) return false;
+  std::vector<Target> nt;
+  std::vector<uint32_t> first;
+  for (uint32_t t = 0; t < P.targets.size(); t++) {
+    const Target &T = P.targets[t];
+    if (T.n_cols == 0 && !nt.empty() && nt.back().n_cols == 0) {
+      Target &M = nt.back();
+      for (size_t o = 0; o < M.outputs.size(); o++) {
+        Node n; n.op = RH_RIR_ADD; n.a = M.outputs[o]; n.b = T.outputs[o]; n.dep = 0;
+        P.nodes.push_back(n);
+        M.outputs[o] = (uint32_t)P.nodes.size() - 1;
+      }
+    } else { nt.push_back(T); first.push_back(t); }
+  }
+  P.targets.swap(nt);
+  old_target_of = first;
+  return true;
+}
+
 // Program -> RIR bytes (the inverse of parse_rir; used by the rh_simplify_rir test hook)
 std::vector<unsigned char> write_rir(const Program &P) {
   std::vector<unsigned char> out;

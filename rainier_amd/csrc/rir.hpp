@@ -36,6 +36,10 @@ bool parse_rir(const void *buf, size_t len, Program &out, std::string &err);
 
 std::vector<unsigned char> write_rir(const Program &p);
 
+// When the program has more targets than the engine holds, merges every run of consecutive data-free targets into one (exact);
+// old_target_of[new target] = index of the first original target it stands for (row targets keep their identity).
+bool merge_data_free_targets(Program &P, std::vector<uint32_t> &old_target_of);
+
 // Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns
 // true when the program was rewritten.

@@ -304,6 +304,8 @@ def _split(ts):
 def _column_density(dist, values) -> Real:
     """Distribution.logDensity(seq) = Vec.from(seq).map(logDensity).columnize (core/Continuous.scala:14): the density of one
     Column holding the observations"""
+    if len(values) == 1:      # the index column [0.0] has a maybeScalar, so Lookup.apply picks the (scalar) entry (compute/Real.scala:310-318)
+        return dist.logDensity(Real.of(float(values[0])))
     return dist.logDensity(Real.doubles(values))
 
 

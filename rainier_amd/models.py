@@ -283,6 +283,37 @@ def eight_schools_reference() -> ModelSpec:
     return spec
 
 
+def ark_reference(data) -> ModelSpec:
+    """bench/stan/ARK.scala:9-21 in the reference's model text: an AR(5) series observed ONE value at a time --
+    `Model.observe(ys(t), Normal(mu, sigma)).merge(m)` 195 times -- so the TargetGroup has one (inlined, data-free) target per
+    observation: 197 targets, which the engine merges into one at rh_model_create (csrc/rir.cpp merge_data_free_targets).
+    data = {"ys": 200 floats} (tests/golden/ark.json)."""
+    from . import modeling as M
+    ys = list(data["ys"])
+    alpha = M.Normal(0, 10).latent
+    sigma = M.Cauchy(0, 2.5).latent.abs()
+    betas = M.Normal(0, 10).latentVec(5)
+    m = M.Model([M.Real.zero])                                         # Model.empty
+    for t in range(5, len(ys)):
+        mu = alpha
+        for k in range(1, 6):
+            mu = mu + betas[k - 1] * ys[t - k]
+        m = M.Model.observe([float(ys[t])], M.Normal(mu, sigma)).merge(m)
+    return m.compile("ark_reference")
+
+
+def kidiq_reference(data, n: int = 400) -> ModelSpec:
+    """bench/stan/KidIQ.scala:16-27 in the reference's model text: kid_score ~ Normal(b0 + b1 mom_iq + b2 mom_hs, sigma) through
+    Model.observe; 2 covariates + intercept distribute into 10 < 20 terms, so the reference inlines it (no data columns).
+    data = tests/golden/kidiq.json."""
+    from . import modeling as M
+    sigma = M.Cauchy(0, 2.5).latent
+    betas = M.Normal(0, 10).latentVec(3)
+    ys, iq, hs = data["kidScore"][:n], data["momIQ"][:n], data["momHS"][:n]
+    m = M.Model.observe_vec(ys, [iq, hs], lambda u, v: M.Normal(betas[0] + betas[1] * u + betas[2] * v, sigma))
+    return m.compile("kidiq_reference_%d" % n)
+
+
 def funnel_reference(dim: int = 10) -> ModelSpec:
     """cfg 1: y = Normal(0, 3).latent, x_i = Normal(0, exp(y / 2)).latent, tracked (Model.track: the likelihood is Real.zero)."""
     from . import modeling as M

@@ -288,3 +288,26 @@ def test_lowdim_gaussmix_reference_benchmark_model():
     assert s3.nrows == [0, 0, 992] and len(s3.columns) == 2
     for q in np.random.default_rng(5).normal(size=(4, 5)) * 0.7:
         np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
+
+
+def test_ark_reference_benchmark_model_has_197_targets_and_the_engine_merges_them():
+    """bench/stan/ARK.scala observes one value at a time (195 x Model.observe(...).merge): one inlined, data-free target per
+    observation.  rh_model_create folds every run of data-free targets into one when there are more than RH_MAX_TARGETS."""
+    import json, os
+    ark = models.ark_reference(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ark.json"))))
+    assert len(ark.nrows) == 197 and ark.columns == [] and ark.n_params == 7
+    import struct
+    w = struct.unpack("<6I", ark.rir[:24])
+    assert w[3] == 197
+    # 65 data-free targets (just above the limit) of a small model lower to ONE rh_target; 64 stay as they are
+    from rainier_amd import modeling as MM
+    def small(n_obs):
+        mu = MM.Normal(0, 1).latent
+        m = MM.Model([MM.Real.zero])
+        for i in range(n_obs):
+            m = MM.Model.observe([0.1 * i], MM.Normal(mu, 1.0)).merge(m)
+        return m.compile("many_targets_%d" % n_obs)
+    s65, s62 = small(64), small(62)          # + prior + Model.empty: 66 and 64 targets
+    src65, _ = _capi.lower_only(s65.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
+    src62, _ = _capi.lower_only(s62.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
+    assert "#define RH_NTARGETS 1\n" in src65 and "#define RH_NTARGETS 64\n" in src62

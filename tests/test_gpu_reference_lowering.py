@@ -190,3 +190,25 @@ def test_lowdim_gaussmix_reference_benchmark_model_on_the_device():
     mu = np.sort(tr.chains[:, :, [0, 2]], axis=2).mean(axis=1)                    # per chain (mu1, mu2) up to label switching
     good = (np.abs(mu[:, 0] + 2.75) < 0.5) & (np.abs(mu[:, 1] - 2.85) < 0.5)      # the data sit around -2.75 and +2.85
     assert good.sum() >= 12, mu
+
+
+def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
+    """The two reference benchmarks that need no data columns.  KidIQ (bench/stan/KidIQ.scala): the reference inlines the
+    2-covariate regression.  ARK (bench/stan/ARK.scala) observes one value at a time, 195 times: 197 data-free targets, merged
+    into one at rh_model_create (more than RH_MAX_TARGETS = 64 would not fit otherwise); parity against the oracle evaluating
+    the original 197."""
+    import json, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    kid = models.kidiq_reference(json.load(open(os.path.join(here, "golden", "kidiq.json"))))
+    assert kid.columns == [] and kid.n_params == 4
+    qs = np.random.default_rng(25).normal(size=(8, 4)) * 0.5
+    _check(kid, R.Model(kid, device=0, math_mode=_capi.MATH_STRICT), qs, 1e-13, O.JM_DET)
+    _check(kid, R.Model(kid, device=0, fp_contract=True, factor_outputs=True), qs, 1e-12)
+    ark = models.ark_reference(json.load(open(os.path.join(here, "golden", "ark.json"))))
+    assert len(ark.nrows) == 197 and ark.columns == [] and ark.n_params == 7
+    m = R.Model(ark, device=0, fp_contract=True, factor_outputs=True)
+    assert m.hip_source.count("template <> struct rh_target<") == 1
+    _check(ark, m, np.random.default_rng(26).normal(size=(8, 7)) * 0.3, 1e-12)
+    tr = m.sample(R.make_config(200, 300), seeds=range(16))
+    rhat = max(r for r, _ in tr.diagnostics())
+    assert rhat < 1.2, rhat
