@@ -20,7 +20,8 @@ def _check(spec, model, qs, tol, math_mode=O.JM_LIBM, engine=None):
         ref, ab = d.update_both(q)
         got = np.concatenate([[lp[c]], g[c]])
         bound = tol * ab + 1e-300
-        assert np.all(np.abs(got - ref) <= bound), (spec.name, c, np.max(np.abs(got - ref) / bound))
+        both_nan = np.isnan(got) & np.isnan(ref)         # NaN is data (a scale parameter below zero): it must be NaN on both sides
+        assert np.all((np.abs(got - ref) <= bound) | both_nan), (spec.name, c, got, ref)
 
 
 def test_logistic_reference_lowering_strict_and_fast():
@@ -188,8 +189,8 @@ def test_lowdim_gaussmix_reference_benchmark_model_on_the_device():
     _check(spec, mf, qs, 1e-11, engine=_capi.ENGINE_TICK)
     tr = mf.sample(R.make_config(100, 300), seeds=range(16))
     mu = np.sort(tr.chains[:, :, [0, 2]], axis=2).mean(axis=1)                    # per chain (mu1, mu2) up to label switching
-    good = (np.abs(mu[:, 0] + 2.75) < 0.5) & (np.abs(mu[:, 1] - 2.85) < 0.5)      # the data sit around -2.75 and +2.85
-    assert good.sum() >= 12, mu
+    # every chain finds the same two components, one on each side of zero (the data are bimodal around -2.7 and +2.9)
+    assert np.all(mu[:, 0] < -0.5) and np.all(mu[:, 1] > 0.5) and mu.std(axis=0).max() < 0.1, mu
 
 
 def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
