@@ -211,5 +211,8 @@ def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
     assert m.hip_source.count("template <> struct rh_target<") == 1
     _check(ark, m, np.random.default_rng(26).normal(size=(8, 7)) * 0.3, 1e-12)
     tr = m.sample(R.make_config(200, 300), seeds=range(16))
-    rhat = max(r for r, _ in tr.diagnostics())
+    from rainier_amd.sampler import diagnostics
+    ch = tr.chains.copy()
+    ch[:, :, 1] = np.abs(ch[:, :, 1])                 # sigma = |latent|: the two signs of the latent are the same model
+    rhat = max(r for r, _ in diagnostics(ch))
     assert rhat < 1.2, rhat
