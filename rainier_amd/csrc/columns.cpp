@@ -22,6 +22,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <thread>
 #include <tuple>
 
 #include "../../include/rainier_hip_rir.h"
@@ -69,10 +70,23 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       for (int i = 0; i < S; i++) sr.push_back((int64_t)i * nr / S);
       sr.push_back(nr - 1);
     }
-    auto verify = [&](int j, auto &&f) {  // every row: col[j][r] == f(r)
+    auto verify = [&](int j, auto &&f) {  // every row: col[j][r] == f(r); the sample rows first, the full scan on several threads
       const double *c = col[(size_t)j];
       for (int64_t r : sr) if (!same(c[r], f(r))) return false;
-      for (int64_t r = 0; r < nr; r++) if (!same(c[r], f(r))) return false;
+      const int nth = nr >= 400000 ? (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), nr / 100000) : 1;
+      if (nth <= 1) {
+        for (int64_t r = 0; r < nr; r++) if (!same(c[r], f(r))) return false;
+        return true;
+      }
+      std::vector<char> ok((size_t)nth, 1);
+      std::vector<std::thread> th;
+      for (int w = 0; w < nth; w++)
+        th.emplace_back([&, w] {
+          const int64_t r0 = nr * w / nth, r1 = nr * (w + 1) / nth;
+          for (int64_t r = r0; r < r1; r++) if (!same(c[r], f(r))) { ok[(size_t)w] = 0; return; }
+        });
+      for (auto &t : th) t.join();
+      for (char o : ok) if (!o) return false;
       return true;
     };
     for (int j = 0; j < nc && nr >= 16; j++) {   // on a handful of rows every column is an affine image of every other
