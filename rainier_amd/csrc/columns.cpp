@@ -17,6 +17,10 @@
 // recomputed value is the very double the reference stored (IEEE negation / multiplication / addition are deterministic);
 // fast mode also accepts value equality (+0 == -0).  The pass also records, for every base column with at most 8 distinct
 // values, that set (Program::col_domain): the emitter may verify a closed form on the values that actually occur.
+//
+// Second job, for programs recognised this way as the reference's lowering: Model.observe's INITIAL CHUNK (1-8 observations in a
+// row target of its own, core/Model.scala:84-96) is unrolled -- its rows substituted as constants and summed in row order -- so
+// that the model is left with one streamed target.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

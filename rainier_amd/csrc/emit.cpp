@@ -1091,9 +1091,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
               EmitInfo *info) {
   if (!o.simplify) return emit_hip_impl(P, o, defines, targets, err, info);
-  Program Q = simplify(P, o.fp_contract);
-  if (o.refactor && o.fp_contract) Q = simplify(refactor(Q), true);
-  return emit_hip_impl(Q, o, defines, targets, err, info);
+  return emit_hip_impl(simplify(P, o.fp_contract), o, defines, targets, err, info);
 }
 static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {

@@ -65,7 +65,6 @@ struct EmitOptions {
   bool fast_log = true;      // fast mode: rh_fast_log (<= 1 ulp, ~40 instructions) instead of the device library's log (RH_FAST_LOG=0)
   bool pack = true;          // data-free models with <= 32 parameters: several chains per wavefront (RH_PACK=0 switches it off)
   bool simplify = true;      // run simplify() before lowering (RH_SIMPLIFY=0 switches it off)
-  bool refactor = false;     // fast mode, set when canonicalize_columns rewrote derived columns: run refactor() as well (RH_REFACTOR=0)
   bool strict_math = false;  // EXP/LOG -> fdlibm
   bool fp_contract = false;  // allow FMA contraction in model code
   int rows_unroll = 4;
