@@ -66,6 +66,7 @@ struct TargetEmitter {
   std::vector<uint32_t> basis;            // basis term node ids, accumulator order
   std::vector<Lin> outs;                  // per output: (basis index in .term, alpha, beta)
   std::map<uint32_t, int> inv_slot;       // non-trivial invariant node -> index in inv[]
+  std::map<uint32_t, int> inv_table;      // row-level LOOKUP whose >= 8 entries are all non-trivial invariants -> first of their CONSECUTIVE inv[] slots
   std::vector<char> reach_row, reach_inv;
 
   TargetEmitter(const Program &p, uint32_t ti, bool f) : P(p), t(ti), factor(f), run_end(ti) {
@@ -257,6 +258,18 @@ struct TargetEmitter {
         if (x >= NONE) return;
         if (P.nodes[x].dep == 0 && !trivial(x) && !inv_slot.count(x)) { int s = (int)inv_slot.size(); inv_slot[x] = s; }
       };
+      // parameter-only tables of a row-level Lookup (alphas(site) with alphas_k = mu + z_k sigma: the reference's GLMMs) get
+      // consecutive slots, so that the row code reads inv[first + k] instead of building the table per row or walking a select chain
+      for (size_t n = 0; n < P.nodes.size(); n++) {
+        const Node &nd = P.nodes[n];
+        if (!reach_row[n] || nd.dep == 0 || nd.op != RH_RIR_LOOKUP || nd.table.size() < 8 || (gather.ok && n == gather.node)) continue;
+        bool all_inv = true, fresh = true;
+        std::map<uint32_t, char> distinct;
+        for (uint32_t e : nd.table) { all_inv = all_inv && P.nodes[e].dep == 0 && !trivial(e); fresh = fresh && !inv_slot.count(e); distinct[e] = 1; }
+        if (!all_inv || !fresh || distinct.size() != nd.table.size()) continue;
+        inv_table[(uint32_t)n] = (int)inv_slot.size();
+        for (uint32_t e : nd.table) { const int sl = (int)inv_slot.size(); inv_slot[e] = sl; }
+      }
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n]) continue;
         if (P.nodes[n].dep == 0) { if (std::find(basis.begin(), basis.end(), (uint32_t)n) != basis.end()) want((uint32_t)n); continue; }
@@ -545,7 +558,7 @@ struct TargetEmitter {
   // <= 64 entries: a select chain in registers; all-constant tables of any size: a read-only array; otherwise a
   // per-evaluation local array (correct for any table, slow for large ones -- parameter tables belong in gather mode).
   template <class RefFn>
-  bool emit_lookup(std::ostringstream &os, uint32_t id, RefFn R, std::string &err) const {
+  bool emit_lookup(std::ostringstream &os, uint32_t id, RefFn R, std::string &err, bool use_inv = true) const {
     const Node &nd = P.nodes[id];
     const std::string k = "k" + std::to_string(id), lhs = "    const double n" + std::to_string(id) + " = ";
     const Node &ix = P.nodes[nd.a];
@@ -559,7 +572,10 @@ struct TargetEmitter {
     // unsigned difference: a saturated index (INT_MIN / INT_MAX) minus `low` must wrap, not overflow a signed int;
     // every use below compares or indexes k as unsigned
     os << "    const int " << k << " = (int)((unsigned)rh_d2i(" << R(nd.a) << ") - (unsigned)(" << nd.low << "));\n";
-    if (nd.table.size() <= 64) {
+    auto it_tab = use_inv ? inv_table.find(id) : inv_table.end();   // (the GLM scalar part has no inv[]: it keeps its own copies)
+    if (it_tab != inv_table.end()) {
+      os << lhs << "((unsigned)" << k << " < " << nd.table.size() << "u) ? inv[" << it_tab->second << " + " << k << "] : RH_NAN;\n";
+    } else if (nd.table.size() <= 64) {
       os << lhs;
       for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
       os << R(nd.table.back()) << ";\n";
@@ -929,7 +945,7 @@ struct TargetEmitter {
       case RH_RIR_ACOS: os << lhs << "acos(" << R(nd.a) << ");\n"; break;
       case RH_RIR_ATAN: os << lhs << "atan(" << R(nd.a) << ");\n"; break;
       case RH_RIR_SEQ: os << lhs << R(nd.b) << ";\n"; break;
-      case RH_RIR_LOOKUP: if (!emit_lookup(os, id, [&](uint32_t x) { return R(x); }, err)) return false; break;
+      case RH_RIR_LOOKUP: if (!emit_lookup(os, id, [&](uint32_t x) { return R(x); }, err, false)) return false; break;
       default: err = "emit: unexpected opcode"; return false;
     }
     return true;
