@@ -64,6 +64,15 @@ struct TargetEmitter {
   std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;  // hash-consing of synthesized nodes
   std::map<uint32_t, Lin> memo;
   std::vector<uint32_t> basis;            // basis term node ids, accumulator order
+  // outputs that are sums of several basis terms (alpha_1 t_1 + alpha_2 t_2 + ... + beta): accepted only when every t_i is
+  // accumulated anyway for another output -- the gradient w.r.t. a hyper-parameter of a Lookup table, sum_k c_k eq(index, k, g, 0)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> outs_multi;   // per output: (basis index, alpha); empty = single-term (outs)
+  // scatter families: basis terms  eq(column, k, g, 0)  for many k with one g (what differentiating Lookup(column, table) leaves,
+  // compute/Gradient.scala:148-152).  Their accumulators are laid out consecutively and the row code does ONE
+  // acc[base + column - kmin] += g  instead of one select per table entry
+  struct Family { uint32_t col = 0, g = 0; int kmin = 0, size = 0, base = 0; };
+  std::vector<Family> families;
+  std::vector<char> in_family;            // per basis index
   std::vector<Lin> outs;                  // per output: (basis index in .term, alpha, beta)
   std::map<uint32_t, int> inv_slot;       // non-trivial invariant node -> index in inv[]
   std::map<uint32_t, int> inv_table;      // row-level LOOKUP whose >= 8 entries are all non-trivial invariants -> first of their CONSECUTIVE inv[] slots
@@ -161,6 +170,37 @@ struct TargetEmitter {
     }
   }
 
+  // id = sum_i alpha_i * t_i + beta with single-term leaves t_i (through +, -, and * or / by invariants)
+  bool lin_multi(uint32_t id, uint32_t scale, std::vector<std::pair<uint32_t, uint32_t>> &terms, uint32_t &beta, int depth = 0) {
+    if (depth > 4096 || terms.size() > 4096) return false;
+    const Node nd = P.nodes[id];
+    if (nd.dep == 0) {
+      uint32_t v = id;
+      if (nd.op == RH_RIR_CONST && nd.cval == 0.0) v = ZERO;
+      if (nd.op == RH_RIR_CONST && nd.cval == 1.0) v = ONE;
+      beta = iadd(beta, imul(scale, v));
+      return true;
+    }
+    switch (nd.op) {
+      case RH_RIR_NOOP: return lin_multi(nd.a, scale, terms, beta, depth + 1);
+      case RH_RIR_SEQ: return lin_multi(nd.b, scale, terms, beta, depth + 1);
+      case RH_RIR_ADD: return lin_multi(nd.a, scale, terms, beta, depth + 1) && lin_multi(nd.b, scale, terms, beta, depth + 1);
+      case RH_RIR_SUB: return lin_multi(nd.a, scale, terms, beta, depth + 1) && lin_multi(nd.b, isub(ZERO, scale), terms, beta, depth + 1);
+      case RH_RIR_MUL:
+        if (P.nodes[nd.a].dep == 0) return lin_multi(nd.b, imul(scale, lin(nd.a).beta), terms, beta, depth + 1);
+        if (P.nodes[nd.b].dep == 0) return lin_multi(nd.a, imul(scale, lin(nd.b).beta), terms, beta, depth + 1);
+        break;
+      case RH_RIR_DIV:
+        if (P.nodes[nd.b].dep == 0) return lin_multi(nd.a, idiv(scale, lin(nd.b).beta), terms, beta, depth + 1);
+        break;
+      default: break;
+    }
+    const Lin l = lin(id);
+    if (l.term != NONE) terms.push_back({l.term, imul(scale, l.alpha)});
+    beta = iadd(beta, imul(scale, l.beta));
+    return true;
+  }
+
   void operands(const Node &nd, std::vector<uint32_t> &out) const {
     out.clear();
     switch (nd.op) {
@@ -229,6 +269,56 @@ struct TargetEmitter {
     return true;
   }
 
+  // what the row code must compute: the basis terms, with every scatter family replaced by its scatter value and index column
+  std::vector<uint32_t> row_roots() const {
+    std::vector<uint32_t> r;
+    for (size_t j = 0; j < basis.size(); j++) if (basis[j] != NONE && !(j < in_family.size() && in_family[j])) r.push_back(basis[j]);
+    for (const Family &f : families) { r.push_back(f.g); r.push_back(f.col); }
+    return r;
+  }
+  void find_families() {
+    in_family.assign(basis.size(), 0);
+    families.clear();
+    if (!has_rows() || !factor || gmode) return;
+    std::map<std::pair<uint32_t, uint32_t>, std::map<int, int>> cand;   // (column node, g) -> k -> basis index
+    for (size_t j = 0; j < basis.size(); j++) {
+      const Node &nd = P.nodes[basis[j]];
+      if (nd.op != RH_RIR_LOOKUP || nd.low != -1 || nd.table.size() != 3 || nd.table[0] != nd.table[2] || !is_const(nd.table[0], 0.0)) continue;
+      const Node &cm = P.nodes[nd.a];
+      if (cm.op != RH_RIR_COMPARE || col_index(cm.a) < 0 || P.nodes[cm.b].op != RH_RIR_CONST) continue;
+      const double kv = P.nodes[cm.b].cval;
+      if (!(kv == std::floor(kv)) || std::fabs(kv) > 1e9) continue;
+      cand[{cm.a, nd.table[1]}][(int)kv] = (int)j;
+    }
+    std::vector<char> moved(basis.size(), 0);
+    std::vector<std::pair<Family, std::map<int, int>>> fams;
+    for (auto &kv : cand) {
+      const int kmin = kv.second.begin()->first, kmax = kv.second.rbegin()->first;
+      if (kv.second.size() < 8 || (size_t)(kmax - kmin + 1) > 2 * kv.second.size()) continue;
+      Family f; f.col = kv.first.first; f.g = kv.first.second; f.kmin = kmin; f.size = kmax - kmin + 1;
+      fams.push_back({f, kv.second});
+      for (auto &m : kv.second) moved[(size_t)m.second] = 1;
+    }
+    if (fams.empty()) return;
+    // new accumulator order: everything else first (old order), then one block per family (gaps keep an unused slot)
+    std::vector<uint32_t> nb;
+    std::vector<int> renum(basis.size(), -1);
+    for (size_t j = 0; j < basis.size(); j++) if (!moved[j]) { renum[j] = (int)nb.size(); nb.push_back(basis[j]); }
+    std::vector<char> fam(nb.size(), 0);
+    for (auto &fm : fams) {
+      fm.first.base = (int)nb.size();
+      for (int k = 0; k < fm.first.size; k++) {
+        auto it = fm.second.find(fm.first.kmin + k);
+        if (it != fm.second.end()) { renum[(size_t)it->second] = (int)nb.size(); nb.push_back(basis[(size_t)it->second]); } else nb.push_back(NONE);
+        fam.push_back(1);
+      }
+      families.push_back(fm.first);
+    }
+    basis.swap(nb);
+    in_family = fam;
+    for (Lin &l : outs) if (l.term != NONE) l.term = (uint32_t)renum[l.term];
+    for (auto &mo : outs_multi) for (auto &tm : mo) tm.first = (uint32_t)renum[tm.first];
+  }
   // synthesized nodes are appended after their operands, so ascending id stays a topological order
   void plan() {
     const Target &T = P.targets[t];
@@ -236,6 +326,10 @@ struct TargetEmitter {
     outs.resize(n_out);
     std::map<uint32_t, int> bidx;
     auto basis_of = [&](uint32_t term) { auto it = bidx.find(term); if (it != bidx.end()) return it->second; int i = (int)basis.size(); basis.push_back(term); bidx[term] = i; return i; };
+    outs_multi.assign(n_out, {});
+    std::vector<Lin> first(n_out);
+    std::map<uint32_t, char> single_terms;   // terms some output accumulates on its own
+    auto sum_like = [&](const Lin &l) { return l.term != NONE && (P.nodes[l.term].op == RH_RIR_ADD || P.nodes[l.term].op == RH_RIR_SUB); };
     for (size_t o = 0; o < n_out; o++) {
       const uint32_t id = T.outputs[o];
       Lin l;
@@ -243,13 +337,34 @@ struct TargetEmitter {
       else if (factor) l = lin(id);
       else if (is_const(id, 0.0) && !std::signbit(P.nodes[id].cval)) { l.term = NONE; l.alpha = ZERO; l.beta = ZERO; }  // += +0.0 is the identity
       else l = opaque(id);  // JVM-faithful: accumulate the output itself (also when it is parameter-only)
+      first[o] = l;
+      if (has_rows() && factor && l.term != NONE && !sum_like(l)) single_terms[l.term] = 1;
+    }
+    for (size_t o = 0; o < n_out; o++) {
+      Lin l = first[o];
+      if (has_rows() && factor && sum_like(l)) {
+        std::vector<std::pair<uint32_t, uint32_t>> terms;
+        uint32_t beta = l.beta;
+        bool ok = lin_multi(l.term, l.alpha, terms, beta) && terms.size() >= 2;
+        for (auto &tm : terms) ok = ok && single_terms.count(tm.first);
+        if (ok) {
+          std::map<uint32_t, uint32_t> merged;   // one entry per basis term
+          std::vector<uint32_t> order;
+          for (auto &tm : terms) { auto it = merged.find(tm.first); if (it == merged.end()) { merged[tm.first] = tm.second; order.push_back(tm.first); } else it->second = iadd(it->second, tm.second); }
+          for (uint32_t tn : order) outs_multi[o].push_back({(uint32_t)basis_of(tn), merged[tn]});
+          Lin r; r.term = NONE; r.alpha = ZERO; r.beta = beta;
+          outs[o] = r;
+          continue;
+        }
+      }
       if (l.term != NONE) l.term = (uint32_t)basis_of(l.term);
       outs[o] = l;
     }
+    find_families();
     reach_row.assign(P.nodes.size(), 0);
     reach_inv.assign(P.nodes.size(), 0);
     if (has_rows()) {
-      for (uint32_t b : basis) reach_row[b] = 1;
+      for (uint32_t b : row_roots()) reach_row[b] = 1;
       if (gather.ok) reach_row[gather.sv] = 1;
       sweep(reach_row);
       // invariants needed: parameter-only operands of row nodes, plus every alpha / beta
@@ -272,11 +387,12 @@ struct TargetEmitter {
       }
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n]) continue;
-        if (P.nodes[n].dep == 0) { if (std::find(basis.begin(), basis.end(), (uint32_t)n) != basis.end()) want((uint32_t)n); continue; }
+        if (P.nodes[n].dep == 0) { const std::vector<uint32_t> rr = row_roots(); if (std::find(rr.begin(), rr.end(), (uint32_t)n) != rr.end()) want((uint32_t)n); continue; }
         operands(P.nodes[n], ops);
         for (uint32_t o : ops) want(o);
       }
       for (const Lin &l : outs) { want(l.alpha); want(l.beta); }
+      for (auto &mo : outs_multi) for (auto &tm : mo) want(tm.second);
       for (auto &kv : inv_slot) reach_inv[kv.first] = 1;
       sweep(reach_inv);
     } else {
@@ -381,7 +497,7 @@ struct TargetEmitter {
     // the value: the one basis term whose E-dependent summands are all coef * log(P | Q)
     Link lk;
     bool found = false;
-    for (uint32_t b : basis) {
+    for (uint32_t b : row_roots()) {
       if (!depE[b]) continue;
       Link cand; cand.L = L; cand.E = E; cand.V = b;
       bool good = true, any = false;
@@ -409,7 +525,7 @@ struct TargetEmitter {
     lk.logm = std::log(m);
     // every other E-dependent root -> its core (peel E-independent factors and negations)
     std::vector<uint32_t> roots;
-    for (uint32_t b : basis) if (b != lk.V && depE[b]) roots.push_back(b);
+    for (uint32_t b : row_roots()) if (b != lk.V && depE[b]) roots.push_back(b);
     if (gather.ok && depE[gather.sv]) roots.push_back(gather.sv);
     std::vector<char> above(N, 0);          // E-dependent nodes that stay (products of a core with E-independent factors)
     for (uint32_t r : roots) {
@@ -425,7 +541,7 @@ struct TargetEmitter {
     }
     // nothing else may need E once V and the cores are closed forms
     { std::vector<char> need(N, 0);
-      for (uint32_t b : basis) need[b] = 1;
+      for (uint32_t b : row_roots()) need[b] = 1;
       if (gather.ok) need[gather.sv] = 1;
       std::vector<uint32_t> ops;
       for (size_t n = N; n-- > 0;) {
@@ -490,7 +606,7 @@ struct TargetEmitter {
     link = lk;
     // liveness again, with V and the cores as leaves
     reach_row.assign(N, 0);
-    for (uint32_t b : basis) reach_row[b] = 1;
+    for (uint32_t b : row_roots()) reach_row[b] = 1;
     if (gather.ok) reach_row[gather.sv] = 1;
     { std::vector<uint32_t> ops;
       for (size_t n = N; n-- > 0;) {
@@ -512,6 +628,7 @@ struct TargetEmitter {
         for (uint32_t o : ops) want(o);
       }
       for (const Lin &l : outs) { want(l.alpha); want(l.beta); }
+      for (auto &mo : outs_multi) for (auto &tm : mo) want(tm.second);
       reach_inv.assign(N, 0);
       for (auto &kv : inv_slot) reach_inv[kv.first] = 1;
       sweep(reach_inv); }
@@ -682,7 +799,7 @@ struct TargetEmitter {
   }
 
   void detect_glm() {
-    if (!has_rows() || !factor || basis.empty()) return;
+    if (!has_rows() || !factor || basis.empty() || !families.empty()) return;
     // the widest linear predictor among the row nodes
     size_t best = 0;
     for (size_t n = 0; n < P.nodes.size(); n++) {
@@ -993,7 +1110,12 @@ struct TargetEmitter {
         }
         if (!emit_node(os, (uint32_t)n, 1, err)) return false;
       }
-      for (size_t j = 0; j < basis.size(); j++) os << accumulate("acc[" + std::to_string(j) + "]", basis[j], 1);
+      for (size_t j = 0; j < basis.size(); j++)
+        if (basis[j] != NONE && !in_family[j]) os << accumulate("acc[" + std::to_string(j) + "]", basis[j], 1);
+      for (const Family &f : families) {   // eq(column, k, g, 0) for every k of the block: the column's value picks the one accumulator
+        os << "    { const double ix = " << ref(f.col, 1) << "; const int kk = (int)ix - (" << f.kmin << ");\n"
+           << "      if (ix == (double)(int)ix && (unsigned)kk < " << f.size << "u) acc[" << f.base << " + kk] += " << ref(f.g, 1) << "; }\n";
+      }
       if (gather.ok) os << accumulate("sv", gather.sv, 1);
       os << "  }\n";
       // ---- finish: tot[o] += alpha * S[j] + nrows * beta
@@ -1003,6 +1125,10 @@ struct TargetEmitter {
         const Lin &l = outs[o];
         std::string e;
         if (l.term != NONE && l.alpha != ZERO) e = l.alpha == ONE ? "S[" + std::to_string(l.term) + "]" : ref(l.alpha, 2) + " * S[" + std::to_string(l.term) + "]";
+        for (auto &tm : outs_multi[o]) {
+          if (tm.second == ZERO) continue;
+          e += (e.empty() ? "" : " + ") + (tm.second == ONE ? "S[" + std::to_string(tm.first) + "]" : ref(tm.second, 2) + " * S[" + std::to_string(tm.first) + "]");
+        }
         if (l.beta != ZERO) e += (e.empty() ? "" : " + ") + ("nrows * " + ref(l.beta, 2));
         if (!e.empty()) os << "    tot[" << o << "] += " << e << ";\n";
       }
