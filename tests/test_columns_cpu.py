@@ -311,3 +311,16 @@ def test_ark_reference_benchmark_model_has_197_targets_and_the_engine_merges_the
     src65, _ = _capi.lower_only(s65.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
     src62, _ = _capi.lower_only(s62.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
     assert "#define RH_NTARGETS 1\n" in src65 and "#define RH_NTARGETS 64\n" in src62
+
+
+def test_glmm_row_code_is_the_natural_poisson_row():
+    """After re-derivation and rolling the emitter sees  eq(site, k, g, 0) / eq(year, j, g, 0)  basis terms: two scatter families with
+    one g, parameter-only tables read through inv[], hyper-parameter gradients as linear combinations in finish()."""
+    spec = _glmm()
+    src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True), columns=spec.columns, nrows=spec.nrows)
+    assert "#define RH_NACC_MAX 141\n" in src                      # the value + 100 site entries + 40 year entries
+    row = src.split("static RH_DEV void row(")[-1].split("static RH_DEV void finish(")[0]
+    assert row.count("acc[") == 3 and "(unsigned)kk < 100u) acc[1 + kk] +=" in row and "(unsigned)kk < 40u) acc[101 + kk] +=" in row
+    assert row.count("RH_EXP(") == 1 and "inv[0 + k" in row and "inv[100 + k" in row and row.count("?") == 2
+    fin = src.split("static RH_DEV void finish(")[-1].split("\n  }\n")[0]
+    assert max(line.count("S[") for line in fin.split("\n")) >= 100   # d/d mu = sum of the 100 site sums
