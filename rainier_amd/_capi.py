@@ -177,9 +177,10 @@ def simplify_rir(rir: bytes, fast: bool = False) -> bytes:
         L.rh_free(out)
 
 
-def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", columns=None, nrows=None):
+def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", columns=None, nrows=None, compile: bool = True):
     """RIR -> HIP source -> gfx950 code object, without a device.  Returns (source, code_size).  With columns / nrows the
-    data-dependent passes of rh_model_create (column canonicalisation) run as well."""
+    data-dependent passes of rh_model_create (column canonicalisation) run as well; compile = False stops after the lowering
+    (source only, code_size 0)."""
     L = lib()
     src = C.c_char_p()
     size = C.c_size_t(0)
@@ -189,9 +190,9 @@ def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", colum
         cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
         arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
         nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
-        rc = L.rh_lower_only_data(buf, len(rir), arr, nr, C.byref(o), arch.encode(), C.byref(src), C.byref(size))
+        rc = L.rh_lower_only_data(buf, len(rir), arr, nr, C.byref(o), arch.encode(), C.byref(src), C.byref(size) if compile else None)
     else:
-        rc = L.rh_lower_only(buf, len(rir), C.byref(o), arch.encode(), C.byref(src), C.byref(size))
+        rc = L.rh_lower_only_data(buf, len(rir), None, None, C.byref(o), arch.encode(), C.byref(src), C.byref(size) if compile else None)
     text = src.value.decode() if src.value else ""
     if src:
         L.rh_free(src)

@@ -626,8 +626,9 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
+    if (!code_size) return;   // source only (the CPU suite's host emulation of the generated code)
     build_code(&m);
-    if (code_size) *code_size = m.code.size();
+    *code_size = m.code.size();
     if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 7) + m.source);
   });
   return rc;

@@ -1,0 +1,74 @@
+"""TEST INFRASTRUCTURE: compiles the per-model code the emitter generates (the rh_target<t> structs between the "generated from RIR"
+marker and the hand-written engine) with the host g++ and evaluates it over the columns row by row, DataFunction-style -- a CPU check
+of the emitter's algebra against the oracle.  Not used by the product path (which only runs on the device)."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_HARNESS = r'''
+template <int T> static void rh_host_target(const double (&th)[RH_NTH], const double *const *cols, const long long *nrows,
+                                            double (&tot)[RH_NOUT], int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    double inv[TG::NINV > 0 ? TG::NINV : 1];
+    TG::invariants(th, inv, err);
+    if constexpr (!TG::HAS_ROWS) {
+      TG::row(th, inv, nullptr, tot, err);
+    } else {
+      double S[TG::NACC > 0 ? TG::NACC : 1];
+      for (int j = 0; j < TG::NACC; j++) S[j] = 0.0;
+      double c[TG::NCOLS > 0 ? TG::NCOLS : 1];
+      for (long long r = 0; r < nrows[T]; r++) {
+        for (int j = 0; j < TG::NCOLS; j++) c[j] = cols[TG::COL0 + j][r];
+        TG::row(th, inv, c, S, err);
+      }
+      TG::finish(th, inv, S, (double)nrows[T], tot);
+    }
+    rh_host_target<T + 1>(th, cols, nrows, tot, err);
+  }
+}
+extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) {
+  double th[RH_NTH], tot[RH_NOUT];
+  for (int i = 0; i < RH_NTH; i++) th[i] = q[i];
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  int err = 0;
+  rh_host_target<0>(th, cols, nrows, tot, err);
+  for (int o = 0; o < RH_NOUT; o++) out[o] = tot[o];
+  return err;
+}
+'''
+
+
+class HostTargets:
+    """The generated rh_target<t> code of one lowered model, compiled for the host."""
+
+    def __init__(self, hip_source: str):
+        head = hip_source[:hip_source.index("// rh_shared.h")]
+        i = hip_source.index("// ---- generated from RIR")
+        gen = hip_source[i:hip_source.index("// rh_engine.hip.h", i)]
+        assert "#define RH_HAS_GATHER 0" in head, "gather-mode row code takes the gathered parameter from the kernel"
+        text = head + '#include "host_target_shim.hpp"\n' + gen + _HARNESS
+        key = hashlib.sha256(text.encode()).hexdigest()[:16]
+        d = os.path.join(tempfile.gettempdir(), "rh_host_targets")
+        os.makedirs(d, exist_ok=True)
+        so = os.path.join(d, key + ".so")
+        if not os.path.exists(so):
+            src = os.path.join(d, key + ".cpp")
+            open(src, "w").write(text)
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
+        self.lib = C.CDLL(so)
+        self.n_out = int(head.split("#define RH_NOUT ")[1].split("\n")[0])
+
+    def eval(self, q, columns, nrows):
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
+        arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[c.ctypes.data_as(C.POINTER(C.c_double)) for c in cols])
+        nr = (C.c_longlong * max(1, len(nrows)))(*[int(x) for x in nrows])
+        qq = np.ascontiguousarray(q, dtype=np.float64)
+        out = np.zeros(self.n_out)
+        err = self.lib.rh_host_eval(qq.ctypes.data_as(C.POINTER(C.c_double)), arr, nr, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out, err

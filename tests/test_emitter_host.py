@@ -1,0 +1,134 @@
+"""The emitter's generated row code, compiled with the host g++ and evaluated DataFunction-style on the CPU (tests/host_emulation.py),
+against the oracle on the ORIGINAL program: covers what only the GPU tier could see before -- invariant hoisting, output factoring,
+outputs as linear combinations of basis sums, scatter families, invariant Lookup tables, the closed-form links, and (through
+rh_lower_only_data) the data-dependent passes of rh_model_create in front of them."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rainier_amd import _capi, models
+from rainier_amd import modeling as M
+from tests import oracle_lib as O
+from tests.host_emulation import HostTargets
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FAST = dict(fp_contract=True, factor_outputs=True)
+STRICT = dict(math_mode=_capi.MATH_STRICT)
+
+
+def _check(spec, opts, qs, tol, with_data=True):
+    """generated code (over the columns rh_model_create would keep) vs the oracle on the original program"""
+    kw = dict(columns=spec.columns, nrows=spec.nrows) if with_data and spec.columns else {}
+    src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, **kw)
+    fast = bool(opts.get("fp_contract"))
+    if kw:
+        _, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=fast)
+        cols = [np.concatenate([np.zeros(n) if j == 0xFFFFFFFF else np.asarray(spec.columns[j], dtype=np.float64)[:n] for j, n in p]) for p in parts]
+    else:
+        cols, nrows = spec.columns, spec.nrows
+    h = HostTargets(src)
+    d = O.OracleDensity(spec)
+    for q in qs:
+        got, err = h.eval(q, cols, nrows)
+        ref, ab = d.update_both(np.asarray(q, dtype=np.float64))
+        assert err == 0
+        both_nan = np.isnan(got) & np.isnan(ref)
+        assert np.all((np.abs(got - ref) <= tol * ab + 1e-300) | both_nan), (spec.name, opts, np.max(np.abs(got - ref) / (tol * ab + 1e-300)))
+    return src
+
+
+def _split_logistic(n, k):
+    cols = models.logistic_data(n, k)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k)
+    return M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic),
+                               split=True).compile("logistic_split_%dx%d" % (k, n))
+
+
+@pytest.mark.parametrize("opts", [STRICT, dict(factor_outputs=True), FAST], ids=["strict", "factored", "fast"])
+def test_natural_forms(opts):
+    rng = np.random.default_rng(31)
+    _check(models.linreg(n=700, k=3), opts, rng.normal(size=(3, 5)) * 0.5, 1e-12)
+    _check(models.logistic(n=500, k=12), opts, rng.normal(size=(3, 13)) * 0.4, 1e-11)
+    _check(models.negbin_glm(n=600, k=3), opts, rng.normal(size=(3, 4)) * 0.5, 1e-11)
+    _check(models.eight_schools(), opts, rng.normal(size=(3, 10)) * 0.7, 1e-13)
+
+
+def test_closed_form_links_are_what_the_literal_code_computes():
+    src = _check(models.logistic(n=500, k=12), FAST, np.random.default_rng(32).normal(size=(4, 13)) * 0.4, 1e-11)
+    assert "struct rh_glm<1>" in src and "rh_logit_link(s * eta, sp, sg);" in src
+    src = _check(models.negbin_glm(n=600, k=3), FAST, np.random.default_rng(33).normal(size=(4, 4)) * 0.5, 1e-11)
+    assert "lk_g" in src
+
+
+def test_lookup_tables_scatter_families_and_linear_combination_outputs():
+    """hier. negative binomial with a 20-entry parameter table on the generic path, and the reference's GLMMPoisson2"""
+    import os as _os
+    _os.environ["RH_GATHER_MIN"] = "1000"
+    try:
+        spec = models.hier_negbin(20, 30)
+        src = _check(spec, FAST, np.random.default_rng(34).normal(size=(3, spec.n_params)) * 0.3, 1e-11)
+    finally:
+        del _os.environ["RH_GATHER_MIN"]
+    assert "acc[" in src and "+ kk] +=" in src
+    glmm = models.glmm_poisson2_reference(100, 40, json.load(open(os.path.join(G, "glmm_poisson2.json"))))
+    src = _check(glmm, FAST, np.random.default_rng(35).normal(size=(3, 146)) * 0.3, 1e-11)
+    assert "#define RH_NACC_MAX 141\n" in src
+    _check(glmm, STRICT, np.random.default_rng(36).normal(size=(2, 146)) * 0.3, 1e-12)    # the literal 8-slot expression, ~450 columns
+
+
+def test_reference_lowerings_through_all_passes():
+    rng = np.random.default_rng(37)
+    for spec, nq in ((models.logistic_reference(n=600, k=8), 9), (_split_logistic(1000, 6), 7), (_split_logistic(2000, 50), 51)):
+        for opts in (STRICT, FAST):
+            if opts is STRICT and spec.n_params > 20:
+                continue                      # the strict 8-slot expression of the 50-covariate model is a 2 MB translation unit
+            _check(spec, opts, rng.normal(size=(2, nq)) * 0.3, 1e-11)
+    mix = models.lowdim_gaussmix_reference(json.load(open(os.path.join(G, "lowdim_gaussmix.json"))))
+    for opts in (STRICT, FAST):
+        _check(mix, opts, rng.normal(size=(3, 5)) * 0.7, 1e-11)
+    kid = models.kidiq_reference(json.load(open(os.path.join(G, "kidiq.json"))))
+    for opts in (STRICT, FAST):
+        _check(kid, opts, np.abs(rng.normal(size=(3, 4))) * 0.5 + 0.1, 1e-12)
+
+
+from tests.realtest_cases import CASES, Alg  # noqa: E402
+from rainier_amd.frontend import Graph  # noqa: E402
+from rainier_amd.models import ModelSpec  # noqa: E402
+
+_SKIP = {"lookup", "cancelling x^2 then distributing", "tanh at infty"}
+
+
+@pytest.mark.parametrize("name,fn", [(c[0], c[1]) for c in CASES if c[0] not in _SKIP])
+def test_realtest_expressions_as_generated_code(name, fn):
+    """RealTest's expressions as 8-slot streamed row terms (see tests/test_columns_cpu.py): through canonicalisation, gradient
+    re-derivation, rolling AND the emitter, as compiled host code, against the oracle on the original program; strict build too."""
+    rng = np.random.default_rng(abs(hash(name)) % 1000 + 7)
+    n, S = 40, 8
+    cols = []
+    for s in range(S):
+        x = rng.uniform(-0.45, 0.45, n)
+        cols += [x, rng.normal(size=n), -x]
+    g = Graph(3, [3 * S])
+    A = Alg(g)
+    th = [g.param(i) for i in range(3)]
+    val = None
+    for s in range(S):
+        x, z, mx = g.col(0, 3 * s), g.col(0, 3 * s + 1), g.col(0, 3 * s + 2)
+        term = fn(A, th[0] * x + th[1]) + th[2] * z + (mx * th[0]) * 0.25
+        val = term if val is None else val + term
+    spec = ModelSpec("realtest_" + name, g.compile([val]), cols, [n], 3, {})
+    qs = [q for q in ([0.7, 0.3, -0.4], [-0.9, -0.2, 0.8], [0.4, 0.45, 0.1]) if np.isfinite(O.OracleDensity(spec).update(np.array(q))[0])]
+    assert qs
+    for opts in (STRICT, FAST):
+        _check(spec, opts, qs, 1e-9)
+
+
+def test_data_free_reference_models_and_many_targets():
+    rng = np.random.default_rng(38)
+    for spec in (models.eight_schools_reference(), models.funnel_reference(10)):
+        for opts in (STRICT, FAST):
+            _check(spec, opts, rng.normal(size=(3, spec.n_params)) * 0.6, 1e-13)
+    ark = models.ark_reference(json.load(open(os.path.join(G, "ark.json"))))       # 197 targets merged into one
+    _check(ark, FAST, rng.normal(size=(2, 7)) * 0.3, 1e-12)
