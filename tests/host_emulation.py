@@ -32,6 +32,37 @@ template <int T> static void rh_host_target(const double (&th)[RH_NTH], const do
     rh_host_target<T + 1>(th, cols, nrows, tot, err);
   }
 }
+#ifdef RH_GLM_TARGET
+// the GLM lowering of the same target (what rh_grad_glm_kernel contracts on the matrix cores): eta = sum_k scale_k theta_k x_k,
+// the scalar part elem(eta, columns) -> (w, others), basis sums  S[pred_acc_k] += w x_k,  S[other_acc_j] += other_j, then finish()
+extern "C" int rh_host_eval_glm(const double *q, const double *const *cols, const long long *nrows, double *out) {
+  typedef rh_glm<RH_GLM_TARGET> GL;
+  typedef rh_target<RH_GLM_TARGET> TG;
+  double th[RH_NTH], tot[RH_NOUT];
+  for (int i = 0; i < RH_NTH; i++) th[i] = q[i];
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  int err = 0;
+  double S[TG::NACC > 0 ? TG::NACC : 1];
+  for (int j = 0; j < TG::NACC; j++) S[j] = 0.0;
+  double thu[GL::NTHU > 0 ? GL::NTHU : 1];
+  for (int k = 0; k < GL::NTHU; k++) thu[k] = th[GL::thu_param[k]];
+  double c[TG::NCOLS > 0 ? TG::NCOLS : 1];
+  for (long long r = 0; r < nrows[RH_GLM_TARGET]; r++) {
+    for (int j = 0; j < TG::NCOLS; j++) c[j] = cols[TG::COL0 + j][r];
+    double eta = 0.0;
+    for (int k = 0; k < GL::P; k++) eta += GL::pred_scale[k] * th[GL::pred_param[k]] * (GL::pred_col[k] >= 0 ? c[GL::pred_col[k]] : 1.0);
+    double w = 0.0, other[GL::NOTHER > 0 ? GL::NOTHER : 1];
+    GL::elem(thu, eta, [&](int j) { return c[j]; }, w, other, err);
+    for (int k = 0; k < GL::P; k++) S[GL::pred_acc[k]] += w * (GL::pred_col[k] >= 0 ? c[GL::pred_col[k]] : 1.0);
+    for (int k = 0; k < GL::NOTHER; k++) S[GL::other_acc[k]] += other[k];
+  }
+  double inv[TG::NINV > 0 ? TG::NINV : 1];
+  TG::invariants(th, inv, err);
+  TG::finish(th, inv, S, (double)nrows[RH_GLM_TARGET], tot);
+  for (int o = 0; o < RH_NOUT; o++) out[o] = tot[o];
+  return err;
+}
+#endif
 extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) {
   double th[RH_NTH], tot[RH_NOUT];
   for (int i = 0; i < RH_NTH; i++) th[i] = q[i];
@@ -52,7 +83,11 @@ class HostTargets:
         i = hip_source.index("// ---- generated from RIR")
         gen = hip_source[i:hip_source.index("// rh_engine.hip.h", i)]
         assert "#define RH_HAS_GATHER 0" in head, "gather-mode row code takes the gathered parameter from the kernel"
-        text = head + '#include "host_target_shim.hpp"\n' + gen + _HARNESS
+        # an anonymous namespace: every model defines rh_target<0>, rh_glm<1>, ... and several models are loaded into one process
+        harness = _HARNESS.replace('extern "C" int rh_host_eval_glm(', 'static int host_eval_glm_impl(').replace('extern "C" int rh_host_eval(', 'static int host_eval_impl(')
+        text = (head + '#include "host_target_shim.hpp"\nnamespace {\n' + gen + harness + '}\n'
+                'extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_impl(q, cols, nrows, out); }\n'
+                '#ifdef RH_GLM_TARGET\nextern "C" int rh_host_eval_glm(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_glm_impl(q, cols, nrows, out); }\n#endif\n')
         key = hashlib.sha256(text.encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "rh_host_targets")
         os.makedirs(d, exist_ok=True)
@@ -60,15 +95,22 @@ class HostTargets:
         if not os.path.exists(so):
             src = os.path.join(d, key + ".cpp")
             open(src, "w").write(text)
-            subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-fno-gnu-unique", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
         self.lib = C.CDLL(so)
         self.n_out = int(head.split("#define RH_NOUT ")[1].split("\n")[0])
 
+    def eval_glm(self, q, columns, nrows):
+        """the GLM target alone, through rh_glm<t> (predictor tables + scalar part) instead of its row()"""
+        return self._call(self.lib.rh_host_eval_glm, q, columns, nrows)
+
     def eval(self, q, columns, nrows):
+        return self._call(self.lib.rh_host_eval, q, columns, nrows)
+
+    def _call(self, fn, q, columns, nrows):
         cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
         arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[c.ctypes.data_as(C.POINTER(C.c_double)) for c in cols])
         nr = (C.c_longlong * max(1, len(nrows)))(*[int(x) for x in nrows])
         qq = np.ascontiguousarray(q, dtype=np.float64)
         out = np.zeros(self.n_out)
-        err = self.lib.rh_host_eval(qq.ctypes.data_as(C.POINTER(C.c_double)), arr, nr, out.ctypes.data_as(C.POINTER(C.c_double)))
+        err = fn(qq.ctypes.data_as(C.POINTER(C.c_double)), arr, nr, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out, err

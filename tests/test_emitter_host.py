@@ -132,3 +132,40 @@ def test_data_free_reference_models_and_many_targets():
             _check(spec, opts, rng.normal(size=(3, spec.n_params)) * 0.6, 1e-13)
     ark = models.ark_reference(json.load(open(os.path.join(G, "ark.json"))))       # 197 targets merged into one
     _check(ark, FAST, rng.normal(size=(2, 7)) * 0.3, 1e-12)
+
+
+def _glm_check(spec, qs, tol, with_data):
+    """the GLM target through rh_glm<t> (+ the other targets through their row code) vs the oracle"""
+    kw = dict(columns=spec.columns, nrows=spec.nrows) if with_data else {}
+    src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**FAST), compile=False, **kw)
+    assert "#define RH_GLM_TARGET " in src
+    gt = int(src.split("#define RH_GLM_TARGET ")[1].split("\n")[0])
+    if with_data:
+        _, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=True, refactor=True)
+        cols = [np.concatenate([np.zeros(n) if j == 0xFFFFFFFF else np.asarray(spec.columns[j], dtype=np.float64)[:n] for j, n in p]) for p in parts]
+    else:
+        cols, nrows = spec.columns, list(spec.nrows)
+    h = HostTargets(src)
+    d = O.OracleDensity(spec)
+    for q in qs:
+        full, _ = h.eval(q, cols, nrows)                                   # every target by its row code
+        only = list(nrows); rest = [0 if t == gt else n for t, n in enumerate(nrows)]
+        glm, err = h.eval_glm(q, cols, only)                               # the GLM target by its predictor tables + elem()
+        others, _ = h.eval(q, cols, rest)                                  # the remaining (data-free / unrolled) targets
+        ref, ab = d.update_both(np.asarray(q, dtype=np.float64))
+        assert err == 0
+        assert np.all(np.abs(glm + others - ref) <= tol * ab + 1e-300), (spec.name, np.max(np.abs(glm + others - ref) / (tol * ab + 1e-300)))
+        assert np.all(np.abs(full - ref) <= tol * ab + 1e-300)
+    return src
+
+
+def test_glm_tables_and_scalar_part():
+    rng = np.random.default_rng(39)
+    src = _glm_check(models.logistic(n=400, k=12), rng.normal(size=(3, 13)) * 0.4, 1e-11, False)
+    assert "rh_logit_link(s * eta, sp, sg);" in src
+    _glm_check(models.linreg(n=400, k=12), rng.normal(size=(3, 14)) * 0.4, 1e-11, False)
+    # the reference's lowerings: negated intercept as a scaled predictor, link verified on the values y takes
+    src = _glm_check(models.logistic_reference(n=600, k=50), rng.normal(size=(2, 51)) * 0.2, 1e-11, True)
+    assert "(-0x1p+0)" in src.split("pred_scale[51]")[1].split(";")[0] and "rh_logit_link(s * eta, sp, sg);" in src
+    src = _glm_check(_split_logistic(2000, 50), rng.normal(size=(2, 51)) * 0.2, 1e-11, True)
+    assert "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in src
