@@ -407,20 +407,30 @@ void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrow
     for (size_t t = 0; t < m->prog.targets.size(); t++)
       for (uint32_t j = 0; j < m->prog.targets[t].n_cols; j++, g++) { m->col_src.push_back({kept[g]}); m->col_len.push_back({nrows_t[t]}); }
   }
-  if (!re) return;
-  // fast builds: re-association, and Model.observe's 8-way split rolled back into rows (refactor.cpp); the row counts follow
   std::vector<int> owner;  // column (before rolling) -> its target
   for (size_t t = 0; t < m->prog.targets.size(); t++) for (uint32_t j = 0; j < m->prog.targets[t].n_cols; j++) owner.push_back((int)t);
   std::vector<std::vector<uint32_t>> parts;
-  rh::Program Q = rh::simplify(m->prog, true);
-  bool rederive = true;
-  if (const char *e = std::getenv("RH_REDERIVE")) rederive = std::atoi(e) != 0;
-  if (rederive) {  // the gradient in its natural form, from the value output (verified against the supplied one): rederive.cpp
-    std::vector<const double *> cp;
-    for (uint32_t c : kept) cp.push_back(columns[c]);
-    Q = rh::simplify(rh::rederive_gradients(Q, cp, nrows_t.data()), true);
+  if (re) {
+    // fast builds: gradient re-derivation, re-association, and Model.observe's 8-way split rolled back into rows
+    rh::Program Q = rh::simplify(m->prog, true);
+    bool rederive = true;
+    if (const char *e = std::getenv("RH_REDERIVE")) rederive = std::atoi(e) != 0;
+    if (rederive) {  // the gradient in its natural form, from the value output (verified against the supplied one): rederive.cpp
+      std::vector<const double *> cp;
+      for (uint32_t c : kept) cp.push_back(columns[c]);
+      Q = rh::simplify(rh::rederive_gradients(Q, cp, nrows_t.data()), true);
+    }
+    m->prog = rh::simplify(rh::refactor(Q, &parts), true);
+  } else {
+    // strict builds: the 8 slots rolled back without re-association (rollstrict.cpp), if the program is the reference's lowering
+    bool rs = changed && !m->eopt.fp_contract && m->eopt.simplify;
+    if (const char *e = std::getenv("RH_ROLL_STRICT")) rs = rs && std::atoi(e) != 0;
+    if (!rs) return;
+    rh::Program Q = rh::simplify(m->prog, false);
+    if (!rh::roll_strict(Q, parts)) return;
+    m->prog = rh::simplify(Q, false);
   }
-  m->prog = rh::simplify(rh::refactor(Q, &parts), true);
+  // the row counts and the caller-side blocks of every column follow
   std::vector<std::vector<uint32_t>> src;
   std::vector<std::vector<int64_t>> len;
   std::vector<int64_t> nr(m->prog.targets.size(), 0);
@@ -649,8 +659,8 @@ extern "C" int rh_simplify_rir(const void *rir, size_t rir_len, int fast, void *
   });
 }
 
-// Test hook (no device needed): the program after column canonicalisation (and, with refactor != 0, after the fast-mode
-// re-association / slot rolling and clean-up) as RIR again, so that the CPU suite can check on the oracle's interpreter that
+// Test hook (no device needed): the program after column canonicalisation (and, with refactor != 0, after everything else
+// rh_model_create does to it in that math mode: re-derivation / re-association / slot rolling, or the strict rolling) as RIR again, so that the CPU suite can check on the oracle's interpreter that
 // the rewrite preserves values.  parts_out receives, per column the rewritten program reads, a count followed by that many
 // (caller column index | 0xFFFFFFFF = zeros, block length) pairs: the data concatenated into it, in order -- at most
 // 3 * original columns words; nrows_out the row

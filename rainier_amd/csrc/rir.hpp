@@ -53,6 +53,10 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
 // block of the target's first column); a target's row count is the sum of its parts'.
 Program refactor(const Program &p, std::vector<std::vector<uint32_t>> *parts = nullptr);
 
+// Strict builds (rollstrict.cpp): Model.observe's 8 slots rolled back into rows without re-association -- the per-slot terms
+// are kept operation for operation, only the shared (parameter-only) terms are scaled by the exact 1 / S.  parts as for refactor.
+bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts);
+
 // Fast mode (rederive.cpp): the gradient outputs of every streamed target re-derived from its value output by reverse-mode
 // differentiation and VERIFIED against the supplied ones on sample rows (cols[c] = host data of column c, nrows per target);
 // targets that do not verify keep their outputs.

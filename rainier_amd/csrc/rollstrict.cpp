@@ -1,0 +1,301 @@
+// rollstrict.cpp -- strict builds: Model.observe's 8 slots rolled back into rows WITHOUT re-association.
+//
+// Fast builds roll the second target Model.observe writes (core/Model.scala:71-132: one expression over the columns of 8
+// observations per "row") in polynomial normal form (refactor.cpp), which re-associates products and sums.  Strict builds keep
+// the reference's arithmetic operation for operation, so here the expression is only cut along its top-level additions (the
+// Translator's left fold of a Line, compute/Translator.scala:91-125): every output is  sum_i term_i ; a term belongs to the slot
+// whose columns it reads, or to nobody (parameter-only: the Line algebra has merged the 8 copies of such a term into ONE with
+// 8 x the coefficient).  If, after renaming slot s's columns onto slot 1's, every term of slot s IS a term of slot 1 -- the very
+// same expression tree, checked by hash-consing the renamed tree into the node table -- the target becomes
+//        out = sum of slot 1's terms, in their original order  +  sum of (shared term) * (1 / S)
+// over S x the rows.  1 / S is exact for S = 8 and the shared terms are the only arithmetic that changes (by a power of two);
+// the order in which the rows are added up changes as it does in any parallel reduction.  Anything that does not match keeps the
+// 8-slot expression.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <tuple>
+
+#include "../../include/rainier_hip_rir.h"
+#include "rir.hpp"
+
+namespace rh {
+namespace {
+
+bool binary_op(uint32_t op) { return (op >= RH_RIR_ADD && op <= RH_RIR_COMPARE) || op == RH_RIR_SEQ; }
+uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xBF58476D1CE4E5B9ull; }
+
+struct Roller {
+  Program &P;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;                       // (op, a, b | ~0)
+  std::map<std::tuple<uint32_t, int32_t, std::vector<uint32_t>>, uint32_t> lookups;        // (index, low, table)
+  std::map<uint64_t, uint32_t> consts;
+  std::map<uint32_t, uint32_t> inputs;
+  std::vector<std::vector<uint32_t>> cols_memo;
+  std::vector<char> cols_done;
+  std::vector<uint64_t> hmemo;
+  std::vector<char> hdone, hasp;
+
+  explicit Roller(Program &p) : P(p) {
+    for (uint32_t i = 0; i < P.nodes.size(); i++) index(i);
+    hasp.assign(P.nodes.size(), 0);
+    for (uint32_t i = 0; i < P.nodes.size(); i++) {
+      const Node &n = P.nodes[i];
+      if (n.op == RH_RIR_INPUT) hasp[i] = n.input < P.n_params;
+      else if (n.op == RH_RIR_CONST) hasp[i] = 0;
+      else if (n.op == RH_RIR_LOOKUP) { hasp[i] = hasp[n.a]; for (uint32_t e : n.table) hasp[i] = hasp[i] || hasp[e]; }
+      else hasp[i] = hasp[n.a] || (binary_op(n.op) && hasp[n.b]);
+    }
+  }
+  void index(uint32_t i) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST) { uint64_t b; std::memcpy(&b, &n.cval, 8); consts.emplace(b, i); }
+    else if (n.op == RH_RIR_INPUT) inputs.emplace(n.input, i);
+    else if (n.op == RH_RIR_LOOKUP) lookups.emplace(std::make_tuple(n.a, n.low, n.table), i);
+    else cons.emplace(std::make_tuple(n.op, n.a, binary_op(n.op) ? n.b : 0xffffffffu), i);
+  }
+  uint32_t push(const Node &n) { P.nodes.push_back(n); const uint32_t i = (uint32_t)P.nodes.size() - 1; index(i); return i; }
+  uint32_t constant(double v) {
+    uint64_t b; std::memcpy(&b, &v, 8);
+    auto it = consts.find(b);
+    if (it != consts.end()) return it->second;
+    Node n; n.op = RH_RIR_CONST; n.cval = v;
+    return push(n);
+  }
+  uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
+    auto it = cons.find(std::make_tuple(op, a, b));
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.b = b; n.dep = P.nodes[a].dep ? P.nodes[a].dep : P.nodes[b].dep;
+    return push(n);
+  }
+  uint32_t op1(uint32_t op, uint32_t a) {
+    auto it = cons.find(std::make_tuple(op, a, 0xffffffffu));
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.dep = P.nodes[a].dep;
+    return push(n);
+  }
+  const std::vector<uint32_t> &cols(uint32_t id) {   // the column inputs a node reaches (sorted); operands have smaller ids
+    if (cols_done.size() < P.nodes.size()) { cols_done.resize(P.nodes.size(), 0); cols_memo.resize(P.nodes.size()); }
+    if (cols_done[id]) return cols_memo[id];
+    std::vector<uint32_t> stack{id};
+    while (!stack.empty()) {   // iterative post-order over the not-yet-done part
+      const uint32_t x = stack.back();
+      if (cols_done[x]) { stack.pop_back(); continue; }
+      const Node &n = P.nodes[x];
+      std::vector<uint32_t> ops;
+      if (n.op != RH_RIR_CONST && n.op != RH_RIR_INPUT) { ops.push_back(n.a); if (n.op == RH_RIR_LOOKUP) ops.insert(ops.end(), n.table.begin(), n.table.end()); else if (binary_op(n.op)) ops.push_back(n.b); }
+      bool ready = true;
+      for (uint32_t o : ops) if (!cols_done[o]) { stack.push_back(o); ready = false; }
+      if (!ready) continue;
+      std::vector<uint32_t> r;
+      if (n.op == RH_RIR_INPUT && n.input >= P.n_params) r.push_back(n.input);
+      for (uint32_t o : ops) r.insert(r.end(), cols_memo[o].begin(), cols_memo[o].end());
+      std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end());
+      cols_memo[x] = r; cols_done[x] = 1;
+      stack.pop_back();
+    }
+    return cols_memo[id];
+  }
+  uint64_t hash(uint32_t id) {   // column-blind structure
+    if (hdone.size() < P.nodes.size()) { hdone.resize(P.nodes.size(), 0); hmemo.resize(P.nodes.size(), 0); }
+    if (hdone[id]) return hmemo[id];
+    for (uint32_t x = 0; x <= id; x++) {   // operands first: ascending ids
+      if (hdone[x]) continue;
+      const Node &n = P.nodes[x];
+      uint64_t h = mix(0x51, n.op);
+      if (n.op == RH_RIR_CONST) { uint64_t b; std::memcpy(&b, &n.cval, 8); h = mix(h, b); }
+      else if (n.op == RH_RIR_INPUT) h = n.input >= P.n_params ? mix(h, 0xC01) : mix(mix(h, 0x9A7), n.input);
+      else {
+        h = mix(h, hmemo[n.a]);
+        if (n.op == RH_RIR_LOOKUP) { h = mix(h, (uint64_t)(int64_t)n.low); for (uint32_t e : n.table) h = mix(h, hmemo[e]); }
+        else if (binary_op(n.op)) h = mix(h, hmemo[n.b]);
+      }
+      hmemo[x] = h; hdone[x] = 1;
+    }
+    return hmemo[id];
+  }
+  // the tree of `id` with columns renamed, hash-consed into the node table (an identical tree comes back as its existing id)
+  uint32_t rename(uint32_t id, const std::map<uint32_t, uint32_t> &cmap, std::map<uint32_t, uint32_t> &memo) {
+    auto it = memo.find(id);
+    if (it != memo.end()) return it->second;
+    const Node n = P.nodes[id];
+    uint32_t r;
+    if (n.dep == 0) r = id;
+    else if (n.op == RH_RIR_INPUT) {
+      auto c = cmap.find(n.input);
+      if (c == cmap.end()) r = id;
+      else { auto ii = inputs.find(c->second); if (ii != inputs.end()) r = ii->second; else { Node q = n; q.input = c->second; r = push(q); } }
+    } else if (n.op == RH_RIR_LOOKUP) {
+      Node q = n; q.a = rename(n.a, cmap, memo);
+      for (uint32_t &e : q.table) e = rename(e, cmap, memo);
+      auto li = lookups.find(std::make_tuple(q.a, q.low, q.table));
+      r = li != lookups.end() ? li->second : push(q);
+    } else if (binary_op(n.op)) { const uint32_t a = rename(n.a, cmap, memo), b = rename(n.b, cmap, memo); r = op2(n.op, a, b); }
+    else r = op1(n.op, rename(n.a, cmap, memo));
+    return memo[id] = r;
+  }
+  void walk(uint32_t id, std::vector<uint32_t> &order, std::map<uint32_t, char> &seen_col, std::map<uint32_t, char> &seen_node) {
+    if (P.nodes[id].dep == 0 || seen_node.count(id)) return;
+    seen_node[id] = 1;
+    const Node &n = P.nodes[id];
+    if (n.op == RH_RIR_INPUT) { if (n.input >= P.n_params && !seen_col.count(n.input)) { seen_col[n.input] = 1; order.push_back(n.input); } return; }
+    walk(n.a, order, seen_col, seen_node);
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) walk(e, order, seen_col, seen_node); }
+    else if (binary_op(n.op)) walk(n.b, order, seen_col, seen_node);
+  }
+};
+
+struct Term { uint32_t node; bool neg; };
+void flatten(const Program &P, uint32_t id, bool neg, std::vector<Term> &out) {
+  std::vector<std::pair<uint32_t, bool>> stack{{id, neg}};
+  std::vector<Term> rev;
+  while (!stack.empty()) {      // left operand first -> original left-to-right order
+    auto [x, ng] = stack.back(); stack.pop_back();
+    const Node &n = P.nodes[x];
+    if (n.dep != 0 && (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB)) { stack.push_back({n.b, n.op == RH_RIR_SUB ? !ng : ng}); stack.push_back({n.a, ng}); }
+    else rev.push_back({x, ng});
+  }
+  out.insert(out.end(), rev.begin(), rev.end());
+}
+
+}  // namespace
+
+bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
+  parts.clear();
+  for (uint32_t c = 0; c < P.n_cols_total; c++) parts.push_back({c});
+  Roller R(P);
+  bool any = false;
+  const size_t NT = P.targets.size();
+  std::vector<std::vector<uint32_t>> keep(NT);
+  std::vector<std::vector<std::vector<uint32_t>>> src(NT);
+  for (size_t t = 0; t < NT; t++) for (uint32_t j = 0; j < P.targets[t].n_cols; j++) { keep[t].push_back(P.targets[t].input_start + j); src[t].push_back({P.targets[t].input_start + j}); }
+  for (size_t t = 0; t < NT; t++) {
+    if (!P.targets[t].n_cols) continue;
+    const size_t no = P.targets[t].outputs.size();
+    std::vector<std::vector<Term>> terms(no);
+    for (size_t o = 0; o < no; o++) flatten(P, P.targets[t].outputs[o], false, terms[o]);
+    // components of the columns: joined when one term reads both
+    std::map<uint32_t, uint32_t> parent;
+    std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { auto it = parent.find(x); if (it == parent.end()) { parent[x] = x; return x; } if (it->second == x) return x; const uint32_t r = find(it->second); parent[x] = r; return r; };
+    std::map<uint32_t, char> param_comp;
+    for (auto &to : terms) for (const Term &tm : to) {
+      const std::vector<uint32_t> c = R.cols(tm.node);
+      for (size_t i = 1; i < c.size(); i++) parent[find(c[i])] = find(c[0]);
+      if (!c.empty()) find(c[0]);
+    }
+    for (auto &to : terms) for (const Term &tm : to) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && R.hasp[tm.node]) param_comp[find(c[0])] = 1; }
+    std::map<uint32_t, std::vector<uint32_t>> comp;
+    for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
+    std::vector<std::vector<uint32_t>> comps;
+    std::map<uint32_t, char> loose;
+    for (auto &kv : comp) { std::sort(kv.second.begin(), kv.second.end()); if (param_comp.count(kv.first)) comps.push_back(kv.second); else for (uint32_t c : kv.second) loose[c] = 1; }
+    std::sort(comps.begin(), comps.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+    if (comps.size() < 2) continue;
+    std::map<uint32_t, size_t> comp_of;
+    for (size_t c = 0; c < comps.size(); c++) for (uint32_t col : comps[c]) comp_of[col] = c;
+    // structural classes of the components -> slots (see refactor.cpp try_roll)
+    std::vector<uint64_t> ch(comps.size(), 0x5107);
+    for (size_t o = 0; o < no; o++) {
+      std::vector<std::vector<uint64_t>> hs(comps.size());
+      for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && !loose.count(c[0])) hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg)); }
+      for (size_t c = 0; c < comps.size(); c++) { std::sort(hs[c].begin(), hs[c].end()); uint64_t h = mix(ch[c], o); for (uint64_t x : hs[c]) h = mix(h, x); ch[c] = h; }
+    }
+    std::map<uint64_t, std::vector<size_t>> classes;
+    for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
+    size_t S = 0; bool ok = true;
+    for (auto &kv : classes) { if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false; }
+    if (!ok || S < 2 || (S & (S - 1)) != 0) continue;            // 1 / S must be exact
+    std::vector<std::map<uint32_t, char>> slot_cols(S);
+    for (auto &kv : classes) for (size_t s = 0; s < S; s++) for (uint32_t col : comps[kv.second[s]]) slot_cols[s][col] = 1;
+    std::map<uint32_t, size_t> slot_of;
+    for (size_t s = 0; s < S; s++) for (auto &kv : slot_cols[s]) slot_of[kv.first] = s;
+    // corresponding columns: a walk over the slot's terms in column-blind hash order
+    std::vector<std::vector<uint32_t>> order(S);
+    {
+      std::vector<std::map<uint32_t, char>> seen_col(S), seen_node(S);
+      for (size_t o = 0; o < no; o++) {
+        std::vector<std::vector<std::pair<uint64_t, uint32_t>>> st(S);
+        for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && !loose.count(c[0])) st[slot_of[c[0]]].push_back({mix(R.hash(tm.node), tm.neg), tm.node}); }
+        for (size_t s = 0; s < S; s++) { std::stable_sort(st[s].begin(), st[s].end(), [](auto &a, auto &b) { return a.first < b.first; }); for (auto &x : st[s]) R.walk(x.second, order[s], seen_col[s], seen_node[s]); }
+      }
+    }
+    const size_t mcols = order[0].size();
+    for (size_t s = 0; s < S && ok; s++) ok = order[s].size() == mcols && mcols == slot_cols[s].size();
+    if (!ok) continue;
+    // verify: slot s's terms, renamed, are slot 0's terms (as multisets, with their signs)
+    std::vector<std::vector<Term>> slot0(no);
+    for (size_t o = 0; o < no && ok; o++) {
+      std::vector<std::vector<std::pair<uint32_t, bool>>> st(S);
+      for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && !loose.count(c[0])) st[slot_of[c[0]]].push_back({tm.node, tm.neg}); }
+      std::vector<std::pair<uint32_t, bool>> want = st[0];
+      std::sort(want.begin(), want.end());
+      for (size_t s = 1; s < S && ok; s++) {
+        std::map<uint32_t, uint32_t> cmap, memo;
+        for (size_t i = 0; i < mcols; i++) cmap[order[s][i]] = order[0][i];
+        std::vector<std::pair<uint32_t, bool>> got;
+        for (auto &x : st[s]) got.push_back({R.rename(x.first, cmap, memo), x.second});
+        std::sort(got.begin(), got.end());
+        ok = got == want;
+      }
+    }
+    if (!ok) continue;
+    // rebuild: original order of the terms that stay (slot 0, loose), shared terms scaled by the exact 1 / S
+    const uint32_t inv_s = R.constant(1.0 / (double)S);
+    std::vector<uint32_t> outs(no);
+    for (size_t o = 0; o < no; o++) {
+      uint32_t acc = 0xFFFFFFFFu;
+      for (const Term &tm : terms[o]) {
+        const std::vector<uint32_t> c = R.cols(tm.node);
+        uint32_t x;
+        if (c.empty()) x = R.op2(RH_RIR_MUL, tm.node, inv_s);
+        else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = tm.node;
+        else continue;
+        if (acc == 0xFFFFFFFFu) acc = tm.neg ? R.op2(RH_RIR_SUB, R.constant(0.0), x) : x;
+        else acc = R.op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x);
+      }
+      outs[o] = acc == 0xFFFFFFFFu ? R.constant(0.0) : acc;
+    }
+    P.targets[t].outputs = outs;
+    keep[t] = order[0];
+    src[t].assign(mcols, {});
+    for (size_t i = 0; i < mcols; i++) for (size_t s = 0; s < S; s++) src[t][i].push_back(order[s][i]);
+    for (auto &kv : loose) {
+      if (kv.first < P.targets[t].input_start || kv.first >= P.targets[t].input_start + P.targets[t].n_cols) continue;
+      keep[t].push_back(kv.first);
+      std::vector<uint32_t> cs{kv.first};
+      for (size_t s = 1; s < S; s++) cs.push_back(0xFFFFFFFFu);
+      src[t].push_back(cs);
+    }
+    any = true;
+  }
+  if (!any) return false;
+  // renumber the columns that are left
+  std::map<uint32_t, uint32_t> renum;
+  std::vector<std::vector<double>> dom;
+  uint32_t in = P.n_params, colc = 0;
+  const uint32_t np = P.n_params;
+  parts.clear();
+  for (size_t t = 0; t < NT; t++) {
+    P.targets[t].input_start = in; P.targets[t].col0 = colc; P.targets[t].n_cols = (uint32_t)keep[t].size();
+    for (size_t i = 0; i < keep[t].size(); i++) {
+      renum[keep[t][i]] = in + (uint32_t)i;
+      std::vector<uint32_t> cs;
+      for (uint32_t old : src[t][i]) cs.push_back(old == 0xFFFFFFFFu ? old : old - np);
+      parts.push_back(cs);
+      dom.push_back({});
+    }
+    in += P.targets[t].n_cols; colc += P.targets[t].n_cols;
+  }
+  P.n_inputs = in; P.n_cols_total = colc; P.col_domain = dom;
+  for (Node &n : P.nodes)
+    if (n.op == RH_RIR_INPUT && n.input >= np) {
+      auto it = renum.find(n.input);
+      if (it != renum.end()) n.input = it->second;
+      else { n.op = RH_RIR_CONST; n.cval = 0.0; n.input = 0; n.dep = 0; }   // only dead nodes still name a dropped column
+    }
+  return true;
+}
+
+}  // namespace rh

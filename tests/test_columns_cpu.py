@@ -163,6 +163,11 @@ def test_eight_way_split_is_rolled_back_into_rows():
     s2, _ = _rewritten(spec, fast=False, refactor=False)
     assert s2.nrows == [0, 0, 124] and 8 * (k + 1) <= len(s2.columns) <= 8 * (k + 2) + 2
     np.testing.assert_allclose(O.OracleDensity(s2).update(q), O.OracleDensity(spec).update(q), rtol=1e-14)
+    # ... and rolled back WITHOUT re-association (csrc/rollstrict.cpp): slot 1's terms operation for operation, the shared terms
+    # scaled by the exact 1/8; y - 1 stays a column of its own in strict mode (signed zeros)
+    s4, kept4 = _rewritten(spec, fast=False, refactor=True)
+    assert s4.nrows == [0, 0, 992] and len(s4.columns) == k + 2 and all(len(p) == 8 for p in kept4)
+    np.testing.assert_allclose(O.OracleDensity(s4).update(q), O.OracleDensity(spec).update(q), rtol=1e-14)
 
 
 def test_cfg4_as_the_reference_hands_it_over():

@@ -24,7 +24,7 @@ def _check(spec, opts, qs, tol, with_data=True):
     src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, **kw)
     fast = bool(opts.get("fp_contract"))
     if kw:
-        _, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=fast)
+        _, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=True)   # as rh_model_create
         cols = [np.concatenate([np.zeros(n) if j == 0xFFFFFFFF else np.asarray(spec.columns[j], dtype=np.float64)[:n] for j, n in p]) for p in parts]
     else:
         cols, nrows = spec.columns, spec.nrows
@@ -82,8 +82,6 @@ def test_reference_lowerings_through_all_passes():
     rng = np.random.default_rng(37)
     for spec, nq in ((models.logistic_reference(n=600, k=8), 9), (_split_logistic(1000, 6), 7), (_split_logistic(2000, 50), 51)):
         for opts in (STRICT, FAST):
-            if opts is STRICT and spec.n_params > 20:
-                continue                      # the strict 8-slot expression of the 50-covariate model is a 2 MB translation unit
             _check(spec, opts, rng.normal(size=(2, nq)) * 0.3, 1e-11)
     mix = models.lowdim_gaussmix_reference(json.load(open(os.path.join(G, "lowdim_gaussmix.json"))))
     for opts in (STRICT, FAST):
