@@ -170,6 +170,7 @@ struct rh_model {
   std::vector<void *> dev_cols;
   void *d_coltab = nullptr;                  // device table of the column pointers (rh_model_data.cols)
   std::vector<std::vector<int64_t>> col_len; // ... and the length of every block (0xFFFFFFFF in col_src = a block of zeros)
+  std::vector<std::vector<double>> synth_cols; // columns lifted out of many same-shaped data-free targets (lift.cpp)
   std::vector<std::vector<uint32_t>> col_src; // engine column -> the caller's columns concatenated into it (one, unless the
                                              // target was rolled back from Model.observe's 8-way split: refactor.cpp)
   int64_t rows_total = 0;
@@ -357,18 +358,33 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
   return opts->device;
 }
 
-// parse + (when there are more targets than the engine holds) merge the runs of data-free targets; the caller's per-target row
-// counts are re-indexed to the targets that are left
-void load_program(rh_model *m, const void *rir, size_t rir_len, const int64_t *nrows, std::vector<int64_t> &nrows_m) {
+// parse; when there are more targets than the engine holds: many data-free targets of one shape become one streamed target
+// (lift.cpp: its columns are synthesised and owned by the model) and the remaining runs of data-free targets are merged.  cols =
+// the caller's column pointers followed by the synthesised ones; nrows_m = the row count of every target that is left.
+void load_program(rh_model *m, const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
+                  std::vector<const double *> &cols, std::vector<int64_t> &nrows_m) {
   std::string err;
   if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
   if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "a density program (header kind 0) is needed"};
-  std::vector<uint32_t> oldt;
-  rh::merge_data_free_targets(m->prog, oldt);
+  const uint32_t caller_cols = m->prog.n_cols_total;
+  std::vector<uint32_t> old1, old2;
+  bool lift = true;
+  if (const char *e = std::getenv("RH_LIFT_CONSTANTS")) lift = std::atoi(e) != 0;
+  if (lift) rh::lift_constants(m->prog, m->synth_cols, old1);
+  else for (uint32_t t = 0; t < m->prog.targets.size(); t++) old1.push_back(t);
+  rh::merge_data_free_targets(m->prog, old2);
   if (m->prog.targets.size() > RH_MAX_TARGETS)
     throw Fail{RH_E_UNSUPPORTED, "more than 64 targets are left after merging the data-free ones (RH_MAX_TARGETS)"};
+  cols.clear();
+  for (uint32_t c = 0; c < caller_cols; c++) cols.push_back(columns ? columns[c] : nullptr);   // (rh_lower_only has no data)
+  for (const auto &sc : m->synth_cols) cols.push_back(sc.data());
   nrows_m.assign(m->prog.targets.size(), 0);
-  for (size_t t = 0; t < m->prog.targets.size(); t++) if (nrows && m->prog.targets[t].n_cols) nrows_m[t] = nrows[oldt[t]];
+  for (size_t t = 0; t < m->prog.targets.size(); t++) {
+    if (!m->prog.targets[t].n_cols) continue;
+    const uint32_t orig = old1[old2[t]];
+    if (orig == 0xFFFFFFFFu) nrows_m[t] = (int64_t)m->synth_cols[0].size();
+    else nrows_m[t] = nrows ? nrows[orig] : -1;
+  }
 }
 
 // derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
@@ -465,21 +481,21 @@ void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void 
 }  // namespace
 
 // ---- seam 1 -----------------------------------------------------------------------------------------
-extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
+extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *const *columns_in, const int64_t *nrows,
                                const rh_compile_opts *opts, rh_model **out) {
   if (!out) { g_err = "rh_model_create: out is NULL"; return RH_E_INVALID; }
   *out = nullptr;
   rh_model *m = new rh_model();
   const int rc = guard(m, [&] {
     std::vector<int64_t> nrows_in;
-    load_program(m, rir, rir_len, nrows, nrows_in);
+    std::vector<const double *> colv;
+    load_program(m, rir, rir_len, columns_in, nrows, colv, nrows_in);
+    if (m->prog.n_cols_total > m->synth_cols.size() && !columns_in) throw Fail{RH_E_INVALID, "columns is NULL but the model has data columns"};
+    const double *const *columns = colv.data();
     const int dev0 = apply_compile_opts(m, opts);
     int dev = dev0;
-    for (size_t t = 0; t < m->prog.targets.size(); t++) {
-      const auto &T = m->prog.targets[t];
-      if (T.n_cols && (!nrows || nrows_in[t] < 0)) throw Fail{RH_E_INVALID, "negative or missing row count"};
-      if (T.n_cols && !columns) throw Fail{RH_E_INVALID, "columns is NULL but the model has data columns"};
-    }
+    for (size_t t = 0; t < m->prog.targets.size(); t++)
+      if (m->prog.targets[t].n_cols && nrows_in[t] < 0) throw Fail{RH_E_INVALID, "negative or missing row count"};
     std::vector<int64_t> nrows_t;
     canonicalize(m, columns, nrows_in.data(), nrows_t);
     assemble_source(m);
@@ -630,9 +646,10 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
   rh_model m;
   const int rc = guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
-    load_program(&m, rir, rir_len, nrows, nrows_in);
+    std::vector<const double *> colv;
+    load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
     (void)apply_compile_opts(&m, opts);
-    if (columns && nrows) { std::vector<int64_t> nrows_t; canonicalize(&m, columns, nrows_in.data(), nrows_t); }
+    if ((columns && nrows) || !m.synth_cols.empty()) { std::vector<int64_t> nrows_t; canonicalize(&m, colv.data(), nrows_in.data(), nrows_t); }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
@@ -670,12 +687,13 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
                                    int64_t *nrows_out) {
   rh_model m;
   return guard(nullptr, [&] {
-    std::string err;
-    if (!rh::parse_rir(rir, rir_len, m.prog, err)) throw Fail{RH_E_INVALID, err};
+    std::vector<int64_t> nrows_in, nr;
+    std::vector<const double *> colv;
+    load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
+    if (!m.synth_cols.empty()) throw Fail{RH_E_UNSUPPORTED, "rh_canonicalize_rir: the program lifts constants into columns of its own (use rh_lift_rir)"};
     m.eopt.fp_contract = fast != 0;
-    m.eopt.simplify = refactor != 0;   // canonicalize() re-associates only when the clean-up pass is on
-    std::vector<int64_t> nr;
-    canonicalize(&m, columns, nrows, nr);
+    m.eopt.simplify = refactor != 0;   // canonicalize() re-associates / rolls only when the clean-up pass is on
+    canonicalize(&m, colv.data(), nrows_in.data(), nr);
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
     uint32_t w = 0;
@@ -685,6 +703,24 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
     }
     *n_parts_words = w;
     for (size_t t = 0; t < nr.size(); t++) nrows_out[t] = nr[t];
+  });
+}
+
+// Test hook (no device needed): what load_program makes of a program with more than RH_MAX_TARGETS targets -- same-shaped
+// data-free targets lifted into one streamed target (lift.cpp), the other runs merged -- as RIR, plus the synthesised columns
+// (column-major, malloc'ed: ncols x nrows doubles; the caller frees with rh_free).  Only for programs without caller columns.
+extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *out_len, double **cols_out, uint32_t *ncols, uint32_t *nrows) {
+  rh_model m;
+  return guard(nullptr, [&] {
+    std::vector<int64_t> nrows_in;
+    std::vector<const double *> colv;
+    load_program(&m, rir, rir_len, nullptr, nullptr, colv, nrows_in);
+    const std::vector<unsigned char> b = rh::write_rir(m.prog);
+    *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
+    *ncols = (uint32_t)m.synth_cols.size();
+    *nrows = m.synth_cols.empty() ? 0u : (uint32_t)m.synth_cols[0].size();
+    *cols_out = (double *)std::malloc(sizeof(double) * std::max<size_t>(1, (size_t)*ncols * *nrows));
+    for (size_t c = 0; c < m.synth_cols.size(); c++) std::memcpy(*cols_out + c * *nrows, m.synth_cols[c].data(), sizeof(double) * *nrows);
   });
 }
 

@@ -134,6 +134,7 @@ bool merge_data_free_targets(Program &P, std::vector<uint32_t> &old_target_of) {
   }
   P.targets.swap(nt);
   old_target_of = first;
+  recompute_deps(P);   // Node::dep names a target by its index
   return true;
 }
 

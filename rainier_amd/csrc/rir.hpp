@@ -40,6 +40,13 @@ std::vector<unsigned char> write_rir(const Program &p);
 // old_target_of[new target] = index of the first original target it stands for (row targets keep their identity).
 bool merge_data_free_targets(Program &P, std::vector<uint32_t> &old_target_of);
 
+// lift.cpp: when the program has more targets than the engine holds, the largest group (>= 32) of data-free targets of one shape
+// -- the same expression with different constants folded in: one Model.observe per observation -- becomes ONE row target whose
+// columns (returned in synth, one row per member) are the constants that differ.  old_target_of as above; 0xFFFFFFFF marks the
+// synthesised target (appended last; its columns follow the caller's).
+bool lift_constants(Program &P, std::vector<std::vector<double>> &synth, std::vector<uint32_t> &old_target_of);
+void recompute_deps(Program &P);
+
 // Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns
 // true when the program was rewritten.

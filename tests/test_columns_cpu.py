@@ -295,37 +295,47 @@ def test_lowdim_gaussmix_reference_benchmark_model():
         np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
 
 
-def test_ark_reference_benchmark_model_has_197_targets_and_the_engine_merges_them():
+def test_ark_reference_benchmark_model_has_197_targets_and_the_engine_rolls_them_into_rows():
     """bench/stan/ARK.scala observes one value at a time (195 x Model.observe(...).merge): one inlined, data-free target per
-    observation.  rh_model_create folds every run of data-free targets into one when there are more than RH_MAX_TARGETS."""
-    import json, os
+    observation, the same expression with different constants folded in.  With more targets than the engine holds, the loader
+    lifts the constants that differ into columns of ONE streamed target (csrc/lift.cpp) -- bit for bit the same values on the
+    oracle's interpreter -- and merges what data-free runs are left."""
+    import json, os, struct
     ark = models.ark_reference(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ark.json"))))
     assert len(ark.nrows) == 197 and ark.columns == [] and ark.n_params == 7
-    import struct
-    w = struct.unpack("<6I", ark.rir[:24])
-    assert w[3] == 197
-    # 65 data-free targets (just above the limit) of a small model lower to ONE rh_target; 64 stay as they are
+    rir2, cols, nr = _capi.lift_rir(ark.rir)
+    w = struct.unpack("<%dI" % (len(rir2) // 4), rir2)
+    assert w[3] == 3 and nr == 195 and len(cols) >= 6           # prior, Model.empty, 195 rows
+    nrows, pos = [], 6
+    for _ in range(w[3]):
+        nrows.append(nr if w[pos] else 0); pos += 3 + w[2]
+    lifted = dataclasses.replace(ark, rir=rir2, columns=cols, nrows=nrows)
+    for q in np.random.default_rng(6).normal(size=(4, 7)) * 0.3:
+        assert np.array_equal(O.OracleDensity(lifted).update(q), O.OracleDensity(ark).update(q))
+    # the row code is an AR(5) regression row again: as many basis sums as a 5-covariate regression needs
+    src, _ = _capi.lower_only(ark.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True), compile=False)
+    assert "#define RH_NROWTARGETS 1\n" in src and int(src.split("#define RH_NACC_MAX ")[1].split("\n")[0]) <= 8
+    # 64 targets are left alone; 66 same-shaped ones are lifted; members of different shapes are merged instead
     from rainier_amd import modeling as MM
-    def small(n_obs):
+    def small(n_obs, shapes=1):
         mu = MM.Normal(0, 1).latent
         m = MM.Model([MM.Real.zero])
         for i in range(n_obs):
-            m = MM.Model.observe([0.1 * i], MM.Normal(mu, 1.0)).merge(m)
-        return m.compile("many_targets_%d" % n_obs)
-    s65, s62 = small(64), small(62)          # + prior + Model.empty: 66 and 64 targets
-    src65, _ = _capi.lower_only(s65.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
-    src62, _ = _capi.lower_only(s62.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))
-    assert "#define RH_NTARGETS 1\n" in src65 and "#define RH_NTARGETS 64\n" in src62
-
-
-def test_glmm_row_code_is_the_natural_poisson_row():
-    """After re-derivation and rolling the emitter sees  eq(site, k, g, 0) / eq(year, j, g, 0)  basis terms: two scatter families with
-    one g, parameter-only tables read through inv[], hyper-parameter gradients as linear combinations in finish()."""
-    spec = _glmm()
-    src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True), columns=spec.columns, nrows=spec.nrows)
-    assert "#define RH_NACC_MAX 141\n" in src                      # the value + 100 site entries + 40 year entries
-    row = src.split("static RH_DEV void row(")[-1].split("static RH_DEV void finish(")[0]
-    assert row.count("acc[") == 3 and "(unsigned)kk < 100u) acc[1 + kk] +=" in row and "(unsigned)kk < 40u) acc[101 + kk] +=" in row
-    assert row.count("RH_EXP(") == 1 and "inv[0 + k" in row and "inv[100 + k" in row and row.count("?") == 2
-    fin = src.split("static RH_DEV void finish(")[-1].split("\n  }\n")[0]
-    assert max(line.count("S[") for line in fin.split("\n")) >= 100   # d/d mu = sum of the 100 site sums
+            d = MM.Normal(mu, 1.0) if i % shapes == 0 else MM.Cauchy(mu, 1.0 + i)
+            m = MM.Model.observe([0.37 + 0.1 * i], d).merge(m)      # (no 0.0 / 1.0 among the values: those fold away structure)
+        return m.compile("many_targets_%d_%d" % (n_obs, shapes))
+    src62, _ = _capi.lower_only(small(62).rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), compile=False)
+    src64, _ = _capi.lower_only(small(64).rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), compile=False)
+    assert "#define RH_NTARGETS 64\n" in src62 and "#define RH_NROWTARGETS 0\n" in src62
+    assert "#define RH_NTARGETS 3\n" in src64 and "#define RH_NROWTARGETS 1\n" in src64
+    mixed = small(90, shapes=3)                                  # 30 Normal + 60 Cauchy observations: the 60 are lifted, the rest merged
+    srcm, _ = _capi.lower_only(mixed.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), compile=False)
+    assert "#define RH_NROWTARGETS 1\n" in srcm
+    rirm, colsm, nrm = _capi.lift_rir(mixed.rir)
+    wm = struct.unpack("<%dI" % (len(rirm) // 4), rirm)
+    nrows_m, pos = [], 6
+    for _ in range(wm[3]):
+        nrows_m.append(nrm if wm[pos] else 0); pos += 3 + wm[2]
+    lm = dataclasses.replace(mixed, rir=rirm, columns=colsm, nrows=nrows_m)
+    q = np.array([0.37])
+    np.testing.assert_allclose(O.OracleDensity(lm).update(q), O.OracleDensity(mixed).update(q), rtol=1e-14)
