@@ -286,7 +286,7 @@ def eight_schools_reference() -> ModelSpec:
 def ark_reference(data) -> ModelSpec:
     """bench/stan/ARK.scala:9-21 in the reference's model text: an AR(5) series observed ONE value at a time --
     `Model.observe(ys(t), Normal(mu, sigma)).merge(m)` 195 times -- so the TargetGroup has one (inlined, data-free) target per
-    observation: 197 targets, which the engine merges into one at rh_model_create (csrc/rir.cpp merge_data_free_targets).
+    observation: 197 targets, which rh_model_create turns into one streamed target of 195 rows (csrc/lift.cpp).
     data = {"ys": 200 floats} (tests/golden/ark.json)."""
     from . import modeling as M
     ys = list(data["ys"])
