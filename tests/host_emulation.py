@@ -32,6 +32,49 @@ template <int T> static void rh_host_target(const double (&th)[RH_NTH], const do
     rh_host_target<T + 1>(th, cols, nrows, tot, err);
   }
 }
+#if RH_HAS_GATHER
+// gather mode (a parameter table indexed by a data column, cfg 5): the row code takes the gathered table entry `gz` from the
+// kernel and hands back the scatter value `sv`; the table parameters' gradients are the per-group sums of sv (rh_grad_gather_kernel)
+template <int T> static void rh_host_gather_target(const double *q, const double (&th)[RH_NTH], const double *const *cols, const long long *nrows,
+                                                   double (&tot)[RH_NOUT], double *tg, int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    double inv[TG::NINV > 0 ? TG::NINV : 1];
+    TG::invariants(th, inv, err);
+    if constexpr (!TG::HAS_ROWS) {
+      TG::row(th, inv, nullptr, tot, err);
+    } else {
+      double S[TG::NACC > 0 ? TG::NACC : 1];
+      for (int j = 0; j < TG::NACC; j++) S[j] = 0.0;
+      double c[TG::NCOLS > 0 ? TG::NCOLS : 1];
+      for (long long r = 0; r < nrows[T]; r++) {
+        for (int j = 0; j < TG::NCOLS; j++) c[j] = cols[TG::COL0 + j][r];
+        double gz = 0.0, sv = 0.0;
+        int g = 0;
+        if constexpr (TG::HAS_GATHER) {
+          g = (int)c[TG::G_COL] - TG::G_LOW;
+          if (g < 0 || g >= TG::G_COUNT) { err = 1; continue; }
+          gz = q[TG::G_FIRST + g];
+        }
+        TG::row(th, inv, c, gz, S, sv, err);
+        if constexpr (TG::HAS_GATHER) tg[g] += sv;
+      }
+      TG::finish(th, inv, S, (double)nrows[T], tot);
+    }
+    rh_host_gather_target<T + 1>(q, th, cols, nrows, tot, tg, err);
+  }
+}
+extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) {
+  double th[RH_NTH], tot[RH_NOUT];
+  for (int i = 0; i < RH_NTH; i++) th[i] = q[i];
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  for (int i = 0; i < 1 + RH_NVARS; i++) out[i] = 0.0;
+  int err = 0;
+  rh_host_gather_target<0>(q, th, cols, nrows, tot, out + 1 + RH_NSHARED, err);
+  for (int o = 0; o < RH_NOUT; o++) out[o] = tot[o];
+  return err;
+}
+#else
 #ifdef RH_GLM_TARGET
 // the GLM lowering of the same target (what rh_grad_glm_kernel contracts on the matrix cores): eta = sum_k scale_k theta_k x_k,
 // the scalar part elem(eta, columns) -> (w, others), basis sums  S[pred_acc_k] += w x_k,  S[other_acc_j] += other_j, then finish()
@@ -72,6 +115,7 @@ extern "C" int rh_host_eval(const double *q, const double *const *cols, const lo
   for (int o = 0; o < RH_NOUT; o++) out[o] = tot[o];
   return err;
 }
+#endif
 '''
 
 
@@ -82,7 +126,6 @@ class HostTargets:
         head = hip_source[:hip_source.index("// rh_shared.h")]
         i = hip_source.index("// ---- generated from RIR")
         gen = hip_source[i:hip_source.index("// rh_engine.hip.h", i)]
-        assert "#define RH_HAS_GATHER 0" in head, "gather-mode row code takes the gathered parameter from the kernel"
         # an anonymous namespace: every model defines rh_target<0>, rh_glm<1>, ... and several models are loaded into one process
         harness = _HARNESS.replace('extern "C" int rh_host_eval_glm(', 'static int host_eval_glm_impl(').replace('extern "C" int rh_host_eval(', 'static int host_eval_impl(')
         text = (head + '#include "host_target_shim.hpp"\nnamespace {\n' + gen + harness + '}\n'
@@ -97,7 +140,7 @@ class HostTargets:
             open(src, "w").write(text)
             subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-fno-gnu-unique", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
         self.lib = C.CDLL(so)
-        self.n_out = int(head.split("#define RH_NOUT ")[1].split("\n")[0])
+        self.n_out = 1 + int(head.split("#define RH_NVARS ")[1].split("\n")[0])    # (gather mode: RH_NOUT covers the shared outputs only)
 
     def eval_glm(self, q, columns, nrows):
         """the GLM target alone, through rh_glm<t> (predictor tables + scalar part) instead of its row()"""

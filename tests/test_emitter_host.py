@@ -178,3 +178,15 @@ def test_glm_tables_and_scalar_part():
     assert "(-0x1p+0)" in src.split("pred_scale[51]")[1].split(";")[0] and "rh_logit_link(s * eta, sp, sg);" in src
     src = _glm_check(_split_logistic(2000, 50), rng.normal(size=(2, 51)) * 0.2, 1e-11, True)
     assert "static constexpr int P = 51, NOTHER = 1, NTHU = 0, NCOLS = 51;" in src
+
+
+def test_gather_mode_row_code():
+    """cfg 5's shape: a parameter table indexed by a data column.  The gather row code takes the table entry from the kernel and hands
+    back ONE scatter value; emulated with the kernel's bookkeeping (per-group sums), it must give the oracle's value and all
+    gradients -- literal and with the verified closed-form negative-binomial term."""
+    rng = np.random.default_rng(40)
+    for spec in (models.hier_negbin(120, 9), models.hier_negbin(70, 31)):
+        for opts in (STRICT, dict(factor_outputs=True), FAST):
+            src = _check(spec, opts, rng.normal(size=(2, spec.n_params)) * 0.3, 1e-11, with_data=False)
+            assert "#define RH_HAS_GATHER 1\n" in src
+    assert "lk_g" in src
