@@ -151,8 +151,9 @@ def canonicalize_rir(rir: bytes, columns, nrows, fast: bool = False, refactor: b
     cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
     arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
     nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
-    words = (C.c_uint32 * max(3, 3 * len(cols)))()
-    nw = C.c_uint32(0)
+    cap = 64 + 3 * len(cols) * 20          # a rolled column has one block per slot (8, or 9 with the initial chunk)
+    words = (C.c_uint32 * cap)()
+    nw = C.c_uint32(cap)
     nr_out = (C.c_int64 * max(1, len(nrows)))()
     out, n = C.c_void_p(), C.c_size_t(0)
     buf = C.create_string_buffer(rir, len(rir))

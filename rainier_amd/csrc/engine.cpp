@@ -679,12 +679,12 @@ extern "C" int rh_simplify_rir(const void *rir, size_t rir_len, int fast, void *
 // Test hook (no device needed): the program after column canonicalisation (and, with refactor != 0, after everything else
 // rh_model_create does to it in that math mode: re-derivation / re-association / slot rolling, or the strict rolling) as RIR again, so that the CPU suite can check on the oracle's interpreter that
 // the rewrite preserves values.  parts_out receives, per column the rewritten program reads, a count followed by that many
-// (caller column index | 0xFFFFFFFF = zeros, block length) pairs: the data concatenated into it, in order -- at most
-// 3 * original columns words; nrows_out the row
+// (caller column index | 0xFFFFFFFF = zeros, block length) pairs: the data concatenated into it, in order (*n_parts_words
+// holds the capacity on entry); nrows_out the row
 // count of every target.  Returns RH_OK also when nothing was rewritten.
 extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows, int fast,
                                    int refactor, void **out, size_t *out_len, uint32_t *parts_out, uint32_t *n_parts_words,
-                                   int64_t *nrows_out) {
+                                   int64_t *nrows_out) {   // *n_parts_words: in = capacity of parts_out, out = words written
   rh_model m;
   return guard(nullptr, [&] {
     std::vector<int64_t> nrows_in, nr;
@@ -697,6 +697,9 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
     uint32_t w = 0;
+    size_t need = 0;
+    for (const auto &cs : m.col_src) need += 1 + 2 * cs.size();
+    if (need > *n_parts_words) throw Fail{RH_E_INVALID, "rh_canonicalize_rir: parts_out is too small"};
     for (size_t c = 0; c < m.col_src.size(); c++) {
       parts_out[w++] = (uint32_t)m.col_src[c].size();
       for (size_t b = 0; b < m.col_src[c].size(); b++) { parts_out[w++] = m.col_src[c][b]; parts_out[w++] = (uint32_t)m.col_len[c][b]; }

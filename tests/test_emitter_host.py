@@ -190,3 +190,57 @@ def test_gather_mode_row_code():
             src = _check(spec, opts, rng.normal(size=(2, spec.n_params)) * 0.3, 1e-11, with_data=False)
             assert "#define RH_HAS_GATHER 1\n" in src
     assert "lk_g" in src
+
+
+def _random_expr(rng, g, leaves, depth):
+    """a random smooth-enough expression over `leaves` (domain-safe: logs of 1 + u^2, divisions by 1 + u^2, small exponents)"""
+    if depth == 0 or rng.random() < 0.15:
+        return leaves[int(rng.integers(len(leaves)))]
+    op = int(rng.integers(9))
+    a = _random_expr(rng, g, leaves, depth - 1)
+    if op <= 1:
+        return a + _random_expr(rng, g, leaves, depth - 1)
+    if op == 2:
+        return a - _random_expr(rng, g, leaves, depth - 1)
+    if op == 3:
+        return a * _random_expr(rng, g, leaves, depth - 1)
+    if op == 4:
+        b = _random_expr(rng, g, leaves, depth - 1)
+        return a / (b * b + 1.0)
+    if op == 5:
+        return (a * 0.3).exp()
+    if op == 6:
+        return (a * a + 1.0).log()
+    if op == 7:
+        return a ** float(rng.integers(2, 4))
+    b = _random_expr(rng, g, leaves, depth - 1)
+    return g.lookup(a.compare(b), [a, a + b, b * 0.5], -1)          # a select on a row-level compare
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_eight_slot_programs(seed):
+    """fuzz: random expressions as the per-observation term of an 8-slot Model.observe-shaped target (with a derived column per
+    slot), gradient by the authoring DSL; both math modes through every pass and the emitter, as host code, against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    n, S, P = 48, 8, 4
+    cols = []
+    for s in range(S):
+        x = rng.uniform(-1, 1, n)
+        cols += [x, rng.uniform(-1, 1, n), -x]
+    g = Graph(P, [3 * S])
+    th = [g.param(i) for i in range(P)]
+    shape_rng_state = rng.integers(1 << 30)
+    val = None
+    for s in range(S):
+        x, z, mx = g.col(0, 3 * s), g.col(0, 3 * s + 1), g.col(0, 3 * s + 2)
+        leaves = th + [x, z, mx * 0.5, g.const(0.7), th[0] * x + th[1], th[2] * z]
+        term = _random_expr(np.random.default_rng(shape_rng_state), g, leaves, 4) + th[3] * z      # the same shape in every slot
+        val = term if val is None else val + term
+    val = val + th[0] * th[1] * 8.0                                     # a shared, parameter-only term (8 copies merged)
+    spec = ModelSpec("fuzz_%d" % seed, g.compile([val]), cols, [n], P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, P)) * 0.6 if np.all(np.isfinite(d.update(q)))][:3]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        _check(spec, opts, qs, 1e-9)
