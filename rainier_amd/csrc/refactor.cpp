@@ -378,36 +378,58 @@ struct Refactor {
     for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); for (size_t i = 1; i < c.size(); i++) parent[find(c[i])] = find(c[0]); if (!c.empty()) find(c[0]); }
     std::map<uint32_t, std::vector<uint32_t>> comp;
     for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
-    // components that only occur in parameter-free monomials are loose data terms, not slots
+    // every component belongs to a structural class (column-blind hash of its monomials in every output).  A slot is one
+    // connected component when the observation's density ties its columns together (the usual case), or one component of every
+    // class when it is additively separable (sum_s A(x_s) + B(z_s): any pairing of the A and B terms into rows gives the same
+    // sum; the s-th of each class, in column order, is taken).  Classes that parameters reach fix the slot count S; a
+    // parameter-free class with S members rolls like any other; a parameter-free component outside such a class is a LOOSE
+    // data term -- the reference's Line keeps the sum of all data-only terms as one column -- and may only be kept, zero-padded
+    // for the other slots, when it is linear in its column (coefficient * column: it vanishes on the padding)
     std::map<uint32_t, char> has_param_comp;
     for (auto &p : po) for (auto &m : p) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && mono_has_param(m.first)) has_param_comp[find(c[0])] = 1; }
     std::map<uint32_t, char> is_loose;
-    std::vector<std::vector<uint32_t>> comps;   // the components that parameters reach
-    for (auto &kv : comp) {
-      std::sort(kv.second.begin(), kv.second.end());
-      if (has_param_comp.count(kv.first)) comps.push_back(kv.second);
-      else for (uint32_t c : kv.second) { R.loose.push_back(c); is_loose[c] = 1; }
-    }
-    std::sort(comps.begin(), comps.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+    std::vector<std::vector<uint32_t>> comps;
+    std::vector<char> comp_param;
+    for (auto &kv : comp) { std::sort(kv.second.begin(), kv.second.end()); comps.push_back(kv.second); comp_param.push_back(has_param_comp.count(kv.first) ? 1 : 0); }
     {
-      // a slot is one connected component when the observation's density ties its columns together (the usual case), or one
-      // component of every structural class when it is additively separable (sum_s A(x_s) + B(z_s): any pairing of the A and
-      // B terms into rows gives the same sum; the s-th of each class, in column order, is taken)
+      std::vector<size_t> idx(comps.size());
+      for (size_t c = 0; c < comps.size(); c++) idx[c] = c;
+      std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return comps[a][0] < comps[b][0]; });
+      std::vector<std::vector<uint32_t>> cs; std::vector<char> cp;
+      for (size_t c : idx) { cs.push_back(comps[c]); cp.push_back(comp_param[c]); }
+      comps.swap(cs); comp_param.swap(cp);
+    }
+    {
       std::map<uint32_t, size_t> comp_of;
       for (size_t c = 0; c < comps.size(); c++) for (uint32_t col : comps[c]) comp_of[col] = c;
       std::vector<uint64_t> ch(comps.size(), 0x5107);
+      std::vector<char> linear(comps.size(), 1);    // all its monomials are  coefficient * column
       for (size_t o = 0; o < no; o++) {
         std::vector<Poly> part(comps.size());
-        for (auto &m : po[o]) { const std::vector<uint32_t> c = mono_cols(m.first); if (!c.empty() && !is_loose.count(c[0])) part[comp_of[c[0]]].push_back(m); }
+        for (auto &m : po[o]) {
+          const std::vector<uint32_t> c = mono_cols(m.first);
+          if (c.empty()) continue;
+          part[comp_of[c[0]]].push_back(m);
+          if (!(m.first.size() == 1 && m.first[0].second == 1 && atoms[m.first[0].first].op == RH_RIR_INPUT)) linear[comp_of[c[0]]] = 0;
+        }
         for (size_t c = 0; c < comps.size(); c++) ch[c] = mix(mix(ch[c], o), h_poly(part[c]));
       }
       std::map<uint64_t, std::vector<size_t>> classes;
       for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
       size_t S0 = 0;
-      for (auto &kv : classes) { if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return why(R, "structural classes of unequal size"); }
+      for (auto &kv : classes) {
+        if (!comp_param[kv.second[0]]) continue;
+        if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return why(R, "structural classes of unequal size");
+      }
       if (S0 < 2) return why(R, "fewer than two structurally equal components");
       R.slots.assign(S0, {});
-      for (auto &kv : classes) for (size_t s = 0; s < S0; s++) for (uint32_t col : comps[kv.second[s]]) R.slots[s].push_back(col);
+      for (auto &kv : classes) {
+        if (kv.second.size() == S0) { for (size_t s = 0; s < S0; s++) for (uint32_t col : comps[kv.second[s]]) R.slots[s].push_back(col); continue; }
+        for (size_t c : kv.second) {
+          if (comp_param[c] || !linear[c]) return why(R, "a data-only term is neither one per slot nor linear in its column");
+          for (uint32_t col : comps[c]) { R.loose.push_back(col); is_loose[col] = 1; }
+        }
+      }
     }
     if (R.slots.size() < 2) return why(R, "fewer than two slots");
     std::sort(R.slots.begin(), R.slots.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });

@@ -188,27 +188,51 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
     for (auto &to : terms) for (const Term &tm : to) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && R.hasp[tm.node]) param_comp[find(c[0])] = 1; }
     std::map<uint32_t, std::vector<uint32_t>> comp;
     for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
+    // every component gets a structural class; classes that parameters reach fix the slot count S; a parameter-free class with S
+    // members rolls like any other; a parameter-free component outside such a class is a loose data term and may only be kept
+    // (zero-padded for the other slots) when its terms are  column  or  constant * column  (they vanish on the padding)
     std::vector<std::vector<uint32_t>> comps;
+    std::vector<char> comp_param;
     std::map<uint32_t, char> loose;
-    for (auto &kv : comp) { std::sort(kv.second.begin(), kv.second.end()); if (param_comp.count(kv.first)) comps.push_back(kv.second); else for (uint32_t c : kv.second) loose[c] = 1; }
-    std::sort(comps.begin(), comps.end(), [](const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) { return a[0] < b[0]; });
+    for (auto &kv : comp) { std::sort(kv.second.begin(), kv.second.end()); comps.push_back(kv.second); comp_param.push_back(param_comp.count(kv.first) ? 1 : 0); }
+    {
+      std::vector<size_t> idx(comps.size());
+      for (size_t c = 0; c < comps.size(); c++) idx[c] = c;
+      std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return comps[a][0] < comps[b][0]; });
+      std::vector<std::vector<uint32_t>> cs; std::vector<char> cp;
+      for (size_t c : idx) { cs.push_back(comps[c]); cp.push_back(comp_param[c]); }
+      comps.swap(cs); comp_param.swap(cp);
+    }
     if (comps.size() < 2) continue;
     std::map<uint32_t, size_t> comp_of;
     for (size_t c = 0; c < comps.size(); c++) for (uint32_t col : comps[c]) comp_of[col] = c;
-    // structural classes of the components -> slots (see refactor.cpp try_roll)
     std::vector<uint64_t> ch(comps.size(), 0x5107);
+    std::vector<char> linear(comps.size(), 1);
+    auto is_col = [&](uint32_t x) { return P.nodes[x].op == RH_RIR_INPUT && P.nodes[x].input >= P.n_params; };
     for (size_t o = 0; o < no; o++) {
       std::vector<std::vector<uint64_t>> hs(comps.size());
-      for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && !loose.count(c[0])) hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg)); }
+      for (const Term &tm : terms[o]) {
+        const std::vector<uint32_t> c = R.cols(tm.node);
+        if (c.empty()) continue;
+        hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg));
+        const Node &n = P.nodes[tm.node];
+        const bool lin = is_col(tm.node) || (n.op == RH_RIR_MUL && ((is_col(n.a) && P.nodes[n.b].op == RH_RIR_CONST) || (is_col(n.b) && P.nodes[n.a].op == RH_RIR_CONST)));
+        if (!lin) linear[comp_of[c[0]]] = 0;
+      }
       for (size_t c = 0; c < comps.size(); c++) { std::sort(hs[c].begin(), hs[c].end()); uint64_t h = mix(ch[c], o); for (uint64_t x : hs[c]) h = mix(h, x); ch[c] = h; }
     }
     std::map<uint64_t, std::vector<size_t>> classes;
     for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
     size_t S = 0; bool ok = true;
-    for (auto &kv : classes) { if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false; }
+    for (auto &kv : classes) { if (!comp_param[kv.second[0]]) continue; if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false; }
     if (!ok || S < 2 || (S & (S - 1)) != 0) continue;            // 1 / S must be exact
+    for (auto &kv : classes) {
+      if (kv.second.size() == S) continue;
+      for (size_t c : kv.second) { if (comp_param[c] || !linear[c]) ok = false; for (uint32_t col : comps[c]) loose[col] = 1; }
+    }
+    if (!ok) continue;
     std::vector<std::map<uint32_t, char>> slot_cols(S);
-    for (auto &kv : classes) for (size_t s = 0; s < S; s++) for (uint32_t col : comps[kv.second[s]]) slot_cols[s][col] = 1;
+    for (auto &kv : classes) if (kv.second.size() == S) for (size_t s = 0; s < S; s++) for (uint32_t col : comps[kv.second[s]]) slot_cols[s][col] = 1;
     std::map<uint32_t, size_t> slot_of;
     for (size_t s = 0; s < S; s++) for (auto &kv : slot_cols[s]) slot_of[kv.first] = s;
     // corresponding columns: a walk over the slot's terms in column-blind hash order

@@ -244,3 +244,29 @@ def test_random_eight_slot_programs(seed):
         pytest.skip("no finite evaluation point")
     for opts in (STRICT, FAST):
         _check(spec, opts, qs, 1e-9)
+
+
+def test_data_only_terms_roll_per_slot_or_stay_linear():
+    """found by the fuzz above: a parameter-free NONLINEAR term of each slot (log(1 + exp(0.3 x_s)^2)) must roll with its slot --
+    padding its column with zeros for the other slots would add f(0) per padded row; only  coefficient * column  terms may be kept
+    as zero-padded loose columns (the reference's Line keeps the sum of all data-only terms as ONE column: GLMMPoisson2)."""
+    rng = np.random.default_rng(77)
+    n, S = 40, 8
+    cols = []
+    for s in range(S):
+        x = rng.uniform(-1, 1, n)
+        cols += [x, rng.uniform(-1, 1, n), -x]
+    cols.append(rng.normal(size=n))                       # one merged data-only column, as the Line algebra would leave it
+    g = Graph(2, [3 * S + 1])
+    th = [g.param(0), g.param(1)]
+    val = g.col(0, 3 * S) * -1.0
+    for s in range(S):
+        x, z, mx = g.col(0, 3 * s), g.col(0, 3 * s + 1), g.col(0, 3 * s + 2)
+        val = val + (((x * 0.3).exp() * (x * 0.3).exp()) + 1.0).log() + th[1] * z + (mx * th[0]) * 0.5
+    spec = ModelSpec("data_only_terms", g.compile([val]), cols, [n], 2, {})
+    for fast in (False, True):
+        rir, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=True)
+        assert nrows == [S * n] and len(parts) == 3 and sum(1 for p in parts if any(j == 0xFFFFFFFF for j, _ in p)) == 1
+    qs = rng.normal(size=(3, 2)) * 0.5
+    for opts in (STRICT, FAST):
+        _check(spec, opts, qs, 1e-11)
