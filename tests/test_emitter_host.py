@@ -270,3 +270,59 @@ def test_data_only_terms_roll_per_slot_or_stay_linear():
     qs = rng.normal(size=(3, 2)) * 0.5
     for opts in (STRICT, FAST):
         _check(spec, opts, qs, 1e-11)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_lookup_table_models(seed):
+    """fuzz: Poisson-type rows with two Lookups over index columns (tables of hierarchical / raw parameter entries, 8-19 and 3-9
+    entries), 8 slots, a derived column per slot: rolling, scatter families, invariant tables, linear-combination outputs"""
+    rng = np.random.default_rng(9000 + seed)
+    n, S = 40, 8
+    K, K2 = int(rng.integers(8, 20)), int(rng.integers(3, 10))
+    hier = rng.random() < 0.5
+    P = 3 + K + K2
+    cols = []
+    for s in range(S):
+        x = rng.uniform(-1, 1, n)
+        cols += [rng.integers(0, 6, n).astype(float), rng.integers(0, K, n).astype(float), rng.integers(0, K2, n).astype(float), x, -x]
+    g = Graph(P, [5 * S])
+    th = [g.param(i) for i in range(P)]
+    tab = [(th[0] + th[3 + k] * th[1].exp()) if hier else th[3 + k] for k in range(K)]
+    tab2 = [th[3 + K + j] * 0.5 + th[2] * (0.1 * j) for j in range(K2)]
+    val = None
+    for s in range(S):
+        y, i1, i2, x, mx = [g.col(0, 5 * s + j) for j in range(5)]
+        eta = g.lookup(i1, tab, 0) + g.lookup(i2, tab2, 0) + th[2] * x + (mx * th[2]) * 0.25
+        term = y * eta - eta.exp()
+        val = term if val is None else val + term
+    spec = ModelSpec("fuzz_lookup_%d" % seed, g.compile([val]), cols, [n], P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(4, P)) * 0.4 if np.all(np.isfinite(d.update(q)))][:2]
+    assert qs
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-9)
+    assert "+ kk] +=" in src and "#define RH_NROWTARGETS 1\n" in src          # fast build: rolled, scatter families
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_single_observation_models(seed):
+    """fuzz: 66-119 data-free targets of one random shape with random constants (one Model.observe per observation): lifted into one
+    streamed target, both math modes"""
+    rng = np.random.default_rng(12000 + seed)
+    P, N = 3, int(rng.integers(66, 120))
+    g = Graph(P, [0] * (N + 1))
+    th = [g.param(i) for i in range(P)]
+    st, depth = rng.integers(1 << 30), int(rng.integers(2, 5))
+    targets = [th[0] * th[0] * -0.5 + th[1] * -0.1]
+    for _ in range(N):
+        c1, c2 = g.const(float(rng.uniform(0.2, 2.0))), g.const(float(rng.normal()))
+        leaves = th + [c1, c2, th[0] * c1 + th[1], th[2] * c2]
+        targets.append(_random_expr(np.random.default_rng(st), g, leaves, depth) + th[2] * c1)
+    spec = ModelSpec("fuzz_single_%d" % seed, g.compile(targets), [], [0] * (N + 1), P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(4, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-9)
+        assert "#define RH_NROWTARGETS 1\n" in src
