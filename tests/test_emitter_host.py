@@ -326,3 +326,41 @@ def test_random_single_observation_models(seed):
     for opts in (STRICT, FAST):
         src = _check(spec, opts, qs, 1e-9)
         assert "#define RH_NROWTARGETS 1\n" in src
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_glms_through_the_glm_lowering(seed):
+    """fuzz: 9-21 predictors with random signs / scales (in the data: negated columns; in the expression: scaled terms, a scaled
+    intercept), four likelihood families; the GLM lowering (predictor tables, pred_scale, scalar part incl. the verified closed
+    forms) emulated on the host against the oracle"""
+    rng = np.random.default_rng(15000 + seed)
+    n, k = 64, int(rng.integers(9, 22))
+    P = k + 2
+    X = [rng.normal(size=n) for _ in range(k)]
+    lik = int(rng.integers(4))
+    y = rng.integers(0, 2, n).astype(float) if lik == 0 else (rng.poisson(2.0, n).astype(float) if lik in (1, 3) else rng.normal(size=n))
+    cols = [y] + [(-x if rng.random() < 0.4 else x) for x in X]
+    g = Graph(P, [1 + k])
+    th = [g.param(i) for i in range(P)]
+    c = [g.col(0, j) for j in range(1 + k)]
+    eta = th[0] * float(rng.choice([1.0, -1.0, 0.5]))
+    for j in range(k):
+        sc = float(rng.choice([1.0, -1.0, 2.0])) if rng.random() < 0.3 else 1.0
+        term = th[1 + j] * c[1 + j]
+        eta = eta + (term * sc if sc != 1.0 else term)
+    if lik == 0:
+        p = 1.0 / ((eta * -1.0).exp() + 1.0)
+        row = g.eq(c[0], 0.0, (1.0 - p).log(), p.log())
+    elif lik == 1:
+        row = c[0] * eta - eta.exp()
+    elif lik == 2:
+        r = c[0] - eta
+        row = (r * r) * (th[P - 1] * -2.0).exp() / -2.0 - th[P - 1]
+    else:
+        p = 1.0 / ((eta * -1.0).exp() * 5.0 + 1.0)
+        row = (1.0 - p).log() * 5.0 + c[0] * p.log()
+    spec = ModelSpec("fuzz_glm_%d" % seed, g.compile([row]), cols, [n], P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(4, P)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    assert qs
+    _glm_check(spec, qs, 1e-9, True)
