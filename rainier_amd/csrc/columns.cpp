@@ -93,18 +93,21 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       for (char o : ok) if (!o) return false;
       return true;
     };
-    for (int j = 0; j < nc && nr >= 16; j++) {   // on a handful of rows every column is an affine image of every other
+    // on a handful of rows every column is an affine image of every other: a small target (Model.observe's initial chunk, when it
+    // is not unrolled) is only searched for copies, negations and products -- the relations its big sibling's slots have too
+    const bool small = nr < 16;
+    for (int j = 0; j < nc && (nr >= 16 || (nr >= 3 && !allow_unroll)); j++) {
       const double *c = col[(size_t)j];
       CExpr e;
       bool found = false;
       // constant (a NaN column is left alone: RIR has no NaN constants)
-      if (c[0] == c[0] && verify(j, [&](int64_t) { return c[0]; })) { e.kind = CExpr::CONST; e.c = c[0]; found = true; }
+      if (!small && c[0] == c[0] && verify(j, [&](int64_t) { return c[0]; })) { e.kind = CExpr::CONST; e.c = c[0]; found = true; }
       for (int a = 0; a < j && !found; a++) {
         const double *ca = col[(size_t)a];
         if (verify(j, [&](int64_t r) { return ca[r]; })) { e.kind = CExpr::ALIAS; e.a = a; found = true; break; }
         if (verify(j, [&](int64_t r) { return -ca[r]; })) { e.kind = CExpr::NEG; e.a = a; found = true; break; }
       }
-      for (int a = 0; a < j && !found; a++) {
+      for (int a = 0; a < j && !found && !small; a++) {
         if (ex[(size_t)a].kind == CExpr::CONST) continue;
         const double *ca = col[(size_t)a];
         {

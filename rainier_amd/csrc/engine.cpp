@@ -389,7 +389,24 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
 
 // derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
 // fills m->col_src (engine column -> the caller's columns it is made of) and the per-target row counts
+void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll);
+// Fast builds first try WITHOUT unrolling Model.observe's initial chunk: after the gradient re-derivation the chunk is the same
+// function as a slot of the big target and is appended to it as rows (refactor.cpp), so no observation is written into the
+// generated source and the code-object cache keeps working across data sets.  If a small row target is still there afterwards
+// (not isomorphic, loose data columns, ...), or in strict builds, the chunk is unrolled into a data-free target instead.
 void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t) {
+  if (m->eopt.fp_contract && m->eopt.simplify && m->prog.n_cols_total > 0) {
+    const rh::Program saved = m->prog;
+    canonicalize_once(m, columns, nrows, nrows_t, false);
+    int64_t big = 0; bool small_left = false;
+    for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) big = std::max(big, nrows_t[t]);
+    for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols && nrows_t[t] >= 1 && nrows_t[t] <= 8 && big >= 16) small_left = true;
+    if (!small_left) return;
+    m->prog = saved;
+  }
+  canonicalize_once(m, columns, nrows, nrows_t, true);
+}
+void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll) {
   std::string err;
   nrows_t.assign(m->prog.targets.size(), 0);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) nrows_t[t] = nrows[t];
@@ -413,7 +430,7 @@ void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrow
           t0.input + nd.table.size() == P.n_params) gather = true;
     }
   }
-  if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, !gather);
+  if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, allow_unroll && !gather);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (!m->prog.targets[t].n_cols) nrows_t[t] = 0;   // an unrolled initial chunk
   bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
   if (const char *e = std::getenv("RH_REFACTOR")) re = re && std::atoi(e) != 0;

@@ -240,7 +240,8 @@ struct Refactor {
   // size, plus column-free ("shared") monomials.  If renaming group s's columns onto group 1's (in column order) turns
   // every output's group-s part into its group-1 part, the target is rolled back:  S times the rows, 1/S of the columns,
   //      out = shared / S + part_1          (S = 8: the division is exact)
-  // (the initial chunk Model.observe writes as a target of its own has been unrolled into a data-free target by columns.cpp).
+  // and the initial chunk Model.observe writes as a row target of its own (1-8 observations), whose outputs are that same
+  // function of its own columns, is appended as further rows -- no observation ends up in the generated source.
   std::map<uint32_t, std::vector<uint32_t>> acols;   // atom -> the column inputs it reaches (sorted)
   const std::vector<uint32_t> &atom_cols(uint32_t a) {
     auto it = acols.find(a);
@@ -358,13 +359,15 @@ struct Refactor {
     std::vector<Poly> outs;                     // per output: shared / S + part_1 + loose data terms
     std::vector<uint32_t> loose;                // columns of parameter-free terms outside every slot (the reference's Line keeps the
                                                 // sum of all data-only terms as ONE column): kept, padded with zeros for the other slots
+    int init_target = -1;
+    std::vector<uint32_t> init_cols;            // the initial chunk's columns, same positions
   };
   // RH_ROLL_WHY=1: say on stderr why a target with several column groups was not rolled
   static Rolled why(Rolled R, const char *reason) {
     if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: target not rolled back into rows: %s\n", reason);
     return R;
   }
-  Rolled try_roll(size_t t) {
+  Rolled try_roll(size_t t, const std::vector<char> &taken) {
     Rolled R;
     const Target &T = P.targets[t];
     const size_t no = T.outputs.size();
@@ -462,6 +465,28 @@ struct Refactor {
       for (auto &m : loose) out.push_back(m);
       normalize(out);
       R.outs.push_back(out);
+    }
+    // an initial chunk: another row target whose outputs are the same function of its own columns
+    for (size_t t0 = 0; t0 < P.targets.size() && R.init_target < 0 && R.loose.empty(); t0++) {
+      const Target &T0 = P.targets[t0];
+      if (t0 == t || !T0.n_cols || taken[t0] || T0.outputs.size() != no) continue;
+      std::vector<Poly> p0(no);
+      std::vector<uint32_t> used;                 // its columns in the order the same structural walk meets them
+      {
+        std::map<uint32_t, char> seen;
+        for (size_t o = 0; o < no; o++) {
+          p0[o] = poly_of(T0.outputs[o]);
+          Poly withcols;
+          for (auto &m : p0[o]) if (!mono_cols(m.first).empty()) withcols.push_back(m);
+          walk_poly(withcols, used, seen);
+        }
+      }
+      if (used.size() != mcols) continue;
+      ColMap c0; for (size_t i = 0; i < mcols; i++) c0[used[i]] = R.slots[0][i];
+      std::map<uint32_t, uint32_t> mm;
+      bool same = true;
+      for (size_t o = 0; o < no && same; o++) same = approx_equal(rename_poly(p0[o], c0, mm), R.outs[o]);
+      if (same) { R.init_target = (int)t0; R.init_cols = used; }
     }
     R.ok = true;
     return R;
@@ -677,6 +702,7 @@ Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
     if (R.bad) return P;
   }
   const size_t NT = P.targets.size();
+  std::vector<char> merged(NT, 0);                                 // initial-chunk targets appended to a rolled target
   std::vector<std::vector<uint32_t>> keep_cols(NT);                // per target: the old input ids it keeps, in order
   std::vector<std::vector<std::vector<uint32_t>>> col_src(NT);     // per kept column: the old input ids concatenated into it
   for (size_t t = 0; t < NT; t++) {
@@ -686,9 +712,9 @@ Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
   }
   for (size_t t = 0; t < NT; t++) {
     Target &T = R.Q.targets[t];
-    if (!T.n_cols) continue;
+    if (!T.n_cols || merged[t]) continue;
     if (parts) {
-      const Refactor::Rolled rr = R.try_roll(t);
+      const Refactor::Rolled rr = R.try_roll(t, merged);
       if (rr.ok) {
         std::vector<uint32_t> rebuilt;
         for (const Poly &p : rr.outs) rebuilt.push_back(R.build_poly(R.intern(p)));
@@ -696,6 +722,7 @@ Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
         keep_cols[t] = rr.slots[0];
         col_src[t].assign(rr.slots[0].size(), {});
         for (size_t i = 0; i < rr.slots[0].size(); i++) {
+          if (rr.init_target >= 0) col_src[t][i].push_back(rr.init_cols[i]);
           for (auto &sl : rr.slots) col_src[t][i].push_back(sl[i]);
         }
         for (uint32_t c : rr.loose) {   // [its data, zeros for the rows of the other slots]
@@ -703,6 +730,11 @@ Program refactor(const Program &P, std::vector<std::vector<uint32_t>> *parts) {
           std::vector<uint32_t> cs{c};
           for (size_t sl = 1; sl < rr.slots.size(); sl++) cs.push_back(ZERO_PART);
           col_src[t].push_back(cs);
+        }
+        if (rr.init_target >= 0) {
+          const size_t t0 = (size_t)rr.init_target;
+          merged[t0] = 1; keep_cols[t0].clear(); col_src[t0].clear();
+          for (uint32_t &o : R.Q.targets[t0].outputs) o = R.k(0.0);
         }
         continue;
       }

@@ -151,8 +151,10 @@ def test_eight_way_split_is_rolled_back_into_rows():
     spec, cols = _logistic_split(n, k)
     assert spec.nrows == [0, 8, 124] and len(spec.columns) == 273           # 8 + 8 x 124 observations, 35 + 8 x ~30 columns
     s3, kept = _rewritten(spec, fast=True, refactor=True)
-    # initial chunk unrolled into a data-free target; the 8 slots are rows again; y and the k covariates are all that is read
-    assert s3.nrows == [0, 0, 992] and len(s3.columns) == k + 1 and all(len(p) == 8 for p in kept)
+    # the 8 slots are rows again and the initial chunk's 8 observations are appended as rows too (9 blocks per column: nothing of
+    # the data ends up in the program); y and the k covariates are all that is read
+    assert s3.nrows == [0, 0, 1000] and len(s3.columns) == k + 1 and all(len(p) == 9 for p in kept)
+    assert len(s3.rir) < 1500
     for q in np.random.default_rng(2).normal(size=(4, k + 1)) * 0.6:
         np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-12, atol=1e-12 * n)
     # ... and it is the natural form's function of the same data
@@ -262,7 +264,7 @@ def test_realtest_expressions_survive_rederivation_and_rolling(name, fn):
 
 def test_split_linear_regression_rolls_back_to_the_natural_row():
     """4 covariates through Model.observe (not inlinable: 21 distributed terms): 8 + 8 x 124 observations, 111 columns ->
-    one streamed target of 5 columns and 992 rows whose row code is the natural form's (residual once, 5 basis sums)."""
+    one streamed target of 5 columns and 1000 rows whose row code is the natural form's (residual once, 5 basis sums)."""
     n, k = 1000, 4
     cols = models.linreg_data(n, k)
     sigma = M.Exponential(1).latent; alpha = M.Normal(0, 1).latent; betas = M.Normal(0, 1).latentVec(k)
@@ -270,7 +272,7 @@ def test_split_linear_regression_rolls_back_to_the_natural_row():
                                split=True).compile("linreg_split_4", inline=False)
     assert spec.nrows == [0, 8, 124] and len(spec.columns) > 100
     s3, kept = _rewritten(spec, fast=True, refactor=True)
-    assert s3.nrows == [0, 0, 992] and len(s3.columns) == k + 1
+    assert s3.nrows == [0, 0, 1000] and len(s3.columns) == k + 1
     q = np.array([-0.3, 0.5, 1.0, -2.0, 0.5, 0.25])
     np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
     np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(models.linreg(n=n, k=k, columns=cols)).update(q), rtol=1e-10)
@@ -284,13 +286,13 @@ def test_split_linear_regression_rolls_back_to_the_natural_row():
 def test_lowdim_gaussmix_reference_benchmark_model():
     """bench/stan/LowDimGaussMix.scala in the reference's model text: Mixture.logDensity = Real.logSumExp (a max through Real.gt
     selects), sigma = |latent| (whose derivative is a select on a parameter between row-level sums).  174 columns -> 2, the 8
-    slots rolled back: 992 rows."""
+    slots and the initial chunk rolled back: 1000 rows."""
     import json, os
     data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lowdim_gaussmix.json")))
     spec = models.lowdim_gaussmix_reference(data)
     assert spec.nrows == [0, 8, 124] and spec.n_params == 5 and len(spec.columns) == 174
     s3, kept = _rewritten(spec, fast=True, refactor=True)
-    assert s3.nrows == [0, 0, 992] and len(s3.columns) == 2
+    assert s3.nrows == [0, 0, 1000] and len(s3.columns) == 2          # all 1000 observations as rows
     for q in np.random.default_rng(5).normal(size=(4, 5)) * 0.7:
         np.testing.assert_allclose(O.OracleDensity(s3).update(q), O.OracleDensity(spec).update(q), rtol=1e-11)
 

@@ -364,3 +364,38 @@ def test_random_glms_through_the_glm_lowering(seed):
     qs = [q for q in rng.normal(size=(4, P)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
     assert qs
     _glm_check(spec, qs, 1e-9, True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_initial_chunk_plus_eight_slots(seed):
+    """fuzz: the two row targets Model.observe writes -- an initial chunk of 1-8 observations and the 8-slot expression -- with a
+    random per-observation term.  Fast builds append the chunk to the rolled target as rows (or unroll it when that fails), strict
+    builds unroll it; either way the generated code must reproduce the original program."""
+    rng = np.random.default_rng(21000 + seed)
+    n, S, P = 40, 8, 4
+    n0 = int(rng.integers(1, 9))
+    x0 = rng.uniform(-1, 1, n0)
+    cols = [x0, rng.uniform(-1, 1, n0), -x0]
+    for s in range(S):
+        x = rng.uniform(-1, 1, n)
+        cols += [x, rng.uniform(-1, 1, n), -x]
+    g = Graph(P, [3, 3 * S])
+    th = [g.param(i) for i in range(P)]
+    st, depth = rng.integers(1 << 30), int(rng.integers(2, 5))
+
+    def term(x, z, mx):
+        leaves = th + [x, z, mx * 0.5, g.const(0.7), th[0] * x + th[1], th[2] * z]
+        return _random_expr(np.random.default_rng(st), g, leaves, depth) + th[3] * z + th[0] * th[1]
+    v0 = term(g.col(0, 0), g.col(0, 1), g.col(0, 2))
+    val = None
+    for s in range(S):
+        t_ = term(g.col(1, 3 * s), g.col(1, 3 * s + 1), g.col(1, 3 * s + 2))
+        val = t_ if val is None else val + t_
+    spec = ModelSpec("fuzz_chunk_%d" % seed, g.compile([v0, val]), cols, [n0, n], P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, P)) * 0.6 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-9)
+        assert "#define RH_NROWTARGETS 1\n" in src
