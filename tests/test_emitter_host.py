@@ -399,3 +399,43 @@ def test_random_initial_chunk_plus_eight_slots(seed):
     for opts in (STRICT, FAST):
         src = _check(spec, opts, qs, 1e-9)
         assert "#define RH_NROWTARGETS 1\n" in src
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_reference_text_models(seed):
+    """fuzz through the REAL front end (rainier_amd/compute.py, modeling.py): random regression models in the reference's model text
+    -- Normal / Bernoulli-logit / Poisson-log / Laplace / Cauchy / NegativeBinomial-logit likelihoods, 1-5 covariates, or a
+    hierarchical Lookup table over a site column -- through Model.observe with and without its split; whatever gradientColumns the
+    reference's algebra produces, the generated code of both math modes must reproduce the original program"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(30000 + seed)
+    k, n, fam = int(rng.integers(1, 6)), int(rng.integers(20, 500)), int(rng.integers(8))
+    X = [rng.normal(size=n) for _ in range(k)]
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k)
+    eta = lambda u: a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])
+    covs = X
+    if fam == 0:
+        ys = rng.normal(size=n); sg = M.Exponential(1).latent; fn = lambda *u: M.Normal(eta(u), sg)
+    elif fam == 1:
+        ys = rng.integers(0, 2, n).astype(float); fn = lambda *u: M.Bernoulli(eta(u).logistic)
+    elif fam == 2:
+        ys = rng.poisson(2.0, n).astype(float); fn = lambda *u: M.Poisson(eta(u).exp())
+    elif fam == 3:
+        ys = rng.normal(size=n); sg = M.Exponential(1).latent; fn = lambda *u: M.Laplace(eta(u), sg)
+    elif fam == 4:
+        ys = rng.normal(size=n); sg = M.Exponential(1).latent; fn = lambda *u: M.Cauchy(eta(u), sg)
+    elif fam == 5:
+        ys = rng.poisson(3.0, n).astype(float); fn = lambda *u: M.NegativeBinomial(eta(u).logistic, 5.0)
+    else:
+        K = int(rng.integers(3, 30))
+        alphas = M.Normal(M.Normal(0, 2).latent, M.Uniform(0, 2).latent).latentVec(K)
+        covs = [rng.integers(0, K, n).astype(float), X[0]]
+        ys = rng.poisson(2.0, n).astype(float) if fam == 6 else rng.integers(0, 2, n).astype(float)
+        lin = lambda s, u: CC.Lookup.apply(s, alphas) + bs[0] * u
+        fn = (lambda s, u: M.Poisson(lin(s, u).exp())) if fam == 6 else (lambda s, u: M.Bernoulli(lin(s, u).logistic))
+    spec = M.Model.observe_vec(ys, covs, fn, split=bool(rng.random() < 0.7)).compile("fuzz_text_%d" % seed, inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.4 if np.all(np.isfinite(d.update(q)))][:2]
+    assert qs
+    for opts in (STRICT, FAST):
+        _check(spec, opts, qs, 1e-9)
