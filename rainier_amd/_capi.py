@@ -116,7 +116,8 @@ def lib():
     L.rh_simplify_rir.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rh_canonicalize_rir.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
-    L.rh_lift_rir.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(dp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rh_lift_rir.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(dp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                              C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rh_selftest.argtypes = [vp, C.c_int32, C.c_int64, dp, dp, C.c_int32]
     _lib = L
     return L
@@ -167,17 +168,24 @@ def canonicalize_rir(rir: bytes, columns, nrows, fast: bool = False, refactor: b
         L.rh_free(out)
 
 
-def lift_rir(rir: bytes):
-    """What rh_model_create's loader makes of a column-free program with more than 64 targets (csrc/lift.cpp + the merge of
-    data-free runs): (RIR, synthesised columns, rows of the synthesised target) -- test hook, no device needed."""
+def lift_rir(rir: bytes, nrows=None):
+    """What rh_model_create's loader makes of a program with more than 64 targets (csrc/lift.cpp + the merge of data-free runs):
+    (RIR, synthesised columns -- they follow the caller's in the rewritten program --, rows of the synthesised target, and with
+    `nrows` the row count of every target of the rewritten program) -- test hook, no device needed."""
     L = lib()
     out, n = C.c_void_p(), C.c_size_t(0)
     cols, nc, nr = C.POINTER(C.c_double)(), C.c_uint32(0), C.c_uint32(0)
     buf = C.create_string_buffer(rir, len(rir))
-    check(L.rh_lift_rir(buf, len(rir), C.byref(out), C.byref(n), C.byref(cols), C.byref(nc), C.byref(nr)))
+    nr_in = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows]) if nrows is not None else None
+    nr_out = (C.c_int64 * 64)() if nrows is not None else None
+    check(L.rh_lift_rir(buf, len(rir), C.byref(out), C.byref(n), C.byref(cols), C.byref(nc), C.byref(nr), nr_in, nr_out))
     try:
         arr = np.ctypeslib.as_array(cols, shape=(max(1, nc.value * nr.value),)).copy()
-        return C.string_at(out, n.value), [arr[c * nr.value:(c + 1) * nr.value] for c in range(nc.value)], nr.value
+        res = C.string_at(out, n.value), [arr[c * nr.value:(c + 1) * nr.value] for c in range(nc.value)], nr.value
+        if nrows is not None:
+            import struct
+            res = res + ([int(nr_out[t]) for t in range(struct.unpack_from("<I", res[0], 12)[0])],)
+        return res
     finally:
         L.rh_free(out); L.rh_free(cols)
 

@@ -728,13 +728,17 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
 
 // Test hook (no device needed): what load_program makes of a program with more than RH_MAX_TARGETS targets -- same-shaped
 // data-free targets lifted into one streamed target (lift.cpp), the other runs merged -- as RIR, plus the synthesised columns
-// (column-major, malloc'ed: ncols x nrows doubles; the caller frees with rh_free).  Only for programs without caller columns.
-extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *out_len, double **cols_out, uint32_t *ncols, uint32_t *nrows) {
+// (column-major, malloc'ed: ncols x nrows doubles; the caller frees with rh_free); they follow the caller's columns in the
+// rewritten program's column order.  nrows_in (per target of the program handed in) -> nrows_out (per target of the rewritten
+// one, at most RH_MAX_TARGETS entries); both may be NULL.
+extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *out_len, double **cols_out, uint32_t *ncols, uint32_t *nrows,
+                           const int64_t *nrows_in_caller, int64_t *nrows_out) {
   rh_model m;
   return guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
     std::vector<const double *> colv;
-    load_program(&m, rir, rir_len, nullptr, nullptr, colv, nrows_in);
+    load_program(&m, rir, rir_len, nullptr, nrows_in_caller, colv, nrows_in);
+    if (nrows_out) for (size_t t = 0; t < nrows_in.size(); t++) nrows_out[t] = nrows_in[t];
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
     *ncols = (uint32_t)m.synth_cols.size();

@@ -21,14 +21,10 @@ STRICT = dict(math_mode=_capi.MATH_STRICT)
 def _check(spec, opts, qs, tol, with_data=True):
     """generated code (over the columns rh_model_create would keep) vs the oracle on the original program"""
     original = spec
-    if len(spec.nrows) > 64 and not spec.columns:      # the loader lifts same-shaped data-free targets into a streamed one (csrc/lift.cpp)
-        import dataclasses, struct
-        rir2, cols2, nr = _capi.lift_rir(spec.rir)
-        w = struct.unpack("<%dI" % (len(rir2) // 4), rir2)
-        nrows2, pos = [], 6
-        for _ in range(w[3]):
-            nrows2.append(nr if w[pos] else 0); pos += 3 + w[2]
-        spec = dataclasses.replace(spec, rir=rir2, columns=cols2, nrows=nrows2)
+    if len(spec.nrows) > 64:      # the loader lifts same-shaped data-free targets into a streamed one (csrc/lift.cpp)
+        import dataclasses
+        rir2, cols2, _, nrows2 = _capi.lift_rir(spec.rir, spec.nrows)
+        spec = dataclasses.replace(spec, rir=rir2, columns=list(spec.columns) + cols2, nrows=nrows2)
     kw = dict(columns=spec.columns, nrows=spec.nrows) if with_data and spec.columns else {}
     src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, **kw)
     fast = bool(opts.get("fp_contract"))
@@ -326,6 +322,48 @@ def test_random_single_observation_models(seed):
     for opts in (STRICT, FAST):
         src = _check(spec, opts, qs, 1e-9)
         assert "#define RH_NROWTARGETS 1\n" in src
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_single_observation_models_in_the_reference_text(seed):
+    """fuzz: time-series models written the way bench/stan/ARK.scala is -- one Model.observe per observation, merged -- through
+    the real front end (its algebra, its gradient), 66-160 observations, four likelihood families, 1-3 lags: lifted into one
+    streamed target, both math modes"""
+    rng = np.random.default_rng(50000 + seed)
+    N, fam, lag = int(rng.integers(66, 160)), int(rng.integers(4)), int(rng.integers(1, 4))
+    ys = rng.normal(size=N + lag) * 0.5 + 1.0
+    a = M.Normal(0, 10).latent; bs = M.Normal(0, 10).latentVec(lag)
+    sg = M.Cauchy(0, 2.5).latent.abs() if rng.random() < 0.5 else M.Exponential(1).latent
+    m = M.Model([M.Real.zero])
+    for t in range(lag, N + lag):
+        mu = a
+        for k in range(1, lag + 1):
+            mu = mu + bs[k - 1] * float(ys[t - k])
+        m = M.Model.observe([float(ys[t])], [M.Normal(mu, sg), M.Laplace(mu, sg), M.Cauchy(mu, sg), M.Normal(mu.exp(), sg)][fam]).merge(m)
+    spec = m.compile("fuzz_reference_single_%d" % seed)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        assert "#define RH_NROWTARGETS 1\n" in _check(spec, opts, qs, 1e-9)
+
+
+def test_single_observations_next_to_a_streamed_likelihood():
+    """a Model.observe over columns (the reference's 8-way split) merged with 70 single-observation models: the loader lifts the
+    70 data-free targets into a second streamed target whose columns follow the caller's"""
+    rng = np.random.default_rng(5)
+    n, k = 300, 2
+    X = [rng.normal(size=n) for _ in range(k)]; ys = rng.normal(size=n)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k); sg = M.Exponential(1).latent
+    m = M.Model.observe_vec(ys, X, lambda *u: M.Cauchy(a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)]), sg), split=True)
+    for i in range(70):
+        m = M.Model.observe([0.3 + 0.07 * i], M.Normal(a * (0.1 + 0.01 * i), sg)).merge(m)
+    spec = m.compile("streamed_plus_singles", inline=False)
+    assert len(spec.nrows) > 64
+    qs = rng.normal(size=(2, spec.n_params)) * 0.4
+    for opts in (STRICT, FAST):
+        assert "#define RH_NROWTARGETS 2\n" in _check(spec, opts, qs, 1e-9)
 
 
 @pytest.mark.parametrize("seed", range(8))
