@@ -44,7 +44,7 @@
 #define RH_RIR_MAGIC 0x31524952u
 #define RH_RIR_VERSION 1u
 #define RH_RIR_MAX_PARAMS (1u << 24) /* header sanity bound; far above any model the engine can hold */
-#define RH_RIR_MAX_COLS 16384u       /* data columns over all targets (the engine keeps their pointers in a device table) */
+#define RH_RIR_MAX_COLS (1u << 20)  /* data columns over all targets (the engine keeps their pointers in a device table) */
 #define RH_RIR_MAX_TARGETS 65536u    /* targets in a blob; the engine merges runs of data-free targets and then holds at most 64 */
 
 enum rh_rir_op {
