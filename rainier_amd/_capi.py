@@ -181,10 +181,18 @@ def lift_rir(rir: bytes, nrows=None):
     check(L.rh_lift_rir(buf, len(rir), C.byref(out), C.byref(n), C.byref(cols), C.byref(nc), C.byref(nr), nr_in, nr_out))
     try:
         arr = np.ctypeslib.as_array(cols, shape=(max(1, nc.value * nr.value),)).copy()
-        res = C.string_at(out, n.value), [arr[c * nr.value:(c + 1) * nr.value] for c in range(nc.value)], nr.value
+        rir2 = C.string_at(out, n.value)
+        cols2 = [arr[c * nr.value:(c + 1) * nr.value] for c in range(nc.value)]   # zero-padded to the longest lifted group
+        res = rir2, cols2, nr.value
         if nrows is not None:
             import struct
-            res = res + ([int(nr_out[t]) for t in range(struct.unpack_from("<I", res[0], 12)[0])],)
+            w = struct.unpack_from("<%dI" % (len(rir2) // 4), rir2)
+            rows_t = [int(nr_out[t]) for t in range(w[3])]
+            per_col, pos = [], 6
+            for t in range(w[3]):                           # targets: { n_cols, reserved, outputs[n_params + 1] }
+                per_col += [rows_t[t]] * w[pos]; pos += 3 + w[2]
+            first = len(per_col) - nc.value                 # the synthesised columns follow the caller's
+            res = rir2, [c[:per_col[first + j]] for j, c in enumerate(cols2)], nr.value, rows_t
         return res
     finally:
         L.rh_free(out); L.rh_free(cols)

@@ -382,7 +382,7 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   for (size_t t = 0; t < m->prog.targets.size(); t++) {
     if (!m->prog.targets[t].n_cols) continue;
     const uint32_t orig = old1[old2[t]];
-    if (orig == 0xFFFFFFFFu) nrows_m[t] = (int64_t)m->synth_cols[0].size();
+    if (orig == 0xFFFFFFFFu) nrows_m[t] = (int64_t)m->synth_cols[m->prog.targets[t].col0 - caller_cols].size();   // a lifted group
     else nrows_m[t] = nrows ? nrows[orig] : -1;
   }
 }
@@ -742,9 +742,10 @@ extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();
     *ncols = (uint32_t)m.synth_cols.size();
-    *nrows = m.synth_cols.empty() ? 0u : (uint32_t)m.synth_cols[0].size();
-    *cols_out = (double *)std::malloc(sizeof(double) * std::max<size_t>(1, (size_t)*ncols * *nrows));
-    for (size_t c = 0; c < m.synth_cols.size(); c++) std::memcpy(*cols_out + c * *nrows, m.synth_cols[c].data(), sizeof(double) * *nrows);
+    *nrows = 0;                                       // several lifted groups: the longest; shorter columns are zero-padded
+    for (const auto &sc : m.synth_cols) *nrows = std::max<uint32_t>(*nrows, (uint32_t)sc.size());
+    *cols_out = (double *)std::calloc(std::max<size_t>(1, (size_t)*ncols * *nrows), sizeof(double));
+    for (size_t c = 0; c < m.synth_cols.size(); c++) std::memcpy(*cols_out + c * *nrows, m.synth_cols[c].data(), sizeof(double) * m.synth_cols[c].size());
   });
 }
 

@@ -9,7 +9,8 @@
 // differ, and the node-to-node mapping must be a function (so shared sub-expressions are shared alike) -- and the constants
 // that differ become COLUMNS of a new row target (one row per member) whose expression is the first member's with those
 // constants replaced by column reads.  Per-row arithmetic is the member's own, operation for operation; only the order in
-// which the members are added up becomes that of a row reduction.  Members that do not match stay data-free.
+// which the members are added up becomes that of a row reduction.  Members that do not match stay data-free.  The step repeats
+// while another group of >= 32 qualifies (two time series observed one value at a time become two streamed targets).
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -50,6 +51,8 @@ bool match(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t
   return true;
 }
 
+bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<uint32_t> &old_target_of);
+
 }  // namespace
 
 void recompute_deps(Program &P) {
@@ -72,7 +75,21 @@ bool lift_constants(Program &P, std::vector<std::vector<double>> &synth, std::ve
   synth.clear();
   old_target_of.clear();
   for (uint32_t t = 0; t < P.targets.size(); t++) old_target_of.push_back(t);
-  if (P.kind != 0 || P.targets.size() <= RH_MAX_TARGETS) return false;
+  if (P.kind != 0) return false;
+  bool any = false;
+  while (any || P.targets.size() > RH_MAX_TARGETS) {   // once a program needs it, every group that qualifies is lifted
+    std::vector<uint32_t> step;                    // target after the step -> target before it, 0xFFFFFFFF = the new row target
+    if (!lift_one(P, synth, step)) break;
+    for (uint32_t &o : step) if (o != 0xFFFFFFFFu) o = old_target_of[o];
+    old_target_of.swap(step);
+    any = true;
+  }
+  return any;
+}
+
+namespace {
+// one group; the new target's columns are appended to `synth` and the target itself to the end of the target list
+bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<uint32_t> &old_target_of) {
   // constant-blind structural hash of every node
   std::vector<uint64_t> h(P.nodes.size());
   for (uint32_t i = 0; i < P.nodes.size(); i++) {
@@ -94,33 +111,41 @@ bool lift_constants(Program &P, std::vector<std::vector<double>> &synth, std::ve
     for (uint32_t o : P.targets[t].outputs) x = mix(x, h[o]);
     groups[x].push_back(t);
   }
-  const std::vector<uint32_t> *best = nullptr;
-  for (auto &kv : groups) if (kv.second.size() >= 32 && (!best || kv.second.size() > best->size())) best = &kv.second;
-  if (!best) return false;
-  const uint32_t tmpl = (*best)[0];
-  const size_t no = P.targets[tmpl].outputs.size();
-  std::vector<uint32_t> members;
+  // candidate groups, largest first; the first one whose members really match (and differ in some constant) is lifted
+  std::vector<const std::vector<uint32_t> *> cands;
+  for (auto &kv : groups) if (kv.second.size() >= 32) cands.push_back(&kv.second);
+  std::sort(cands.begin(), cands.end(), [](auto *a, auto *b) { return a->size() != b->size() ? a->size() > b->size() : (*a)[0] < (*b)[0]; });
+  uint32_t tmpl = 0;
+  std::vector<uint32_t> members, slots;
   std::vector<std::map<uint32_t, uint32_t>> maps;
-  for (uint32_t g : *best) {
-    std::map<uint32_t, uint32_t> memo;
-    bool ok = true;
-    for (size_t o = 0; o < no && ok; o++) ok = match(P, P.targets[tmpl].outputs[o], P.targets[g].outputs[o], memo);
-    if (ok) { members.push_back(g); maps.push_back(std::move(memo)); }
-  }
-  if (members.size() < 32) return false;
-  // the template's constants that differ between members -> columns
-  std::vector<uint32_t> slots;
-  for (auto &kv : maps[0]) {
-    if (P.nodes[kv.first].op != RH_RIR_CONST) continue;
-    bool differs = false;
-    const double v0 = P.nodes[kv.first].cval;
-    for (size_t g = 1; g < members.size() && !differs; g++) {
-      const double v = P.nodes[maps[g].at(kv.first)].cval;
-      differs = std::memcmp(&v, &v0, 8) != 0;
+  bool found = false;
+  for (const std::vector<uint32_t> *cand : cands) {
+    tmpl = (*cand)[0];
+    const size_t no = P.targets[tmpl].outputs.size();
+    members.clear(); maps.clear(); slots.clear();
+    for (uint32_t g : *cand) {
+      std::map<uint32_t, uint32_t> memo;
+      bool ok = true;
+      for (size_t o = 0; o < no && ok; o++) ok = match(P, P.targets[tmpl].outputs[o], P.targets[g].outputs[o], memo);
+      if (ok) { members.push_back(g); maps.push_back(std::move(memo)); }
     }
-    if (differs) slots.push_back(kv.first);
+    if (members.size() < 32) continue;
+    // the template's constants that differ between members -> columns
+    for (auto &kv : maps[0]) {
+      if (P.nodes[kv.first].op != RH_RIR_CONST) continue;
+      bool differs = false;
+      const double v0 = P.nodes[kv.first].cval;
+      for (size_t g = 1; g < members.size() && !differs; g++) {
+        const double v = P.nodes[maps[g].at(kv.first)].cval;
+        differs = std::memcmp(&v, &v0, 8) != 0;
+      }
+      if (differs) slots.push_back(kv.first);
+    }
+    if (slots.empty() || slots.size() > 4096) continue;
+    found = true;
+    break;
   }
-  if (slots.empty() || slots.size() > 4096) return false;
+  if (!found) return false;
   for (uint32_t s : slots) {
     std::vector<double> col;
     for (size_t g = 0; g < members.size(); g++) col.push_back(P.nodes[maps[g].at(s)].cval);
@@ -169,5 +194,6 @@ bool lift_constants(Program &P, std::vector<std::vector<double>> &synth, std::ve
   recompute_deps(P);
   return true;
 }
+}  // namespace
 
 }  // namespace rh

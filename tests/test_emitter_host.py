@@ -366,6 +366,27 @@ def test_single_observations_next_to_a_streamed_likelihood():
         assert "#define RH_NROWTARGETS 2\n" in _check(spec, opts, qs, 1e-9)
 
 
+def test_two_series_observed_one_value_at_a_time_become_two_streamed_targets():
+    """two groups of same-shaped single-observation models (90 Normal AR(1) terms, 70 Laplace ones): both are lifted (lift.cpp
+    repeats while a group of >= 32 qualifies), each with its own row count"""
+    rng = np.random.default_rng(9)
+    ya, yb = rng.normal(size=92) * 0.5 + 1, rng.normal(size=71) * 0.3
+    a = M.Normal(0, 10).latent; b1 = M.Normal(0, 10).latent; sg = M.Exponential(1).latent
+    c = M.Normal(0, 5).latent; tau = M.Cauchy(0, 2.5).latent.abs()
+    m = M.Model([M.Real.zero])
+    for t in range(2, 92):
+        m = M.Model.observe([float(ya[t])], M.Normal(a + b1 * float(ya[t - 1]), sg)).merge(m)
+    for t in range(1, 71):
+        m = M.Model.observe([float(yb[t])], M.Laplace(c * float(yb[t - 1]), tau)).merge(m)
+    spec = m.compile("two_series")
+    assert len(spec.nrows) == 162 and not spec.columns
+    _, cols, _, rows = _capi.lift_rir(spec.rir, spec.nrows)
+    assert sorted(r for r in rows if r) == [70, 90] and sorted(set(len(c) for c in cols)) == [70, 90]
+    qs = rng.normal(size=(2, spec.n_params)) * 0.3
+    for opts in (STRICT, FAST):
+        assert "#define RH_NROWTARGETS 2\n" in _check(spec, opts, qs, 1e-9)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_glms_through_the_glm_lowering(seed):
     """fuzz: 9-21 predictors with random signs / scales (in the data: negated columns; in the expression: scaled terms, a scaled
