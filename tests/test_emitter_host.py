@@ -366,6 +366,36 @@ def test_single_observations_next_to_a_streamed_likelihood():
         assert "#define RH_NROWTARGETS 2\n" in _check(spec, opts, qs, 1e-9)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_groups_of_single_observation_targets(seed):
+    """fuzz: two or three families of data-free targets (random shape each, 33-80 members with random constants) interleaved with a
+    few odd ones: every family is lifted into a streamed target of its own, the rest is merged; both math modes"""
+    rng = np.random.default_rng(16000 + seed)
+    P, nfam = 3, int(rng.integers(2, 4))
+    counts = [int(rng.integers(33, 81)) for _ in range(nfam)]
+    g = Graph(P, [0] * (sum(counts) + 4))
+    th = [g.param(i) for i in range(P)]
+    shapes = [(int(rng.integers(1 << 30)), int(rng.integers(2, 5))) for _ in range(nfam)]
+    fam_of = np.repeat(np.arange(nfam), counts); rng.shuffle(fam_of)
+    targets = [th[0] * th[0] * -0.5 + th[1] * -0.1]
+    for f in fam_of:
+        c1, c2 = g.const(float(rng.uniform(0.2, 2.0))), g.const(float(rng.normal()))
+        leaves = th + [c1, c2, th[0] * c1 + th[1], th[2] * c2]
+        targets.append(_random_expr(np.random.default_rng(shapes[f][0]), g, leaves, shapes[f][1]) + th[int(f) % P] * c1)
+        if len(targets) in (17, 60, 101):
+            targets.append(th[1] * th[2] * float(rng.normal()))          # an odd one in between
+    while len(targets) < sum(counts) + 4:
+        targets.append(th[0] * float(rng.normal()))
+    spec = ModelSpec("fuzz_groups_%d" % seed, g.compile(targets), [], [0] * len(targets), P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-9)
+        assert "#define RH_NROWTARGETS %d\n" % nfam in src
+
+
 def test_two_series_observed_one_value_at_a_time_become_two_streamed_targets():
     """two groups of same-shaped single-observation models (90 Normal AR(1) terms, 70 Laplace ones): both are lifted (lift.cpp
     repeats while a group of >= 32 qualifies), each with its own row count"""

@@ -30,4 +30,5 @@ import rainier_amd._capi as capi  # noqa: E402
 capi.LIB_PATH = LIB
 import pytest  # noqa: E402
 
-sys.exit(pytest.main(["tests", "-s", "-p", "no:cacheprovider"] + sys.argv[1:]))
+where = [] if any(os.path.exists(a.split("::")[0]) for a in sys.argv[1:]) else ["tests"]   # explicit test paths replace the default
+sys.exit(pytest.main(where + ["-s", "-p", "no:cacheprovider"] + sys.argv[1:]))
