@@ -160,7 +160,6 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
   for (auto &kv : maps[0]) order.push_back(kv.first);
   std::sort(order.begin(), order.end());
   std::map<uint32_t, uint32_t> copy;
-  const size_t n_before = P.nodes.size();
   for (uint32_t x : order) {
     const Node n = P.nodes[x];
     auto si = slot_input.find(x);
@@ -177,7 +176,6 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
     P.nodes.push_back(q);
     copy[x] = (uint32_t)P.nodes.size() - 1;
   }
-  (void)n_before;
   Target R;
   R.n_cols = (uint32_t)slots.size(); R.input_start = in0; R.col0 = P.n_cols_total;
   for (uint32_t o : P.targets[tmpl].outputs) { auto it = copy.find(o); R.outputs.push_back(it != copy.end() ? it->second : o); }

@@ -244,3 +244,37 @@ def test_logit_family_links_are_lowered_in_closed_form_only_when_verified():
     bad = g.compile([a * a * -0.5, row], gradients=[g.gradient(a * a * -0.5), [gr[0] * gr[0], gr[1]]])
     src, _ = _capi.lower_only(bad, fast)
     assert "rh_logit_link(" not in gen(src)
+
+
+def test_lowering_is_thread_safe():
+    """`rh_model_create`'s host side (parser, data-dependent passes, emitter) from 6 threads at once: the same source as serially
+    (the JVM calls it from whatever thread builds a model; nothing but the error slot and the kernel cache is shared)"""
+    import hashlib
+    import json
+    import threading
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    load = lambda n: json.load(open(os.path.join(G, n)))
+    specs = [models.eight_schools_reference(), models.ark_reference(load("ark.json")), models.glmm_poisson2_reference(100, 40, load("glmm_poisson2.json")),
+             models.lowdim_gaussmix_reference(load("lowdim_gaussmix.json")), models.linreg(n=20000, k=3), models.hier_negbin(40, 6, seed=2)]
+    opts = [dict(fp_contract=True, factor_outputs=True), dict(math_mode=_capi.MATH_STRICT)]
+
+    def run(s, o):
+        kw = dict(columns=s.columns, nrows=s.nrows) if s.columns else {}
+        return hashlib.sha256(_capi.lower_only(s.rir, _capi.compile_opts(**o), compile=False, **kw)[0].encode()).hexdigest()
+
+    serial = {(i, j): run(s, o) for i, s in enumerate(specs) for j, o in enumerate(opts)}
+    wrong = []
+
+    def worker(k):
+        try:
+            for i in np.random.default_rng(k).permutation(len(specs)):
+                for j, o in enumerate(opts):
+                    if run(specs[i], o) != serial[(i, j)]:
+                        wrong.append((k, i, j))
+        except Exception as e:  # noqa: BLE001
+            wrong.append((k, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not wrong, wrong[:3]
