@@ -1232,8 +1232,18 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
 }
 bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std::string &targets, std::string &err,
               EmitInfo *info) {
-  if (!o.simplify) return emit_hip_impl(P, o, defines, targets, err, info);
-  return emit_hip_impl(simplify(P, o.fp_contract), o, defines, targets, err, info);
+  const Program Q = o.simplify ? simplify(P, o.fp_contract) : P;
+  if (emit_hip_impl(Q, o, defines, targets, err, info)) return true;
+  // a model that has the shape of gather mode (a Lookup over a long run of trailing parameters indexed by a column) but not its
+  // preconditions -- e.g. the table's prior sits in a data-free target -- is lowered on the generic path (the table as a
+  // per-evaluation array: correct, slow) as long as it has few enough parameters for it
+  if (err.rfind("gather mode:", 0) != 0) return false;
+  EmitOptions o2 = o;
+  o2.gather_min = 0x7fffffff;
+  std::string err2;
+  if (!emit_hip_impl(Q, o2, defines, targets, err2, info)) return false;   // (err keeps the gather-mode reason)
+  err.clear();
+  return true;
 }
 static bool emit_requirements_impl(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
 bool emit_requirements(const Program &P, const EmitOptions &o, std::string &defines, std::string &body, std::string &err) {

@@ -10,8 +10,11 @@
 // that differ become COLUMNS of a new row target (one row per member) whose expression is the first member's with those
 // constants replaced by column reads.  Per-row arithmetic is the member's own, operation for operation; only the order in
 // which the members are added up becomes that of a row reduction.  Members that do not match stay data-free.  The step repeats
-// while another group of >= 32 qualifies (two time series observed one value at a time become two streamed targets).
+// while another group of >= 32 qualifies (two time series observed one value at a time become two streamed targets).  When no
+// group differs in constants alone, families whose members differ in a parameter are looked for (lift_one, second half).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -26,7 +29,7 @@ bool binary_op(uint32_t op) { return (op >= RH_RIR_ADD && op <= RH_RIR_COMPARE) 
 uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xBF58476D1CE4E5B9ull; }
 
 // member node b against template node a; memo: template node -> member node (must be consistent)
-bool match(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t> &memo) {
+bool match(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t> &memo, bool any_param = false) {
   std::vector<std::pair<uint32_t, uint32_t>> stack{{a, b}};
   while (!stack.empty()) {
     auto [x, y] = stack.back(); stack.pop_back();
@@ -37,7 +40,7 @@ bool match(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t
     memo[x] = y;
     switch (nx.op) {
       case RH_RIR_CONST: break;
-      case RH_RIR_INPUT: if (nx.input != ny.input) return false; break;
+      case RH_RIR_INPUT: if (nx.input != ny.input && !any_param) return false; break;
       case RH_RIR_LOOKUP:
         if (nx.low != ny.low || nx.table.size() != ny.table.size()) return false;
         stack.push_back({nx.a, ny.a});
@@ -145,26 +148,161 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
     found = true;
     break;
   }
-  if (!found) return false;
+  // no family that differs in constants only: families whose members also differ in a PARAMETER (one Model.observe per group of
+  // a hierarchical model).  Grouped by the parameter-blind structure of the value output; the parameter becomes a Lookup over a
+  // lifted index column, and the gradient outputs -- which sit at different output positions from member to member -- become
+  // eq(index, k, g, 0) terms (compute/Gradient.scala's derivative of a Lookup), which is what the emitter's scatter families read.
+  std::vector<uint32_t> pslots;                                  // template parameters that vary (one INPUT node of each)
+  std::vector<std::vector<uint32_t>> pnodes;                     // ... all INPUT nodes of each (seen from the value output)
+  std::vector<std::vector<uint32_t>> ptable;                     // per parameter slot: the distinct parameters, ascending
+  if (!found) {
+    std::vector<uint64_t> h2(P.nodes.size());
+    for (uint32_t i = 0; i < P.nodes.size(); i++) {
+      const Node &n = P.nodes[i];
+      uint64_t x = mix(0x72, n.op);
+      if (n.op == RH_RIR_CONST) x = mix(x, 0xC0);
+      else if (n.op == RH_RIR_INPUT) x = mix(x, 0x9A7);
+      else {
+        x = mix(x, h2[n.a]);
+        if (n.op == RH_RIR_LOOKUP) { x = mix(x, (uint64_t)(int64_t)n.low); for (uint32_t e : n.table) x = mix(x, h2[e]); }
+        else if (binary_op(n.op)) x = mix(x, h2[n.b]);
+      }
+      h2[i] = x;
+    }
+    std::map<uint64_t, std::vector<uint32_t>> groups2;
+    for (uint32_t t = 0; t < P.targets.size(); t++) if (!P.targets[t].n_cols) groups2[h2[P.targets[t].outputs[0]]].push_back(t);
+    cands.clear();
+    for (auto &kv : groups2) if (kv.second.size() >= 32) cands.push_back(&kv.second);
+    std::sort(cands.begin(), cands.end(), [](auto *a, auto *b) { return a->size() != b->size() ? a->size() > b->size() : (*a)[0] < (*b)[0]; });
+    auto is_zero = [&](uint32_t id) { return P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == 0.0; };
+    const uint32_t np = P.n_params;
+    const bool why = std::getenv("RH_LIFT_WHY") != nullptr;
+    if (why) std::fprintf(stderr, "lift: %zu parameter-blind candidate groups\n", cands.size());
+    for (const std::vector<uint32_t> *cand : cands) {
+      tmpl = (*cand)[0];
+      const std::vector<uint32_t> &to = P.targets[tmpl].outputs;
+      // pass 1: value outputs -> which parameter nodes vary
+      std::vector<uint32_t> ok1;
+      std::vector<std::map<uint32_t, uint32_t>> m1;
+      for (uint32_t g : *cand) {
+        std::map<uint32_t, uint32_t> memo;
+        if (match(P, to[0], P.targets[g].outputs[0], memo, true)) { ok1.push_back(g); m1.push_back(std::move(memo)); }
+      }
+      if (why) std::fprintf(stderr, "lift: group of %zu, %zu match the template's value\n", cand->size(), ok1.size());
+      if (ok1.size() < 32) continue;
+      pslots.clear(); pnodes.clear();
+      std::vector<char> fixed_param(np, 0), varies(np, 0);
+      for (auto &kv : m1[0]) {   // (a parameter may have several INPUT nodes)
+        if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
+        for (size_t g = 1; g < ok1.size() && !varies[P.nodes[kv.first].input]; g++)
+          varies[P.nodes[kv.first].input] = P.nodes[m1[g].at(kv.first)].input != P.nodes[kv.first].input;
+      }
+      for (auto &kv : m1[0]) {
+        if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
+        const uint32_t q = P.nodes[kv.first].input;
+        if (!varies[q]) { fixed_param[q] = 1; continue; }
+        size_t j = 0;
+        while (j < pslots.size() && P.nodes[pslots[j]].input != q) j++;
+        if (j == pslots.size()) { pslots.push_back(kv.first); pnodes.push_back({}); }
+        pnodes[j].push_back(kv.first);
+      }
+      if (why) for (uint32_t x : pslots) std::fprintf(stderr, "lift:   template parameter %u varies\n", P.nodes[x].input);
+      if (pslots.empty() || pslots.size() > 64) continue;
+      std::vector<char> in_s0(np, 0);
+      for (uint32_t x : pslots) in_s0[P.nodes[x].input] = 1;
+      // pass 2: per member, the gradient outputs -- by slot for its own varying parameters, by position for the others
+      members.clear(); maps.clear(); slots.clear();
+      for (size_t k = 0; k < ok1.size(); k++) {
+        const std::vector<uint32_t> &go = P.targets[ok1[k]].outputs;
+        std::map<uint32_t, uint32_t> &memo = m1[k];
+        std::vector<char> in_sg(np, 0);
+        bool ok = true;
+        for (size_t j = 0; j < pslots.size() && ok; j++) {
+          const uint32_t q = P.nodes[memo.at(pslots[j])].input;
+          if (in_sg[q] || fixed_param[q]) { ok = false; break; }   // one parameter in two roles: its gradient is a sum, not a slot
+          for (uint32_t x : pnodes[j]) if (P.nodes[memo.at(x)].input != q) ok = false;
+          in_sg[q] = 1;
+        }
+        for (size_t j = 0; j < pslots.size() && ok; j++)
+          ok = match(P, to[1 + P.nodes[pslots[j]].input], go[1 + P.nodes[memo.at(pslots[j])].input], memo, true);
+        for (uint32_t q = 0; q < np && ok; q++) {
+          if (in_sg[q]) { if (!in_s0[q]) ok = is_zero(to[1 + q]); continue; }
+          if (in_s0[q]) ok = is_zero(go[1 + q]);
+          else ok = match(P, to[1 + q], go[1 + q], memo, true);
+        }
+        // the renaming may only touch the slots
+        for (auto &kv : memo) if (ok && P.nodes[kv.first].op == RH_RIR_INPUT && P.nodes[kv.second].input != P.nodes[kv.first].input) {
+          size_t j = 0;
+          while (j < pslots.size() && P.nodes[pslots[j]].input != P.nodes[kv.first].input) j++;
+          if (j == pslots.size() || P.nodes[kv.second].input != P.nodes[memo.at(pslots[j])].input) ok = false;
+        }
+        if (ok) { members.push_back(ok1[k]); maps.push_back(std::move(memo)); }
+      }
+      if (why) std::fprintf(stderr, "lift: %zu varying parameters, %zu members with matching gradients\n", pslots.size(), members.size());
+      if (members.size() < 32 || members[0] != tmpl) continue;
+      for (auto &kv : maps[0]) {
+        if (P.nodes[kv.first].op != RH_RIR_CONST) continue;
+        bool differs = false;
+        const double v0 = P.nodes[kv.first].cval;
+        for (size_t g = 1; g < members.size() && !differs; g++) {
+          auto it = maps[g].find(kv.first);          // (a zero some member never reaches: an output position it does not use)
+          if (it == maps[g].end()) continue;
+          const double v = P.nodes[it->second].cval;
+          differs = std::memcmp(&v, &v0, 8) != 0;
+        }
+        if (differs) slots.push_back(kv.first);
+      }
+      if (slots.size() > 4096) continue;
+      ptable.assign(pslots.size(), {});
+      for (size_t j = 0; j < pslots.size(); j++) {
+        for (size_t g = 0; g < members.size(); g++) ptable[j].push_back(P.nodes[maps[g].at(pslots[j])].input);
+        std::sort(ptable[j].begin(), ptable[j].end());
+        ptable[j].erase(std::unique(ptable[j].begin(), ptable[j].end()), ptable[j].end());
+      }
+      found = true;
+      break;
+    }
+    if (!found) return false;
+  }
   for (uint32_t s : slots) {
     std::vector<double> col;
-    for (size_t g = 0; g < members.size(); g++) col.push_back(P.nodes[maps[g].at(s)].cval);
+    for (size_t g = 0; g < members.size(); g++) { auto it = maps[g].find(s); col.push_back(P.nodes[it != maps[g].end() ? it->second : s].cval); }
     synth.push_back(col);
   }
-  // the new row target: the template's expression with the slot constants replaced by column reads
+  for (size_t j = 0; j < pslots.size(); j++) {   // index columns: the position of the member's parameter in the slot's table
+    std::vector<double> col;
+    for (size_t g = 0; g < members.size(); g++)
+      col.push_back((double)(std::lower_bound(ptable[j].begin(), ptable[j].end(), P.nodes[maps[g].at(pslots[j])].input) - ptable[j].begin()));
+    synth.push_back(col);
+  }
+  // the new row target: the template's expression with the slot constants replaced by column reads (and the varying parameters by
+  // Lookups over their index columns)
   const uint32_t in0 = P.n_inputs;
-  std::map<uint32_t, uint32_t> slot_input;
-  for (size_t j = 0; j < slots.size(); j++) slot_input[slots[j]] = in0 + (uint32_t)j;
+  auto push = [&](const Node &q) { P.nodes.push_back(q); return (uint32_t)P.nodes.size() - 1; };
+  auto input_node = [&](uint32_t input) { Node q; q.op = RH_RIR_INPUT; q.input = input; return push(q); };
+  auto const_node = [&](double v) { Node q; q.op = RH_RIR_CONST; q.cval = v; return push(q); };
+  std::map<uint32_t, uint32_t> copy;
   std::vector<char> touched(P.nodes.size(), 0);   // reaches a slot
+  std::map<uint32_t, uint32_t> slot_input;        // (their INPUT nodes are created where the constant stood, in node order)
+  for (size_t j = 0; j < slots.size(); j++) slot_input[slots[j]] = in0 + (uint32_t)j;
+  std::vector<uint32_t> pcol(pslots.size());
+  for (size_t j = 0; j < pslots.size(); j++) {
+    pcol[j] = input_node(in0 + (uint32_t)(slots.size() + j));
+    Node L; L.op = RH_RIR_LOOKUP; L.a = pcol[j]; L.low = 0;
+    for (uint32_t q : ptable[j]) L.table.push_back(input_node(q));
+    const uint32_t lk = push(L);
+    for (auto &kv : maps[0])
+      if (P.nodes[kv.first].op == RH_RIR_INPUT && kv.first < touched.size() && P.nodes[kv.first].input == P.nodes[pslots[j]].input) { copy[kv.first] = lk; touched[kv.first] = 1; }
+  }
   std::vector<uint32_t> order;                    // template nodes, ascending
   for (auto &kv : maps[0]) order.push_back(kv.first);
   std::sort(order.begin(), order.end());
-  std::map<uint32_t, uint32_t> copy;
+  touched.resize(P.nodes.size(), 0);
   for (uint32_t x : order) {
     const Node n = P.nodes[x];
     auto si = slot_input.find(x);
-    if (si != slot_input.end()) { Node q; q.op = RH_RIR_INPUT; q.input = si->second; P.nodes.push_back(q); copy[x] = (uint32_t)P.nodes.size() - 1; touched[x] = 1; continue; }
-    if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+    if (si != slot_input.end()) { copy[x] = input_node(si->second); touched[x] = 1; continue; }
+    if (copy.count(x) || n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
     bool t = touched[n.a];
     if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) t = t || touched[e]; } else if (binary_op(n.op)) t = t || touched[n.b];
     if (!t) continue;
@@ -173,12 +311,35 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
     auto cp = [&](uint32_t y) { auto it = copy.find(y); return it != copy.end() ? it->second : y; };
     q.a = cp(n.a);
     if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : q.table) e = cp(e); } else if (binary_op(n.op)) q.b = cp(n.b);
-    P.nodes.push_back(q);
-    copy[x] = (uint32_t)P.nodes.size() - 1;
+    copy[x] = push(q);
   }
   Target R;
-  R.n_cols = (uint32_t)slots.size(); R.input_start = in0; R.col0 = P.n_cols_total;
-  for (uint32_t o : P.targets[tmpl].outputs) { auto it = copy.find(o); R.outputs.push_back(it != copy.end() ? it->second : o); }
+  R.n_cols = (uint32_t)(slots.size() + pslots.size()); R.input_start = in0; R.col0 = P.n_cols_total;
+  auto cpo = [&](uint32_t o) { auto it = copy.find(o); return it != copy.end() ? it->second : o; };
+  const std::vector<uint32_t> tout = P.targets[tmpl].outputs;
+  if (pslots.empty()) {
+    for (uint32_t o : tout) R.outputs.push_back(cpo(o));
+  } else {
+    R.outputs.push_back(cpo(tout[0]));
+    std::vector<char> in_s0(P.n_params, 0);
+    for (uint32_t x : pslots) in_s0[P.nodes[x].input] = 1;
+    const uint32_t zero = const_node(0.0);
+    for (uint32_t q = 0; q < P.n_params; q++) {
+      uint32_t acc = in_s0[q] ? zero : cpo(tout[1 + q]);         // a fixed parameter's gradient (or the zero everybody has there)
+      for (size_t j = 0; j < pslots.size(); j++) {
+        auto it = std::lower_bound(ptable[j].begin(), ptable[j].end(), q);
+        if (it == ptable[j].end() || *it != q) continue;
+        Node c; c.op = RH_RIR_COMPARE; c.a = pcol[j]; c.b = const_node((double)(it - ptable[j].begin()));
+        Node e; e.op = RH_RIR_LOOKUP; e.a = push(c); e.low = -1;
+        const uint32_t gslot = cpo(tout[1 + P.nodes[pslots[j]].input]);
+        e.table = {zero, gslot, zero};                           // eq(index, k, g, 0): compute/Real.scala:83-99
+        const uint32_t term = push(e);
+        if (P.nodes[acc].op == RH_RIR_CONST && P.nodes[acc].cval == 0.0) acc = term;
+        else { Node a; a.op = RH_RIR_ADD; a.a = acc; a.b = term; acc = push(a); }
+      }
+      R.outputs.push_back(acc);
+    }
+  }
   // the target list: members removed, the new row target appended
   std::vector<char> is_member(P.targets.size(), 0);
   for (uint32_t g : members) is_member[g] = 1;

@@ -417,6 +417,88 @@ def test_two_series_observed_one_value_at_a_time_become_two_streamed_targets():
         assert "#define RH_NROWTARGETS 2\n" in _check(spec, opts, qs, 1e-9)
 
 
+def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path():
+    """a Lookup over 70 trailing parameters indexed by a column has the shape of gather mode, but the table's prior sits in the
+    data-free target (gather mode wants every table gradient to come from row targets): lowered on the generic path instead of
+    being refused"""
+    rng = np.random.default_rng(2)
+    G, per = 70, 5
+    n = G * per
+    site = np.repeat(np.arange(G), per).astype(float); x = rng.normal(size=n); y = rng.normal(size=n)
+    P = 2 + G
+    g = Graph(P, [0, 3])
+    th = [g.param(i) for i in range(P)]
+    prior = th[0] * th[0] * -0.5 + th[1] * th[1] * -0.5
+    for k in range(G):
+        prior = prior + th[2 + k] * th[2 + k] * -0.5
+    r = g.col(1, 2) - (th[0] + th[1] * g.col(1, 1) + g.lookup(g.col(1, 0), th[2:], 0))
+    spec = ModelSpec("gather_fallback", g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
+    for opts in (STRICT, FAST):
+        _check(spec, opts, rng.normal(size=(2, P)) * 0.4, 1e-10)
+
+
+def test_one_observe_per_group_of_a_hierarchical_model_is_lifted_with_a_lookup():
+    """80 schools, one Model.observe each (non-centred: mu + tau * eta_j, known sigma_j): the members differ in constants AND in
+    the parameter eta_j -> one streamed target of 80 rows whose eta is a Lookup over a lifted index column and whose d/d eta_j are
+    eq(index, j, g, 0) terms.  The table is a run of trailing parameters long enough for gather mode, whose preconditions do not
+    hold (the eta prior is data-free): the emitter falls back to the generic path"""
+    rng = np.random.default_rng(3)
+    J = 80
+    ys, sig = rng.normal(size=J) * 5, rng.uniform(5, 15, size=J)
+    mu = M.Normal(0, 5).latent; tau = M.Cauchy(0, 5).latent.abs(); etas = M.Normal(0, 1).latentVec(J)
+    m = M.Model([M.Real.zero])
+    for j in range(J):
+        m = M.Model.observe([float(ys[j])], M.Normal(mu + tau * etas[j], float(sig[j]))).merge(m)
+    spec = m.compile("schools80")
+    assert len(spec.nrows) == 82 and spec.n_params == 82
+    _, cols, _, rows = _capi.lift_rir(spec.rir, spec.nrows)
+    assert rows == [0, 0, 80] and sorted(cols[-1]) == list(range(80))            # the index column: every eta once
+    qs = rng.normal(size=(2, spec.n_params)) * 0.4
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-10)
+        assert "#define RH_NROWTARGETS 1\n" in src and len(src) < 200_000           # 540 KB as straight-line code
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_families_that_differ_in_a_parameter(seed):
+    """fuzz: 33-89 data-free targets of one random shape whose members differ in constants and in one or two parameters (drawn from
+    tables, several members may share one; now and then a member uses one parameter in both roles and must stay behind), next to
+    fixed parameters and a few odd targets; both math modes against the oracle on the original program"""
+    rng = np.random.default_rng(70000 + seed)
+    nfix, nvar, N = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(33, 90))
+    tables = [int(rng.integers(max(2, N // 3), N + 1)) for _ in range(nvar)]
+    P = nfix + sum(tables)
+    ntarg = max(65, 1 + N + int(rng.integers(0, 4)))
+    g = Graph(P, [0] * ntarg)
+    th = [g.param(i) for i in range(P)]
+    st, depth = int(rng.integers(1 << 30)), int(rng.integers(2, 5))
+    prior = th[0] * th[0] * -0.5
+    for i in range(1, P):
+        prior = prior + th[i] * th[i] * -0.5
+    targets = [prior]
+    base = [nfix + sum(tables[:j]) for j in range(nvar)]
+    perm = [rng.permutation(tables[j]) for j in range(nvar)]
+    for k in range(N):
+        c1, c2 = g.const(float(rng.uniform(0.2, 2.0))), g.const(float(rng.normal()))
+        vs = [th[base[j] + int(perm[j][k % tables[j]])] for j in range(nvar)]
+        leaves = th[:nfix] + vs + [c1, c2, vs[0] * c1 + th[0]]
+        if rng.random() < 0.05 and nvar == 2:
+            leaves[nfix + 1] = leaves[nfix]
+        targets.append(_random_expr(np.random.default_rng(st), g, leaves, depth) + vs[-1] * c1)
+        if len(targets) in (9, 40):
+            targets.append(th[0] * th[min(1, P - 1)] * float(rng.normal()))
+    while len(targets) < ntarg:
+        targets.append(th[0] * float(rng.normal()))
+    targets = targets[:ntarg]
+    spec = ModelSpec("fuzz_param_family_%d" % seed, g.compile(targets), [], [0] * ntarg, P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
+    for opts in (STRICT, FAST):
+        _check(spec, opts, qs, 1e-9)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_glms_through_the_glm_lowering(seed):
     """fuzz: 9-21 predictors with random signs / scales (in the data: negated columns; in the expression: scaled terms, a scaled
