@@ -420,6 +420,7 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
   // gather mode (a Lookup over a long run of trailing parameters indexed by a column: emit.cpp) keeps its targets as they are
   bool gather = false;
   {
+    uint32_t first_table_param = m->prog.n_params;
     int gmin = m->eopt.gather_min;
     if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
     const rh::Program &P = m->prog;
@@ -427,7 +428,16 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
       if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < gmin) continue;
       const rh::Node &ix = P.nodes[nd.a], &t0 = P.nodes[nd.table[0]];
       if (ix.op == RH_RIR_INPUT && ix.input >= P.n_params && t0.op == RH_RIR_INPUT && t0.input < P.n_params &&
-          t0.input + nd.table.size() == P.n_params) gather = true;
+          t0.input + nd.table.size() == P.n_params) { gather = true; first_table_param = std::min(first_table_param, t0.input); }
+    }
+    // ... unless gather mode cannot apply anyway: a data-free target already has a gradient with respect to a table parameter
+    // (the table's prior, in any model that comes from the reference's front end) and the emitter will take the generic path
+    for (const rh::Target &T : P.targets) {
+      if (T.n_cols) continue;
+      for (uint32_t q = first_table_param; q < P.n_params && gather; q++) {
+        const rh::Node &g = P.nodes[T.outputs[1 + q]];
+        if (!(g.op == RH_RIR_CONST && g.cval == 0.0)) gather = false;
+      }
     }
   }
   if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, allow_unroll && !gather);

@@ -418,6 +418,10 @@ struct Refactor {
       std::map<uint64_t, std::vector<size_t>> classes;
       for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
       size_t S0 = 0;
+      if (std::getenv("RH_ROLL_WHY"))
+        for (auto &kv : classes)
+          std::fprintf(stderr, "rainier-hip:   class of %zu component(s), %zu column(s) each, %s, first column input %u\n", kv.second.size(),
+                       comps[kv.second[0]].size(), comp_param[kv.second[0]] ? "reached by parameters" : "data only", comps[kv.second[0]][0]);
       for (auto &kv : classes) {
         if (!comp_param[kv.second[0]]) continue;
         if (S0 == 0) S0 = kv.second.size(); else if (kv.second.size() != S0) return why(R, "structural classes of unequal size");

@@ -437,6 +437,25 @@ def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path
         _check(spec, opts, rng.normal(size=(2, P)) * 0.4, 1e-10)
 
 
+@pytest.mark.parametrize("split", [True, False])
+def test_reference_text_model_with_a_raw_table_of_100_trailing_parameters(split):
+    """the usual non-centred hierarchical model in the reference's text: z = Normal(0,1).latentVec(100) created last, eta = a +
+    tau * z(site) + b x, Poisson likelihood.  The Lookup has the shape of gather mode, but every model that comes from the
+    reference's front end carries the table's prior in a data-free target: generic path, initial chunk unrolled as usual"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
+    zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(2.0, n).astype(float)
+    fn = lambda s, u: M.Poisson((a + tau * CC.Lookup.apply(s, zs) + b * u).exp())
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("raw_table_100", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    for opts in (STRICT, FAST):
+        assert "#define RH_NROWTARGETS 1\n" in _check(spec, opts, qs, 1e-9)
+
+
 def test_one_observe_per_group_of_a_hierarchical_model_is_lifted_with_a_lookup():
     """80 schools, one Model.observe each (non-centred: mu + tau * eta_j, known sigma_j): the members differ in constants AND in
     the parameter eta_j -> one streamed target of 80 rows whose eta is a Lookup over a lifted index column and whose d/d eta_j are
