@@ -372,6 +372,13 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   if (const char *e = std::getenv("RH_LIFT_CONSTANTS")) lift = std::atoi(e) != 0;
   if (lift) rh::lift_constants(m->prog, m->synth_cols, old1);
   else for (uint32_t t = 0; t < m->prog.targets.size(); t++) old1.push_back(t);
+  {  // a gather-shaped parameter table whose prior is data-free: the prior terms become a row target over the group index (lift.cpp)
+    bool lp = true;
+    if (const char *e = std::getenv("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
+    int gmin = m->eopt.gather_min;
+    if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
+    if (lp && rh::lift_table_priors(m->prog, m->synth_cols, gmin)) old1.push_back(0xFFFFFFFFu);
+  }
   rh::merge_data_free_targets(m->prog, old2);
   if (m->prog.targets.size() > RH_MAX_TARGETS)
     throw Fail{RH_E_UNSUPPORTED, "more than 64 targets are left after merging the data-free ones (RH_MAX_TARGETS)"};

@@ -355,4 +355,156 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
 }
 }  // namespace
 
+// ---- table priors -> a row target over the group index ---------------------------------------------------------------------
+// (see rir.hpp) The data-free target's value is cut along its top-level additions (the Translator's left fold of a Line); a term
+// belongs to table entry k when k is the only table parameter it reaches.  Every entry must have the same terms as the first one
+// up to the renaming z_first -> z_k (constants that differ become columns), its gradient output likewise, and no other output of
+// the target may reach a table parameter.  Per-row arithmetic is the entry's own; the order of the additions changes as in any
+// row reduction.
+namespace {
+struct STerm { uint32_t node; bool neg; };
+void flatten_sum(const Program &P, uint32_t id, std::vector<STerm> &out) {
+  std::vector<std::pair<uint32_t, bool>> stack{{id, false}};
+  while (!stack.empty()) {      // left operand first -> original left-to-right order
+    auto [x, ng] = stack.back(); stack.pop_back();
+    const Node &n = P.nodes[x];
+    if (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB) { stack.push_back({n.b, n.op == RH_RIR_SUB ? !ng : ng}); stack.push_back({n.a, ng}); }
+    else out.push_back({x, ng});
+  }
+}
+}  // namespace
+
+bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min) {
+  auto no = [](int where) { if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table prior not lifted (check %d)\n", where); return false; };
+  if (P.kind != 0) return false;
+  const uint32_t np = P.n_params;
+  uint32_t t0 = np;
+  for (const Node &nd : P.nodes) {
+    if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < gather_min) continue;
+    const Node &ix = P.nodes[nd.a], &e0 = P.nodes[nd.table[0]];
+    if (ix.op == RH_RIR_INPUT && ix.input >= np && e0.op == RH_RIR_INPUT && e0.input < np && e0.input + nd.table.size() == np) t0 = std::min(t0, e0.input);
+  }
+  if (t0 >= np) return false;
+  const uint32_t G = np - t0;
+  auto is_zero = [&](uint32_t id) { return P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == 0.0; };
+  int tp = -1;                                    // the one data-free target with a gradient w.r.t. a table entry
+  for (size_t t = 0; t < P.targets.size(); t++) {
+    if (P.targets[t].n_cols) continue;
+    bool dep = false;
+    for (uint32_t k = t0; k < np && !dep; k++) dep = !is_zero(P.targets[t].outputs[1 + k]);
+    if (dep) { if (tp >= 0) return no(1); tp = (int)t; }
+  }
+  if (tp < 0 || P.targets.size() + 1 > RH_MAX_TARGETS) return no(2);
+  // table support of every node: -1 none, k one entry, -2 several
+  std::vector<int64_t> sup(P.nodes.size(), -1);
+  auto join = [](int64_t a, int64_t b) { return a == -1 ? b : (b == -1 || a == b) ? a : (int64_t)-2; };
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST) continue;
+    if (n.op == RH_RIR_INPUT) { if (n.input >= t0 && n.input < np) sup[i] = n.input; continue; }
+    int64_t s = sup[n.a];
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) s = join(s, sup[e]); } else if (binary_op(n.op)) s = join(s, sup[n.b]);
+    sup[i] = s;
+  }
+  const std::vector<uint32_t> outs = P.targets[(size_t)tp].outputs;
+  std::vector<STerm> vterms, rest;
+  flatten_sum(P, outs[0], vterms);
+  std::vector<std::vector<STerm>> val(G), grad(G);
+  for (const STerm &tm : vterms) {
+    if (sup[tm.node] == -2) return no(3);
+    if (sup[tm.node] == -1) rest.push_back(tm); else val[(size_t)(sup[tm.node] - t0)].push_back(tm);
+  }
+  for (uint32_t q = 0; q < t0; q++) if (sup[outs[1 + q]] != -1) return no(4);           // the prior ties a shared parameter to the table
+  for (uint32_t k = t0; k < np; k++) {
+    flatten_sum(P, outs[1 + k], grad[k - t0]);
+    for (const STerm &tm : grad[k - t0]) if (sup[tm.node] != -1 && sup[tm.node] != (int64_t)k) return no(5);
+    if (val[k - t0].empty()) return no(6);
+  }
+  // every entry against the first: same terms in the same order, the only renaming z_first -> z_k
+  std::vector<std::map<uint32_t, uint32_t>> maps(G);
+  for (uint32_t g = 0; g < G; g++) {
+    if (val[g].size() != val[0].size() || grad[g].size() != grad[0].size()) return no(7);
+    std::map<uint32_t, uint32_t> &memo = maps[g];
+    for (size_t i = 0; i < val[0].size(); i++) if (val[g][i].neg != val[0][i].neg || !match(P, val[0][i].node, val[g][i].node, memo, true)) return no(8);
+    for (size_t i = 0; i < grad[0].size(); i++) if (grad[g][i].neg != grad[0][i].neg || !match(P, grad[0][i].node, grad[g][i].node, memo, true)) return no(9);
+    for (auto &kv : memo) {
+      if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
+      const uint32_t a = P.nodes[kv.first].input, b = P.nodes[kv.second].input;
+      if (!(a == t0 ? b == t0 + g : (a == b && a < t0))) return no(10);
+    }
+  }
+  std::vector<uint32_t> slots;                    // constants that differ between entries -> columns
+  for (auto &kv : maps[0]) {
+    if (P.nodes[kv.first].op != RH_RIR_CONST) continue;
+    const double v0 = P.nodes[kv.first].cval;
+    bool differs = false;
+    for (uint32_t g = 1; g < G && !differs; g++) { const double v = P.nodes[maps[g].at(kv.first)].cval; differs = std::memcmp(&v, &v0, 8) != 0; }
+    if (differs) slots.push_back(kv.first);
+  }
+  if (slots.size() > 4096) return no(11);
+  for (uint32_t s : slots) { std::vector<double> col; for (uint32_t g = 0; g < G; g++) col.push_back(P.nodes[maps[g].at(s)].cval); synth.push_back(col); }
+  { std::vector<double> col; for (uint32_t g = 0; g < G; g++) col.push_back((double)g); synth.push_back(col); }
+  // the row target
+  const uint32_t in0 = P.n_inputs;
+  auto push = [&](const Node &q) { P.nodes.push_back(q); return (uint32_t)P.nodes.size() - 1; };
+  auto input_node = [&](uint32_t input) { Node q; q.op = RH_RIR_INPUT; q.input = input; return push(q); };
+  auto const_node = [&](double v) { Node q; q.op = RH_RIR_CONST; q.cval = v; return push(q); };
+  auto op2 = [&](uint32_t op, uint32_t a, uint32_t b) { Node q; q.op = op; q.a = a; q.b = b; return push(q); };
+  const size_t n_old = P.nodes.size();
+  std::map<uint32_t, uint32_t> copy;
+  std::vector<char> touched(n_old, 0);
+  for (size_t j = 0; j < slots.size(); j++) { copy[slots[j]] = input_node(in0 + (uint32_t)j); touched[slots[j]] = 1; }
+  const uint32_t idx = input_node(in0 + (uint32_t)slots.size());
+  {
+    Node L; L.op = RH_RIR_LOOKUP; L.a = idx; L.low = 0;
+    for (uint32_t k = t0; k < np; k++) L.table.push_back(input_node(k));
+    const uint32_t lk = push(L);
+    for (auto &kv : maps[0]) if (P.nodes[kv.first].op == RH_RIR_INPUT && P.nodes[kv.first].input == t0) { copy[kv.first] = lk; touched[kv.first] = 1; }
+  }
+  std::vector<uint32_t> order;
+  for (auto &kv : maps[0]) order.push_back(kv.first);
+  std::sort(order.begin(), order.end());
+  auto cp = [&](uint32_t y) { auto it = copy.find(y); return it != copy.end() ? it->second : y; };
+  for (uint32_t x : order) {
+    const Node n = P.nodes[x];
+    if (copy.count(x) || n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+    bool t = touched[n.a];
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) t = t || touched[e]; } else if (binary_op(n.op)) t = t || touched[n.b];
+    if (!t) continue;
+    touched[x] = 1;
+    Node q = n;
+    q.a = cp(n.a);
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : q.table) e = cp(e); } else if (binary_op(n.op)) q.b = cp(n.b);
+    copy[x] = push(q);
+  }
+  const uint32_t zero = const_node(0.0);
+  auto chain = [&](const std::vector<STerm> &ts, bool copied) {
+    uint32_t acc = 0xFFFFFFFFu;
+    for (const STerm &tm : ts) {
+      const uint32_t x = copied ? cp(tm.node) : tm.node;
+      if (acc == 0xFFFFFFFFu) acc = tm.neg ? op2(RH_RIR_SUB, zero, x) : x;
+      else acc = op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x);
+    }
+    return acc == 0xFFFFFFFFu ? zero : acc;
+  };
+  Target R;
+  R.n_cols = (uint32_t)slots.size() + 1; R.input_start = in0; R.col0 = P.n_cols_total;
+  R.outputs.push_back(chain(val[0], true));
+  const uint32_t gnode = chain(grad[0], true);
+  for (uint32_t q = 0; q < t0; q++) R.outputs.push_back(zero);
+  for (uint32_t g = 0; g < G; g++) {
+    Node e; e.op = RH_RIR_LOOKUP; e.a = op2(RH_RIR_COMPARE, idx, const_node((double)g)); e.low = -1;
+    e.table = {zero, gnode, zero};                               // eq(index, g, f'(z), 0): compute/Real.scala:83-99
+    R.outputs.push_back(push(e));
+  }
+  // the data-free target keeps the rest
+  Target &T = P.targets[(size_t)tp];
+  T.outputs[0] = chain(rest, false);
+  for (uint32_t k = t0; k < np; k++) T.outputs[1 + k] = zero;
+  P.targets.push_back(R);
+  P.n_inputs = in0 + R.n_cols; P.n_cols_total += R.n_cols;
+  recompute_deps(P);
+  return true;
+}
+
 }  // namespace rh

@@ -46,6 +46,11 @@ bool merge_data_free_targets(Program &P, std::vector<uint32_t> &old_target_of);
 // synthesised target (appended last; its columns follow the caller's).
 bool lift_constants(Program &P, std::vector<std::vector<double>> &synth, std::vector<uint32_t> &old_target_of);
 void recompute_deps(Program &P);
+// A table of >= gather_min trailing parameters indexed by a data column whose PRIOR sits in a data-free target (where the
+// reference's front end puts it): the per-entry prior terms become one more row target over a synthesised index column 0..G-1
+// (appended to `synth`; the target is appended to the list), so that every gradient with respect to a table entry comes from
+// row targets -- the precondition of gather mode (emit.cpp).  Returns false (and changes nothing) when the shape is not there.
+bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min);
 
 // Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns

@@ -21,9 +21,9 @@ STRICT = dict(math_mode=_capi.MATH_STRICT)
 def _check(spec, opts, qs, tol, with_data=True):
     """generated code (over the columns rh_model_create would keep) vs the oracle on the original program"""
     original = spec
-    if len(spec.nrows) > 64:      # the loader lifts same-shaped data-free targets into a streamed one (csrc/lift.cpp)
-        import dataclasses
-        rir2, cols2, _, nrows2 = _capi.lift_rir(spec.rir, spec.nrows)
+    import dataclasses
+    rir2, cols2, _, nrows2 = _capi.lift_rir(spec.rir, spec.nrows)      # what the loader lifts into streamed targets of its own (csrc/lift.cpp)
+    if cols2:
         spec = dataclasses.replace(spec, rir=rir2, columns=list(spec.columns) + cols2, nrows=nrows2)
     kw = dict(columns=spec.columns, nrows=spec.nrows) if with_data and spec.columns else {}
     src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, **kw)
@@ -419,8 +419,9 @@ def test_two_series_observed_one_value_at_a_time_become_two_streamed_targets():
 
 def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path():
     """a Lookup over 70 trailing parameters indexed by a column has the shape of gather mode, but the table's prior sits in the
-    data-free target (gather mode wants every table gradient to come from row targets): lowered on the generic path instead of
-    being refused"""
+    data-free target (gather mode wants every table gradient to come from row targets).  A prior on each entry alone is lifted into
+    a row target over the group index by the loader; one that involves a shared parameter is not, and the model is lowered on the
+    generic path instead of being refused"""
     rng = np.random.default_rng(2)
     G, per = 70, 5
     n = G * per
@@ -428,39 +429,105 @@ def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path
     P = 2 + G
     g = Graph(P, [0, 3])
     th = [g.param(i) for i in range(P)]
-    prior = th[0] * th[0] * -0.5 + th[1] * th[1] * -0.5
-    for k in range(G):
-        prior = prior + th[2 + k] * th[2 + k] * -0.5
     r = g.col(1, 2) - (th[0] + th[1] * g.col(1, 1) + g.lookup(g.col(1, 0), th[2:], 0))
-    spec = ModelSpec("gather_fallback", g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
-    for opts in (STRICT, FAST):
-        _check(spec, opts, rng.normal(size=(2, P)) * 0.4, 1e-10)
+    for centred in (True, False):
+        prior = th[0] * th[0] * -0.5 + th[1] * th[1] * -0.5
+        for k in range(G):      # centred: the prior ties every entry to a shared parameter and stays where it is -> generic path
+            prior = prior + ((th[2 + k] - th[0]) * (th[2 + k] - th[0]) if centred else th[2 + k] * th[2 + k]) * -0.5
+        spec = ModelSpec("gather_fallback", g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
+        for opts in (STRICT, FAST):
+            src = _check(spec, opts, rng.normal(size=(2, P)) * 0.4, 1e-10)
+            assert ("#define RH_HAS_GATHER 1\n" in src) == (not centred)   # a standard prior is lifted into a row target: gather mode
 
 
-@pytest.mark.parametrize("split", [True, False])
-def test_reference_text_model_with_a_raw_table_of_100_trailing_parameters(split):
-    """the usual non-centred hierarchical model in the reference's text: z = Normal(0,1).latentVec(100) created last, eta = a +
-    tau * z(site) + b x, Poisson likelihood.  The Lookup has the shape of gather mode, but every model that comes from the
-    reference's front end carries the table's prior in a data-free target: generic path, initial chunk unrolled as usual"""
+@pytest.mark.parametrize("family", ["negbin-split", "negbin", "poisson-split"])
+def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family):
+    """the usual non-centred hierarchical model in the reference's text (cfg 5's shape): z = Normal(0,1).latentVec(K) created last,
+    eta = a + tau * z(site) + b x.  The reference's front end puts the z prior into the data-free target; the loader lifts it into a
+    row target over the group index (lift_table_priors), after which fast builds -- whose gradient is re-derived into
+    eq(index, k, g, 0) form -- run in gather mode, also through Model.observe's 8-way split (rolled back first).  Strict builds keep
+    the reference's mask-column gradient and take the generic path; so does a Poisson likelihood through the split (its 8 slots
+    cannot be rolled: DESIGN 8)"""
     from rainier_amd import compute as CC
     rng = np.random.default_rng(4)
     K, n = 100, 1500
     a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
     zs = M.Normal(0, 1).latentVec(K)
-    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(2.0, n).astype(float)
-    fn = lambda s, u: M.Poisson((a + tau * CC.Lookup.apply(s, zs) + b * u).exp())
-    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("raw_table_100", inline=False)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n)
+    eta = lambda s, u: a + tau * CC.Lookup.apply(s, zs) + b * u
+    if family.startswith("negbin"):
+        ys = rng.poisson(3.0, n).astype(float); fn = lambda s, u: M.NegativeBinomial(eta(s, u).logistic, 5.0)
+    else:
+        ys = rng.poisson(2.0, n).astype(float); fn = lambda s, u: M.Poisson(eta(s, u).exp())
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=family.endswith("split")).compile("raw_table_" + family, inline=False)
     d = O.OracleDensity(spec)
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    gather = {opts is FAST: "#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-9) for opts in (STRICT, FAST)}
+    assert gather == {True: family.startswith("negbin"), False: False}
+
+
+def test_gather_mode_beyond_the_generic_path_s_parameter_limit():
+    """603 parameters (a 600-entry table): outside gather mode a model may have 512.  As the reference's front end hands it over the
+    table's prior is data-free; lifted, the model runs in gather mode"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(5)
+    K, n = 600, 3000
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
+    zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((a + tau * CC.Lookup.apply(s, zs) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("raw_table_600", inline=False)
+    assert spec.n_params == 603
+    src = _check(spec, FAST, rng.normal(size=(1, 603)) * 0.3, 1e-9)
+    assert "#define RH_HAS_GATHER 1\n" in src
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_table_priors(seed):
+    """fuzz: a Lookup over 65-139 trailing parameters indexed by a column, with the table's prior folded into the data-free target the
+    way the reference's front end leaves it -- standard, a random per-entry shape with per-entry constants (lifted as columns), two
+    terms per entry, or tied to a shared parameter (not lifted: generic path) -- a shared term in the middle of the fold; gather
+    mode exactly when the prior could be lifted, both math modes against the oracle on the original program"""
+    rng = np.random.default_rng(90000 + seed)
+    G, per = int(rng.integers(65, 140)), int(rng.integers(2, 6))
+    n, nsh = G * per, int(rng.integers(2, 4))
+    P = nsh + G
+    site = rng.permutation(np.repeat(np.arange(G), per)).astype(float); x = rng.normal(size=n); y = rng.normal(size=n)
+    g = Graph(P, [0, 3])
+    th = [g.param(i) for i in range(P)]
+    mode = seed % 4
+    prior = th[0] * th[0] * -0.5
+    for i in range(1, nsh):
+        prior = prior + th[i] * th[i] * -0.5
+    st, depth = int(rng.integers(1 << 30)), int(rng.integers(1, 4))
+    for k in range(G):
+        z = th[nsh + k]
+        if mode == 0:
+            prior = prior + z * z * -0.5
+        elif mode == 1:
+            c1, c2 = g.const(float(rng.uniform(0.5, 2.0))), g.const(float(rng.normal()))
+            prior = prior + _random_expr(np.random.default_rng(st), g, [z, c1, c2, z * c1], depth) + z * z * -0.5
+        elif mode == 2:
+            prior = prior + z * z * -0.5 - (z * z + 1.0).log() * 0.5
+        else:
+            prior = prior + (z - th[0]) * (z - th[0]) * -0.5
+        if k == G // 2:
+            prior = prior + th[1] * float(rng.normal())
+    r = g.col(1, 2) - (th[0] + th[1] * g.col(1, 1) + g.lookup(g.col(1, 0), th[nsh:], 0))
+    spec = ModelSpec("fuzz_table_prior_%d" % seed, g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:2]
+    if not qs:
+        pytest.skip("no finite evaluation point")
     for opts in (STRICT, FAST):
-        assert "#define RH_NROWTARGETS 1\n" in _check(spec, opts, qs, 1e-9)
+        assert ("#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-9)) == (mode != 3)
 
 
 def test_one_observe_per_group_of_a_hierarchical_model_is_lifted_with_a_lookup():
     """80 schools, one Model.observe each (non-centred: mu + tau * eta_j, known sigma_j): the members differ in constants AND in
     the parameter eta_j -> one streamed target of 80 rows whose eta is a Lookup over a lifted index column and whose d/d eta_j are
-    eq(index, j, g, 0) terms.  The table is a run of trailing parameters long enough for gather mode, whose preconditions do not
-    hold (the eta prior is data-free): the emitter falls back to the generic path"""
+    eq(index, j, g, 0) terms.  The table is a run of trailing parameters long enough for gather mode, and the eta prior -- data-free
+    as it comes -- is lifted into a row target over the group index as well (lift_table_priors), so gather mode applies"""
     rng = np.random.default_rng(3)
     J = 80
     ys, sig = rng.normal(size=J) * 5, rng.uniform(5, 15, size=J)
@@ -471,11 +538,13 @@ def test_one_observe_per_group_of_a_hierarchical_model_is_lifted_with_a_lookup()
     spec = m.compile("schools80")
     assert len(spec.nrows) == 82 and spec.n_params == 82
     _, cols, _, rows = _capi.lift_rir(spec.rir, spec.nrows)
-    assert rows == [0, 0, 80] and sorted(cols[-1]) == list(range(80))            # the index column: every eta once
+    assert rows == [0, 0, 80, 80] and sorted(cols[-2]) == list(range(80))        # the observations (index column: every eta once) ...
+    assert list(cols[-1]) == list(range(80))                                      # ... and the eta prior, lifted next (group index)
     qs = rng.normal(size=(2, spec.n_params)) * 0.4
     for opts in (STRICT, FAST):
         src = _check(spec, opts, qs, 1e-10)
-        assert "#define RH_NROWTARGETS 1\n" in src and len(src) < 200_000           # 540 KB as straight-line code
+        assert "#define RH_NROWTARGETS 2\n" in src and len(src) < 200_000           # 540 KB as straight-line code
+        assert "#define RH_HAS_GATHER 1\n" in src                                   # both targets read eta through the gather kernel
 
 
 @pytest.mark.parametrize("seed", range(6))
