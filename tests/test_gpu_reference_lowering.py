@@ -216,3 +216,44 @@ def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
     ch[:, :, 1] = np.abs(ch[:, :, 1])                 # sigma = |latent|: the two signs of the latent are the same model
     rhat = max(r for r, _ in diagnostics(ch))
     assert rhat < 1.3, rhat
+
+
+def test_hierarchical_models_as_the_front_end_hands_them_over_run_in_gather_mode():
+    """Written after this round's GPU budget was spent: the generated row code of both models is checked on the CPU
+    (tests/test_emitter_host.py, gather-mode emulation); this is their first run through rh_grad_gather_kernel.
+    (a) cfg 5's shape in the reference's own text -- NegBin-logit, eta = a + tau * z(site) + b x, z = Normal(0,1).latentVec(100)
+    created last -- through Model.observe's 8-way split: the z prior arrives in the data-free target and is lifted into a row
+    target over the group index (csrc/lift.cpp lift_table_priors), the split is rolled back, the gradient re-derived into
+    eq(index, k, g, 0) form: gather mode.  (b) 80 schools, one Model.observe per school: the members differ in a parameter, which
+    becomes a Lookup over a lifted index column; the eta prior is lifted as well."""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
+    zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((a + tau * CC.Lookup.apply(s, zs) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=True).compile("raw_table_negbin_split", inline=False)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "#define RH_HAS_GATHER 1\n" in m.hip_source
+    qs = rng.normal(size=(6, spec.n_params)) * 0.3
+    _check(spec, m, qs, 1e-10)
+    _check(spec, m, qs, 1e-10, engine=_capi.ENGINE_TICK)
+    tr = m.sample(R.make_config(20, 40), seeds=range(8))
+    assert np.all(np.isfinite(tr.chains))
+
+    J = 80
+    y8, sig = rng.normal(size=J) * 5, rng.uniform(5, 15, size=J)
+    mu = M.Normal(0, 5).latent; t8 = M.Cauchy(0, 5).latent.abs(); etas = M.Normal(0, 1).latentVec(J)
+    mod = M.Model([M.Real.zero])
+    for j in range(J):
+        mod = M.Model.observe([float(y8[j])], M.Normal(mu + t8 * etas[j], float(sig[j]))).merge(mod)
+    schools = mod.compile("schools80")
+    qs = rng.normal(size=(6, schools.n_params)) * 0.4
+    ms = R.Model(schools, device=0, math_mode=_capi.MATH_STRICT)
+    assert "#define RH_HAS_GATHER 1\n" in ms.hip_source and "#define RH_NROWTARGETS 2\n" in ms.hip_source
+    _check(schools, ms, qs, 1e-12, O.JM_DET)
+    mf = R.Model(schools, device=0, fp_contract=True, factor_outputs=True)
+    _check(schools, mf, qs, 1e-11)
+    _check(schools, mf, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    assert np.all(np.isfinite(mf.sample(R.make_config(20, 40), seeds=range(8)).chains))
