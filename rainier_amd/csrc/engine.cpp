@@ -396,7 +396,8 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
 
 // derived columns (copies, negations, products, affine images, constants) -> expressions over the base columns (columns.cpp);
 // fills m->col_src (engine column -> the caller's columns it is made of) and the per-target row counts
-void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll);
+void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll,
+                       bool *unroll_blocked = nullptr);
 // Fast builds first try WITHOUT unrolling Model.observe's initial chunk: after the gradient re-derivation the chunk is the same
 // function as a slot of the big target and is appended to it as rows (refactor.cpp), so no observation is written into the
 // generated source and the code-object cache keeps working across data sets.  If a small row target is still there afterwards
@@ -404,7 +405,9 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
 void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t) {
   if (m->eopt.fp_contract && m->eopt.simplify && m->prog.n_cols_total > 0) {
     const rh::Program saved = m->prog;
-    canonicalize_once(m, columns, nrows, nrows_t, false);
+    bool blocked = false;                     // gather mode keeps the chunk as a row target: a second attempt would change nothing
+    canonicalize_once(m, columns, nrows, nrows_t, false, &blocked);
+    if (blocked) return;
     int64_t big = 0; bool small_left = false;
     for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) big = std::max(big, nrows_t[t]);
     for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols && nrows_t[t] >= 1 && nrows_t[t] <= 8 && big >= 16) small_left = true;
@@ -413,7 +416,8 @@ void canonicalize(rh_model *m, const double *const *columns, const int64_t *nrow
   }
   canonicalize_once(m, columns, nrows, nrows_t, true);
 }
-void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll) {
+void canonicalize_once(rh_model *m, const double *const *columns, const int64_t *nrows, std::vector<int64_t> &nrows_t, bool allow_unroll,
+                       bool *unroll_blocked) {
   std::string err;
   nrows_t.assign(m->prog.targets.size(), 0);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) nrows_t[t] = nrows[t];
@@ -447,6 +451,7 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
       }
     }
   }
+  if (unroll_blocked) *unroll_blocked = gather;
   if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, allow_unroll && !gather);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (!m->prog.targets[t].n_cols) nrows_t[t] = 0;   // an unrolled initial chunk
   bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
