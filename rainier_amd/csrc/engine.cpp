@@ -377,6 +377,9 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
     if (const char *e = std::getenv("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
     int gmin = m->eopt.gather_min;
     if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
+    bool hoist = lp;
+    if (const char *e = std::getenv("RH_HOIST_TABLES")) hoist = std::atoi(e) != 0;
+    if (hoist) rh::hoist_table_maps(m->prog, gmin);
     if (lp && rh::lift_table_priors(m->prog, m->synth_cols, gmin)) old1.push_back(0xFFFFFFFFu);
   }
   rh::merge_data_free_targets(m->prog, old2);

@@ -507,4 +507,101 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
   return true;
 }
 
+// ---- the affine map of a parameter table moved behind the lookup (see rir.hpp) ----------------------------------------------
+bool hoist_table_maps(Program &P, int gather_min) {
+  auto no = [](int where) { if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table map not hoisted (check %d)\n", where); return false; };
+  if (P.kind != 0) return false;
+  const uint32_t np = P.n_params;
+  std::vector<char> reaches_param(P.nodes.size(), 0);
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST) continue;
+    if (n.op == RH_RIR_INPUT) { reaches_param[i] = n.input < np; continue; }
+    char r = reaches_param[n.a];
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) r = r || reaches_param[e]; } else if (binary_op(n.op)) r = r || reaches_param[n.b];
+    reaches_param[i] = r;
+  }
+  std::vector<uint32_t> cands;
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &nd = P.nodes[i];
+    if (nd.op != RH_RIR_LOOKUP) continue;
+    const Node &ix = P.nodes[nd.a];
+    if (!(ix.op == RH_RIR_INPUT && ix.input >= np)) continue;        // (selects on a compare, parameter-indexed tables: not ours)
+    bool params_only = true, any_param = false;                       // a PARAMETER table: entries free of data, not all constant
+    for (uint32_t e : nd.table) { params_only = params_only && P.nodes[e].dep == 0; any_param = any_param || reaches_param[e]; }
+    if (!params_only || !any_param) continue;                         // (a select between row-level terms: Real.eq over a column)
+    if ((int)nd.table.size() < gather_min) return no(1);              // a second, small parameter table: gather mode has one
+    cands.push_back(i);
+  }
+  if (cands.empty()) return no(2);
+  const Node L0 = P.nodes[cands[0]];
+  for (uint32_t c : cands) if (P.nodes[c].table != L0.table || P.nodes[c].low != L0.low) return no(3);
+  const uint32_t K = (uint32_t)L0.table.size();
+  if (K > np || P.nodes[L0.table[0]].op == RH_RIR_INPUT) return no(4);                // already raw
+  for (uint32_t e : L0.table) if (P.nodes[e].dep != 0) return no(5);
+  const uint32_t t0 = np - K;
+  // every entry against the first; the one parameter that varies must be t0 + k
+  std::map<uint32_t, uint32_t> memo0;
+  if (!match(P, L0.table[0], L0.table[0], memo0, true)) return no(6);
+  std::vector<uint32_t> zin(K, 0xFFFFFFFFu);       // the INPUT node of z_k
+  for (uint32_t k = 0; k < K; k++) {
+    std::map<uint32_t, uint32_t> memo;
+    if (!match(P, L0.table[0], L0.table[k], memo, true)) return no(7);
+    for (auto &kv : memo) {
+      const Node &a = P.nodes[kv.first], &b = P.nodes[kv.second];
+      if (a.op == RH_RIR_CONST) { if (std::memcmp(&a.cval, &b.cval, 8) != 0) return no(8); continue; }
+      if (a.op != RH_RIR_INPUT) continue;
+      if (a.input == t0) { if (b.input != t0 + k) return no(9); zin[k] = kv.second; }
+      else if (a.input != b.input || a.input >= t0) return no(10);
+    }
+    if (zin[k] == 0xFFFFFFFFu) return no(11);
+  }
+  std::vector<uint32_t> tmpl;                      // the first entry's nodes, ascending
+  for (auto &kv : memo0) tmpl.push_back(kv.first);
+  std::sort(tmpl.begin(), tmpl.end());
+  std::vector<char> is_cand(P.nodes.size(), 0);
+  for (uint32_t c : cands) is_cand[c] = 1;
+  // rebuild the node list (operands keep smaller ids than their users)
+  std::vector<Node> Q;
+  std::vector<uint32_t> m(P.nodes.size(), 0);
+  auto push = [&](const Node &q) { Q.push_back(q); return (uint32_t)Q.size() - 1; };
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_SEQ) { m[i] = m[n.b]; continue; }   // the Translator's VarDef chain that evaluates every entry before the lookup:
+                                                           // value = second operand; the entries are no longer evaluated one by one
+    if (!is_cand[i]) {
+      Node q = n;
+      if (n.op != RH_RIR_CONST && n.op != RH_RIR_INPUT) {
+        q.a = m[n.a];
+        if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : q.table) e = m[e]; } else if (binary_op(n.op)) q.b = m[n.b];
+      }
+      m[i] = push(q);
+      continue;
+    }
+    Node L; L.op = RH_RIR_LOOKUP; L.a = m[n.a]; L.low = n.low;
+    for (uint32_t k = 0; k < K; k++) L.table.push_back(m[zin[k]]);
+    const uint32_t lk = push(L);
+    std::map<uint32_t, uint32_t> copy;             // template node -> its copy over the looked-up entry
+    for (uint32_t x : tmpl) {
+      const Node &t = P.nodes[x];
+      if (t.op == RH_RIR_INPUT) { if (t.input == t0) copy[x] = lk; continue; }
+      if (t.op == RH_RIR_CONST) continue;
+      auto cp = [&](uint32_t y) { auto it = copy.find(y); return it != copy.end() ? it->second : m[y]; };
+      bool touched = copy.count(t.a) != 0;
+      if (t.op == RH_RIR_LOOKUP) { for (uint32_t e : t.table) touched = touched || copy.count(e); } else if (binary_op(t.op)) touched = touched || copy.count(t.b);
+      if (!touched) continue;
+      Node q = t;
+      q.a = cp(t.a);
+      if (t.op == RH_RIR_LOOKUP) { for (uint32_t &e : q.table) e = cp(e); } else if (binary_op(t.op)) q.b = cp(t.b);
+      copy[x] = push(q);
+    }
+    auto it = copy.find(L0.table[0]);
+    m[i] = it != copy.end() ? it->second : m[L0.table[0]];
+  }
+  P.nodes.swap(Q);
+  for (Target &T : P.targets) for (uint32_t &o : T.outputs) o = m[o];
+  recompute_deps(P);
+  return true;
+}
+
 }  // namespace rh

@@ -51,6 +51,10 @@ void recompute_deps(Program &P);
 // (appended to `synth`; the target is appended to the list), so that every gradient with respect to a table entry comes from
 // row targets -- the precondition of gather mode (emit.cpp).  Returns false (and changes nothing) when the shape is not there.
 bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min);
+// Lookup(column, [f(z_0), f(z_1), ...]) -> f(Lookup(column, [z_0, z_1, ...])) when every entry is the same function of one of
+// >= gather_min consecutive trailing parameters (Normal(mu, sd).latentVec(G)(site): z_k * sd + mu) and it is the program's only
+// column-indexed table: the same arithmetic on the selected entry (bit-identical), and the shape gather mode reads.
+bool hoist_table_maps(Program &P, int gather_min);
 
 // Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns

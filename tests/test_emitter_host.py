@@ -466,6 +466,72 @@ def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family):
     assert gather == {True: family.startswith("negbin"), False: False}
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_the_canonical_hierarchical_construction_runs_in_gather_mode(split):
+    """alphas = Normal(mu, sd).latentVec(K) -- entries z_k * sd + mu -- created last, eta = alphas(site) + b x: the loader moves the
+    affine map behind the lookup (hoist_table_maps: Lookup(site, [f(z_k)]) = f(Lookup(site, [z_k])), the same arithmetic on the
+    selected entry; the Translator's VarDef chain over the entries goes), lifts the z prior, and fast builds run in gather mode"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    b = M.Normal(0, 1).latent
+    alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("centred_table_100", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    assert "#define RH_HAS_GATHER 1\n" in _check(spec, FAST, qs, 1e-9)
+    assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)     # the reference's mask-column gradient: generic path
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_hierarchical_models_in_the_reference_text(seed):
+    """fuzz through the real front end: a table of 65-129 entries built six ways (z sd + mu, z sd, exp-type, raw, not trailing, next
+    to a second small table), three likelihoods, with and without Model.observe's split; whatever the loader can hoist, lift and
+    roll, both math modes must reproduce the original program"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(110000 + seed)
+    K = int(rng.integers(65, 130)); n = int(rng.integers(2 * K, 6 * K)); kind = seed % 6; lik = int(rng.integers(3)); split = bool(rng.random() < 0.4)
+    pre = M.Normal(0, 1).latent
+    late = None
+    if kind == 1:
+        tab = M.Normal(0, M.Exponential(1).latent).latentVec(K)
+    elif kind == 2:
+        tab = [z.exp() for z in M.Normal(0, 0.3).latentVec(K)]
+    elif kind == 3:
+        tab = M.Normal(0, 1).latentVec(K)
+    else:
+        tab = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    if kind == 4:
+        late = M.Normal(0, 1).latent
+    tab2 = M.Normal(0, 1).latentVec(7) if kind == 5 else None
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); s2 = rng.integers(0, 7, n).astype(float)
+
+    def eta(s, u, v=None):
+        e = CC.Lookup.apply(s, tab) + pre * u
+        if late is not None:
+            e = e + late * u
+        if tab2 is not None:
+            e = e + CC.Lookup.apply(v, tab2)
+        return e
+    covs = [site, x] + ([s2] if tab2 is not None else [])
+    if lik == 0:
+        ys = rng.poisson(3.0, n).astype(float); fn = lambda *a: M.NegativeBinomial(eta(*a).logistic, 5.0)
+    elif lik == 1:
+        ys = rng.integers(0, 2, n).astype(float); fn = lambda *a: M.Bernoulli(eta(*a).logistic)
+    else:
+        ys = rng.normal(size=n); fn = lambda *a: M.Cauchy(eta(*a), 1.5)
+    spec = M.Model.observe_vec(ys, covs, fn, split=split).compile("fuzz_hier_%d" % seed, inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    assert qs
+    for opts in (STRICT, FAST):
+        src = _check(spec, opts, qs, 1e-9)
+        if kind in (4, 5):
+            assert "#define RH_HAS_GATHER 1\n" not in src
+
+
 def test_gather_mode_beyond_the_generic_path_s_parameter_limit():
     """603 parameters (a 600-entry table): outside gather mode a model may have 512.  As the reference's front end hands it over the
     table's prior is data-free; lifted, the model runs in gather mode"""
