@@ -1238,6 +1238,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   // preconditions -- e.g. the table's prior sits in a data-free target -- is lowered on the generic path (the table as a
   // per-evaluation array: correct, slow) as long as it has few enough parameters for it
   if (err.rfind("gather mode:", 0) != 0) return false;
+  if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: generic path instead of gather mode: %s\n", err.c_str());
   EmitOptions o2 = o;
   o2.gather_min = 0x7fffffff;
   std::string err2;

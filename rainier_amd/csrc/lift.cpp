@@ -535,7 +535,14 @@ bool hoist_table_maps(Program &P, int gather_min) {
   }
   if (cands.empty()) return no(2);
   const Node L0 = P.nodes[cands[0]];
-  for (uint32_t c : cands) if (P.nodes[c].table != L0.table || P.nodes[c].low != L0.low) return no(3);
+  for (uint32_t c : cands) {                       // the same table everywhere: the very nodes, or copies of them (8 slots)
+    const Node &Lc = P.nodes[c];
+    if (Lc.low != L0.low || Lc.table.size() != L0.table.size()) return no(3);
+    if (Lc.table == L0.table) continue;
+    std::map<uint32_t, uint32_t> same;
+    for (size_t k = 0; k < L0.table.size(); k++) if (!match(P, L0.table[k], Lc.table[k], same, false)) return no(3);
+    for (auto &kv : same) if (P.nodes[kv.first].op == RH_RIR_CONST && std::memcmp(&P.nodes[kv.first].cval, &P.nodes[kv.second].cval, 8) != 0) return no(3);
+  }
   const uint32_t K = (uint32_t)L0.table.size();
   if (K > np || P.nodes[L0.table[0]].op == RH_RIR_INPUT) return no(4);                // already raw
   for (uint32_t e : L0.table) if (P.nodes[e].dep != 0) return no(5);
