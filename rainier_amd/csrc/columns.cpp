@@ -22,6 +22,7 @@
 // row target of its own, core/Model.scala:84-96) is unrolled -- its rows substituted as constants and summed in row order -- so
 // that the model is left with one streamed target.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -96,19 +97,27 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     // on a handful of rows every column is an affine image of every other: a small target (Model.observe's initial chunk, when it
     // is not unrolled) is only searched for copies, negations and products -- the relations its big sibling's slots have too
     const bool small = nr < 16;
-    for (int j = 0; j < nc && (nr >= 16 || (nr >= 3 && !allow_unroll)); j++) {
+    const bool search = nr >= 16 || (nr >= 3 && !allow_unroll);
+    // constant columns first (a NaN column is left alone: RIR has no NaN constants); the search below skips them as operands
+    std::vector<char> is_const((size_t)nc, 0);
+    for (int j = 0; j < nc && search && !small; j++) {
+      const double *c = col[(size_t)j];
+      if (c[0] == c[0] && verify(j, [&](int64_t) { return c[0]; })) is_const[(size_t)j] = 1;
+    }
+    // every column against the columns before it: independent of each other, so models with thousands of columns (a mask per table
+    // entry and slot) are searched on several threads -- unless the row scans themselves are threaded (verify, big targets)
+    auto process = [&](int j) {
       const double *c = col[(size_t)j];
       CExpr e;
       bool found = false;
-      // constant (a NaN column is left alone: RIR has no NaN constants)
-      if (!small && c[0] == c[0] && verify(j, [&](int64_t) { return c[0]; })) { e.kind = CExpr::CONST; e.c = c[0]; found = true; }
+      if (is_const[(size_t)j]) { e.kind = CExpr::CONST; e.c = c[0]; found = true; }
       for (int a = 0; a < j && !found; a++) {
         const double *ca = col[(size_t)a];
         if (verify(j, [&](int64_t r) { return ca[r]; })) { e.kind = CExpr::ALIAS; e.a = a; found = true; break; }
         if (verify(j, [&](int64_t r) { return -ca[r]; })) { e.kind = CExpr::NEG; e.a = a; found = true; break; }
       }
       for (int a = 0; a < j && !found && !small; a++) {
-        if (ex[(size_t)a].kind == CExpr::CONST) continue;
+        if (is_const[(size_t)a]) continue;
         const double *ca = col[(size_t)a];
         {
           const double al = c[0] - ca[0];
@@ -127,16 +136,31 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       }
       // (quadratic in the number of earlier columns: bounded, so that a model with thousands of columns is not held up here)
       for (int a = 0; a < j && !found && (int64_t)j * j <= 4000000; a++) {
-        if (ex[(size_t)a].kind == CExpr::CONST) continue;
+        if (is_const[(size_t)a]) continue;
         const double *ca = col[(size_t)a];
         for (int b = a; b < j && !found; b++) {
-          if (ex[(size_t)b].kind == CExpr::CONST) continue;
+          if (is_const[(size_t)b]) continue;
           const double *cb = col[(size_t)b];
           if (verify(j, [&](int64_t r) { return ca[r] * cb[r]; })) { e.kind = CExpr::MUL; e.a = a; e.b = b; found = true; }
           else if (verify(j, [&](int64_t r) { return -(ca[r] * cb[r]); })) { e.kind = CExpr::MUL; e.a = a; e.b = b; e.c = -1.0; found = true; }
         }
       }
-      if (found) { ex[(size_t)j] = e; changed = true; }
+      if (found) ex[(size_t)j] = e;
+      return found;
+    };
+    if (search) {
+      const int nth = (nr < 400000 && nc >= 64) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+      if (nth <= 1) {
+        for (int j = 0; j < nc; j++) if (process(j)) changed = true;
+      } else {
+        std::atomic<int> next{0};
+        std::atomic<bool> any{false};
+        std::vector<std::thread> th;
+        for (int w = 0; w < nth; w++)
+          th.emplace_back([&] { for (int j = next++; j < nc; j = next++) if (process(j)) any = true; });
+        for (auto &t : th) t.join();
+        if (any) changed = true;
+      }
     }
   }
   // Model.observe's initial chunk (core/Model.scala:84-96): a row target with at most 8 rows next to a big one.  Its rows are
