@@ -381,6 +381,7 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
     if (const char *e = std::getenv("RH_HOIST_TABLES")) hoist = std::atoi(e) != 0;
     if (hoist) rh::hoist_table_maps(m->prog, gmin);
     if (lp && rh::lift_table_priors(m->prog, m->synth_cols, gmin)) old1.push_back(0xFFFFFFFFu);
+    if (lp) for (int k = rh::lift_single_entry_targets(m->prog, m->synth_cols, gmin); k > 0; k--) old1.push_back(0xFFFFFFFFu);
   }
   rh::merge_data_free_targets(m->prog, old2);
   if (m->prog.targets.size() > RH_MAX_TARGETS)

@@ -611,4 +611,91 @@ bool hoist_table_maps(Program &P, int gather_min) {
   return true;
 }
 
+// ---- a data-free expression over one table entry -> a one-row target (see rir.hpp) ----------------------------------------------
+int lift_single_entry_targets(Program &P, std::vector<std::vector<double>> &synth, int gather_min) {
+  if (P.kind != 0) return 0;
+  const uint32_t np = P.n_params;
+  uint32_t t0 = np; int32_t low = 0;
+  for (const Node &nd : P.nodes) {
+    if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < gather_min) continue;
+    const Node &ix = P.nodes[nd.a], &e0 = P.nodes[nd.table[0]];
+    if (ix.op == RH_RIR_INPUT && ix.input >= np && e0.op == RH_RIR_INPUT && e0.input < np && e0.input + nd.table.size() == np && e0.input < t0) { t0 = e0.input; low = nd.low; }
+  }
+  if (t0 >= np) return 0;
+  const uint32_t G = np - t0;
+  std::vector<int64_t> sup(P.nodes.size(), -1);   // table support: -1 none, k one entry, -2 several
+  auto join = [](int64_t a, int64_t b) { return a == -1 ? b : (b == -1 || a == b) ? a : (int64_t)-2; };
+  for (uint32_t i = 0; i < P.nodes.size(); i++) {
+    const Node &n = P.nodes[i];
+    if (n.op == RH_RIR_CONST) continue;
+    if (n.op == RH_RIR_INPUT) { if (n.input >= t0 && n.input < np) sup[i] = n.input; continue; }
+    int64_t s = sup[n.a];
+    if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) s = join(s, sup[e]); } else if (binary_op(n.op)) s = join(s, sup[n.b]);
+    sup[i] = s;
+  }
+  auto is_zero = [&](uint32_t id) { return P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == 0.0; };
+  int lifted = 0;
+  const size_t NT = P.targets.size();
+  for (size_t t = 0; t < NT && lifted < 4 && P.targets.size() < RH_MAX_TARGETS; t++) {
+    const std::vector<uint32_t> outs = P.targets[t].outputs;
+    int64_t k = -1;
+    bool ok = true;
+    for (uint32_t o : outs) { ok = ok && P.nodes[o].dep == 0; k = join(k, sup[o]); }
+    if (!ok || k < 0) continue;
+    for (uint32_t q = t0; q < np && ok; q++) if ((int64_t)q != k) ok = is_zero(outs[1 + q]);
+    if (!ok) continue;
+    // the one-row target: the entry read through a Lookup over the new column
+    const uint32_t in0 = P.n_inputs;
+    auto push = [&](const Node &q) { P.nodes.push_back(q); return (uint32_t)P.nodes.size() - 1; };
+    auto input_node = [&](uint32_t input) { Node q; q.op = RH_RIR_INPUT; q.input = input; return push(q); };
+    auto const_node = [&](double v) { Node q; q.op = RH_RIR_CONST; q.cval = v; return push(q); };
+    const size_t n_old = P.nodes.size();
+    const uint32_t idx = input_node(in0);
+    Node L; L.op = RH_RIR_LOOKUP; L.a = idx; L.low = low;
+    for (uint32_t q = t0; q < np; q++) L.table.push_back(input_node(q));
+    const uint32_t lk = push(L);
+    std::vector<uint32_t> cpy(n_old, 0xFFFFFFFFu);
+    std::vector<char> reach(n_old, 0);
+    for (uint32_t o : outs) reach[o] = 1;
+    for (size_t i = n_old; i-- > 0;) {
+      if (!reach[i]) continue;
+      const Node &n = P.nodes[i];
+      if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+      reach[n.a] = 1;
+      if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) reach[e] = 1; } else if (binary_op(n.op)) reach[n.b] = 1;
+    }
+    for (uint32_t i = 0; i < n_old; i++) {
+      if (!reach[i] || sup[i] != k) continue;
+      const Node n = P.nodes[i];
+      if (n.op == RH_RIR_INPUT) { cpy[i] = lk; continue; }
+      auto cp = [&](uint32_t y) { return cpy[y] != 0xFFFFFFFFu ? cpy[y] : y; };
+      Node q = n;
+      q.a = cp(n.a);
+      if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : q.table) e = cp(e); } else if (binary_op(n.op)) q.b = cp(n.b);
+      cpy[i] = push(q);
+    }
+    auto cpo = [&](uint32_t o) { return cpy[o] != 0xFFFFFFFFu ? cpy[o] : o; };
+    const uint32_t zero = const_node(0.0);
+    Target R;
+    R.n_cols = 1; R.input_start = in0; R.col0 = P.n_cols_total;
+    R.outputs.push_back(cpo(outs[0]));
+    for (uint32_t q = 0; q < t0; q++) R.outputs.push_back(cpo(outs[1 + q]));
+    const uint32_t gnode = cpo(outs[1 + (uint32_t)k]);
+    for (uint32_t g = 0; g < G; g++) {
+      Node c; c.op = RH_RIR_COMPARE; c.a = idx; c.b = const_node((double)((int64_t)g + low));
+      Node e; e.op = RH_RIR_LOOKUP; e.a = push(c); e.low = -1;
+      e.table = {zero, gnode, zero};                               // eq(index, low + g, d/dz, 0)
+      R.outputs.push_back(push(e));
+    }
+    for (uint32_t &o : P.targets[t].outputs) o = zero;
+    P.targets.push_back(R);
+    P.n_inputs = in0 + 1; P.n_cols_total += 1;
+    synth.push_back({(double)((int64_t)((uint32_t)k - t0) + low)});
+    lifted++;
+    sup.resize(P.nodes.size(), -1);
+  }
+  if (lifted) recompute_deps(P);
+  return lifted;
+}
+
 }  // namespace rh

@@ -55,6 +55,11 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
 // >= gather_min consecutive trailing parameters (Normal(mu, sd).latentVec(G)(site): z_k * sd + mu) and it is the program's only
 // column-indexed table: the same arithmetic on the selected entry (bit-identical), and the shape gather mode reads.
 bool hoist_table_maps(Program &P, int gather_min);
+// A target whose expression is data-free and reaches exactly ONE entry of a gather-shaped table -- Model.observe's initial chunk when
+// it has a single row: the front end folds a single observation into constants, Lookup(constant, table) into the entry -- becomes a
+// one-row target over a synthesised index column, so that the entry is read through the gather again.  Appends to `synth`, returns
+// the number of targets appended (each after the existing ones).
+int lift_single_entry_targets(Program &P, std::vector<std::vector<double>> &synth, int gather_min);
 
 // Column canonicalisation (columns.cpp): derived columns (copies, negations, products, affine images of earlier columns,
 // constants) are replaced by expressions over the base columns.  kept[new global column] = caller's column index.  Returns

@@ -532,6 +532,24 @@ def test_random_hierarchical_models_in_the_reference_text(seed):
             assert "#define RH_HAS_GATHER 1\n" not in src
 
 
+def test_a_one_row_initial_chunk_is_read_through_the_gather_too():
+    """n mod 8 = 1: Model.observe's initial chunk is a single observation, which the front end folds into constants -- its
+    Lookup(constant, table) becomes the table entry itself, read outside any gather.  The loader turns such an expression (data-free,
+    one table entry) into a one-row target over a synthesised index column (lift_single_entry_targets); with 603 parameters the
+    model would otherwise be refused for one value of n in eight"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(6)
+    K, n = 600, 2401
+    b = M.Normal(0, 1).latent
+    alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=True).compile("one_row_chunk", inline=False)
+    assert 1 in spec.nrows and spec.n_params == 603
+    src = _check(spec, FAST, rng.normal(size=(1, 603)) * 0.3, 1e-9)
+    assert "#define RH_HAS_GATHER 1\n" in src
+
+
 def test_gather_mode_beyond_the_generic_path_s_parameter_limit():
     """603 parameters (a 600-entry table): outside gather mode a model may have 512.  As the reference's front end hands it over the
     table's prior is data-free; lifted, the model runs in gather mode"""
