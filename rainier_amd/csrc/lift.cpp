@@ -12,6 +12,13 @@
 // which the members are added up becomes that of a row reduction.  Members that do not match stay data-free.  The step repeats
 // while another group of >= 32 qualifies (two time series observed one value at a time become two streamed targets).  When no
 // group differs in constants alone, families whose members differ in a parameter are looked for (lift_one, second half).
+//
+// The second half of the file prepares parameter TABLES for gather mode (emit.cpp detect_gather), again by undoing
+// what the reference's front end folded: hoist_table_maps (the entries' common map moved behind the lookup), lift_table_priors
+// (the table's prior, data-free as it comes, becomes a row target over the group index) and lift_single_entry_targets (a
+// data-free expression over one entry -- Model.observe's one-row initial chunk -- becomes a one-row target).  Everything here
+// runs in rh_model_create's loader (engine.cpp load_program), before the data-dependent passes; synthesised columns follow the
+// caller's.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
