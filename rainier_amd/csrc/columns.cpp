@@ -230,20 +230,20 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     Node n; n.op = RH_RIR_CONST; n.cval = v;
     return consts[bits(v)] = push(n);
   };
-  auto input = [&](uint32_t idx, uint8_t dep) {
+  auto input = [&](uint32_t idx, uint32_t dep) {
     auto it = inputs.find(idx);
     if (it != inputs.end()) return it->second;
     Node n; n.op = RH_RIR_INPUT; n.input = idx; n.dep = dep;
     return inputs[idx] = push(n);
   };
-  auto op2 = [&](uint32_t op, uint32_t a, uint32_t b, uint8_t dep) {
+  auto op2 = [&](uint32_t op, uint32_t a, uint32_t b, uint32_t dep) {
     auto key = std::make_tuple(op, a, b);
     auto it = cons.find(key);
     if (it != cons.end()) return it->second;
     Node n; n.op = op; n.a = a; n.b = b; n.dep = dep;
     return cons[key] = push(n);
   };
-  auto op1 = [&](uint32_t op, uint32_t a, uint8_t dep) {
+  auto op1 = [&](uint32_t op, uint32_t a, uint32_t dep) {
     auto key = std::make_tuple(op, a, 0xffffffffu);
     auto it = cons.find(key);
     if (it != cons.end()) return it->second;
@@ -254,7 +254,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
   std::function<uint32_t(size_t, int)> column = [&](size_t t, int j) -> uint32_t {
     auto it = col_node[t].find(j);
     if (it != col_node[t].end()) return it->second;
-    const uint8_t dep = (uint8_t)(t + 1);
+    const uint32_t dep = (uint32_t)(t + 1);
     const CExpr &e = exprs[t][(size_t)j];
     uint32_t id = 0;
     switch (e.kind) {

@@ -102,7 +102,7 @@ struct TargetEmitter {
     P.nodes.push_back(n);
     return (uint32_t)P.nodes.size() - 1;
   }
-  uint32_t mk(uint32_t op, uint32_t a, uint32_t b, uint8_t dep) {
+  uint32_t mk(uint32_t op, uint32_t a, uint32_t b, uint32_t dep) {
     auto key = std::make_tuple(op, a, b);
     auto it = cons.find(key);
     if (it != cons.end()) return it->second;
@@ -155,7 +155,7 @@ struct TargetEmitter {
         if (a.beta == ZERO && b.beta == ZERO) {
           Lin r;
           const uint32_t lo = std::min(a.term, b.term), hi = std::max(a.term, b.term);
-          r.term = (a.alpha == ONE && b.alpha == ONE) ? id : mk(RH_RIR_MUL, lo, hi, (uint8_t)(t + 1));
+          r.term = (a.alpha == ONE && b.alpha == ONE) ? id : mk(RH_RIR_MUL, lo, hi, (uint32_t)(t + 1));
           r.alpha = imul(a.alpha, b.alpha);
           return r;
         }

@@ -372,7 +372,10 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   if (const char *e = std::getenv("RH_LIFT_CONSTANTS")) lift = std::atoi(e) != 0;
   if (lift) rh::lift_constants(m->prog, m->synth_cols, old1);
   else for (uint32_t t = 0; t < m->prog.targets.size(); t++) old1.push_back(t);
-  {  // a gather-shaped parameter table whose prior is data-free: the prior terms become a row target over the group index (lift.cpp)
+  // (rh_lower_only has no data: the preparation of parameter tables for gather mode synthesises columns NEXT TO the caller's, and
+  //  what follows from it -- canonicalisation, re-derivation, rolling -- needs all of them, so it waits for rh_model_create)
+  const bool have_data = columns != nullptr || caller_cols == 0;
+  if (have_data) {  // a gather-shaped parameter table whose prior is data-free: the prior terms become a row target over the group index (lift.cpp)
     bool lp = true;
     if (const char *e = std::getenv("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
     int gmin = m->eopt.gather_min;
@@ -692,7 +695,9 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
     std::vector<const double *> colv;
     load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
     (void)apply_compile_opts(&m, opts);
-    if ((columns && nrows) || !m.synth_cols.empty()) { std::vector<int64_t> nrows_t; canonicalize(&m, colv.data(), nrows_in.data(), nrows_t); }
+    bool all_cols = true;   // the data-dependent passes need every column (the caller's and the lifted ones) on the host
+    for (const double *c : colv) all_cols = all_cols && c != nullptr;
+    if (all_cols && ((columns && nrows) || !m.synth_cols.empty())) { std::vector<int64_t> nrows_t; canonicalize(&m, colv.data(), nrows_in.data(), nrows_t); }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }

@@ -67,11 +67,11 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
 
 void recompute_deps(Program &P) {
   for (Node &n : P.nodes) {
-    uint8_t dep = 0;
+    uint32_t dep = 0;
     if (n.op == RH_RIR_INPUT) {
       if (n.input >= P.n_params)
         for (size_t t = 0; t < P.targets.size(); t++)
-          if (n.input >= P.targets[t].input_start && n.input < P.targets[t].input_start + P.targets[t].n_cols) dep = (uint8_t)(t + 1);
+          if (n.input >= P.targets[t].input_start && n.input < P.targets[t].input_start + P.targets[t].n_cols) dep = (uint32_t)(t + 1);
     } else if (n.op != RH_RIR_CONST) {
       dep = P.nodes[n.a].dep;
       if (n.op == RH_RIR_LOOKUP) { for (uint32_t e : n.table) if (P.nodes[e].dep) dep = P.nodes[e].dep; }

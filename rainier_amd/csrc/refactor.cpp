@@ -41,7 +41,7 @@ struct Atom {
   uint32_t input = 0;
   int32_t low = 0;
   std::vector<uint32_t> kids;      // polynomial ids
-  uint8_t dep = 0;
+  uint32_t dep = 0;
   bool operator<(const Atom &o) const { return std::tie(op, input, low, kids) < std::tie(o.op, o.input, o.low, o.kids); }
 };
 constexpr uint32_t SUM_ATOM = 0xFFFFFFFFu;
@@ -71,7 +71,7 @@ struct Refactor {
     atoms.push_back(a);
     return atom_ids[a] = (uint32_t)atoms.size() - 1;
   }
-  uint8_t poly_dep(const Poly &p) const {
+  uint32_t poly_dep(const Poly &p) const {
     for (auto &t : p) for (auto &f : t.first) if (atoms[f.first].dep) return atoms[f.first].dep;
     return 0;
   }

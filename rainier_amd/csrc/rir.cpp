@@ -59,10 +59,10 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
   for (uint32_t i = 0; i < n_nodes; i++) {
     Node &nd = P.nodes[i];
     nd.op = r.u32();
-    uint8_t dep = 0;
+    uint32_t dep = 0;
     auto use = [&](uint32_t x) -> bool {
       if (x >= i) { err = "RIR: node " + std::to_string(i) + " references a later node"; return false; }
-      const uint8_t d = P.nodes[x].dep;
+      const uint32_t d = P.nodes[x].dep;
       if (d) { if (dep && dep != d) { err = "RIR: node " + std::to_string(i) + " mixes columns of two targets"; return false; } dep = d; }
       return true;
     };
@@ -76,7 +76,7 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
         if (nd.input >= P.n_inputs) { err = "RIR: input index out of range"; return false; }
         if (nd.input >= P.n_params)
           for (uint32_t t = 0; t < n_targets; t++)
-            if (nd.input >= P.targets[t].input_start && nd.input < P.targets[t].input_start + P.targets[t].n_cols) dep = (uint8_t)(t + 1);
+            if (nd.input >= P.targets[t].input_start && nd.input < P.targets[t].input_start + P.targets[t].n_cols) dep = (uint32_t)(t + 1);
         break;
       case RH_RIR_ADD: case RH_RIR_SUB: case RH_RIR_MUL: case RH_RIR_DIV: case RH_RIR_POW: case RH_RIR_COMPARE:
       case RH_RIR_SEQ:
@@ -106,7 +106,7 @@ bool parse_rir(const void *buf, size_t len, Program &P, std::string &err) {
   // a target's outputs may only reach its own columns
   for (uint32_t t = 0; t < n_targets; t++)
     for (uint32_t o : P.targets[t].outputs) {
-      const uint8_t d = P.nodes[o].dep;
+      const uint32_t d = P.nodes[o].dep;
       if (d && d != t + 1) { err = "RIR: target " + std::to_string(t) + " reads a column of another target"; return false; }
     }
   return true;

@@ -12,7 +12,7 @@ struct Node {
   uint32_t input = 0;
   int32_t low = 0;
   std::vector<uint32_t> table;
-  uint8_t dep = 0;  // 0: parameters only; t+1: reads a column of target t
+  uint32_t dep = 0;  // 0: parameters only; t+1: reads a column of target t
 };
 
 struct Target {

@@ -35,7 +35,7 @@ struct Builder {
   std::map<uint32_t, uint32_t> inputs;
 
   uint32_t push(const Node &n) { Q.nodes.push_back(n); return (uint32_t)Q.nodes.size() - 1; }
-  uint8_t dep2(uint32_t a, uint32_t b) const { return Q.nodes[a].dep ? Q.nodes[a].dep : Q.nodes[b].dep; }
+  uint32_t dep2(uint32_t a, uint32_t b) const { return Q.nodes[a].dep ? Q.nodes[a].dep : Q.nodes[b].dep; }
   uint32_t constant(double v) {
     uint64_t bits; std::memcpy(&bits, &v, 8);
     auto it = consts.find(bits);

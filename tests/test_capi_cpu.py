@@ -278,3 +278,45 @@ def test_lowering_is_thread_safe():
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not wrong, wrong[:3]
+
+
+def test_lower_only_without_data_keeps_working_for_gather_shaped_models(lib):
+    """rh_lower_only has no columns: the loader's preparation of a parameter table for gather mode (lift.cpp: it synthesises
+    columns next to the caller's) waits for rh_model_create, and the model lowers on the generic path as it arrives -- a
+    latentVec(K >= 65) hierarchical model from the reference's front end (it used to fail with 'a column pointer is
+    NULL'); with the data in hand the same program reaches gather mode"""
+    from rainier_amd import compute as CC, modeling as M
+    rng = np.random.default_rng(4)
+    K, n = 100, 400
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
+    zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((a + tau * CC.Lookup.apply(s, zs) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("raw_table_lower_only", inline=False)
+    fast = _capi.compile_opts(fp_contract=True, factor_outputs=True)
+    for opts in (fast, _capi.compile_opts(math_mode=_capi.MATH_STRICT)):
+        src, _ = _capi.lower_only(spec.rir, opts, compile=False)
+        assert "rh_chain_kernel" in src and "#define RH_HAS_GATHER 1\n" not in src
+    src, _ = _capi.lower_only(spec.rir, fast, compile=False, columns=spec.columns, nrows=spec.nrows)
+    assert "#define RH_HAS_GATHER 1\n" in src
+
+
+def test_a_row_target_behind_more_than_255_data_free_targets(lib):
+    """Node::dep names a target by index + 1: with an 8-bit field a row target at index >= 255 wrapped to 'parameters only' and
+    the parser's cross-target checks went wrong modulo 256.  299 data-free targets followed by one row target parse,
+    merge (runs of data-free targets become one) and lower; a row target that reads another target's column is still refused."""
+    from rainier_amd.frontend import Graph
+    ntar = 300
+    g = Graph(1, [0] * (ntar - 1) + [2])
+    a = g.param(0)
+    terms = [a * a * (-0.5 / ntar) for _ in range(ntar - 1)] + [(g.col(ntar - 1, 0) - a * g.col(ntar - 1, 1)) * a]
+    rir = g.compile(terms)
+    src, _ = _capi.lower_only(rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), compile=False)
+    assert "#define RH_NROWTARGETS 1\n" in src
+    _capi.simplify_rir(rir)                                         # parses, cleans up and serialises again
+    # ... and the check that a target only reaches its OWN columns still bites at index 299 (it compared indices modulo 256)
+    g = Graph(1, [2] + [0] * (ntar - 2) + [2])
+    a = g.param(0)
+    bad = g.compile([g.col(0, 0) * a] + [a * a * -0.5 for _ in range(ntar - 2)] + [g.col(0, 1) * a + g.col(ntar - 1, 0)])
+    with pytest.raises(_capi.RainierHipError, match="two targets|another target"):
+        _capi.lower_only(bad, compile=False)
