@@ -362,7 +362,7 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
 // (lift.cpp: its columns are synthesised and owned by the model) and the remaining runs of data-free targets are merged.  cols =
 // the caller's column pointers followed by the synthesised ones; nrows_m = the row count of every target that is left.
 void load_program(rh_model *m, const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
-                  std::vector<const double *> &cols, std::vector<int64_t> &nrows_m) {
+                  std::vector<const double *> &cols, std::vector<int64_t> &nrows_m, bool tables_without_data = false) {
   std::string err;
   if (!rh::parse_rir(rir, rir_len, m->prog, err)) throw Fail{RH_E_INVALID, err};
   if (m->prog.kind != 0) throw Fail{RH_E_INVALID, "a density program (header kind 0) is needed"};
@@ -374,7 +374,8 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   else for (uint32_t t = 0; t < m->prog.targets.size(); t++) old1.push_back(t);
   // (rh_lower_only has no data: the preparation of parameter tables for gather mode synthesises columns NEXT TO the caller's, and
   //  what follows from it -- canonicalisation, re-derivation, rolling -- needs all of them, so it waits for rh_model_create)
-  const bool have_data = columns != nullptr || caller_cols == 0;
+  //  -- unless the caller only wants to see the lifted program: rh_lift_rir)
+  const bool have_data = columns != nullptr || caller_cols == 0 || tables_without_data;
   if (have_data) {  // a gather-shaped parameter table whose prior is data-free: the prior terms become a row target over the group index (lift.cpp)
     bool lp = true;
     if (const char *e = std::getenv("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
@@ -768,7 +769,7 @@ extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *
   return guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
     std::vector<const double *> colv;
-    load_program(&m, rir, rir_len, nullptr, nrows_in_caller, colv, nrows_in);
+    load_program(&m, rir, rir_len, nullptr, nrows_in_caller, colv, nrows_in, true);
     if (nrows_out) for (size_t t = 0; t < nrows_in.size(); t++) nrows_out[t] = nrows_in[t];
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
     *out = std::malloc(b.size()); std::memcpy(*out, b.data(), b.size()); *out_len = b.size();

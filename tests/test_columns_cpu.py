@@ -221,6 +221,40 @@ def test_a_gradient_that_is_not_the_derivative_is_kept():
     assert abs(good[2] - a[2]) > 1e-3 and n_params == k + 1
 
 
+def test_a_slightly_wrong_or_small_wrong_gradient_is_kept():
+    """The acceptance bound of the re-derivation is the parity contract's own (1e-11 * that output's sum of magnitudes over the
+    sample, row by row and in the sum; csrc/rederive.cpp), per output: (i) a supplied derivative that is off by 1e-7 relative and
+    (ii) one whose SMALL component (1e-9 of the largest) is off by half were both accepted by the former 1e-6-of-the-row-maximum
+    gate -- the program must come back computing its own outputs; the same program with the exact derivative is re-derived."""
+    from rainier_amd.frontend import Graph
+    rng = np.random.default_rng(3)
+    n = 400
+    x, y, z = rng.normal(size=n), rng.normal(size=n), rng.normal(size=n)
+    cols = [x, y, -x, z]                                             # the third column is a derived one: the passes run
+
+    def build(f1, f2):
+        g = Graph(2, [0, 4])
+        a, b = g.param(0), g.param(1)
+        r = g.col(1, 1) + a * g.col(1, 2)                           # y - a x
+        row = r * r * -0.5 + b * g.col(1, 3) * 1e-9
+        prior = (a * a + b * b) * -0.5
+        grads = [g.gradient(prior), [r * g.col(1, 0) * f1, g.col(1, 3) * (1e-9 * f2)]]
+        return models.ModelSpec("wrong_grad", g.compile([prior, row], gradients=grads), cols, [0, n], 2)
+
+    q = np.array([0.4, -0.3])
+    exact = O.OracleDensity(build(1.0, 1.0)).update(q)
+    for f1, f2 in ((1.0 + 1e-7, 1.0), (1.0, 1.5)):
+        bad = build(f1, f2)
+        s3, _ = _rewritten(bad, fast=True, refactor=True)
+        a, b = O.OracleDensity(bad).update(q), O.OracleDensity(s3).update(q)
+        np.testing.assert_allclose(b, a, rtol=1e-12)                # its own (wrong) outputs, not the true derivative
+        assert np.max(np.abs(a[1:] - exact[1:])) > 1e-9                # ... which differs from it
+    good = build(1.0, 1.0)
+    s3, kept = _rewritten(good, fast=True, refactor=True)
+    assert len(kept) == 3                                           # -x folded away, gradient in its natural form over x, y, z
+    np.testing.assert_allclose(O.OracleDensity(s3).update(q), exact, rtol=1e-12)
+
+
 # ---- property test: the reference's RealTest expressions as streamed row terms, through every data-dependent pass -----------
 from tests.realtest_cases import CASES, Alg  # noqa: E402
 
