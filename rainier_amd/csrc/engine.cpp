@@ -1290,6 +1290,7 @@ extern "C" int rh_sample(rh_model *m, const rh_config *cfg, const int64_t *seeds
 extern "C" int rh_sample_multi(rh_model *const *models, int32_t n_models, const rh_config *cfg, const int64_t *seeds,
                                int32_t chains, double *draws, double *mass_diag, rh_chain_stats *stats) {
   if (!models || n_models <= 0 || !cfg || !seeds || chains <= 0) { g_err = "rh_sample_multi: bad arguments"; return RH_E_INVALID; }
+  if (cfg->struct_size != (int32_t)sizeof(rh_config)) { g_err = "rh_config.struct_size mismatch"; return RH_E_INVALID; }   // before *cfg is copied per shard
   const int nv = models[0] ? rh_model_nvars(models[0]) : -1;
   for (int g = 0; g < n_models; g++) {
     if (!models[g] || !models[g]->loaded) { g_err = "rh_sample_multi: model " + std::to_string(g) + " not loaded"; return RH_E_INVALID; }

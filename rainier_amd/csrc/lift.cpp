@@ -575,14 +575,19 @@ bool hoist_table_maps(Program &P, int gather_min) {
   std::sort(tmpl.begin(), tmpl.end());
   std::vector<char> is_cand(P.nodes.size(), 0);
   for (uint32_t c : cands) is_cand[c] = 1;
+  std::vector<char> is_entry(P.nodes.size(), 0);   // entries of the tables that are hoisted
+  for (uint32_t c : cands) for (uint32_t e : P.nodes[c].table) is_entry[e] = 1;
+  for (uint32_t i = 0; i < P.nodes.size(); i++)    // ... and the balanced tree of SeqIRs over them (ir/IR.scala:25-39)
+    if (P.nodes[i].op == RH_RIR_SEQ && is_entry[P.nodes[i].a] && is_entry[P.nodes[i].b]) is_entry[i] = 1;
   // rebuild the node list (operands keep smaller ids than their users)
   std::vector<Node> Q;
   std::vector<uint32_t> m(P.nodes.size(), 0);
   auto push = [&](const Node &q) { Q.push_back(q); return (uint32_t)Q.size() - 1; };
   for (uint32_t i = 0; i < P.nodes.size(); i++) {
     const Node &n = P.nodes[i];
-    if (n.op == RH_RIR_SEQ) { m[i] = m[n.b]; continue; }   // the Translator's VarDef chain that evaluates every entry before the lookup:
-                                                           // value = second operand; the entries are no longer evaluated one by one
+    // the Translator's VarDef chain that evaluates every entry before the lookup (SeqIR(defs :+ LookupIR)): value = second
+    // operand; the hoisted table's entries are no longer evaluated one by one.  Any other SEQ of the program stays.
+    if (n.op == RH_RIR_SEQ && is_entry[n.a]) { m[i] = m[n.b]; continue; }
     if (!is_cand[i]) {
       Node q = n;
       if (n.op != RH_RIR_CONST && n.op != RH_RIR_INPUT) {

@@ -155,6 +155,23 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_sample(
     RH_JNI_DCFG(X)
 #undef X
   }
+  { /* a wrongly sized Java array must become an exception, not a native heap overflow: draws [chains][iterations][nvars],
+     * mass [chains][nvars] (rh_sample's contract), staticMass [nvars] */
+    const int nv = ms[0] ? rh_model_nvars(ms[0]) : -1;
+    const long long want_draws = (long long)chains * (long long)cfg.iterations * (long long)nv;
+    const char *bad = NULL;
+    if (nv <= 0) bad = "models[0] is not a model handle";
+    else if (cfg.iterations < 0 || (long long)(*env)->GetArrayLength(env, draws) != want_draws) bad = "draws must hold chains * iterations * nvars doubles";
+    else if ((long long)(*env)->GetArrayLength(env, mass) != (long long)chains * nv) bad = "mass must hold chains * nvars doubles";
+    else if (staticMass && (*env)->GetArrayLength(env, staticMass) != nv) bad = "staticMass must hold nvars doubles";
+    if (bad) {
+      (*env)->ReleaseDoubleArrayElements(env, dcfg, dc, JNI_ABORT);
+      (*env)->ReleaseIntArrayElements(env, icfg, ic, JNI_ABORT);
+      free(ms);
+      throw_msg(env, RH_E_INVALID, bad);
+      return;
+    }
+  }
   jdouble *sm = staticMass ? (*env)->GetDoubleArrayElements(env, staticMass, NULL) : NULL;
   jdouble *nn = rngNextGaussian ? (*env)->GetDoubleArrayElements(env, rngNextGaussian, NULL) : NULL;
   cfg.static_mass = sm;
@@ -183,7 +200,8 @@ JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_sample(
   if (sm) (*env)->ReleaseDoubleArrayElements(env, staticMass, sm, JNI_ABORT);
   (*env)->ReleaseDoubleArrayElements(env, dcfg, dc, JNI_ABORT);
   (*env)->ReleaseIntArrayElements(env, icfg, ic, JNI_ABORT);
-  if (rc != RH_OK) throw_rh(env, ms[0], rc);
+  /* rh_sample_multi reports a shard's failure through the calling thread's error slot (rh_last_error(NULL)), not through models[0] */
+  if (rc != RH_OK) throw_rh(env, nmodels == 1 ? ms[0] : NULL, rc);
   free(ms);
 }
 

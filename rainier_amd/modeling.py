@@ -294,7 +294,7 @@ NumSplits = 8   # core/Model.scala:98
 def _split(ts):
     """Model.split (core/Model.scala:117-132): an initial chunk + NumSplits equal chunks"""
     ts = list(ts)
-    splitSize = (len(ts) - 1) // NumSplits
+    splitSize = int((len(ts) - 1) / NumSplits)   # Scala's Int division truncates toward zero: an empty list gives 0, not -1
     initSize = len(ts) - splitSize * NumSplits
     if splitSize == 0:
         return ts[:initSize], []

@@ -311,8 +311,8 @@ def sample_multi(models, config: SamplerConfig = None, seeds: Sequence[int] = No
     st = (_capi.ChainStats * chains)()
     handles = (C.c_void_p * len(models))(*[m._h for m in models])
     sd = (C.c_int64 * chains)(*[int(x) for x in seeds])
-    _capi.check(_capi.lib().rh_sample_multi(handles, len(models), C.byref(cfg), sd, chains, _capi.dptr(draws), _capi.dptr(mass), st),
-                models[0]._h)
+    # a shard's failure is reported through the calling thread's error slot (rh_last_error(NULL)), not through models[0]
+    _capi.check(_capi.lib().rh_sample_multi(handles, len(models), C.byref(cfg), sd, chains, _capi.dptr(draws), _capi.dptr(mass), st))
     stats = [Stats(s.leapfrog_steps, s.warmup_leapfrog_steps, s.gradient_evaluations, s.accepted, s.mean_accept_prob, s.step_size, s.bfmi)
              for s in st]
     return Trace(draws, mass, stats)

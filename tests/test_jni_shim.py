@@ -185,7 +185,7 @@ def test_shim_rejects_malformed_arrays_without_leaking(fj):
         call(fj, "sample", JArr(fj, np.zeros(1, dtype=np.int64)), JArr(fj, ic[:-1]), JArr(fj, dc), None, None, seeds, draws, mass, None)
     with pytest.raises(RuntimeError, match="IllegalArgumentException.*stats"):
         call(fj, "sample", JArr(fj, np.zeros(1, dtype=np.int64)), JArr(fj, ic), JArr(fj, dc), None, None, seeds, draws, mass, JArr(fj, np.zeros(3)))
-    with pytest.raises(RuntimeError, match="IllegalArgumentException.*not loaded"):   # a null handle never reaches the device
+    with pytest.raises(RuntimeError, match="IllegalArgumentException.*not a model handle"):   # a null handle never reaches the device
         call(fj, "sample", JArr(fj, np.zeros(2, dtype=np.int64)), JArr(fj, ic), JArr(fj, dc), None, None, seeds, draws, mass, None)
 
 
@@ -244,6 +244,14 @@ def test_shim_sample_is_bit_identical_to_the_ctypes_path(jvm):
     d, _, _ = _sample(fj, [h], R.HMC(10, 5, 2), [st ^ 0x5DEECE66D for st in states], 10, nn=nn)
     ref = R.Model(spec, device=0, math_mode=1).sample(R.HMC(10, 5, 2), rng_states=[(st, None if np.isnan(g) else g) for st, g in zip(states, nn)])
     assert np.array_equal(d, ref.chains)
+    # wrongly sized result arrays become exceptions before anything is written (they were native heap overflows)
+    ic, dc = flat_cfg(R.HMC(10, 5, 2), 10)
+    args = lambda draws, mass: (JArr(fj, np.array([h], dtype=np.int64)), JArr(fj, ic), JArr(fj, dc), None, None,
+                                JArr(fj, np.array(seeds, dtype=np.int64)), JArr(fj, np.zeros(draws)), JArr(fj, np.zeros(mass)), None)
+    with pytest.raises(RuntimeError, match="IllegalArgumentException.*draws must hold"):
+        call(fj, "sample", *args(5 * 5 * 10 - 1, 50))
+    with pytest.raises(RuntimeError, match="IllegalArgumentException.*mass must hold"):
+        call(fj, "sample", *args(5 * 5 * 10, 49))
     call(fj, "modelDestroy", h)
 
 
