@@ -116,6 +116,31 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
             "row_chain_evals_per_s": total * n_s / dt}
 
 
+def gpu_inlined(R, models, device, L):
+    """cfg 2 as the reference would REALLY hand it over (compute/Target.scala:20-24, PartialEvaluator.scala:90-97): 3 covariates
+    = 15 distributed terms < 20, so TargetGroup inlines the likelihood into a 5-parameter data-free target -- O(1) per gradient,
+    no rows streamed.  `models.linreg_reference` is that program from the reference's own front end (restated, compute.py); it
+    runs on rh_chain_kernel (packed chains).  The like-for-like partner of cpu_baseline.inlined_sufficient_statistics.
+    The compiled program has the same size for any row count; it is built from the first 20 000 rows here because the Python
+    restatement of PartialEvaluator folds the rows one by one like the reference does (70 s at 1e6 rows)."""
+    t0 = time.perf_counter()
+    spec = models.linreg_reference(n=20_000, k=3)
+    build_s = time.perf_counter() - t0
+    assert spec.rows_streamed == 0
+    model = R.Model(spec, device=device, fp_contract=True, factor_outputs=True)
+    res = {"what": "cfg 2 inlined by the reference's own front end (5-parameter data-free target) on rh_chain_kernel, static HMC L=%d, "
+                   "DualAvgTuner(0.8), identity mass" % L, "unit": "leapfrog steps/s", "front_end_seconds": build_s, "rows_folded": 20_000}
+    for chains in (1024, 32768):
+        cfg = R.make_config(100, 50, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner())
+        s = R.Sampler(model, cfg, [1000 + c for c in range(chains)])
+        s.warmup()
+        t0 = time.perf_counter(); s.run(100); dt = time.perf_counter() - t0
+        stats, _ = s.stats()
+        s.close()
+        res["chains_%d" % chains] = sum(st.leapfrogSteps for st in stats) / dt
+    return res
+
+
 def side_workload(a, R, models, rank, local_rank, world, dist):
     """The other BASELINE.json configurations, for reference timings (the judged bench line is cfg 2):
       cfg1 funnel 10-d, HMC L=5                                  (data-free, chain-per-wavefront engine)
@@ -205,6 +230,10 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--leapfrog", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
+    ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
+    ap.add_argument("--ess-iters", type=int, default=256)
+    ap.add_argument("--ess-warmup", type=int, default=384)
     ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
                     help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC")
     ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3", "cfg4", "cfg5"], default="cfg2",
@@ -246,10 +275,10 @@ def main():
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
     engine = {"auto": 0, "chain": 1, "tick": 2}[a.engine]
 
-    def leg(iters, warm):
+    def leg(iters, warm, mass_tuner=None):
         """One sampler run: `warm` untimed warm-up iterations, then `iters` timed ones + (N > 1) the ONE collective.
         Returns (seconds [max over ranks], all draws on rank 0, stats, timing)."""
-        cfg = R.make_config(iters, warm, R.HMCSampler(L), R.DualAvgTuner(0.8), R.IdentityMassMatrixTuner(), engine=engine,
+        cfg = R.make_config(iters, warm, R.HMCSampler(L), R.DualAvgTuner(0.8), mass_tuner or R.IdentityMassMatrixTuner(), engine=engine,
                             gradSplits=a.grad_splits)
         s = R.Sampler(model, cfg, seeds)
         s.warmup()                      # untimed warm-up steps (incl. LeapFrog.initialize + step-size search)
@@ -276,13 +305,26 @@ def main():
     steps_local = sum(st.leapfrogSteps for st in stats)
     assert steps_local == K * L * cpg, (steps_local, K, L, cpg)
     total_steps = steps_local * world
-    # ESS/s leg, independent of the driver's --steps/--warmup: dual averaging needs ~100 iterations before the step size
-    # (and with it the autocorrelation) is meaningful, and Trace.diagnostics needs a few dozen draws per chain
-    ess_iters, ess_warm = max(K, 64), max(W, 128)
-    if (ess_iters, ess_warm) == (K, W):
-        ess_dt, ess_draws, ess_stats = dt, draws, stats
-    else:
-        ess_dt, ess_draws, ess_stats, _ = leg(ess_iters, ess_warm)
+    # ESS/s legs, independent of the driver's --steps/--warmup.  The chains start from N(0,1) draws and the posterior is 7e-4 wide:
+    # they need a few hundred iterations to get there (R-hat says whether they did), and Trace.autocorrelation (core/Trace.scala:
+    # 93-109) can only sum lags < the draw count, so >= 256 timed draws per chain.  Two configurations: the bench's (identity
+    # mass) and DefaultConfig's windowed diagonal mass adaptation (sampler/Sampler.scala:24-25) with the same static L.
+    ess_iters, ess_warm = max(K, a.ess_iters), max(W, a.ess_warmup)
+    ess_runs = {}
+    for name, mt in (("identity_mass", R.IdentityMassMatrixTuner()), ("default_diag_mass", R.DiagonalMassMatrixTuner(50, 1.5, 50, 50))):
+        if a.no_ess:
+            break
+        e_dt, e_draws, e_stats, _ = leg(ess_iters, ess_warm, mt)
+        if rank == 0:
+            diag = R.diagnostics(e_draws)
+            ess_runs[name] = {
+                "iterations": ess_iters, "warmup": ess_warm, "seconds": e_dt,
+                "rhat": [float(r) for r, _ in diag], "ess": [float(e) for _, e in diag],
+                "rhat_max": float(max(r for r, _ in diag)), "ess_min": float(min(e for _, e in diag)),
+                "ess_per_s": float(min(e for _, e in diag)) / e_dt, "draws_total": int(e_draws.shape[0] * e_draws.shape[1]),
+                "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in e_stats])),
+                "step_size_mean": float(np.mean([st.stepSize for st in e_stats])),
+                "converged": bool(max(r for r, _ in diag) < 1.01)}
     if rank != 0:
         if dist is not None:
             dist.close()
@@ -291,7 +333,7 @@ def main():
     rows = spec.rows_streamed
     value = total_steps / dt
     rce = value * rows
-    ess_min = min(e for _, e in R.diagnostics(ess_draws)) if ess_draws.shape[0] >= 2 else None
+    ident = ess_runs.get("identity_mass")
     # dominant kernel, this rank: HIP events recorded on the engine's stream around each launch
     k_s = tim["kernel_ms"] / 1e3
     algo_bytes = tim["row_chain_evals"] * spec.bytes_per_row          # 8*(K+1) = 32 B per row-chain eval
@@ -308,12 +350,12 @@ def main():
                    "engine": tim["dominant_kernel"], "grad_chains": a.grad_chains, "grad_unroll": a.grad_unroll,
                    "grad_splits": a.grad_splits, "generated_source_sha16": src_sha},
         "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,
-        "ess_per_s": (ess_min / ess_dt) if ess_min is not None else None,
-        "ess_leg": {"iterations": ess_iters, "warmup": ess_warm, "seconds": ess_dt, "ess_min": ess_min,
-                    "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in ess_stats])),
-                    "step_size_mean": float(np.mean([st.stepSize for st in ess_stats])),
-                    "note": "separate sampler run with >= 128 untimed adaptation iterations and >= 64 timed draws, so that "
-                            "ESS/s does not depend on --steps/--warmup; same chains, seeds and kernels as the timed region"},
+        # ESS/s = min over parameters of Trace.diagnostics' ESS, over the leg's wall time; quoted for the bench's own configuration
+        # (identity mass) -- see ess_leg for R-hat and the per-parameter figures, ess_leg_default_mass for DefaultConfig's tuner
+        "ess_per_s": ident["ess_per_s"] if ident else None,
+        "ess_leg": dict(ident, note="separate sampler run (same model, seeds, kernels): untimed warm-up until the chains have converged "
+                                    "(rhat_max < 1.01 says so), then the timed draws; ess = Trace.diagnostics' formula per parameter") if ident else None,
+        "ess_leg_default_mass": ess_runs.get("default_diag_mass"),
         "mean_accept_prob": float(np.mean([st.meanAcceptProb for st in stats])),
         # The kernel is fp64-compute-bound (the 32 MB data set is served from cache, HBM-side traffic is ~1e-3 of the
         # algorithmic bytes), so the binding roofline is the fp64 VALU pipe (the kernel issues v_fma_f64): 78.6 TFLOP/s.
@@ -346,6 +388,8 @@ def main():
         else:
             out["roofline"]["traffic_source"] = "none: profiles/%s was taken on different kernel source or workload (sha16 %s vs %s)" % (
                 TRAFFIC_PROFILE, pj.get("generated_source_sha16"), src_sha)
+    if not a.no_inlined and world == 1:
+        out["gpu_inlined"] = gpu_inlined(R, models, local_rank, L)
     if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(spec, L)
     print(json.dumps(out))

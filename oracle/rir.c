@@ -243,6 +243,69 @@ int rir_density_update(void *d, const double *q, double *out) { return update_im
 int rir_density_abs_sums(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_ABS); }
 int rir_density_update_ld(rir_density *d, const double *q, double *o) { return update_impl(d, q, o, ACC_LD); }
 
+/* Extended-precision evaluation of the same program (x87 long double: 64-bit significand, node by node AND in the row sums):
+ * not the reference's arithmetic -- the JVM computes in binary64 -- but the yardstick that tells the reference's own rounding
+ * (naive 1 - p, masked gradient columns ...) from the device's when the two differ by more than the stated tolerance.
+ * Semantics (compare, D2I, lookup range) as in eval_node. */
+static inline void eval_node_x(const rir_prog *p, long double *v, uint32_t id, const long double *in, int *lookup_error) {
+  const rir_node *n = &p->nodes[id];
+  switch (n->op) {
+  case RIR_CONST: v[id] = (long double)n->cval; break;
+  case RIR_INPUT: v[id] = in[n->input]; break;
+  case RIR_ADD: v[id] = v[n->a] + v[n->b]; break;
+  case RIR_SUB: v[id] = v[n->a] - v[n->b]; break;
+  case RIR_MUL: v[id] = v[n->a] * v[n->b]; break;
+  case RIR_DIV: v[id] = v[n->a] / v[n->b]; break;
+  case RIR_POW: {
+    const long double x = v[n->a], y = v[n->b];
+    v[id] = y == 0.0L ? 1.0L : (isnan(y) || (isinf(y) && fabsl(x) == 1.0L)) ? (long double)NAN : powl(x, y);
+    break;
+  }
+  case RIR_COMPARE: v[id] = v[n->a] > v[n->b] ? 1.0L : (v[n->a] == v[n->b] ? 0.0L : -1.0L); break;
+  case RIR_EXP: v[id] = expl(v[n->a]); break;
+  case RIR_LOG: v[id] = logl(v[n->a]); break;
+  case RIR_ABS: v[id] = fabsl(v[n->a]); break;
+  case RIR_NOOP: v[id] = v[n->a]; break;
+  case RIR_SIN: v[id] = sinl(v[n->a]); break;
+  case RIR_COS: v[id] = cosl(v[n->a]); break;
+  case RIR_TAN: v[id] = tanl(v[n->a]); break;
+  case RIR_ASIN: v[id] = asinl(v[n->a]); break;
+  case RIR_ACOS: v[id] = acosl(v[n->a]); break;
+  case RIR_ATAN: v[id] = atanl(v[n->a]); break;
+  case RIR_LOOKUP: {
+    int64_t k = (int64_t)java_d2i((double)v[n->a]) - (int64_t)n->low;
+    if (k < 0 || k >= (int64_t)n->count) { *lookup_error = 1; v[id] = (long double)NAN; }
+    else v[id] = v[n->table[k]];
+    break;
+  }
+  case RIR_SEQ: v[id] = v[n->b]; break;
+  }
+}
+int rir_density_update_x(rir_density *d, const double *q, double *out) {
+  const rir_prog *p = d->prog;
+  const uint32_t nout = p->n_params + 1;
+  long double *in = calloc(p->n_inputs ? p->n_inputs : 1, sizeof(long double));
+  long double *v = calloc(p->n_nodes ? p->n_nodes : 1, sizeof(long double));
+  long double *acc = calloc(nout, sizeof(long double));
+  for (uint32_t i = 0; i < p->n_params; i++) in[i] = (long double)q[i];
+  int lookup_error = 0;
+  size_t colbase = 0;
+  for (uint32_t t = 0; t < p->n_targets; t++) {
+    const rir_target *tg = &p->targets[t];
+    for (uint32_t i = 0; i < tg->n_once; i++) eval_node_x(p, v, tg->once_nodes[i], in, &lookup_error);
+    int64_t rows = tg->n_cols ? d->nrows[t] : 1;
+    for (int64_t k = 0; k < rows; k++) {
+      for (uint32_t j = 0; j < tg->n_cols; j++) in[tg->input_start + j] = (long double)d->cols[colbase + j][k];
+      for (uint32_t i = 0; i < tg->n_row; i++) eval_node_x(p, v, tg->row_nodes[i], in, &lookup_error);
+      for (uint32_t o = 0; o < nout; o++) acc[o] += v[tg->outputs[o]];
+    }
+    colbase += tg->n_cols;
+  }
+  for (uint32_t o = 0; o < nout; o++) out[o] = (double)acc[o];
+  free(in); free(v); free(acc);
+  return lookup_error;
+}
+
 /* Generator.prepare (core/Generator.scala:76-84): the compiled requirements evaluated at one draw.
  * A requirements program has one data-free target per requirement, outputs[0] = the requirement. */
 int rir_requirements_eval(rir_density *d, const double *q, double *out) {

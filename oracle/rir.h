@@ -72,6 +72,10 @@ int rir_density_abs_sums(rir_density *d, const double *q, double *abs_out);
 int rir_density_update_both(rir_density *d, const double *q, double *out, double *abs_out);
 /* long-double accumulation variant (which side is closer to the true sum) */
 int rir_density_update_ld(rir_density *d, const double *q, double *out);
+/* the same program evaluated node by node and summed in extended precision (long double), rounded to double at the end: the
+ * yardstick for "whose rounding is it" when device and oracle differ by more than the stated tolerance -- NOT the reference's
+ * arithmetic */
+int rir_density_update_x(rir_density *d, const double *q, double *out);
 /* requirements program (header kind 1): out[t] = value of target t's outputs[0] at q */
 int rir_requirements_eval(rir_density *d, const double *q, double *out);
 #endif

@@ -1024,21 +1024,21 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #ifndef RH_GRAD_WAVES
 #define RH_GRAD_WAVES 1
 #endif
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
-rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
-               double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
-               const int chains, const int nsplit, const int xcd_aware) {
+// returns the first chain of the workgroup's chain group, or -1 when there is nothing to do for it (no chain waits for a gradient)
+RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ active, double *partial,
+                        int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit,
+                        const int xcd_aware, int &group) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0; // re-armed for the tick kernel that follows in stream order
-  int group, split;
+  int split;
   if (xcd_aware && (nsplit % 8) == 0) {
     const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
     split = xcd + 8 * (idx % spx);
     group = idx / spx;
   } else { split = b % nsplit; group = b / nsplit; }
   const int chain0 = group * RH_GRAD_K;
-  if (chain0 >= chains) return;
+  if (chain0 >= chains) return -1;
   bool any = false;
   double th[RH_GRAD_K][RH_NTH];
 #pragma unroll
@@ -1048,10 +1048,18 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 #pragma unroll
     for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i]; // wave-uniform address -> s_load
   }
-  if (!any) return;
+  if (!any) return -1;
   int err = 0;
   rh_grad_targets<0>(th, d, lane, split, nsplit, chain0, chains, partial, err);
   if (err && lane == 0) atomicOr(err_out, 1);
+  return chain0;
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
+rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+               double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+               const int chains, const int nsplit, const int xcd_aware) {
+  int group;
+  (void)rh_grad_body(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
 }
 
 // ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
@@ -1747,6 +1755,138 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 
 #ifndef RH_TICK_FAST
 #define RH_TICK_FAST 1
+#endif
+
+// ---- the mid-trajectory leapfrog update fused into the gradient launch ---------------------------------------------------------
+// All but one of the L gradient requests of a static-HMC trajectory are followed by `twoFullSteps` (LeapFrog.scala:175-184):
+//   p += eps * grad;  q += eps * velocity(p)
+// -- a dozen flops per chain for which the tick engine paid a kernel launch (rh_tick_kernel's fast path: ~15 us + the gap, 6 % of a
+// cfg-2 leapfrog step).  rh_grad_fused_kernel is rh_grad_kernel plus an epilogue: every workgroup publishes its partial sums
+// (release fence), bumps its chain group's arrival counter, and the LAST of the group's nsplit workgroups combines the partials
+// and advances the group's RH_GRAD_K chains itself -- all of them at once, 64 / RH_GRAD_K lanes per chain -- and publishes the
+// next q.  The next gradient launch follows directly; the host issues a tick only where a trajectory ends (engine.cpp).
+// Bit-identical chains by construction: the splits are summed in the very order rh_combine_targets uses (per-slot ascending sums,
+// then the 64-slot xor butterfly -- its upper levels happen between a lane's own registers here, the lower ones between the lanes
+// of the chain's group; IEEE addition commutes), the same generated finish() / data-free row() code runs on the sums, and the
+// update is spelled as wv_axpy / rh_velocity spell it (multiply, round, add, round; contraction off).  A chain that is not in
+// that state (or a Lookup error) is left alone: it stays `active`, its gradient is recomputed identically by the next launch
+// and consumed by the next tick.  Memory-side: agent-scope release / acquire fences around a relaxed atomic counter -- the
+// partials cross XCDs (each XCD has its own L2) through the Infinity Cache.
+#if RH_NROWTARGETS > 0 && !RH_HAS_GATHER && !RH_BIGN && !RH_WITH_DENSE && !RH_WITH_NUTS && RH_PACK_L == 64 && RH_SLOTS == 1
+#if (RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8 || RH_GRAD_K == 16) && (RH_NVARS * RH_GRAD_K <= 64)
+#define RH_HAVE_FUSED 1
+template <int T>
+RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *partial, const long long *nrows, const int nsplit,
+                                      const int chain, const int chains, const int j, double (&tot)[RH_NOUT], int &err) {
+  if constexpr (T < RH_NTARGETS) {
+    typedef rh_target<T> TG;
+    if constexpr (!TG::HAS_ROWS) {
+      double inv[1];
+      TG::row(th, inv, nullptr, tot, err);
+    } else {
+      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1, M = RH_GRAD_K, LPC = 64 / RH_GRAD_K;
+      double S[NA];
+#pragma unroll
+      for (int o = 0; o < NA; o++) {
+        double r[M];  // slot j + LPC * m of the 64-slot butterfly rh_combine_targets runs over the splits
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          double a = 0.0;
+          for (int sp = j + LPC * m; sp < nsplit; sp += 64)
+            a += partial[(((size_t)TG::ROWT * nsplit + sp) * chains + chain) * RH_NACC_MAX + o];
+          r[m] = a;
+        }
+#pragma unroll
+        for (int off = 32; off >= LPC; off >>= 1) {  // butterfly levels whose partner slot lives in this lane
+          double t[M];
+#pragma unroll
+          for (int m = 0; m < M; m++) t[m] = r[m] + r[m ^ (off / LPC)];
+#pragma unroll
+          for (int m = 0; m < M; m++) r[m] = t[m];
+        }
+        double v = r[0];
+#pragma unroll
+        for (int off = LPC / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);  // ... and in the chain's other lanes
+        S[o] = v;
+      }
+      double inv[TG::NINV > 0 ? TG::NINV : 1];
+      TG::invariants(th, inv, err);
+      TG::finish(th, inv, S, (double)nrows[T], tot);
+    }
+    rh_combine_targets_packed<T + 1>(th, partial, nrows, nsplit, chain, chains, j, tot, err);
+  }
+}
+
+RH_DEV void rh_fused_epilogue(const rh_model_data &d, rh_u64 *state, double *qbuf, const double *partial, const int chains,
+                              const int nsplit, const int chain0, const int lane) {
+  constexpr int LPC = 64 / RH_GRAD_K;
+  const int kk = lane / LPC, j = lane & (LPC - 1), base = lane & ~(LPC - 1);
+  const bool exists = chain0 + kk < chains;
+  const int chain = exists ? chain0 + kk : chains - 1;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
+  rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+  const int pc = (int)(rh_i64)sc[RH_SI_pc], need = (int)(rh_i64)sc[RH_SI_need_eval];
+  const int ts_i = (int)(rh_i64)sc[RH_SI_ts_i], ts_l = (int)(rh_i64)sc[RH_SI_ts_l];
+  const bool fast = exists && pc == RH_S_TS_MID && need != 0 && ts_i < ts_l;
+  if (!__any(fast)) return;
+  const bool identity = (int)(rh_i64)sc[RH_SI_mass_identity] != 0, sampling = (int)(rh_i64)sc[RH_SI_sampling_started] != 0;
+  const int cerr = (int)(rh_i64)sc[RH_SI_err];
+  const double eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
+  const rh_i64 n_grad = (rh_i64)sc[RH_SI_n_grad], n_leap = (rh_i64)sc[RH_SI_n_leapfrog], n_warm = (rh_i64)sc[RH_SI_n_warm_leapfrog];
+  const bool live = j < RH_NVARS;
+  double bq = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + j]) : 0.0;
+  double bp = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + j]) : 0.0;
+  const double mm = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS) * 64 + j]) : 0.0;
+  double th[RH_NTH];
+#pragma unroll
+  for (int i = 0; i < RH_NTH; i++) th[i] = __shfl(bq, base + i, 64);
+  double tot[RH_NOUT];
+#pragma unroll
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  int err = 0;
+  rh_combine_targets_packed<0>(th, partial, d.nrows, nsplit, chain, chains, j, tot, err);
+  const double logp = tot[0];
+  double g = 0.0;
+#pragma unroll
+  for (int i = 0; i < RH_NVARS; i++) g = (j == i) ? tot[1 + i] : g;
+  // RH_S_TS_MID with ts_i < ts_l:  BU = -logp; Bg = grad;  wv_axpy(Bp, eps, Bg);  rh_new_qs: wv_axpy(Bq, eps, velocity(Bp))
+  bp += eps * g;
+  const double vel = identity ? bp : bp * mm;
+  bq += eps * vel;
+#pragma unroll
+  for (int off = LPC / 2; off >= 1; off >>= 1) err |= __shfl_xor(err, off, 64);
+  if (fast && live) {
+    qbuf[(size_t)chain * RH_NVARS + j] = bq;
+    st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(bq);
+    st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(bp);
+    st[(size_t)(RH_VI_Bg * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(g);
+    st[(size_t)(RH_VI_pend_g * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(g);
+  }
+  if (fast && j == 0) {
+    sc[RH_SI_BU] = (rh_u64)__double_as_longlong(logp * -1); sc[RH_SI_pend_logp] = (rh_u64)__double_as_longlong(logp);
+    sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)(cerr | err);
+    sc[RH_SI_n_grad] = (rh_u64)(n_grad + 1);
+    if (sampling) sc[RH_SI_n_leapfrog] = (rh_u64)(n_leap + 1); else sc[RH_SI_n_warm_leapfrog] = (rh_u64)(n_warm + 1);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
+rh_grad_fused_kernel(const rh_model_data d, double *q, const int *__restrict__ active, double *partial,
+                     int *__restrict__ err_out, int *__restrict__ n_running, rh_u64 *state, int *group_cnt,
+                     const int chains, const int nsplit, const int xcd_aware) {
+  int group;
+  const int chain0 = rh_grad_body(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
+  if (chain0 < 0) return;   // the same for every workgroup of the group: nobody counts
+  const int lane = threadIdx.x;
+  __threadfence();          // release: this workgroup's partial sums are visible device-wide before it is counted
+  int last = 0;
+  if (lane == 0) last = (atomicAdd(&group_cnt[group], 1) == nsplit - 1) ? 1 : 0;
+  if (!__builtin_amdgcn_readfirstlane(last)) return;
+  if (lane == 0) group_cnt[group] = 0;  // re-armed for the next launch
+  __threadfence();          // acquire: the other workgroups' partial sums
+  rh_fused_epilogue(d, state, q, partial, chains, nsplit, chain0, lane);
+}
+#endif
 #endif
 extern "C" __global__ void __launch_bounds__(64)
 rh_tick_kernel(const rh_model_data d,

@@ -152,6 +152,7 @@ struct rh_model {
   bool loaded = false;
   hipModule_t module = nullptr;
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
+  hipFunction_t k_grad_fused = nullptr;  // rh_grad_kernel + the mid-trajectory leapfrog update as its epilogue (static HMC); absent when the model does not qualify
   int grad_w = 8, ncols_max = 0, glm_ncols = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
@@ -195,7 +196,8 @@ struct rh_sampler {
   // tick engine
   bool tick_engine = false;
   int nsplit = 0, xcd_aware = 1;
-  void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
+  void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr, *d_groupcnt = nullptr;
+  bool fuse = false;  // static HMC on the plain gradient kernel: mid-trajectory updates run as the gradient launch's epilogue
   std::vector<hipEvent_t> ev;
   GatherBufs *gb = nullptr;
   std::vector<rh_chain_stats_dev> last_stats;
@@ -279,6 +281,8 @@ void load_module(rh_model *m) {
     HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_grad_lds, m->module, "rh_grad_lds_kernel"));
     HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
+    // compiled only for models whose chain group fits one wavefront's lanes (RH_HAVE_FUSED in rh_engine.hip.h)
+    if (hipModuleGetFunction(&m->k_grad_fused, m->module, "rh_grad_fused_kernel") != hipSuccess) { m->k_grad_fused = nullptr; (void)hipGetLastError(); }
   }
   m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
@@ -1036,6 +1040,17 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
       HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
+      {  // the fused launch needs the base sampler-kernel variant (its state layout is compiled into the gradient module), the
+         // plain VALU gradient kernel and a lock-step sampler: static HMC.  RH_FUSE=0 keeps one tick launch per gradient.
+        bool fuse = m->k_grad_fused && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm && !m->use_lds_grad;
+        if (const char *e = std::getenv("RH_FUSE")) fuse = fuse && std::atoi(e) != 0;
+        if (fuse) {
+          const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
+          HIPCHK(hipMalloc(&s->d_groupcnt, sizeof(int) * ngroups));
+          HIPCHK(hipMemset(s->d_groupcnt, 0, sizeof(int) * ngroups));
+          s->fuse = true;
+        }
+      }
       if (m->info.gather_mode) {
         HIPCHK(hipMemset(s->d_partial, 0, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
         s->gb = new GatherBufs(); s->gb->build(m, chains, nsplit);
@@ -1050,7 +1065,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
 extern "C" void rh_sampler_destroy(rh_sampler *s) {
   if (!s) return;
   if (s->m) hipSetDevice(s->m->device);
-  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr})
+  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_groupcnt})
     if (p) hipFree(p);
   for (hipEvent_t e : s->ev) hipEventDestroy(e);
   delete s->gb;
@@ -1078,6 +1093,16 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
   auto grad = [&]() { launch_grad(m, s->gb, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
+  auto grad_fused = [&]() {   // gradient + the mid-trajectory update of every chain that is in that state (no tick follows)
+    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &s->d_state, &s->d_groupcnt, &chains, &nsplit, &xcd};
+    launch(m->k_grad_fused, (unsigned)(((chains + m->grad_k - 1) / m->grad_k) * nsplit), 64, m->stream, args);
+  };
+  // Static HMC in the sampling phase runs in lock step: every chain was paused at the head of the same iteration, so gradient
+  // request j of a trajectory is request j of every chain, and all but the L-th are followed by the plain update the fused
+  // launch performs itself.  (A chain that is out of step anyway is simply served by the next tick: rh_fused_epilogue.)
+  const int L = std::max(1, s->cfg.hmc_steps);
+  const bool fuse_now = s->fuse && s->warmed && s->cfg.sampler == RH_SAMPLER_HMC && L > 1;
+  long long pos = 0;  // gradient launches since the first tick of this call
   // batch size between host checks: exact for static HMC in the sampling phase, otherwise 32 ticks
   int remaining_hint = 32;
   if (s->cfg.sampler == RH_SAMPLER_HMC && s->warmed) {
@@ -1100,10 +1125,13 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     while ((int)s->ev.size() < 2 * B) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev.push_back(e); }
     HIPCHK(hipEventRecord(s->e0, m->stream));
     for (int i = 0; i < B; i++) {
+      // the last launch of a batch is always followed by a tick: it is the tick that counts the chains still running
+      const bool fused = fuse_now && (int)(pos % L) + 1 < L && i != B - 1;
       HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
-      grad();
+      if (fused) grad_fused(); else grad();
       HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
-      tick(0, false);
+      if (!fused) tick(0, false);
+      pos++;
     }
     HIPCHK(hipEventRecord(s->e1, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -1265,7 +1293,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

@@ -65,7 +65,7 @@ def load():
     lib.rir_density_new.restype = C.c_void_p
     lib.rir_density_new.argtypes = [C.c_void_p, C.POINTER(dp), C.POINTER(C.c_int64), C.c_int]
     lib.rir_density_free.argtypes = [C.c_void_p]
-    for f in (lib.rir_density_update, lib.rir_density_abs_sums, lib.rir_density_update_ld):
+    for f in (lib.rir_density_update, lib.rir_density_abs_sums, lib.rir_density_update_ld, lib.rir_density_update_x):
         f.restype = C.c_int; f.argtypes = [C.c_void_p, dp, dp]
     lib.rir_requirements_eval.restype = C.c_int; lib.rir_requirements_eval.argtypes = [C.c_void_p, dp, dp]
     lib.orc_sample_chain.restype = C.c_int
@@ -157,6 +157,10 @@ class OracleDensity:
         return out, ab
 
     def update_ld(self, q): return self._call(self.lib.rir_density_update_ld, q)[1]
+
+    def update_x(self, q):
+        """the program evaluated and summed in extended precision (rir_density_update_x): a yardstick, not the reference's arithmetic"""
+        return self._call(self.lib.rir_density_update_x, q)[1]
 
     def __del__(self):
         try:

@@ -1,0 +1,114 @@
+"""The SAMPLER configurations BASELINE.json names for cfg 3, cfg 4 and cfg 5, at the stated sizes (VERDICT r2 next #1a; the
+density side of the same configurations is tests/test_gpu_baseline_sizes.py):
+
+  cfg 3  eight schools, NUTS(max depth 10) + DefaultConfig's tuners (DualAvgTuner(0.8), DiagonalMassMatrixTuner(50, 1.5, 50, 50),
+         sampler/Sampler.scala:17-27), 1024 chains per GPU -- the one-chain-per-wavefront variant of the sampler kernels (fewer
+         than 4096 chains): 32 of the chains bit for bit against the oracle's nuts_iteration, every parameter R-hat < 1.01.
+  cfg 4  logistic GLM, 50 covariates x 1e7 rows, NUTS(10) + windowed diagonal mass + DualAvg on the MFMA gradient kernel,
+         256 chains: a short run at full size (the 2e5-row run of test_gpu_baseline_sizes.py checks convergence).
+  cfg 5  hierarchical NegBin GLM, 10 000 groups x 100 observations (nVars 10 004, gather kernel, HBM-resident chain state),
+         NUTS(10) with enough warm-up for the trees to leave max depth: finite draws, R-hat of the 4 shared parameters, mean
+         tree depth reported.
+The plugin point is sampler/Sampler.scala:52-62, the U-turn primitive sampler/LeapFrog.scala:35-47; NUTS itself is an
+extension (the reference has none): parity is against the oracle's statement of the algorithm."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import rainier_amd as R
+from rainier_amd import _capi, models
+from tests import oracle_lib as O
+from tests.test_gpu_parity import _oracle_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _note(line):
+    print(line)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "baseline_samplers.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def test_cfg3_eight_schools_nuts10_default_tuners_1024_chains():
+    spec = models.eight_schools()
+    chains, warm, iters = 1024, 300, 200
+    cfg = R.make_config(iters, warm, R.NUTSSampler(10))      # DefaultConfig's DualAvgTuner(0.8) + DiagonalMassMatrixTuner(50, 1.5, 50, 50)
+    seeds = [8000 + c for c in range(chains)]
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    t0 = time.time()
+    tr = m.sample(cfg, seeds=seeds)
+    dt = time.time() - t0
+    ocfg = _oracle_cfg(cfg, O.JM_DET)
+    for c in list(range(16)) + list(range(chains - 16, chains)):          # both ends of the launch
+        want, mass, st = O.sample_model(spec, ocfg, seeds[c])
+        assert np.array_equal(tr.chains[c], want), (c, np.argwhere(tr.chains[c] != want)[:3])
+        assert np.array_equal(tr.mass[c], mass) and tr.stats[c].leapfrogSteps == st.leapfrog_steps and tr.stats[c].stepSize == st.step_size
+    diag = tr.diagnostics()
+    rhat = max(r for r, _ in diag)
+    steps = sum(st.leapfrogSteps for st in tr.stats)
+    _note("cfg3 NUTS(10) 1024 chains x (%d + %d): rhat_max %.4f, ess_min %.0f, mean leapfrog / iteration %.1f, accept %.3f, %.2f s wall" % (
+        warm, iters, rhat, min(e for _, e in diag), steps / (chains * iters), np.mean([st.meanAcceptProb for st in tr.stats]), dt))
+    assert rhat < 1.01, rhat
+    assert 0.7 < np.mean([st.meanAcceptProb for st in tr.stats]) < 0.92
+
+
+def test_cfg4_sampler_config_at_1e7_rows_short():
+    n, k, chains = 10_000_000, 50, 256
+    spec = models.logistic(n=n, k=k)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "rh_grad_glm_kernel" in m.hip_source
+    warm, iters = 40, 8
+    cfg = R.make_config(iters, warm, R.NUTSSampler(10), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(10, 1.5, 10, 5), engine=_capi.ENGINE_TICK)
+    s = R.Sampler(m, cfg, [4000 + c for c in range(chains)])
+    t0 = time.time(); s.warmup(); s.run(iters); dt = time.time() - t0
+    assert s.timing()["dominant_kernel"] == "rh_grad_glm_kernel"
+    draws = s.draws()
+    stats, mass = s.stats()
+    s.close(); m.close()
+    assert np.all(np.isfinite(draws)) and not np.allclose(mass, 1.0)
+    rng = np.random.default_rng(4); rng.standard_normal((k, n)); beta_true = rng.standard_normal(k)
+    post_mean = draws.reshape(-1, k + 1).mean(axis=0)
+    dev = float(np.max(np.abs(post_mean[1:] - beta_true)))
+    lf, wlf = sum(st.leapfrogSteps for st in stats), sum(st.warmupLeapfrogSteps for st in stats)
+    _note("cfg4 NUTS(10) + diag mass at 1e7 x 50, 256 chains x (%d + %d): mean leapfrog / iteration %.1f (warm-up %.1f), accept %.3f, "
+          "max |posterior mean - beta| %.2e, %.1f s wall" % (warm, iters, lf / (chains * iters), wlf / (chains * warm),
+                                                              np.mean([st.meanAcceptProb for st in stats]), dev, dt))
+    # posterior sd ~ 2 / sqrt(n) ~ 7e-4 per coefficient; after 40 adaptation iterations every chain sits in the bulk
+    assert abs(post_mean[0]) < 0.01 and dev < 0.01, dev
+
+
+def test_cfg5_hier_negbin_nuts10_at_full_size():
+    G, per, chains = 10_000, 100, 64
+    spec = models.hier_negbin(G, per)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "rh_grad_gather_kernel" in m.hip_source and "#define RH_BIGN 1" in m.hip_source
+    warm, iters = 150, 40
+    cfg = R.make_config(iters, warm, R.NUTSSampler(10), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(20, 1.5, 20, 20))
+    s = R.Sampler(m, cfg, [9000 + c for c in range(chains)])
+    t0 = time.time(); s.warmup(); tw = time.time() - t0
+    t0 = time.time(); s.run(iters); dt = time.time() - t0
+    draws = s.draws()
+    stats, mass = s.stats()
+    s.close()
+    assert draws.shape == (chains, iters, spec.n_params) and np.all(np.isfinite(draws))
+    shared = R.diagnostics(draws[:, :, :4])
+    rhat = [r for r, _ in shared]
+    lf = sum(st.leapfrogSteps for st in stats) / (chains * iters)
+    wlf = sum(st.warmupLeapfrogSteps for st in stats) / (chains * warm)
+    _note("cfg5 NUTS(10) 10 000 x 100, %d chains x (%d + %d): mean leapfrog / iteration %.1f (tree depth ~%.1f; warm-up %.1f), accept %.3f, "
+          "rhat of the 4 shared parameters %s, warm-up %.1f s, run %.1f s (%.2f ms per leapfrog step)" % (
+              chains, warm, iters, lf, np.log2(lf + 1), wlf, np.mean([st.meanAcceptProb for st in stats]),
+              ["%.3f" % r for r in rhat], tw, dt, dt / (lf * iters) * 1e3))
+    assert lf < 600, lf                                   # the trees have left max depth (1023 leaves)
+    assert not np.allclose(mass, 1.0)
+    assert max(rhat) < 1.3, rhat                          # 40 draws per chain: a convergence smoke check, not a precision claim
+    # the data-generating shared parameters of models.hier_negbin_data are recovered (mu enters as 10 * mu)
+    post = draws[:, :, :4].reshape(-1, 4).mean(axis=0)
+    _note("cfg5 posterior means of the shared parameters: %s" % np.array2string(post, precision=4))

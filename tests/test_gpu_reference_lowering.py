@@ -14,14 +14,28 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(spec, model, qs, tol, math_mode=O.JM_LIBM, engine=None):
+    """|device - oracle| <= tol * sum_rows |term| per output (1e-12 for N <= 1e4); the worst ratio that occurred is
+    appended to gpurun_out/parity_worst.txt (DESIGN 4 quotes the measured figures per model)"""
     d = O.OracleDensity(spec, math_mode)
     lp, g = model.density_batch(qs) if engine is None else model.density_batch(qs, engine=engine)
+    worst = 0.0
     for c, q in enumerate(qs):
         ref, ab = d.update_both(q)
         got = np.concatenate([[lp[c]], g[c]])
-        bound = tol * ab + 1e-300
         both_nan = np.isnan(got) & np.isnan(ref)         # NaN is data (a scale parameter below zero): it must be NaN on both sides
-        assert np.all((np.abs(got - ref) <= bound) | both_nan), (spec.name, c, got, ref)
+        ratio = np.where(both_nan, 0.0, np.abs(got - ref) / (ab + 1e-300))
+        worst = max(worst, float(np.nanmax(ratio)))
+        assert np.all((np.abs(got - ref) <= tol * ab + 1e-300) | both_nan), (spec.name, c, float(np.nanmax(ratio)), got, ref)
+    try:
+        import os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_worst.txt"), "a") as f:
+            f.write("%s %s engine=%s worst |delta| / sum|term| = %.3e (bound %.0e)\n" % (
+                spec.name, "strict" if "RH_FP_CONTRACT 0" in model.hip_source else "fast", engine, worst, tol))
+    except OSError:
+        pass
+    return worst
 
 
 def test_logistic_reference_lowering_strict_and_fast():
@@ -162,8 +176,8 @@ def test_glmm_poisson2_reference_benchmark_model_on_the_device():
     m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
     assert "NCOLS = 4, COL0 = 0" in m.hip_source and "#define RH_NROWTARGETS 1\n" in m.hip_source
     qs = np.random.default_rng(23).normal(size=(4, 146)) * 0.3
-    _check(spec, m, qs, 1e-11)
-    _check(spec, m, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    _check(spec, m, qs, 1e-12)
+    _check(spec, m, qs, 1e-12, engine=_capi.ENGINE_TICK)
     import time
     t0 = time.time()
     tr = m.sample(R.make_config(10, 20, R.HMCSampler(5)), seeds=range(8))   # dual averaging + windowed diagonal mass, L = 5
@@ -185,8 +199,8 @@ def test_lowdim_gaussmix_reference_benchmark_model_on_the_device():
     _check(spec, ms, qs, 1e-12, O.JM_DET)
     mf = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
     assert "NCOLS = 2, COL0 = 0" in mf.hip_source and "#define RH_NROWTARGETS 1\n" in mf.hip_source
-    _check(spec, mf, qs, 1e-11)
-    _check(spec, mf, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    _check(spec, mf, qs, 1e-12)
+    _check(spec, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
     tr = mf.sample(R.make_config(60, 200), seeds=range(16))
     mu = np.sort(tr.chains[:, :, [0, 2]], axis=2).mean(axis=1)                    # per chain (mu1, mu2) up to label switching
     # every chain finds the same two components, one on each side of zero (the data are bimodal around -2.7 and +2.9)
@@ -219,9 +233,7 @@ def test_ark_and_kidiq_reference_benchmark_models_on_the_device():
 
 
 def test_hierarchical_models_as_the_front_end_hands_them_over_run_in_gather_mode():
-    """Written after this round's GPU budget was spent: the generated row code of both models is checked on the CPU
-    (tests/test_emitter_host.py, gather-mode emulation); this is their first run through rh_grad_gather_kernel.
-    (a) cfg 5's shape in the reference's own text -- NegBin-logit, eta = a + tau * z(site) + b x, z = Normal(0,1).latentVec(100)
+    """(a) cfg 5's shape in the reference's own text -- NegBin-logit, eta = a + tau * z(site) + b x, z = Normal(0,1).latentVec(100)
     created last -- through Model.observe's 8-way split: the z prior arrives in the data-free target and is lifted into a row
     target over the group index (csrc/lift.cpp lift_table_priors), the split is rolled back, the gradient re-derived into
     eq(index, k, g, 0) form: gather mode.  (b) 80 schools, one Model.observe per school: the members differ in a parameter, which
@@ -237,8 +249,8 @@ def test_hierarchical_models_as_the_front_end_hands_them_over_run_in_gather_mode
     m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
     assert "#define RH_HAS_GATHER 1\n" in m.hip_source
     qs = rng.normal(size=(6, spec.n_params)) * 0.3
-    _check(spec, m, qs, 1e-10)
-    _check(spec, m, qs, 1e-10, engine=_capi.ENGINE_TICK)
+    _check(spec, m, qs, 1e-12)
+    _check(spec, m, qs, 1e-12, engine=_capi.ENGINE_TICK)
     tr = m.sample(R.make_config(20, 40), seeds=range(8))
     assert np.all(np.isfinite(tr.chains))
 
@@ -254,6 +266,6 @@ def test_hierarchical_models_as_the_front_end_hands_them_over_run_in_gather_mode
     assert "#define RH_HAS_GATHER 1\n" in ms.hip_source and "#define RH_NROWTARGETS 2\n" in ms.hip_source
     _check(schools, ms, qs, 1e-12, O.JM_DET)
     mf = R.Model(schools, device=0, fp_contract=True, factor_outputs=True)
-    _check(schools, mf, qs, 1e-11)
-    _check(schools, mf, qs, 1e-11, engine=_capi.ENGINE_TICK)
+    _check(schools, mf, qs, 1e-12)
+    _check(schools, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
     assert np.all(np.isfinite(mf.sample(R.make_config(20, 40), seeds=range(8)).chains))
