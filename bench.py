@@ -232,7 +232,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
     ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
-    ap.add_argument("--ess-iters", type=int, default=256)
+    ap.add_argument("--ess-iters", type=int, default=1536,
+                    help="timed draws per chain of the ESS legs: static HMC with L=32 resonates on this posterior (autocorrelation time ~27 "
+                         "iterations), so R-hat only falls below 1.01 with > 1350 draws per chain")
     ap.add_argument("--ess-warmup", type=int, default=384)
     ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
                     help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC")
@@ -306,8 +308,9 @@ def main():
     assert steps_local == K * L * cpg, (steps_local, K, L, cpg)
     total_steps = steps_local * world
     # ESS/s legs, independent of the driver's --steps/--warmup.  The chains start from N(0,1) draws and the posterior is 7e-4 wide:
-    # they need a few hundred iterations to get there (R-hat says whether they did), and Trace.autocorrelation (core/Trace.scala:
-    # 93-109) can only sum lags < the draw count, so >= 256 timed draws per chain.  Two configurations: the bench's (identity
+    # they need a few hundred iterations to get there, and a static L=32 trajectory is ~5 periods of this posterior long, so a
+    # chain's draws are strongly autocorrelated (tau ~ 27 iterations, measured): R-hat = sqrt(1 + (tau - 1) / n) falls below 1.01
+    # only with n > 1350 draws per chain.  Trace.autocorrelation (core/Trace.scala:93-109) sums lags < min(n, 100).  Two configurations: the bench's (identity
     # mass) and DefaultConfig's windowed diagonal mass adaptation (sampler/Sampler.scala:24-25) with the same static L.
     ess_iters, ess_warm = max(K, a.ess_iters), max(W, a.ess_warmup)
     ess_runs = {}

@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 3  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
-                             3: rh_density_eval_ex, rh_sample_multi, rh_comm_* (RCCL all-gather of the draws) */
+#define RH_ABI_VERSION 4  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
+                             3: rh_density_eval_ex, rh_sample_multi, rh_comm_* (RCCL all-gather of the draws);
+                             4: rh_model_clone */
 
 enum rh_status {
   RH_OK = 0,
@@ -79,6 +80,12 @@ typedef struct rh_compile_opts {
  * The engine copies the columns to HBM; the caller keeps ownership of its arrays. */
 int rh_model_create(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
                     const rh_compile_opts *opts, rh_model **out);
+/* The same model on another device of this process -- what Model.sample's loop over chains (core/Model.scala:16-22) needs when
+ * the chains are spread over several GPUs (rh_sample_multi): the lowered program and its code object are reused as they are
+ * (no parsing, no data-dependent passes, no compilation unless the architectures differ) and the observation columns are
+ * copied device to device over xGMI; the host arrays rh_model_create was given are not needed again.  device = -1: the
+ * current device (a second, independent handle on the same device). */
+int rh_model_clone(const rh_model *src, int32_t device, rh_model **out);
 void rh_model_destroy(rh_model *m);
 int rh_model_nvars(const rh_model *m);
 /* the generated HIP source (the analogue of rainier-decompile's view of the generated bytecode) */

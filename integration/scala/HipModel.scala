@@ -108,7 +108,9 @@ object HipModel {
                   devices: Seq[Int] = Seq(-1))(implicit rng: RNG = RNG.default): Trace = {
       val n = model.parameters.size
       val nuts = config.sampler().isInstanceOf[NUTSSampler]
-      val handles = devices.map(d => create(opts.copy(device = d, with_nuts = if (nuts) 1 else opts.with_nuts))).toArray
+      // lowered and compiled ONCE (for the first device); the other devices get clones: code object reused, columns copied over xGMI
+      val first = create(opts.copy(device = devices.head, with_nuts = if (nuts) 1 else opts.with_nuts))
+      val handles = (first +: devices.tail.map(d => Native.modelClone(first, d))).toArray
       try {
         val seeds = Array.fill(nChains)(java.lang.Double.doubleToRawLongBits(rng.standardUniform))
         val (icfg, dcfg, staticMass) = HipConfig.flatten(config)

@@ -11,6 +11,8 @@ object Native {
   /** copts = rh_compile_opts field by field: see HipOptions.copts */
   @native def modelCreate(rir: Array[Byte], columns: Array[Array[Double]], nrows: Array[Long],
                           copts: Array[Int]): Long                                                // rh_model_create
+  /** the same compiled model on another device: no second lowering, columns copied device to device */
+  @native def modelClone(model: Long, device: Int): Long                                          // rh_model_clone
   @native def modelDestroy(model: Long): Unit                                                     // rh_model_destroy
   @native def modelNVars(model: Long): Int                                                        // rh_model_nvars
   /** engine / gradSplits: 0, 0 = the engine's choice (rh_density_eval) */

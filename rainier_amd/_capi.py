@@ -24,7 +24,7 @@ ENGINE_AUTO, ENGINE_CHAIN, ENGINE_TICK = 0, 1, 2
 
 # every symbol include/rainier_hip.h declares (checked by tests/test_capi_cpu.py)
 EXPORTS = [
-    "rh_model_create", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
+    "rh_model_create", "rh_model_clone", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
     "rh_density_eval", "rh_density_eval_ex", "rh_config_default", "rh_sample", "rh_sample_multi", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
     "rh_sampler_timing", "rh_sampler_progress", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
@@ -81,6 +81,8 @@ def lib():
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     L.rh_model_create.restype = C.c_int
     L.rh_model_create.argtypes = [vp, C.c_size_t, C.POINTER(dp), C.POINTER(C.c_int64), C.POINTER(CompileOpts), C.POINTER(vp)]
+    L.rh_model_clone.restype = C.c_int
+    L.rh_model_clone.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.rh_model_destroy.argtypes = [vp]
     L.rh_model_nvars.argtypes = [vp]
     L.rh_model_hip_source.restype = C.c_char_p; L.rh_model_hip_source.argtypes = [vp]

@@ -927,7 +927,9 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
-template <int T>
+// COHERENT: the partial sums are stored with agent-scope (write-through) stores -- rh_grad_fused_kernel, whose epilogue reads them
+// from another XCD within the same launch
+template <int T, bool COHERENT>
 RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const int lane,
                             const int split, const int nsplit, const int chain0, const int chains,
                             double *__restrict__ partial, int &err) {
@@ -1010,11 +1012,14 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #pragma unroll
         for (int o = 0; o < NA; o++) {
           const double v = rh_wave_sum(acc[kk][o]);
-          if (lane == 0 && chain0 + kk < chains) out[o] = v;
+          if (lane == 0 && chain0 + kk < chains) {
+            if constexpr (COHERENT) __hip_atomic_store(out + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[o] = v;
+          }
         }
       }
     }
-    rh_grad_targets<T + 1>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+    rh_grad_targets<T + 1, COHERENT>(th, d, lane, split, nsplit, chain0, chains, partial, err);
   }
 }
 #pragma clang fp contract(off)
@@ -1025,6 +1030,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #define RH_GRAD_WAVES 1
 #endif
 // returns the first chain of the workgroup's chain group, or -1 when there is nothing to do for it (no chain waits for a gradient)
+template <bool COHERENT>
 RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ active, double *partial,
                         int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit,
                         const int xcd_aware, int &group) {
@@ -1050,7 +1056,7 @@ RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__re
   }
   if (!any) return -1;
   int err = 0;
-  rh_grad_targets<0>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+  rh_grad_targets<0, COHERENT>(th, d, lane, split, nsplit, chain0, chains, partial, err);
   if (err && lane == 0) atomicOr(err_out, 1);
   return chain0;
 }
@@ -1059,7 +1065,7 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
                double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                const int chains, const int nsplit, const int xcd_aware) {
   int group;
-  (void)rh_grad_body(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
+  (void)rh_grad_body<false>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
 }
 
 // ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
@@ -1566,14 +1572,24 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
 // ---- gather mode: a parameter table indexed by a data column (cfg 5: group effects alphas(site)) ------------------
 // Reference semantics: Lookup(index, table of G parameter expressions) evaluates ALL table entries per row and the
 // gradient adds one eq-lookup per entry per row (compute/Translator.scala:51-61, compute/Gradient.scala:148-152):
-// O(rows x G).  Here rows are sorted by index and walked GROUP by GROUP: the group's table parameter is a wave-uniform
-// scalar load for each of the K chains of the wavefront (no per-lane gather), the row term is evaluated with it, and the
-// scatter value (the common adjoint g of all the eq-lookups) is summed over the group's rows by the fixed-order wave
-// butterfly and stored once per (chain, group): a segmented reduction, no atomics, deterministic.  Shared outputs are
-// accumulated per lane across all groups of the split exactly as in rh_grad_kernel.
+// O(rows x G).  Here rows are sorted by index, so a group's rows are contiguous: the table parameter reaches a row through one
+// per-lane load, the row term is evaluated with it, and the scatter value (the common adjoint g of all the eq-lookups) is summed
+// over the group's rows by a fixed-order segmented scan and stored once per (chain, group): no atomics, deterministic.  Shared
+// outputs are accumulated per lane across the whole split exactly as in rh_grad_kernel.
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
+// fixed-order SEGMENTED inclusive scan over the wavefront: lane l ends with the sum of v over the lanes [max(start_l, 0), l] of its
+// own segment (start = first lane of the segment, <= 0 when the segment began in an earlier tile).  Hillis-Steele with ds_bpermute.
+RH_DEV double rh_segmented_scan(double v, const int start, const int lane) {
+  const int s0 = start > 0 ? start : 0;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const double t = __shfl_up(v, dlt, 64);
+    v += (lane - dlt >= s0) ? t : 0.0;
+  }
+  return v;
+}
 template <int T>
 RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
                               const double *__restrict__ q, const int lane, const int split, const int nsplit,
@@ -1594,29 +1610,53 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
       for (int kk = 0; kk < K; kk++)
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
+      // The split's rows are one contiguous range (splits are cut at group boundaries, rows are sorted by group): the wavefront
+      // walks it in full 64-row tiles, ACROSS group boundaries -- every lane evaluates a row whatever the group sizes are
+      // (cfg 5: 100 rows per group used to run as 64 + 36 lanes).  A lane takes its row's table entry with a per-lane load (a
+      // tile touches one to three neighbouring entries per chain), and the scatter value is summed per group by a segmented
+      // scan over the tile; a group that continues in the next tile hands its running sum over in `carry`.
       const int *goff = gd.goff[TG::ROWT];
       const int g0 = gd.gsplit[TG::ROWT][split], g1 = gd.gsplit[TG::ROWT][split + 1];
-      for (int g = g0; g < g1; g++) {
-        const int r0 = goff[g], r1 = goff[g + 1];
+      const int r0 = goff[g0], r1 = goff[g1];
+      size_t qoff[K];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+      double carry[K];
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) carry[kk] = 0.0;
+      for (int base = r0; base < r1; base += 64) {
+        const int r = base + lane;
+        const bool live = r < r1;
+        const int rr = live ? r : r1 - 1;
+        double cc[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) cc[j] = cp[j][rr];
+        int g = g0, gbeg = base, gend = r1;   // a target without a gather: one segment, nothing is stored per group
+        if constexpr (TG::HAS_GATHER) {
+          g = (int)cc[TG::G_COL] - TG::G_LOW;  // in range: rh_model_create walked the index column (RH_E_LOOKUP)
+          gbeg = goff[g]; gend = goff[g + 1];
+        }
         double gz[K], sv[K];
 #pragma unroll
         for (int kk = 0; kk < K; kk++) {
-          const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
-          gz[kk] = TG::HAS_GATHER ? q[(size_t)c * RH_NVARS + TG::G_FIRST + g] : 0.0;
+          gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
           sv[kk] = 0.0;
         }
-        for (int r = r0 + lane; r < r1; r += 64) {
-          double cc[NC];
-#pragma unroll
-          for (int j = 0; j < NC; j++) cc[j] = cp[j][r];
+        if (live) {
 #pragma unroll
           for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
         }
         if constexpr (TG::HAS_GATHER) {
+          const int start = gbeg - base;                      // first lane of this lane's group (<= 0: it began earlier)
+          const bool tail = live && (r == gend - 1);          // last row of its group
+          const int last = (r1 - base < 64 ? r1 - base : 64) - 1;   // last live lane of the tile (wave-uniform)
+          const int last_open = __builtin_amdgcn_readlane(tail ? 0 : 1, last);
 #pragma unroll
           for (int kk = 0; kk < K; kk++) {
-            const double v = rh_wave_sum(sv[kk]);
-            if (lane == 0 && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + g] = v;
+            double v = rh_segmented_scan(sv[kk], start, lane);
+            v += (start < 0) ? carry[kk] : 0.0;               // the group that was open at the end of the previous tile
+            if (tail && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + g] = v;
+            carry[kk] = last_open ? rh_readlane(v, last) : 0.0;
           }
         }
       }
@@ -1775,6 +1815,21 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 #if RH_NROWTARGETS > 0 && !RH_HAS_GATHER && !RH_BIGN && !RH_WITH_DENSE && !RH_WITH_NUTS && RH_PACK_L == 64 && RH_SLOTS == 1
 #if (RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8 || RH_GRAD_K == 16) && (RH_NVARS * RH_GRAD_K <= 64)
 #define RH_HAVE_FUSED 1
+// How the partial sums cross from the workgroups that wrote them (any XCD, each with its own L2) to the group's last workgroup:
+//   RH_FUSE_SYNC 2 (default): agent-scope write-through stores / loads that bypass the XCD-local L2 (sc1), ordered by the counter
+//                 atomic and s_waitcnt -- no cache-wide operation at all;
+//   RH_FUSE_SYNC 1: plain stores, an agent-scope RELEASE fence (buffer_wbl2) per workgroup and an ACQUIRE fence (buffer_inv: the
+//                 whole L2 of that XCD) in the last workgroup of every chain group.
+#ifndef RH_FUSE_SYNC
+#define RH_FUSE_SYNC 2
+#endif
+RH_DEV double rh_fused_load(const double *p) {
+#if RH_FUSE_SYNC == 2
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
 template <int T>
 RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *partial, const long long *nrows, const int nsplit,
                                       const int chain, const int chains, const int j, double (&tot)[RH_NOUT], int &err) {
@@ -1786,25 +1841,44 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
     } else {
       constexpr int NA = TG::NACC > 0 ? TG::NACC : 1, M = RH_GRAD_K, LPC = 64 / RH_GRAD_K;
       double S[NA];
+      double r[NA][M];  // r[o][m]: slot j + LPC * m of the 64-slot butterfly rh_combine_targets runs over the splits, output o
+      // splits 0..63: one address per slot (clamped: every lane loads, the surplus is masked after the load), the outputs at fixed
+      // offsets from it; all NA * M loads are in flight together
 #pragma unroll
-      for (int o = 0; o < NA; o++) {
-        double r[M];  // slot j + LPC * m of the 64-slot butterfly rh_combine_targets runs over the splits
+      for (int m = 0; m < M; m++) {
+        const int sp = j + LPC * m, spc = sp < nsplit ? sp : nsplit - 1;
+        const double *pm = partial + (((size_t)TG::ROWT * nsplit + spc) * chains + chain) * RH_NACC_MAX;
+#pragma unroll
+        for (int o = 0; o < NA; o++) r[o][m] = rh_fused_load(pm + o);
+      }
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        const bool have = j + LPC * m < nsplit;
+#pragma unroll
+        for (int o = 0; o < NA; o++) r[o][m] = 0.0 + (have ? r[o][m] : 0.0);   // rh_combine_targets starts every slot at 0.0
+      }
+      for (int base = 64; base < nsplit; base += 64) {   // more than 64 splits (few chains): the slot's further splits, ascending
 #pragma unroll
         for (int m = 0; m < M; m++) {
-          double a = 0.0;
-          for (int sp = j + LPC * m; sp < nsplit; sp += 64)
-            a += partial[(((size_t)TG::ROWT * nsplit + sp) * chains + chain) * RH_NACC_MAX + o];
-          r[m] = a;
+          const int sp = base + j + LPC * m;
+          if (sp < nsplit) {
+            const double *pm = partial + (((size_t)TG::ROWT * nsplit + sp) * chains + chain) * RH_NACC_MAX;
+#pragma unroll
+            for (int o = 0; o < NA; o++) r[o][m] += rh_fused_load(pm + o);
+          }
         }
+      }
+#pragma unroll
+      for (int o = 0; o < NA; o++) {
 #pragma unroll
         for (int off = 32; off >= LPC; off >>= 1) {  // butterfly levels whose partner slot lives in this lane
           double t[M];
 #pragma unroll
-          for (int m = 0; m < M; m++) t[m] = r[m] + r[m ^ (off / LPC)];
+          for (int m = 0; m < M; m++) t[m] = r[o][m] + r[o][m ^ (off / LPC)];
 #pragma unroll
-          for (int m = 0; m < M; m++) r[m] = t[m];
+          for (int m = 0; m < M; m++) r[o][m] = t[m];
         }
-        double v = r[0];
+        double v = r[o][0];
 #pragma unroll
         for (int off = LPC / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);  // ... and in the chain's other lanes
         S[o] = v;
@@ -1875,15 +1949,25 @@ rh_grad_fused_kernel(const rh_model_data d, double *q, const int *__restrict__ a
                      int *__restrict__ err_out, int *__restrict__ n_running, rh_u64 *state, int *group_cnt,
                      const int chains, const int nsplit, const int xcd_aware) {
   int group;
-  const int chain0 = rh_grad_body(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
+  const int chain0 = rh_grad_body<RH_FUSE_SYNC == 2>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
   if (chain0 < 0) return;   // the same for every workgroup of the group: nobody counts
   const int lane = threadIdx.x;
-  __threadfence();          // release: this workgroup's partial sums are visible device-wide before it is counted
+#if RH_FUSE_SYNC == 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's write-through partial sums have reached memory before it is counted
+#else
+  // release ONLY (L2 write-back of this workgroup's partial sums, no invalidate): an acquire here would drop the XCD's L2 -- the
+  // row tiles every other workgroup of the XCD is still streaming -- once per workgroup (measured: +95 us per launch)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
   int last = 0;
-  if (lane == 0) last = (atomicAdd(&group_cnt[group], 1) == nsplit - 1) ? 1 : 0;
+  if (lane == 0) last = (__hip_atomic_fetch_add(&group_cnt[group], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1) ? 1 : 0;
   if (!__builtin_amdgcn_readfirstlane(last)) return;
-  if (lane == 0) group_cnt[group] = 0;  // re-armed for the next launch
-  __threadfence();          // acquire: the other workgroups' partial sums
+  if (lane == 0) __hip_atomic_store(&group_cnt[group], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+#if RH_FUSE_SYNC == 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the counter's return value has arrived; the loads below bypass the local L2)
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' partial sums: only the group's last workgroup invalidates
+#endif
   rh_fused_epilogue(d, state, q, partial, chains, nsplit, chain0, lane);
 }
 #endif

@@ -234,6 +234,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_CHAIN_WAVES")) defines += "#define RH_CHAIN_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
@@ -643,6 +644,61 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
       }
     }
     // the pointer table itself (dev_cols is in flattened column order: targets ascending, then column)
+    HIPCHK(hipMalloc(&m->d_coltab, std::max<size_t>(1, m->dev_cols.size()) * sizeof(void *)));
+    if (!m->dev_cols.empty()) HIPCHK(hipMemcpy(m->d_coltab, m->dev_cols.data(), m->dev_cols.size() * sizeof(void *), hipMemcpyHostToDevice));
+    m->data.cols = (const double *const *)m->d_coltab;
+  });
+  if (rc != RH_OK) { rh_model_destroy(m); return rc; }
+  *out = m;
+  return RH_OK;
+}
+
+// The same model on another device: everything rh_model_create derived on the host is copied, the code object is loaded as it
+// is, the columns travel device to device.
+extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **out) {
+  if (!out) { g_err = "rh_model_clone: out is NULL"; return RH_E_INVALID; }
+  *out = nullptr;
+  if (!src || !src->loaded) { g_err = "rh_model_clone: model not loaded"; return RH_E_INVALID; }
+  rh_model *m = new rh_model();
+  const int rc = guard(m, [&] {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Fail{RH_E_DEVICE, "no HIP device available"};
+    int dev = device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) throw Fail{RH_E_INVALID, "device ordinal out of range"};
+    m->prog = src->prog; m->eopt = src->eopt; m->info = src->info; m->want_nuts = src->want_nuts;
+    m->source = src->source; m->nacc_max = src->nacc_max; m->grad_k = src->grad_k; m->has_glm = src->has_glm;
+    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w;
+    m->goff_host = src->goff_host; m->gather_count = src->gather_count; m->col_len = src->col_len; m->col_src = src->col_src;
+    m->rows_total = src->rows_total; m->data = src->data; m->data.cols = nullptr;
+    m->device = dev;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    m->arch = prop.gcnArchName;
+    const auto colon = m->arch.find(':');
+    if (colon != std::string::npos) m->arch = m->arch.substr(0, colon);
+    if (m->arch == src->arch) m->code = src->code; else build_code(m);   // (a mixed node: compiled or fetched from the cache for that architecture)
+    load_module(m);
+    if (m->want_nuts) (void)load_variant(m, 1);
+    // observation columns and group offsets: device to device (src's copies are immutable after rh_model_create)
+    size_t c = 0;
+    for (size_t t = 0; t < m->prog.targets.size(); t++) {
+      const auto &T = m->prog.targets[t];
+      for (uint32_t j = 0; j < T.n_cols; j++, c++) {
+        const size_t bytes = (size_t)m->data.nrows[t] * sizeof(double);
+        void *d = nullptr;
+        HIPCHK(hipMalloc(&d, bytes ? bytes : 8));
+        m->dev_cols.push_back(d);
+        if (bytes) HIPCHK(hipMemcpyPeer(d, dev, src->dev_cols[c], src->device, bytes));
+      }
+    }
+    for (size_t rt = 0; rt < src->goff_dev.size(); rt++) {
+      const size_t bytes = m->goff_host[rt].size() * sizeof(int);
+      void *dp = nullptr;
+      HIPCHK(hipMalloc(&dp, bytes));
+      m->goff_dev.push_back(dp);
+      HIPCHK(hipMemcpy(dp, m->goff_host[rt].data(), bytes, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMalloc(&m->d_coltab, std::max<size_t>(1, m->dev_cols.size()) * sizeof(void *)));
     if (!m->dev_cols.empty()) HIPCHK(hipMemcpy(m->d_coltab, m->dev_cols.data(), m->dev_cols.size() * sizeof(void *), hipMemcpyHostToDevice));
     m->data.cols = (const double *const *)m->d_coltab;

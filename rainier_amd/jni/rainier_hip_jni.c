@@ -78,6 +78,15 @@ JNIEXPORT jlong JNICALL Java_com_stripe_rainier_hip_Native_00024_modelCreate(
   return (jlong)(intptr_t)m;
 }
 
+/* long modelClone(long model, int device): the same compiled model on another device (rh_model_clone) */
+JNIEXPORT jlong JNICALL Java_com_stripe_rainier_hip_Native_00024_modelClone(JNIEnv *env, jobject self, jlong h, jint device) {
+  (void)self;
+  rh_model *m = NULL;
+  const int rc = rh_model_clone((const rh_model *)(intptr_t)h, device, &m);
+  if (rc != RH_OK) { throw_rh(env, NULL, rc); return 0; }
+  return (jlong)(intptr_t)m;
+}
+
 JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_modelDestroy(JNIEnv *env, jobject self, jlong h) {
   (void)env; (void)self;
   rh_model_destroy((rh_model *)(intptr_t)h);

@@ -336,6 +336,15 @@ class Model:
         self._h = C.c_void_p()
         _capi.check(L.rh_model_create(blob, len(spec.rir), colarr, nrows, C.byref(opts), C.byref(self._h)))
 
+    def clone(self, device: int = -1) -> "Model":
+        """the same compiled model on another device of this process (rh_model_clone): code object reused, columns copied
+        device to device -- one per GPU for sample_multi"""
+        other = object.__new__(Model)
+        other.spec, other.nVars, other._cols = self.spec, self.nVars, self._cols
+        other._h = C.c_void_p()
+        _capi.check(_capi.lib().rh_model_clone(self._h, int(device), C.byref(other._h)))
+        return other
+
     @property
     def hip_source(self) -> str: return _capi.lib().rh_model_hip_source(self._h).decode()
 

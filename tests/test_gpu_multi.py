@@ -34,7 +34,7 @@ def test_rh_sample_multi_is_independent_of_the_shard_count(builder, engine, stri
     m0 = R.Model(spec, device=0, **strict)
     base = m0.sample(_cfg(engine), seeds=seeds)
     for nshards in (1, 2, 3, 5, 16):
-        ms = [m0] + [R.Model(spec, device=0, **strict) for _ in range(min(nshards, 3) - 1)]
+        ms = [m0] + [m0.clone(0) for _ in range(min(nshards, 3) - 1)]    # rh_model_clone: code object reused, columns copied device to device
         ms = (ms * nshards)[:nshards]                     # several shards may share a model handle (calls serialise on it)
         tr = R.sample_multi(ms, _cfg(engine), seeds)
         assert np.array_equal(tr.chains, base.chains), nshards

@@ -75,6 +75,56 @@ __global__ void __launch_bounds__(64) k_mfma(double *out, unsigned long long *cy
     cyc[4 * blockIdx.x + 3] = t0;
   }
 }
+// v_mfma_f64_4x4x4_4b_f64: four 4x4x4 blocks per instruction (512 flop), one accumulator double per lane; NT independent accumulators
+template <int NT>
+__global__ void __launch_bounds__(64) k_mfma4(double *out, unsigned long long *cyc, const double *in, int iters) {
+  double acc[NT];
+  const double a = in[2 + threadIdx.x], b = in[70 + threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < NT; i++) acc[i] = in[i];
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < NT; i++) s += acc[i];
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    cyc[4 * blockIdx.x] = t1 - t0; cyc[4 * blockIdx.x + 1] = r1 - r0;
+    cyc[4 * blockIdx.x + 2] = ((unsigned long long)(xcc & 0xf) << 32) | (hw & 0xfffffff0u);
+    cyc[4 * blockIdx.x + 3] = t0;
+  }
+}
+template <int NT, bool SMALL>
+void run_mfma_shape(int w, double *out, unsigned long long *cyc, double *in) {
+  const int iters = 20000, blocks = 256 * 4 * w;
+  if (SMALL) k_mfma4<NT><<<blocks, 64>>>(out, cyc, in, iters); else k_mfma<NT><<<blocks, 64>>>(out, cyc, in, iters);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(4 * blocks);
+  hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  std::map<unsigned long long, std::pair<int, double>> simd;
+  std::vector<double> c(blocks), r(blocks);
+  for (int i = 0; i < blocks; i++) {
+    c[i] = (double)h[4 * i]; r[i] = (double)h[4 * i + 1];
+    auto &e = simd[h[4 * i + 2]];
+    e.first += 1; e.second = std::max(e.second, c[i]);
+  }
+  std::sort(c.begin(), c.end()); std::sort(r.begin(), r.end());
+  const double instr = (double)iters * NT, flop = SMALL ? 512.0 : 2048.0;
+  double rate = 0; int n = 0;
+  for (auto &kv : simd) { rate += kv.second.first * instr / kv.second.second; n++; }
+  printf("%-26s acc=%2d blocks/SIMD=%d  median cycles/mfma/wave %.2f  clock %.0f MHz | %.4f mfma/cycle/SIMD = %.1f flop/cycle/SIMD (%.0f flop each; VALU fma: 32)\n",
+         SMALL ? "v_mfma_f64_4x4x4_4b_f64" : "v_mfma_f64_16x16x4_f64", NT, w, c[blocks / 2] / instr, c[blocks / 2] / r[blocks / 2] * 100.0, rate / n,
+         rate / n * flop, flop);
+}
+
 template <int NT>
 void run_mfma(int w, double *out, unsigned long long *cyc, double *in) {
   const int iters = 20000, blocks = 256 * 4 * w;
@@ -126,6 +176,12 @@ int main(int argc, char **argv) {
   hipMalloc(&in, 4096 * 8); hipMalloc(&out, 256 * 4 * 8 * 64 * 8); hipMalloc(&cyc, 256 * 4 * 8 * 4 * 8);
   std::vector<double> h(4096, 1.0000001); h[3000] = 1.0;
   hipMemcpy(in, h.data(), 4096 * 8, hipMemcpyHostToDevice);
+  if (argc > 1 && argv[1][0] == 'm') {   // `fma64_cycles mfma`: the two fp64 matrix shapes only, two wavefronts per SIMD -- the run the
+    // counters (SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES) are collected on: 4 dispatches, in this order
+    run_mfma_shape<4, false>(2, out, cyc, in); run_mfma_shape<8, false>(2, out, cyc, in);
+    run_mfma_shape<8, true>(2, out, cyc, in); run_mfma_shape<16, true>(2, out, cyc, in);
+    return 0;
+  }
   if (argc > 1) {   // `fma64_cycles dpp`: only the DPP-broadcast FMA against the plain one
     for (int w = 1; w <= 2; w++) {
       run<16, 0>("fma(v, s, acc)", w, out, cyc, in);
