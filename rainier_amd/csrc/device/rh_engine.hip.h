@@ -66,10 +66,8 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
       for (int j = 0; j < NC; j++) c[j] = cp[j][k];
       TG::row(th, inv, c, acc, err);
     }
-    double S[NA];
-#pragma unroll
-    for (int o = 0; o < NA; o++) S[o] = rh_wave_sum(acc[o]);
-    TG::finish(th, inv, S, (double)n, tot);
+    rh_wave_sum_all(acc);
+    TG::finish(th, inv, acc, (double)n, tot);
   }
 }
 template <int T>
@@ -377,11 +375,29 @@ RH_DEV void rh_velocity(const rh_chain &c, const wvec &p, wvec &out, const bool 
 }
 // energy (LeapFrog.scala:131-136)
 RH_DEV double rh_energy(const rh_chain &c, const wvec &p, const double U, const bool identity) {
+#if RH_BIGN
+  // big mode: velocity, product and sum in ONE pass over p (and M) instead of two temporaries written to and read back from HBM;
+  // the same per-element arithmetic and the same summation order as the composition below (lane partials over ascending slots)
+  double part = 0.0;
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {
+    double pa[RH_BIGU], ma[RH_BIGU];
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {
+      const int kc = k + j < RH_SLOTS ? k + j : RH_SLOTS - 1;
+      pa[j] = p.s[kc]; ma[j] = identity ? 1.0 : c.M.s[kc];
+    }
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {
+      const double v = identity ? pa[j] : pa[j] * ma[j];
+      part += ((k + j) * 64 + (int)threadIdx.x < RH_NVARS) ? v * pa[j] : 0.0;
+    }
+  }
+  return U + rh_wave_sum(part) / 2.0;
+#else
   RH_TMP(v); RH_TMP(pr);
   rh_velocity(c, p, v, identity);
   wv_mul(pr, v, p);
   const double kinetic = wv_sum_seq(pr) / 2.0;
   return U + kinetic;
+#endif
 }
 RH_DEV double rh_log_accept(const double deltaH) { // LeapFrog.scala:138-142
   if (deltaH != deltaH) return -RH_INF;
@@ -545,10 +561,24 @@ RH_DEV double rh_ring_sample(rh_chain &c, const int size) { // Stats.scala:40-45
 #endif
 }
 RH_DEV bool rh_is_uturn(const rh_chain &c) { // LeapFrog.scala:35-47
+#if RH_BIGN
+  double part = 0.0;  // one pass, no temporaries (see rh_energy)
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {
+    double qa[RH_BIGU], q0[RH_BIGU], pa[RH_BIGU];
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {
+      const int kc = k + j < RH_SLOTS ? k + j : RH_SLOTS - 1;
+      qa[j] = c.Bq.s[kc]; q0[j] = c.Pq.s[kc]; pa[j] = c.Bp.s[kc];
+    }
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++)
+      part += ((k + j) * 64 + (int)threadIdx.x < RH_NVARS) ? (qa[j] - q0[j]) * pa[j] : 0.0;
+  }
+  const double out = rh_wave_sum(part);
+#else
   RH_TMP(dq); RH_TMP(pr);
   wv_sub(dq, c.Bq, c.Pq);
   wv_mul(pr, dq, c.Bp);
   const double out = wv_sum_seq(pr);
+#endif
   if (out != out) return true;
   return out < 0;
 }
@@ -585,15 +615,34 @@ RH_DEV double rh_logaddexp(const double a, const double b) {
 }
 // v = M^-1 r; r_sum' = r_sum - (r_left + r_right)/2; turning iff v_left . r_sum' <= 0 or v_right . r_sum' <= 0 (NaN: turning)
 RH_DEV bool rh_nuts_is_turning(const rh_chain &c, const wvec &rl, const wvec &rr, const wvec &rsum, const bool identity) {
+#if RH_BIGN
+  double partl = 0.0, partr = 0.0;  // one pass over (rl, rr, rsum, M), no temporaries: 13 reads + 5 writes of 80 KB become 4 reads
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU / 2) {
+    double la[RH_BIGU / 2], ra[RH_BIGU / 2], sa[RH_BIGU / 2], ma[RH_BIGU / 2];
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU / 2; j++) {
+      const int kc = k + j < RH_SLOTS ? k + j : RH_SLOTS - 1;
+      la[j] = rl.s[kc]; ra[j] = rr.s[kc]; sa[j] = rsum.s[kc]; ma[j] = identity ? 1.0 : c.M.s[kc];
+    }
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU / 2; j++) {
+      const bool live = (k + j) * 64 + (int)threadIdx.x < RH_NVARS;
+      const double adj = sa[j] - (la[j] + ra[j]) / 2.0;
+      const double vl = identity ? la[j] : la[j] * ma[j], vr = identity ? ra[j] : ra[j] * ma[j];
+      partl += live ? vl * adj : 0.0;
+      partr += live ? vr * adj : 0.0;
+    }
+  }
+  const double dl = rh_wave_sum(partl), dr = rh_wave_sum(partr);
+  return !(dl > 0.0) || !(dr > 0.0);
+#else
   RH_TMP(adj); RH_TMP(vl); RH_TMP(vr); RH_TMP(pl); RH_TMP(pr);
-RH_UNROLL_SLOTS
-  for (int k = 0; k < RH_SLOTS; k++) adj.s[k] = rsum.s[k] - (rl.s[k] + rr.s[k]) / 2.0;
+  wv_nuts_adj(adj, rsum, rl, rr);
   rh_velocity(c, rl, vl, identity);
   rh_velocity(c, rr, vr, identity);
   wv_mul(pl, vl, adj);
   wv_mul(pr, vr, adj);
   const double dl = wv_sum_seq(pl), dr = wv_sum_seq(pr);
   return !(dl > 0.0) || !(dr > 0.0);
+#endif
 }
 #endif
 
@@ -793,8 +842,7 @@ RH_UNROLL_SLOTS
       rh_rng r = rh_rng_of(c); const double u = rh_rng_uniform(r); rh_rng_put(c, r);
       if (c.n_leaf == 0 || u < rh_strict_exp(leaf_logw - new_logw)) { c.Sq = c.Bq; c.Sg = c.Bg; c.SU = c.BU; }
       c.n_sub_logw = new_logw;
-RH_UNROLL_SLOTS
-      for (int k = 0; k < RH_SLOTS; k++) c.Sp.s[k] += c.Bp.s[k]; // subtree momentum sum lives in Sp
+      wv_acc(c.Sp, c.Bp); // subtree momentum sum lives in Sp
       // checkpoints (NumPyro _leaf_idx_to_ckpt_idxs)
       int idx_max = 0;
       for (int x = c.n_leaf >> 1; x > 0; x >>= 1) idx_max += (x & 1);
@@ -830,8 +878,7 @@ RH_UNROLL_SLOTS
           }
 #endif
           RH_TMP(sub);
-RH_UNROLL_SLOTS
-          for (int s2 = 0; s2 < RH_SLOTS; s2++) sub.s[s2] = c.Sp.s[s2] - rsk.s[s2] + rk.s[s2];
+          wv_sub_add(sub, c.Sp, rsk, rk);
           sub_turning = rh_nuts_is_turning(c, rk, c.Bp, sub, ident);
         }
       }
@@ -842,8 +889,7 @@ RH_UNROLL_SLOTS
         rh_rng r2 = rh_rng_of(c); const double u2 = rh_rng_uniform(r2); rh_rng_put(c, r2);
         if (u2 < rh_strict_exp(c.n_sub_logw - c.n_tree_logw)) { c.Pq = c.Sq; c.Pg = c.Sg; c.PU = c.SU; }
         c.n_tree_logw = rh_logaddexp(c.n_tree_logw, c.n_sub_logw);
-RH_UNROLL_SLOTS
-        for (int k = 0; k < RH_SLOTS; k++) c.Nrsum.s[k] += c.Sp.s[k];
+        wv_acc(c.Nrsum, c.Sp);
         if (c.n_right) { c.NRq = c.Bq; c.NRp = c.Bp; c.NRg = c.Bg; } else { c.NLq = c.Bq; c.NLp = c.Bp; c.NLg = c.Bg; }
         c.n_depth += 1;
         c.pc = rh_nuts_is_turning(c, c.NLp, c.NRp, c.Nrsum, ident) ? RH_S_NUTS_DONE : RH_S_NUTS_DOUBLE;
@@ -885,6 +931,7 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
                 const rh_i64 *__restrict__ seeds, const double *__restrict__ static_mass,
                 double *__restrict__ draws, rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running,
                 const int chains, const int it_stop, const int max_ticks, const int fresh) {
+  rh_lk_init();
   const int chain = blockIdx.x * (64 / RH_LANES) + (int)(threadIdx.x / RH_LANES);  // RH_LANES lanes per chain (64 unless packed)
   const int lane = threadIdx.x & (RH_LANES - 1);
   if (chain >= chains) return;
@@ -1008,13 +1055,13 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
       }
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
+        rh_wave_sum_all(acc[kk]);   // a chain's NA sums level by level: their exchanges overlap
         double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
+        if (lane == 0 && chain0 + kk < chains) {
 #pragma unroll
-        for (int o = 0; o < NA; o++) {
-          const double v = rh_wave_sum(acc[kk][o]);
-          if (lane == 0 && chain0 + kk < chains) {
-            if constexpr (COHERENT) __hip_atomic_store(out + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else out[o] = v;
+          for (int o = 0; o < NA; o++) {
+            if constexpr (COHERENT) __hip_atomic_store(out + o, acc[kk][o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[o] = acc[kk][o];
           }
         }
       }
@@ -1064,6 +1111,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
 rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
   int group;
   (void)rh_grad_body<false>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
 }
@@ -1142,11 +1190,11 @@ RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_
       if (compute) {
 #pragma unroll
         for (int kk = 0; kk < K; kk++) {
+          rh_wave_sum_all(acc[kk]);
           double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
+          if (lane == 0 && chain0 + kk < chains) {
 #pragma unroll
-          for (int o = 0; o < NA; o++) {
-            const double v = rh_wave_sum(acc[kk][o]);
-            if (lane == 0 && chain0 + kk < chains) out[o] = v;
+            for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
           }
         }
       }
@@ -1161,6 +1209,7 @@ extern "C" __global__ void __launch_bounds__(64 * RH_GRAD_W)
 rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
@@ -1216,6 +1265,7 @@ extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIM
 rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
   typedef rh_glm<RH_GLM_TARGET> GL;
   typedef rh_target<RH_GLM_TARGET> TG;
   constexpr int P = GL::P, NC = GL::NCOLS, W = RH_GLM_W;
@@ -1229,7 +1279,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   constexpr int MYC = (NC + W - 1) / W;
   // row tiles are double-buffered in LDS while two of them fit the 160 KB of a CU (<= 155 columns); wider models (<= 310
   // columns) keep one tile and pay a second barrier per tile.  The host sizes the dynamic LDS with the same rule.
-  constexpr int NBUF = (2 * NC * RH_GLM_TRP * 8 <= 160 * 1024) ? 2 : 1;
+  constexpr int NBUF = (2 * NC * RH_GLM_TRP * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1;   // (4112 B: the link table, when the model has one)
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -1470,6 +1520,7 @@ extern "C" __global__ void __launch_bounds__(64)
 rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                     double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                     const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
   typedef rh_glm<RH_GLM_TARGET> GL;
   typedef rh_target<RH_GLM_TARGET> TG;
   constexpr int P = GL::P, NC = GL::NCOLS, PT = (P + 3) / 4, CTN = RH_GLMS_CT;
@@ -1613,14 +1664,69 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
       // The split's rows are one contiguous range (splits are cut at group boundaries, rows are sorted by group): the wavefront
       // walks it in full 64-row tiles, ACROSS group boundaries -- every lane evaluates a row whatever the group sizes are
       // (cfg 5: 100 rows per group used to run as 64 + 36 lanes).  A lane takes its row's table entry with a per-lane load (a
-      // tile touches one to three neighbouring entries per chain), and the scatter value is summed per group by a segmented
-      // scan over the tile; a group that continues in the next tile hands its running sum over in `carry`.
+      // tile touches one to three neighbouring entries per chain).  The scatter value is summed per group in one of two ways:
+      // groups of >= 64 rows through two per-lane running sums and ONE wave reduction per group (below); smaller groups through a
+      // segmented scan over every tile, a group that continues in the next tile handing its running sum over in `carry`.
       const int *goff = gd.goff[TG::ROWT];
       const int g0 = gd.gsplit[TG::ROWT][split], g1 = gd.gsplit[TG::ROWT][split + 1];
       const int r0 = goff[g0], r1 = goff[g1];
       size_t qoff[K];
 #pragma unroll
       for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+      if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
+        // Every non-empty group has at least 64 rows (cfg 5: 100): a tile touches at most two groups, A (the one that is open) and
+        // the one after it.  Each lane keeps a running scatter sum for either; when the tile's last row is no longer in A, A is
+        // complete: one wave reduction per GROUP (not per tile), as in the group-major walk, but with every lane busy.
+        int gA = 0;
+        if constexpr (TG::HAS_GATHER) { if (r0 < r1) gA = (int)cp[TG::G_COL][r0] - TG::G_LOW; }
+        double accA[K], accB[K];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) { accA[kk] = 0.0; accB[kk] = 0.0; }
+        auto flush = [&](const int gdone) {   // wave-uniform
+          rh_wave_sum_all(accA);
+#pragma unroll
+          for (int kk = 0; kk < K; kk++)
+            if (lane == 0 && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + gdone] = accA[kk];
+        };
+        for (int base = r0; base < r1; base += 64) {
+          const int r = base + lane;
+          const bool live = r < r1;
+          const int rr = live ? r : r1 - 1;
+          double cc[NC];
+#pragma unroll
+          for (int j = 0; j < NC; j++) cc[j] = cp[j][rr];
+          int g = 0;
+          if constexpr (TG::HAS_GATHER) g = (int)cc[TG::G_COL] - TG::G_LOW;
+          double gz[K], sv[K];
+#pragma unroll
+          for (int kk = 0; kk < K; kk++) {
+            gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
+            sv[kk] = 0.0;
+          }
+          if (live) {
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
+          }
+          if constexpr (TG::HAS_GATHER) {
+            if (g == gA) {
+#pragma unroll
+              for (int kk = 0; kk < K; kk++) accA[kk] += sv[kk];
+            } else {
+#pragma unroll
+              for (int kk = 0; kk < K; kk++) accB[kk] += sv[kk];
+            }
+            const int last = (r1 - base < 64 ? r1 - base : 64) - 1;
+            const int gLast = __builtin_amdgcn_readlane(g, last);
+            if (gLast != gA) {
+              flush(gA);
+#pragma unroll
+              for (int kk = 0; kk < K; kk++) { accA[kk] = accB[kk]; accB[kk] = 0.0; }
+              gA = gLast;
+            }
+          }
+        }
+        if constexpr (TG::HAS_GATHER) { if (r0 < r1) flush(gA); }
+      } else {
       double carry[K];
 #pragma unroll
       for (int kk = 0; kk < K; kk++) carry[kk] = 0.0;
@@ -1660,13 +1766,14 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
           }
         }
       }
+      }
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
+        rh_wave_sum_all(acc[kk]);
         double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
+        if (lane == 0 && chain0 + kk < chains) {
 #pragma unroll
-        for (int o = 0; o < NA; o++) {
-          const double v = rh_wave_sum(acc[kk][o]);
-          if (lane == 0 && chain0 + kk < chains) out[o] = v;
+          for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
         }
       }
     }
@@ -1679,6 +1786,7 @@ extern "C" __global__ void __launch_bounds__(64)
 rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
                       const int *__restrict__ active, double *__restrict__ partial, int *__restrict__ err_out,
                       int *__restrict__ n_running, const int chains, const int nsplit) {
+  rh_lk_init();
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0;
@@ -1723,8 +1831,7 @@ RH_DEV void rh_combine_targets(const double (&th)[RH_NTH], const double *__restr
 #pragma unroll
         for (int o = 0; o < NA; o++) S[o] += p[o];
       }
-#pragma unroll
-      for (int o = 0; o < NA; o++) S[o] = rh_wave_sum(S[o]);
+      rh_wave_sum_all(S);
       double inv[TG::NINV > 0 ? TG::NINV : 1];
       TG::invariants(th, inv, err);
       TG::finish(th, inv, S, (double)nrows[T], tot);
@@ -1891,26 +1998,44 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
   }
 }
 
-RH_DEV void rh_fused_epilogue(const rh_model_data &d, rh_u64 *state, double *qbuf, const double *partial, const int chains,
-                              const int nsplit, const int chain0, const int lane) {
+// what the epilogue needs of the chains' state: loaded by EVERY workgroup right after its partial sums are stored, so that these
+// loads share the one memory round trip the stores need anyway and the group's last workgroup has a single dependent round
+// trip left after the counter -- the partial sums themselves (the tail of the launch is pure latency: every step counts)
+struct rh_fused_pre {
+  int pc, need, ts_i, ts_l, identity, sampling, cerr;
+  double eps, bq, bp, mm;
+  rh_i64 n_grad, n_leap, n_warm;
+};
+RH_DEV void rh_fused_prefetch(rh_fused_pre &f, const rh_u64 *state, const int chains, const int chain0, const int lane) {
+  constexpr int LPC = 64 / RH_GRAD_K;
+  const int kk = lane / LPC, j = lane & (LPC - 1);
+  const int chain = chain0 + kk < chains ? chain0 + kk : chains - 1;
+  const rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
+  const rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+  const int jc = j < RH_NVARS ? j : 0;
+  f.pc = (int)(rh_i64)sc[RH_SI_pc]; f.need = (int)(rh_i64)sc[RH_SI_need_eval];
+  f.ts_i = (int)(rh_i64)sc[RH_SI_ts_i]; f.ts_l = (int)(rh_i64)sc[RH_SI_ts_l];
+  f.identity = (int)(rh_i64)sc[RH_SI_mass_identity]; f.sampling = (int)(rh_i64)sc[RH_SI_sampling_started];
+  f.cerr = (int)(rh_i64)sc[RH_SI_err];
+  f.eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
+  f.n_grad = (rh_i64)sc[RH_SI_n_grad]; f.n_leap = (rh_i64)sc[RH_SI_n_leapfrog]; f.n_warm = (rh_i64)sc[RH_SI_n_warm_leapfrog];
+  f.bq = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + jc]);
+  f.bp = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + jc]);
+  f.mm = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS) * 64 + jc]);
+}
+RH_DEV void rh_fused_epilogue(const rh_fused_pre &f, const rh_model_data &d, rh_u64 *state, double *qbuf, const double *partial,
+                              const int chains, const int nsplit, const int chain0, const int lane) {
   constexpr int LPC = 64 / RH_GRAD_K;
   const int kk = lane / LPC, j = lane & (LPC - 1), base = lane & ~(LPC - 1);
   const bool exists = chain0 + kk < chains;
   const int chain = exists ? chain0 + kk : chains - 1;
   rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
-  const int pc = (int)(rh_i64)sc[RH_SI_pc], need = (int)(rh_i64)sc[RH_SI_need_eval];
-  const int ts_i = (int)(rh_i64)sc[RH_SI_ts_i], ts_l = (int)(rh_i64)sc[RH_SI_ts_l];
-  const bool fast = exists && pc == RH_S_TS_MID && need != 0 && ts_i < ts_l;
+  const bool fast = exists && f.pc == RH_S_TS_MID && f.need != 0 && f.ts_i < f.ts_l;
   if (!__any(fast)) return;
-  const bool identity = (int)(rh_i64)sc[RH_SI_mass_identity] != 0, sampling = (int)(rh_i64)sc[RH_SI_sampling_started] != 0;
-  const int cerr = (int)(rh_i64)sc[RH_SI_err];
-  const double eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
-  const rh_i64 n_grad = (rh_i64)sc[RH_SI_n_grad], n_leap = (rh_i64)sc[RH_SI_n_leapfrog], n_warm = (rh_i64)sc[RH_SI_n_warm_leapfrog];
-  const bool live = j < RH_NVARS;
-  double bq = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + j]) : 0.0;
-  double bp = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + j]) : 0.0;
-  const double mm = live ? __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS) * 64 + j]) : 0.0;
+  const bool identity = f.identity != 0, live = j < RH_NVARS;
+  double bq = live ? f.bq : 0.0, bp = live ? f.bp : 0.0;
+  const double mm = live ? f.mm : 0.0, eps = f.eps;
   double th[RH_NTH];
 #pragma unroll
   for (int i = 0; i < RH_NTH; i++) th[i] = __shfl(bq, base + i, 64);
@@ -1938,9 +2063,9 @@ RH_DEV void rh_fused_epilogue(const rh_model_data &d, rh_u64 *state, double *qbu
   }
   if (fast && j == 0) {
     sc[RH_SI_BU] = (rh_u64)__double_as_longlong(logp * -1); sc[RH_SI_pend_logp] = (rh_u64)__double_as_longlong(logp);
-    sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)(cerr | err);
-    sc[RH_SI_n_grad] = (rh_u64)(n_grad + 1);
-    if (sampling) sc[RH_SI_n_leapfrog] = (rh_u64)(n_leap + 1); else sc[RH_SI_n_warm_leapfrog] = (rh_u64)(n_warm + 1);
+    sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(f.ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)(f.cerr | err);
+    sc[RH_SI_n_grad] = (rh_u64)(f.n_grad + 1);
+    if (f.sampling) sc[RH_SI_n_leapfrog] = (rh_u64)(f.n_leap + 1); else sc[RH_SI_n_warm_leapfrog] = (rh_u64)(f.n_warm + 1);
   }
 }
 
@@ -1948,10 +2073,13 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
 rh_grad_fused_kernel(const rh_model_data d, double *q, const int *__restrict__ active, double *partial,
                      int *__restrict__ err_out, int *__restrict__ n_running, rh_u64 *state, int *group_cnt,
                      const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
   int group;
   const int chain0 = rh_grad_body<RH_FUSE_SYNC == 2>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
   if (chain0 < 0) return;   // the same for every workgroup of the group: nobody counts
   const int lane = threadIdx.x;
+  rh_fused_pre pre;
+  rh_fused_prefetch(pre, state, chains, chain0, lane);   // in flight together with the partial-sum stores
 #if RH_FUSE_SYNC == 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's write-through partial sums have reached memory before it is counted
 #else
@@ -1962,13 +2090,13 @@ rh_grad_fused_kernel(const rh_model_data d, double *q, const int *__restrict__ a
   int last = 0;
   if (lane == 0) last = (__hip_atomic_fetch_add(&group_cnt[group], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1) ? 1 : 0;
   if (!__builtin_amdgcn_readfirstlane(last)) return;
-  if (lane == 0) __hip_atomic_store(&group_cnt[group], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (lane == 0) __hip_atomic_store(&group_cnt[group], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (nobody waits for it)
 #if RH_FUSE_SYNC == 2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the counter's return value has arrived; the loads below bypass the local L2)
+  asm volatile("" ::: "memory");   // the loads below bypass the local L2 (sc1) and follow the counter in program order
 #else
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' partial sums: only the group's last workgroup invalidates
 #endif
-  rh_fused_epilogue(d, state, q, partial, chains, nsplit, chain0, lane);
+  rh_fused_epilogue(pre, d, state, q, partial, chains, nsplit, chain0, lane);
 }
 #endif
 #endif
@@ -2080,6 +2208,7 @@ RH_UNROLL_SLOTS
 extern "C" __global__ void __launch_bounds__(64)
 rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,
                   double *__restrict__ grad, int *__restrict__ err_out, const int chains) {
+  rh_lk_init();
   const int chain = blockIdx.x * (64 / RH_LANES) + (int)(threadIdx.x / RH_LANES);  // RH_LANES lanes per chain (64 unless packed)
   const int lane = threadIdx.x & (RH_LANES - 1);
   if (chain >= chains) return;
@@ -2143,6 +2272,7 @@ RH_UNROLL_SLOTS
 // 8 = sin, 9 = cos, 10 = tan, 11 = asin, 12 = acos, 13 = atan, 14 = Math.pow (in[2i], in[2i+1]), 15 = abs, 16 = fast-mode exp, 17 / 18 = rh_logit_link's softplus / sigmoid
 extern "C" __global__ void __launch_bounds__(64)
 rh_selftest_kernel(const int mode, const rh_i64 seed, const double *__restrict__ in, double *__restrict__ out, const int n) {
+  rh_lk_init();
   const int lane = threadIdx.x;
   if (mode <= 1) {
     rh_rng r; rh_rng_init(r, seed);

@@ -250,6 +250,24 @@ __device__ __attribute__((aligned(16))) const double rh_lk_tab[2 * 257] = {
   0x1.0204081020408p-1, 0x1.5ee02a9241676p-1, 0x1.0182436517a37p-1, 0x1.5fe1edad18919p-1, 0x1.0101010101010p-1, 0x1.60e32f44788d9p-1,
   0x1.0080402010080p-1, 0x1.61e3efda46467p-1, 0x1.0000000000000p-1, 0x1.62e42fefa39efp-1
 };
+// Where the table is read from.  With RH_LK_LDS (set by the host for models whose row code calls rh_logit_link) every kernel copies
+// it into LDS first (rh_lk_init) and the per-lane 16-byte read is a ds_read_b128: reading it from global memory shares the
+// in-order vmcnt counter with the row-tile prefetches of the gradient kernels, so the first table read of a tile waits for the
+// NEXT tile's rows to arrive (measured on cfg 4: 17.4 -> 21.9 ms per gradient).
+#ifndef RH_LK_LDS
+#define RH_LK_LDS 0
+#endif
+#if RH_LK_LDS
+__shared__ __attribute__((aligned(16))) double rh_lk_lds[2 * 257];
+#define RH_LK_TAB rh_lk_lds
+RH_DEV void rh_lk_init() {   // at the top of a kernel, before any thread returns
+  for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) rh_lk_lds[i] = rh_lk_tab[i];
+  __syncthreads();
+}
+#else
+#define RH_LK_TAB rh_lk_tab
+RH_DEV void rh_lk_init() {}
+#endif
 RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
   const double at = __builtin_fabs(t);
   // e^{-|t|}: k = round(x / ln 2), r = x - k ln 2 in [-0.347, 0.347], degree-13 Taylor polynomial, scale by 2^k.
@@ -274,7 +292,7 @@ RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
   p = __builtin_fma(p, r, 1.0);
   const double u = __builtin_ldexp(p, (int)kf);            // v_ldexp_f64: correct gradual underflow
   const int j = (int)__builtin_rint(u * 256.0);            // 0 .. 256
-  const double rc = rh_lk_tab[2 * j], L = rh_lk_tab[2 * j + 1];   // one 16-byte load
+  const double rc = RH_LK_TAB[2 * j], L = RH_LK_TAB[2 * j + 1];   // one 16-byte load
   const double r2 = __builtin_fma(u, rc, rc - 1.0);
   double q = __builtin_fma(r2, 0x1.5555555555555p-3, -0x1.999999999999ap-3);   // 1/6, -1/5
   q = __builtin_fma(q, r2, 0.25);
@@ -387,6 +405,21 @@ RH_DEV double rh_wave_sum(double v) {
   for (int off = RH_LANES / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// The same butterfly for N values at once, level by level: every value goes through exactly the operations rh_wave_sum applies to
+// it (bit-identical), but the N cross-lane exchanges of a level are in flight together.  One after the other they cost a
+// ds_bpermute round trip per level and value -- 40 sums at the end of rh_grad_kernel's row walk were 240 serial round trips
+// (~11 us of pure latency per workgroup, at the tail of the launch where nothing else hides it).
+template <int N>
+RH_DEV void rh_wave_sum_all(double (&v)[N]) {
+#pragma unroll
+  for (int off = RH_LANES / 2; off >= 1; off >>= 1) {
+    double t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = __shfl_xor(v[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += t[i];
+  }
+}
 
 // length-RH_NVARS vector, element i in lane (i % 64), slot (i / 64); unused lanes hold 0.
 // Two storage classes behind one interface (v.s[k], wv_* helpers, assignment copies the data):
@@ -411,6 +444,12 @@ struct rh_slotref {
   RH_DEV double &operator[](int k) const { return p[(size_t)k * 64 + threadIdx.x]; }
 };
 #define RH_POOL_VECS 12
+// slots whose loads are issued together before the first dependent store / add (one wavefront walks RH_SLOTS x 512 B per vector:
+// with a single load in flight the walk costs a memory round trip per slot -- cfg 5: 157 of them).  The last block is masked, not
+// walked slot by slot.
+#ifndef RH_BIGU
+#define RH_BIGU 16
+#endif
 __shared__ double *rh_pool_base; // per chain (one chain per workgroup): RH_POOL_VECS scratch vectors
 __shared__ int rh_pool_depth[64];
 struct wvec {
@@ -426,14 +465,12 @@ struct wvec {
   }
   RH_DEV ~wvec() { if (pooled) rh_pool_depth[threadIdx.x] -= 1; }
   RH_DEV wvec(const wvec &) = delete;
-  RH_DEV wvec &operator=(const wvec &o) { // copies the DATA (each lane its own elements); 8 loads in flight per lane
-    int k = 0;
-    _Pragma("unroll 1") for (; k + 8 <= RH_SLOTS; k += 8) {
-      double t[8];
-      _Pragma("unroll") for (int j = 0; j < 8; j++) t[j] = o.s[k + j];
-      _Pragma("unroll") for (int j = 0; j < 8; j++) s[k + j] = t[j];
+  RH_DEV wvec &operator=(const wvec &o) { // copies the DATA (each lane its own elements); RH_BIGU loads in flight per lane
+    _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {
+      double t[RH_BIGU];
+      _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) t[j] = o.s[k + j < RH_SLOTS ? k + j : RH_SLOTS - 1];
+      _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) if (k + j < RH_SLOTS) s[k + j] = t[j];
     }
-    _Pragma("unroll 1") for (; k < RH_SLOTS; k++) s[k] = o.s[k];
     return *this;
   }
 };
@@ -453,17 +490,36 @@ RH_DEV void wv_fill(wvec &v, double x, int lane) {
 // before the first dependent store so that the walk is bandwidth- rather than latency-bound (the pointers may alias as far
 // as the compiler knows, so it cannot do this itself)
 #define RH_BIG2(expr)                                                                                  \
-  int k = 0;                                                                                             \
-  _Pragma("unroll 1") for (; k + 8 <= RH_SLOTS; k += 8) {                                              \
-    double xa[8], ya[8];                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 8; j++) { xa[j] = x.s[k + j]; ya[j] = y.s[k + j]; }          \
-    _Pragma("unroll") for (int j = 0; j < 8; j++) { const double xv = xa[j], yv = ya[j]; (void)xv; (void)yv; o.s[k + j] = (expr); } \
-  }                                                                                                      \
-  _Pragma("unroll 1") for (; k < RH_SLOTS; k++) { const double xv = x.s[k], yv = y.s[k]; (void)xv; (void)yv; o.s[k] = (expr); }
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {                                     \
+    double xa[RH_BIGU], ya[RH_BIGU];                                                                     \
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {                                                \
+      const int kc = k + j < RH_SLOTS ? k + j : RH_SLOTS - 1;                                            \
+      xa[j] = x.s[kc]; ya[j] = y.s[kc];                                                                  \
+    }                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {                                                \
+      const double xv = xa[j], yv = ya[j]; (void)xv; (void)yv;                                           \
+      if (k + j < RH_SLOTS) o.s[k + j] = (expr);                                                         \
+    }                                                                                                    \
+  }
 // y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
 RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) { wvec &o = y; RH_BIG2(yv + a * xv) }
 RH_DEV void wv_mul(wvec &o, const wvec &x, const wvec &y) { RH_BIG2(xv * yv) }
 RH_DEV void wv_sub(wvec &o, const wvec &x, const wvec &y) { RH_BIG2(xv - yv) }
+RH_DEV void wv_acc(wvec &y, const wvec &x) { wvec &o = y; RH_BIG2(yv + xv) }   // y(i) += x(i)
+#define RH_BIG3(expr)                                                                                  \
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {                                     \
+    double xa[RH_BIGU], ya[RH_BIGU], za[RH_BIGU];                                                        \
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {                                                \
+      const int kc = k + j < RH_SLOTS ? k + j : RH_SLOTS - 1;                                            \
+      xa[j] = x.s[kc]; ya[j] = y.s[kc]; za[j] = z.s[kc];                                                 \
+    }                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) {                                                \
+      const double xv = xa[j], yv = ya[j], zv = za[j];                                                   \
+      if (k + j < RH_SLOTS) o.s[k + j] = (expr);                                                         \
+    }                                                                                                    \
+  }
+RH_DEV void wv_sub_add(wvec &o, const wvec &x, const wvec &y, const wvec &z) { RH_BIG3(xv - yv + zv) }          // o = x - y + z
+RH_DEV void wv_nuts_adj(wvec &o, const wvec &x, const wvec &y, const wvec &z) { RH_BIG3(xv - (yv + zv) / 2.0) }  // o = x - (y + z) / 2
 #else
 // y(i) += a * x(i)   -- multiply, round, add, round (LeapFrog.scala:148,170)
 RH_DEV void wv_axpy(wvec &y, double a, const wvec &x) {
@@ -477,6 +533,18 @@ RH_DEV void wv_mul(wvec &out, const wvec &x, const wvec &y) {
 RH_DEV void wv_sub(wvec &out, const wvec &x, const wvec &y) {
   RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) out.s[k] = x.s[k] - y.s[k];
+}
+RH_DEV void wv_acc(wvec &y, const wvec &x) {   // y(i) += x(i)
+  RH_UNROLL_SLOTS
+  for (int k = 0; k < RH_SLOTS; k++) y.s[k] += x.s[k];
+}
+RH_DEV void wv_sub_add(wvec &o, const wvec &x, const wvec &y, const wvec &z) {   // o = x - y + z
+  RH_UNROLL_SLOTS
+  for (int k = 0; k < RH_SLOTS; k++) o.s[k] = x.s[k] - y.s[k] + z.s[k];
+}
+RH_DEV void wv_nuts_adj(wvec &o, const wvec &x, const wvec &y, const wvec &z) {  // o = x - (y + z) / 2
+  RH_UNROLL_SLOTS
+  for (int k = 0; k < RH_SLOTS; k++) o.s[k] = x.s[k] - (y.s[k] + z.s[k]) / 2.0;
 }
 #endif
 RH_DEV void wv_set(wvec &v, int i, double x, int lane) { // i wave-uniform
@@ -494,7 +562,11 @@ RH_DEV double wv_sum_seq(const wvec &x) {
   // big mode: per-lane partial sums over ascending slots + the fixed-order butterfly (deterministic; not the
   // reference's strictly sequential order -- tolerance parity, like the row sums)
   double part = 0.0;
-  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k++) part += (k * 64 + (int)threadIdx.x < RH_NVARS) ? x.s[k] : 0.0;
+  _Pragma("unroll 1") for (int k = 0; k < RH_SLOTS; k += RH_BIGU) {
+    double t[RH_BIGU];
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) t[j] = x.s[k + j < RH_SLOTS ? k + j : RH_SLOTS - 1];
+    _Pragma("unroll") for (int j = 0; j < RH_BIGU; j++) part += ((k + j) * 64 + (int)threadIdx.x < RH_NVARS) ? t[j] : 0.0;   // (k + j >= RH_SLOTS: past RH_NVARS)
+  }
   return rh_wave_sum(part);
 #else
   double acc = 0.0;

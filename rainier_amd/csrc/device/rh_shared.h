@@ -38,6 +38,7 @@ typedef struct rh_gather_data {
   const int *goff[RH_MAX_TARGETS];   /* [ngroups + 1] first row of each group */
   const int *gsplit[RH_MAX_TARGETS]; /* [nsplit + 1] first group of each split */
   double *sbuf[RH_MAX_TARGETS];      /* [chains][G_COUNT] per-group sums of the scatter value (gather targets only) */
+  int gmin[RH_MAX_TARGETS];          /* rows of the smallest non-empty group: >= 64 means a 64-row tile touches at most two groups */
 } rh_gather_data;
 
 /* per-chain result record written by the kernels (mirrors rh_chain_stats) */

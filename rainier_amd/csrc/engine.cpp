@@ -157,6 +157,7 @@ struct rh_model {
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
+  bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
@@ -237,6 +238,11 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
+  // row code that calls the closed-form logit link reads its table from LDS (rh_prelude.hip.h: RH_LK_LDS)
+  { bool lds = targets.find("rh_logit_link(") != std::string::npos;
+    if (const char *e = std::getenv("RH_LK_LDS")) lds = lds && std::atoi(e) != 0;
+    m->lk_lds = lds;
+    if (lds) defines += "#define RH_LK_LDS 1\n"; }
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
@@ -298,7 +304,7 @@ void load_module(rh_model *m) {
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
-  if (!m->glm_small && (size_t)m->glm_ncols * 66u * sizeof(double) > 160u * 1024u) m->k_grad_glm = nullptr;
+  if (!m->glm_small && (size_t)m->glm_ncols * 66u * sizeof(double) + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
@@ -668,7 +674,7 @@ extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **ou
     if (dev >= ndev) throw Fail{RH_E_INVALID, "device ordinal out of range"};
     m->prog = src->prog; m->eopt = src->eopt; m->info = src->info; m->want_nuts = src->want_nuts;
     m->source = src->source; m->nacc_max = src->nacc_max; m->grad_k = src->grad_k; m->has_glm = src->has_glm;
-    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w;
+    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds;
     m->goff_host = src->goff_host; m->gather_count = src->gather_count; m->col_len = src->col_len; m->col_src = src->col_src;
     m->rows_total = src->rows_total; m->data = src->data; m->data.cols = nullptr;
     m->device = dev;
@@ -865,6 +871,10 @@ struct GatherBufs {
       HIPCHK(hipMemcpy(dg, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
       gd.goff[rt] = (const int *)m->goff_dev[rt];
       gd.gsplit[rt] = (const int *)dg;
+      int gmin = 0x7fffffff;   // smallest non-empty group (the gather kernel's two-accumulator walk needs >= 64 rows per group)
+      for (int gi = 0; gi < ng; gi++) { const int sz = off[(size_t)gi + 1] - off[(size_t)gi]; if (sz > 0) gmin = std::min(gmin, sz); }
+      gd.gmin[rt] = gmin;
+      if (const char *e = std::getenv("RH_GATHER_SCAN")) if (std::atoi(e)) gd.gmin[rt] = 0;   // tests: the general (segmented scan) walk
       if (m->gather_count[rt] > 0) {
         void *sb = nullptr;
         const size_t bytes = sizeof(double) * (size_t)chains * m->gather_count[rt];
@@ -911,7 +921,7 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
     const unsigned tile = (unsigned)m->glm_ncols * 66u * sizeof(double);  // rh_grad_glm_kernel's NBUF rule: two tiles while they fit
-    const unsigned lds = (2u * tile <= 160u * 1024u ? 2u : 1u) * tile;
+    const unsigned lds = (2u * tile + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else if (m->use_lds_grad) {
     const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
