@@ -159,8 +159,8 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
         spec = models.eight_schools(); cfg = R.make_config(a.steps, a.warmup)
     elif w == "cfg4":
         spec = models.logistic(n=a.rows if a.rows != 1_000_000 else 10_000_000, k=50); cfg = R.make_config(a.steps, a.warmup, R.NUTSSampler(10))
-    else:
-        spec = models.hier_negbin(10_000, 100); cfg = R.make_config(a.steps, a.warmup, R.NUTSSampler(10))
+    else:   # --rows scales the number of groups (100 observations each); the BASELINE size is 10 000 groups
+        spec = models.hier_negbin(10_000 if a.rows == 1_000_000 else max(100, a.rows // 100), 100); cfg = R.make_config(a.steps, a.warmup, R.NUTSSampler(10))
     if a.sampler == "nuts":
         cfg.sampler = lambda: R.NUTSSampler(10)
     model = R.Model(spec, device=local_rank, **fast)

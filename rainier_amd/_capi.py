@@ -170,7 +170,7 @@ def canonicalize_rir(rir: bytes, columns, nrows, fast: bool = False, refactor: b
         L.rh_free(out)
 
 
-def lift_rir(rir: bytes, nrows=None):
+def lift_rir(rir: bytes, nrows=None, fast: bool = False):
     """What rh_model_create's loader makes of a program with more than 64 targets (csrc/lift.cpp + the merge of data-free runs):
     (RIR, synthesised columns -- they follow the caller's in the rewritten program --, rows of the synthesised target, and with
     `nrows` the row count of every target of the rewritten program) -- test hook, no device needed."""
@@ -180,7 +180,7 @@ def lift_rir(rir: bytes, nrows=None):
     buf = C.create_string_buffer(rir, len(rir))
     nr_in = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows]) if nrows is not None else None
     nr_out = (C.c_int64 * 64)() if nrows is not None else None
-    check(L.rh_lift_rir(buf, len(rir), C.byref(out), C.byref(n), C.byref(cols), C.byref(nc), C.byref(nr), nr_in, nr_out))
+    check(L.rh_lift_rir(buf, len(rir), C.byref(out), C.byref(n), C.byref(cols), C.byref(nc), C.byref(nr), nr_in, nr_out, int(fast)))
     try:
         arr = np.ctypeslib.as_array(cols, shape=(max(1, nc.value * nr.value),)).copy()
         rir2 = C.string_at(out, n.value)

@@ -9,7 +9,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <chrono>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 
 #include <dlfcn.h>
@@ -52,6 +56,27 @@ std::mutex g_mu;
 enum { kNcclFloat64 = 8, kNcclMax = 2 };
 
 int fail(int code, const std::string &msg) { rh_set_thread_error_(msg.c_str()); return code; }
+// A rank that never arrives (its rh_model_create failed, its process died) must not hang the others for ever: communicator
+// set-up and every collective are bounded by RH_COMM_TIMEOUT_S seconds (default 180) and fail with RH_E_DEVICE.
+double comm_timeout_s() {
+  if (const char *e = std::getenv("RH_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) return v; }
+  return 180.0;
+}
+// hipStreamSynchronize with a deadline (the collective's kernel cannot be recalled; the caller reports and gives up)
+bool wait_stream(hipStream_t st, const char *what, std::string &err) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const double limit = comm_timeout_s();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { err = std::string(what) + ": " + hipGetErrorString(q); return false; }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      err = std::string(what) + ": no completion within " + std::to_string((int)limit) + " s (RH_COMM_TIMEOUT_S) -- a rank is missing or stuck";
+      return false;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
 int nccl_fail(const char *what, int rc) {
   return fail(RH_E_DEVICE, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
 }
@@ -92,8 +117,23 @@ extern "C" int rh_comm_create(const unsigned char id[RH_COMM_ID_BYTES], int32_t 
   c->world = world; c->rank = rank; c->device = device;
   nccl_uid u;
   std::memcpy(u.internal, id, RH_COMM_ID_BYTES);
-  int rc = g_rccl.CommInitRank(&c->comm, world, u, rank);
-  if (rc) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+  // ncclCommInitRank blocks until all `world` ranks have called it: run it on a helper thread and give up after the deadline
+  // (the helper then stays blocked inside RCCL; the caller is about to report the failure and exit)
+  struct Init { nccl_comm comm = nullptr; std::promise<int> done; };
+  auto st = std::make_shared<Init>();
+  std::future<int> fut = st->done.get_future();
+  std::thread([st, world, u, rank, device] {
+    (void)hipSetDevice(device);
+    st->done.set_value(g_rccl.CommInitRank(&st->comm, world, u, rank));
+  }).detach();
+  if (fut.wait_for(std::chrono::duration<double>(comm_timeout_s())) != std::future_status::ready) {
+    delete c;
+    return fail(RH_E_DEVICE, "ncclCommInitRank: rank " + std::to_string(rank) + " of " + std::to_string(world) + " waited " +
+                             std::to_string((int)comm_timeout_s()) + " s (RH_COMM_TIMEOUT_S) for the other ranks -- one of them never reached rh_comm_create");
+  }
+  const int rc = fut.get();
+  c->comm = st->comm;
+  if (rc) { c->comm = nullptr; delete c; return nccl_fail("ncclCommInitRank", rc); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_scalar, 2 * sizeof(double)) != hipSuccess) {
     rh_comm_destroy(c);
     return fail(RH_E_DEVICE, "rh_comm_create: stream / buffer allocation failed");
@@ -132,7 +172,7 @@ extern "C" int rh_comm_allgather_draws(rh_comm *c, rh_sampler *s, double *host_o
   // the sampler's launches are complete when rh_sampler_run returns (it synchronises its stream): no cross-stream event needed
   const int rc = g_rccl.AllGather(d_draws, c->d_gather, (size_t)count, kNcclFloat64, c->comm, c->stream);
   if (rc) return nccl_fail("ncclAllGather", rc);
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(RH_E_DEVICE, "rh_comm_allgather_draws: stream synchronise failed");
+  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allgather_draws (ncclAllGather)", werr)) return fail(RH_E_DEVICE, werr); }
   if (host_out && hipMemcpy(host_out, c->d_gather, bytes, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(RH_E_DEVICE, "rh_comm_allgather_draws: copy to host failed");
   if (dev_out) *dev_out = c->d_gather;
@@ -146,7 +186,7 @@ extern "C" int rh_comm_allreduce_max(rh_comm *c, double *value) {
   if (hipMemcpy(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(RH_E_DEVICE, "copy failed");
   const int rc = g_rccl.AllReduce(c->d_scalar, (char *)c->d_scalar + sizeof(double), 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
   if (rc) return nccl_fail("ncclAllReduce", rc);
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(RH_E_DEVICE, "stream synchronise failed");
+  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allreduce_max (ncclAllReduce)", werr)) return fail(RH_E_DEVICE, werr); }
   if (hipMemcpy(value, (char *)c->d_scalar + sizeof(double), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(RH_E_DEVICE, "copy failed");
   return RH_OK;
 }

@@ -395,7 +395,9 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
     bool hoist = lp;
     if (const char *e = std::getenv("RH_HOIST_TABLES")) hoist = std::atoi(e) != 0;
     if (hoist) rh::hoist_table_maps(m->prog, gmin);
-    if (lp && rh::lift_table_priors(m->prog, m->synth_cols, gmin)) old1.push_back(0xFFFFFFFFu);
+    // (fast builds also lift a prior that ties the entries to shared parameters -- the centred parameterisation -- with both
+    //  gradients derived again and verified: lift.cpp)
+    if (lp && rh::lift_table_priors(m->prog, m->synth_cols, gmin, m->eopt.fp_contract)) old1.push_back(0xFFFFFFFFu);
     if (lp) for (int k = rh::lift_single_entry_targets(m->prog, m->synth_cols, gmin); k > 0; k--) old1.push_back(0xFFFFFFFFu);
   }
   rh::merge_data_free_targets(m->prog, old2);
@@ -547,10 +549,10 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
   const int rc = guard(m, [&] {
     std::vector<int64_t> nrows_in;
     std::vector<const double *> colv;
+    const int dev0 = apply_compile_opts(m, opts);   // first: the loader's rewrites depend on the math mode
     load_program(m, rir, rir_len, columns_in, nrows, colv, nrows_in);
     if (m->prog.n_cols_total > m->synth_cols.size() && !columns_in) throw Fail{RH_E_INVALID, "columns is NULL but the model has data columns"};
     const double *const *columns = colv.data();
-    const int dev0 = apply_compile_opts(m, opts);
     int dev = dev0;
     for (size_t t = 0; t < m->prog.targets.size(); t++)
       if (m->prog.targets[t].n_cols && nrows_in[t] < 0) throw Fail{RH_E_INVALID, "negative or missing row count"};
@@ -760,8 +762,8 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
   const int rc = guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
     std::vector<const double *> colv;
-    load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
     (void)apply_compile_opts(&m, opts);
+    load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
     bool all_cols = true;   // the data-dependent passes need every column (the caller's and the lifted ones) on the host
     for (const double *c : colv) all_cols = all_cols && c != nullptr;
     if (all_cols && ((columns && nrows) || !m.synth_cols.empty())) { std::vector<int64_t> nrows_t; canonicalize(&m, colv.data(), nrows_in.data(), nrows_t); }
@@ -804,9 +806,9 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
   return guard(nullptr, [&] {
     std::vector<int64_t> nrows_in, nr;
     std::vector<const double *> colv;
+    m.eopt.fp_contract = fast != 0;
     load_program(&m, rir, rir_len, columns, nrows, colv, nrows_in);
     if (!m.synth_cols.empty()) throw Fail{RH_E_UNSUPPORTED, "rh_canonicalize_rir: the program lifts constants into columns of its own (use rh_lift_rir)"};
-    m.eopt.fp_contract = fast != 0;
     m.eopt.simplify = refactor != 0;   // canonicalize() re-associates / rolls only when the clean-up pass is on
     canonicalize(&m, colv.data(), nrows_in.data(), nr);
     const std::vector<unsigned char> b = rh::write_rir(m.prog);
@@ -830,11 +832,12 @@ extern "C" int rh_canonicalize_rir(const void *rir, size_t rir_len, const double
 // rewritten program's column order.  nrows_in (per target of the program handed in) -> nrows_out (per target of the rewritten
 // one, at most RH_MAX_TARGETS entries); both may be NULL.
 extern "C" int rh_lift_rir(const void *rir, size_t rir_len, void **out, size_t *out_len, double **cols_out, uint32_t *ncols, uint32_t *nrows,
-                           const int64_t *nrows_in_caller, int64_t *nrows_out) {
+                           const int64_t *nrows_in_caller, int64_t *nrows_out, int fast) {
   rh_model m;
   return guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
     std::vector<const double *> colv;
+    m.eopt.fp_contract = fast != 0;   // fast builds lift more (centred table priors)
     load_program(&m, rir, rir_len, nullptr, nrows_in_caller, colv, nrows_in, true);
     if (nrows_out) for (size_t t = 0; t < nrows_in.size(); t++) nrows_out[t] = nrows_in[t];
     const std::vector<unsigned char> b = rh::write_rir(m.prog);

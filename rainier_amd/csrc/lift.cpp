@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 
@@ -59,6 +60,38 @@ bool match(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t
     }
   }
   return true;
+}
+
+// The same for the per-entry terms of a parameter table: table parameter `from` of the template must correspond to `to` of the
+// member, every other parameter to itself -- and the operands of + and * may come in either order (the reference's Line / LogLine
+// algebra orders the factors of a product by its own bookkeeping: alpha_0 * mu next to mu * alpha_1; IEEE + and * commute exactly)
+bool match_entry(const Program &P, uint32_t a, uint32_t b, std::map<uint32_t, uint32_t> &memo, uint32_t from, uint32_t to, uint32_t t0) {
+  auto it = memo.find(a);
+  if (it != memo.end()) return it->second == b;
+  const Node &na = P.nodes[a], &nb = P.nodes[b];
+  if (na.op != nb.op) return false;
+  switch (na.op) {
+    case RH_RIR_CONST: memo[a] = b; return true;
+    case RH_RIR_INPUT:
+      if (!(na.input == from ? nb.input == to : (na.input == nb.input && (na.input < t0 || na.input >= P.n_params)))) return false;
+      memo[a] = b; return true;
+    case RH_RIR_LOOKUP: {
+      if (na.low != nb.low || na.table.size() != nb.table.size()) return false;
+      memo[a] = b;
+      if (!match_entry(P, na.a, nb.a, memo, from, to, t0)) return false;
+      for (size_t e = 0; e < na.table.size(); e++) if (!match_entry(P, na.table[e], nb.table[e], memo, from, to, t0)) return false;
+      return true;
+    }
+    default: {
+      if (!binary_op(na.op)) { memo[a] = b; return match_entry(P, na.a, nb.a, memo, from, to, t0); }
+      const std::map<uint32_t, uint32_t> saved = memo;
+      memo[a] = b;
+      if (match_entry(P, na.a, nb.a, memo, from, to, t0) && match_entry(P, na.b, nb.b, memo, from, to, t0)) return true;
+      if (na.op != RH_RIR_ADD && na.op != RH_RIR_MUL) return false;
+      memo = saved; memo[a] = b;
+      return match_entry(P, na.a, nb.b, memo, from, to, t0) && match_entry(P, na.b, nb.a, memo, from, to, t0);
+    }
+  }
 }
 
 bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<uint32_t> &old_target_of);
@@ -381,7 +414,7 @@ void flatten_sum(const Program &P, uint32_t id, std::vector<STerm> &out) {
 }
 }  // namespace
 
-bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min) {
+bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min, bool rederive_ok) {
   auto no = [](int where) { if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table prior not lifted (check %d)\n", where); return false; };
   if (P.kind != 0) return false;
   const uint32_t np = P.n_params;
@@ -421,24 +454,23 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
     if (sup[tm.node] == -2) return no(3);
     if (sup[tm.node] == -1) rest.push_back(tm); else val[(size_t)(sup[tm.node] - t0)].push_back(tm);
   }
-  for (uint32_t q = 0; q < t0; q++) if (sup[outs[1 + q]] != -1) return no(4);           // the prior ties a shared parameter to the table
+  // `simple`: the supplied gradient is per-entry too (a standard prior on the entries); otherwise the prior ties shared parameters
+  // to the table (centred parameterisation) and the gradients are derived again below (fast builds only)
+  bool simple = true;
+  for (uint32_t q = 0; q < t0; q++) if (sup[outs[1 + q]] != -1) simple = false;
   for (uint32_t k = t0; k < np; k++) {
     flatten_sum(P, outs[1 + k], grad[k - t0]);
-    for (const STerm &tm : grad[k - t0]) if (sup[tm.node] != -1 && sup[tm.node] != (int64_t)k) return no(5);
+    for (const STerm &tm : grad[k - t0]) if (sup[tm.node] != -1 && sup[tm.node] != (int64_t)k) simple = false;
     if (val[k - t0].empty()) return no(6);
   }
+  if (!simple && !rederive_ok) return no(4);
   // every entry against the first: same terms in the same order, the only renaming z_first -> z_k
   std::vector<std::map<uint32_t, uint32_t>> maps(G);
   for (uint32_t g = 0; g < G; g++) {
-    if (val[g].size() != val[0].size() || grad[g].size() != grad[0].size()) return no(7);
+    if (val[g].size() != val[0].size() || (simple && grad[g].size() != grad[0].size())) return no(7);
     std::map<uint32_t, uint32_t> &memo = maps[g];
-    for (size_t i = 0; i < val[0].size(); i++) if (val[g][i].neg != val[0][i].neg || !match(P, val[0][i].node, val[g][i].node, memo, true)) return no(8);
-    for (size_t i = 0; i < grad[0].size(); i++) if (grad[g][i].neg != grad[0][i].neg || !match(P, grad[0][i].node, grad[g][i].node, memo, true)) return no(9);
-    for (auto &kv : memo) {
-      if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
-      const uint32_t a = P.nodes[kv.first].input, b = P.nodes[kv.second].input;
-      if (!(a == t0 ? b == t0 + g : (a == b && a < t0))) return no(10);
-    }
+    for (size_t i = 0; i < val[0].size(); i++) if (val[g][i].neg != val[0][i].neg || !match_entry(P, val[0][i].node, val[g][i].node, memo, t0, t0 + g, t0)) return no(8);
+    if (simple) for (size_t i = 0; i < grad[0].size(); i++) if (grad[g][i].neg != grad[0][i].neg || !match_entry(P, grad[0][i].node, grad[g][i].node, memo, t0, t0 + g, t0)) return no(9);
   }
   std::vector<uint32_t> slots;                    // constants that differ between entries -> columns
   for (auto &kv : maps[0]) {
@@ -497,20 +529,114 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
   Target R;
   R.n_cols = (uint32_t)slots.size() + 1; R.input_start = in0; R.col0 = P.n_cols_total;
   R.outputs.push_back(chain(val[0], true));
-  const uint32_t gnode = chain(grad[0], true);
-  for (uint32_t q = 0; q < t0; q++) R.outputs.push_back(zero);
-  for (uint32_t g = 0; g < G; g++) {
-    Node e; e.op = RH_RIR_LOOKUP; e.a = op2(RH_RIR_COMPARE, idx, const_node((double)g)); e.low = -1;
-    e.table = {zero, gnode, zero};                               // eq(index, g, f'(z), 0): compute/Real.scala:83-99
-    R.outputs.push_back(push(e));
+  if (simple) {
+    const uint32_t gnode = chain(grad[0], true);
+    for (uint32_t q = 0; q < t0; q++) R.outputs.push_back(zero);
+    for (uint32_t g = 0; g < G; g++) {
+      Node e; e.op = RH_RIR_LOOKUP; e.a = op2(RH_RIR_COMPARE, idx, const_node((double)g)); e.low = -1;
+      e.table = {zero, gnode, zero};                               // eq(index, g, f'(z), 0): compute/Real.scala:83-99
+      R.outputs.push_back(push(e));
+    }
+    // the data-free target keeps the rest
+    Target &T = P.targets[(size_t)tp];
+    T.outputs[0] = chain(rest, false);
+    for (uint32_t k = t0; k < np; k++) T.outputs[1 + k] = zero;
+    P.targets.push_back(R);
+    P.n_inputs = in0 + R.n_cols; P.n_cols_total += R.n_cols;
+    recompute_deps(P);
+    return true;
   }
-  // the data-free target keeps the rest
-  Target &T = P.targets[(size_t)tp];
-  T.outputs[0] = chain(rest, false);
-  for (uint32_t k = t0; k < np; k++) T.outputs[1 + k] = zero;
-  P.targets.push_back(R);
-  P.n_inputs = in0 + R.n_cols; P.n_cols_total += R.n_cols;
-  recompute_deps(P);
+  // ---- centred: both gradients derived again from the two values, then checked against the outputs the program came with
+  const size_t synth0 = synth.size() - (slots.size() + 1);
+  const uint32_t rest_value = chain(rest, false);
+  Program Q = P;                                           // built on a copy: the check below decides
+  Q.n_inputs = in0 + R.n_cols; Q.n_cols_total += R.n_cols;  // the new inputs exist before nodes over them are differentiated
+  {
+    const std::vector<uint32_t> gr = derive_gradient(Q, R.outputs[0]);
+    for (uint32_t q = 0; q < np; q++) R.outputs.push_back(gr[q]);
+    const std::vector<uint32_t> gd = derive_gradient(Q, rest_value);
+    Target &T = Q.targets[(size_t)tp];
+    T.outputs[0] = rest_value;
+    for (uint32_t q = 0; q < np; q++) T.outputs[1 + q] = gd[q];
+  }
+  Q.targets.push_back(R);
+  recompute_deps(Q);
+  {
+    // original outputs against  data-free part + sum over the G rows of the row target, at 6 random points; per output:
+    // |difference| <= 1e-11 * (sum of magnitudes), evaluated in extended precision; one-sided non-finite values reject
+    bool ok = true;
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) / 9007199254740992.0 - 0.5; };
+    static const double kScale[6] = {1.0, 1.0, 0.2, 2.5, 1.0, 0.2};
+    constexpr int B = 32;
+    const Target &T = Q.targets[(size_t)tp], &RT = Q.targets.back();
+    // The row target's table-entry outputs are eq(index, k, g, 0) (the Lookup rule of the derivation): row g contributes to entry g
+    // alone, so those outputs are checked row by row -- own entry only -- on up to 8 blocks of 32 entries spread over the table (every
+    // entry is the same expression over the looked-up value); the value and the shared parameters' outputs are summed over ALL rows.
+    const std::vector<uint32_t> roots_old(outs.begin(), outs.end()), roots_df(T.outputs.begin(), T.outputs.end());
+    const std::vector<uint32_t> roots_sh(RT.outputs.begin(), RT.outputs.begin() + 1 + t0);
+    std::vector<long double> val_o, val_d, val_r;
+    std::vector<char> rok;
+    const BlockEvaluator ev_old(P, roots_old), ev_df(Q, roots_df), ev_sh(Q, roots_sh);
+    for (int trial = 0; trial < 6 && ok; trial++) {
+      std::vector<double> th(np);
+      for (uint32_t q = 0; q < np; q++) th[q] = kScale[trial] * uni();
+      std::vector<long double> in1((size_t)P.n_inputs, 0.0L);
+      for (uint32_t q = 0; q < np; q++) in1[q] = th[q];
+      if (!ev_old.run(in1, 1, val_o, rok) || !rok[0]) { ok = false; break; }
+      std::vector<long double> in2((size_t)Q.n_inputs, 0.0L);
+      for (uint32_t q = 0; q < np; q++) in2[q] = th[q];
+      if (!ev_df.run(in2, 1, val_d, rok) || !rok[0]) { ok = false; break; }
+      std::vector<long double> sum(t0 + 1), mag(t0 + 1);
+      for (uint32_t o = 0; o <= t0; o++) { sum[o] = val_d[T.outputs[o]]; mag[o] = std::fabs(sum[o]); }
+      std::vector<long double> inb((size_t)Q.n_inputs * B, 0.0L);
+      for (uint32_t q = 0; q < np; q++) for (int r = 0; r < B; r++) inb[(size_t)q * B + r] = th[q];   // the parameters: once per point
+      auto fill = [&](uint32_t g0) {                                                                   // the block's rows
+        for (int r = 0; r < B; r++) {
+          const uint32_t g = std::min(g0 + (uint32_t)r, G - 1);
+          for (uint32_t j = 0; j < RT.n_cols; j++) inb[(size_t)(RT.input_start + j) * B + r] = synth[synth0 + j][g];
+        }
+      };
+      auto differs = [&](long double a, long double b, long double m) {
+        if (!std::isfinite(a) || !std::isfinite(b)) return std::isfinite(a) != std::isfinite(b) || std::isnan(a) != std::isnan(b) || (std::isinf(a) && a != b);
+        return std::fabs(a - b) > 1e-11L * std::max(m, std::fabs(a)) + 1e-300L;
+      };
+      for (uint32_t g0 = 0; g0 < G && ok; g0 += B) {
+        const int nb = (int)std::min<uint32_t>(B, G - g0);
+        fill(g0);
+        if (!ev_sh.run(inb, B, val_r, rok)) { ok = false; break; }
+        for (int r = 0; r < nb && ok; r++) {
+          if (!rok[(size_t)r]) { ok = false; break; }
+          for (uint32_t o = 0; o <= t0; o++) { const long double v = val_r[(size_t)RT.outputs[o] * B + r]; sum[o] += v; mag[o] += std::fabs(v); }
+        }
+      }
+      for (uint32_t o = 0; o <= t0 && ok; o++)
+        if (differs(val_o[outs[o]], sum[o], mag[o])) {
+          ok = false;
+          if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: output %u differs (%.6Lg vs %.6Lg; data-free part %.6Lg)\n", o, val_o[outs[o]], sum[o], val_d[T.outputs[o]]);
+        }
+      const uint32_t nblk = (G + B - 1) / B, stride = std::max<uint32_t>(1, nblk / 8);
+      for (uint32_t blk = 0; blk < nblk && ok; blk += stride) {
+        const uint32_t g0 = blk * B;
+        const int nb = (int)std::min<uint32_t>(B, G - g0);
+        std::vector<uint32_t> roots_e;
+        for (int r = 0; r < nb; r++) roots_e.push_back(RT.outputs[1 + t0 + g0 + (uint32_t)r]);
+        const BlockEvaluator ev_e(Q, roots_e);
+        fill(g0);
+        if (!ev_e.run(inb, B, val_r, rok)) { ok = false; break; }
+        for (int r = 0; r < nb && ok; r++) {
+          const uint32_t o = 1 + t0 + g0 + (uint32_t)r;
+          const long double a = val_o[outs[o]], b = val_d[T.outputs[o]] + val_r[(size_t)RT.outputs[o] * B + r];
+          if (!rok[(size_t)r] || differs(a, b, std::fabs(b))) {
+            ok = false;
+            if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: entry output %u differs (%.6Lg vs %.6Lg)\n", o, a, b);
+          }
+        }
+      }
+    }
+    if (!ok && !std::getenv("RH_LIFT_NOVERIFY")) { synth.resize(synth0); return no(12); }   // (the variable is a debugging aid)
+  }
+  P = std::move(Q);
   return true;
 }
 

@@ -153,8 +153,13 @@ struct Deriver {
       }
     }
     std::vector<uint32_t> out(Q.n_params, zero);
-    for (uint32_t i = 0; i < N0; i++)
-      if (Q.nodes[i].op == RH_RIR_INPUT && Q.nodes[i].input < Q.n_params) { auto it = adj.find(i); if (it != adj.end()) out[Q.nodes[i].input] = it->second; }
+    for (uint32_t i = 0; i < N0; i++)   // (a parameter may be read through several INPUT nodes: the Translator does not share them)
+      if (Q.nodes[i].op == RH_RIR_INPUT && Q.nodes[i].input < Q.n_params) {
+        auto it = adj.find(i);
+        if (it == adj.end()) continue;
+        uint32_t &o = out[Q.nodes[i].input];
+        o = (o == zero) ? it->second : op2(RH_RIR_ADD, o, it->second);
+      }
     return out;
   }
 };
@@ -226,6 +231,20 @@ struct Evaluator {
 };
 
 }  // namespace
+
+// exported for lift.cpp: d value / d theta_p for every parameter as new nodes of P (reverse mode, compute/Gradient.scala:60-160)
+std::vector<uint32_t> derive_gradient(Program &P, uint32_t value) {
+  Deriver D(P);
+  std::vector<uint32_t> g = D.gradient(value);
+  P.nodes.swap(D.Q.nodes);
+  return g;
+}
+// exported for lift.cpp: the block interpreter above behind an opaque handle (the live set of `roots` is computed once)
+BlockEvaluator::BlockEvaluator(const Program &P, const std::vector<uint32_t> &roots) : impl(new Evaluator(P, roots)) {}
+BlockEvaluator::~BlockEvaluator() { delete static_cast<Evaluator *>(impl); }
+bool BlockEvaluator::run(const std::vector<long double> &inputs, int B, std::vector<long double> &val, std::vector<char> &ok) const {
+  return static_cast<const Evaluator *>(impl)->run(inputs, B, val, ok);
+}
 
 Program rederive_gradients(const Program &P, const std::vector<const double *> &cols, const int64_t *nrows, bool *changed) {
   if (changed) *changed = false;

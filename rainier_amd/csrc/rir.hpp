@@ -50,7 +50,12 @@ void recompute_deps(Program &P);
 // reference's front end puts it): the per-entry prior terms become one more row target over a synthesised index column 0..G-1
 // (appended to `synth`; the target is appended to the list), so that every gradient with respect to a table entry comes from
 // row targets -- the precondition of gather mode (emit.cpp).  Returns false (and changes nothing) when the shape is not there.
-bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min);
+// rederive_ok (fast builds): a prior that ties the entries to SHARED parameters -- the centred parameterisation, entries
+// alpha_k ~ Normal(mu, sigma) written with Real.parameter (compute/Real.scala:63-78) -- is lifted too: the per-entry value terms
+// become the row target as before, and because the reference hands the shared parameters' gradients over as sums that run over
+// all entries (not per-entry expressions), both targets' gradients are derived again from their values and the rewrite is
+// accepted only if, at random points, the new outputs add up to the original ones.
+bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min, bool rederive_ok = false);
 // Lookup(column, [f(z_0), f(z_1), ...]) -> f(Lookup(column, [z_0, z_1, ...])) when every entry is the same function of one of
 // >= gather_min consecutive trailing parameters (Normal(mu, sd).latentVec(G)(site): z_k * sd + mu) and it is the program's only
 // column-indexed table: the same arithmetic on the selected entry (bit-identical), and the shape gather mode reads.
@@ -82,6 +87,19 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts);
 // differentiation and VERIFIED against the supplied ones on sample rows (cols[c] = host data of column c, nrows per target);
 // targets that do not verify keep their outputs.
 Program rederive_gradients(const Program &p, const std::vector<const double *> &cols, const int64_t *nrows, bool *changed = nullptr);
+
+// rederive.cpp, for the loader's own rewrites: the gradient of `value` with respect to every parameter as new nodes of P, and the
+// extended-precision block interpreter the rewrites are verified with (inputs[i * B + r] = input i at block row r)
+std::vector<uint32_t> derive_gradient(Program &P, uint32_t value);
+struct BlockEvaluator {   // val[node * B + r]; ok[r] = 0 where a Lookup index left its table; P must outlive the evaluator
+  BlockEvaluator(const Program &P, const std::vector<uint32_t> &roots);
+  ~BlockEvaluator();
+  BlockEvaluator(const BlockEvaluator &) = delete;
+  BlockEvaluator &operator=(const BlockEvaluator &) = delete;
+  bool run(const std::vector<long double> &inputs, int B, std::vector<long double> &val, std::vector<char> &ok) const;
+ private:
+  void *impl;
+};
 
 // Exact clean-up of the DAG (select-of-select folding, select sinking, constant selects, CSE): simplify.cpp
 Program simplify(const Program &p, bool fast = false);

@@ -236,6 +236,38 @@ def hier_negbin(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fai
                      {"kind": "hier_negbin", "groups": G})
 
 
+def hier_negbin_centred(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fail: float = 10.0) -> ModelSpec:
+    """cfg 5's model in its CENTRED parameterisation: theta = (b0, b1, mu, s, alpha_0 .. alpha_{G-1}) with the group effects themselves
+    as parameters, alpha_g ~ Normal(mu, e^s) -- what `Real.parameter { a => Normal(mu, sigma).logDensity(a) }`
+    (compute/Real.scala:63-78) gives -- instead of the non-centred alpha_g = mu + e^s z_g.  With 100 observations per group the data
+    pin every alpha_g, and it is this form whose posterior is close to a product of well-scaled marginals.  Written as the
+    reference would hand it over: the alpha prior sits in the DATA-FREE target (a sum of G terms that all read mu and s; its
+    gradient with respect to mu and s runs over all entries), the likelihood reads `alphas(site)` = Lookup(index, alphas) with
+    eq(index, k, g, 0) gradients.  The loader lifts the prior into a row target over the group index (csrc/lift.cpp, fast builds)
+    and the model runs in gather mode."""
+    G = int(groups)
+    n_params = 4 + G
+    g = Graph(n_params, [0, 5])
+    b0, b1, mu, s = (g.param(i) for i in range(4))
+    al = [g.param(4 + k) for k in range(G)]
+    prior = std_normal_logpdf(b0) + std_normal_logpdf(b1) + std_normal_logpdf(mu * 0.5) + (s - s.exp())
+    inv_var = (s * -2.0).exp()
+    # sum_k Normal(mu, e^s).logDensity(alpha_k) = sum_k -(alpha_k - mu)^2 / (2 e^{2s})  -  G (s + log sqrt(2 pi)): the parameter-only
+    # part merged into one term with the coefficient G, as the reference's Line algebra merges equal terms (compute/LineOps.scala)
+    prior = prior + (s + HALF_LOG_2PI) * float(-G)
+    for a in al:
+        d = a - mu
+        prior = prior + (d * d) * inv_var * -0.5
+    v, crow, gid, x0, x1 = (g.col(1, j) for j in range(5))
+    eta = g.lookup(gid, al, 0) + b0 * x0 + b1 * x1
+    p = 1.0 / ((eta * -1.0).exp() * n_fail + 1.0)
+    row = crow + (1.0 - p).log() * n_fail + v * p.log()
+    rir = g.compile([prior, row])
+    dv, dc, dg, dx0, dx1 = hier_negbin_data(G, per_group, seed, n_fail)
+    return ModelSpec("hier_negbin_centred_%dx%d" % (G, per_group), rir, [dv, dc, dg, dx0, dx1], [0, G * per_group], n_params,
+                     {"kind": "hier_negbin_centred", "groups": G})
+
+
 def negbin_glm(n: int = 100_000, k: int = 3, seed: int = 7, n_fail: float = 5.0) -> ModelSpec:
     """A negative-binomial GLM without group effects: theta = (a, b_0..b_{k-1}) ~ N(0,1), p = 1 / (1 + n e^{-eta}) so that the
     mean is e^eta, NegativeBinomial(p, n).logDensity(v) written as core/Discrete.scala:111-114 does (the data-only factorial

@@ -22,12 +22,12 @@ def _check(spec, opts, qs, tol, with_data=True):
     """generated code (over the columns rh_model_create would keep) vs the oracle on the original program"""
     original = spec
     import dataclasses
-    rir2, cols2, _, nrows2 = _capi.lift_rir(spec.rir, spec.nrows)      # what the loader lifts into streamed targets of its own (csrc/lift.cpp)
+    fast = bool(opts.get("fp_contract"))
+    rir2, cols2, _, nrows2 = _capi.lift_rir(spec.rir, spec.nrows, fast=fast)      # what the loader lifts into streamed targets of its own (csrc/lift.cpp)
     if cols2:
         spec = dataclasses.replace(spec, rir=rir2, columns=list(spec.columns) + cols2, nrows=nrows2)
     kw = dict(columns=spec.columns, nrows=spec.nrows) if with_data and spec.columns else {}
     src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, **kw)
-    fast = bool(opts.get("fp_contract"))
     if kw:
         _, parts, nrows = _capi.canonicalize_rir(spec.rir, spec.columns, spec.nrows, fast=fast, refactor=True)   # as rh_model_create
         cols = [np.concatenate([np.zeros(n) if j == 0xFFFFFFFF else np.asarray(spec.columns[j], dtype=np.float64)[:n] for j, n in p]) for p in parts]
@@ -420,8 +420,9 @@ def test_two_series_observed_one_value_at_a_time_become_two_streamed_targets():
 def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path():
     """a Lookup over 70 trailing parameters indexed by a column has the shape of gather mode, but the table's prior sits in the
     data-free target (gather mode wants every table gradient to come from row targets).  A prior on each entry alone is lifted into
-    a row target over the group index by the loader; one that involves a shared parameter is not, and the model is lowered on the
-    generic path instead of being refused"""
+    a row target over the group index by the loader in both math modes; one that involves a shared parameter (the centred
+    parameterisation) only in fast builds, where both targets' gradients may be derived again (lift.cpp) -- a strict build of it is
+    lowered on the generic path instead of being refused"""
     rng = np.random.default_rng(2)
     G, per = 70, 5
     n = G * per
@@ -432,12 +433,12 @@ def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path
     r = g.col(1, 2) - (th[0] + th[1] * g.col(1, 1) + g.lookup(g.col(1, 0), th[2:], 0))
     for centred in (True, False):
         prior = th[0] * th[0] * -0.5 + th[1] * th[1] * -0.5
-        for k in range(G):      # centred: the prior ties every entry to a shared parameter and stays where it is -> generic path
+        for k in range(G):      # centred: the prior ties every entry to a shared parameter
             prior = prior + ((th[2 + k] - th[0]) * (th[2 + k] - th[0]) if centred else th[2 + k] * th[2 + k]) * -0.5
         spec = ModelSpec("gather_fallback", g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
         for opts in (STRICT, FAST):
             src = _check(spec, opts, rng.normal(size=(2, P)) * 0.4, 1e-10)
-            assert ("#define RH_HAS_GATHER 1\n" in src) == (not centred)   # a standard prior is lifted into a row target: gather mode
+            assert ("#define RH_HAS_GATHER 1\n" in src) == (not centred or opts is FAST)
 
 
 @pytest.mark.parametrize("family", ["negbin-split", "negbin", "poisson-split"])
@@ -483,6 +484,33 @@ def test_the_canonical_hierarchical_construction_runs_in_gather_mode(split):
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
     assert "#define RH_HAS_GATHER 1\n" in _check(spec, FAST, qs, 1e-9)
     assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)     # the reference's mask-column gradient: generic path
+
+
+@pytest.mark.parametrize("split,lik", [(False, "negbin"), (True, "negbin"), (False, "normal")])
+def test_a_centred_hierarchical_table_runs_in_gather_mode(split, lik):
+    """The CENTRED parameterisation: the table entries are raw parameters with the prior alpha_k ~ Normal(mu, sigma) written through
+    Real.parameter (compute/Real.scala:63-78) -- the prior ties every entry to the shared parameters mu and sigma, and the
+    reference hands d/d mu and d/d sigma of it over as sums that run over all entries.  Fast builds lift the per-entry prior
+    terms into a row target over the group index all the same (lift.cpp: both targets' gradients derived again from their values,
+    accepted only when they add up to the original outputs) and run in gather mode; strict builds keep the generic path.  Both
+    must reproduce the original program."""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(9)
+    K, n = 100, 1400
+    b = M.Normal(0, 1).latent; mu = M.Normal(0, 2).latent; sigma = M.Exponential(1).latent
+    alphas = [CC.Real.parameter(lambda a: M.Normal(mu, sigma).logDensity(a)) for _ in range(K)]
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n)
+    if lik == "negbin":
+        ys = rng.poisson(3.0, n).astype(float); fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    else:
+        ys = rng.normal(size=n); fn = lambda s, u: M.Normal(CC.Lookup.apply(s, alphas) + b * u, 0.7)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("centred_raw_%s" % lik, inline=False)
+    assert spec.n_params == K + 3
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    src = _check(spec, FAST, qs, 1e-9)
+    assert "#define RH_HAS_GATHER 1\n" in src and "#define RH_NSHARED 3\n" in src
+    assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -570,8 +598,9 @@ def test_gather_mode_beyond_the_generic_path_s_parameter_limit():
 def test_random_table_priors(seed):
     """fuzz: a Lookup over 65-139 trailing parameters indexed by a column, with the table's prior folded into the data-free target the
     way the reference's front end leaves it -- standard, a random per-entry shape with per-entry constants (lifted as columns), two
-    terms per entry, or tied to a shared parameter (not lifted: generic path) -- a shared term in the middle of the fold; gather
-    mode exactly when the prior could be lifted, both math modes against the oracle on the original program"""
+    terms per entry, or tied to a shared parameter (the centred parameterisation: lifted in fast builds only, with re-derived and
+    verified gradients; generic path in strict builds) -- a shared term in the middle of the fold; gather mode exactly when the
+    prior could be lifted, both math modes against the oracle on the original program"""
     rng = np.random.default_rng(90000 + seed)
     G, per = int(rng.integers(65, 140)), int(rng.integers(2, 6))
     n, nsh = G * per, int(rng.integers(2, 4))
@@ -604,7 +633,7 @@ def test_random_table_priors(seed):
     if not qs:
         pytest.skip("no finite evaluation point")
     for opts in (STRICT, FAST):
-        assert ("#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-9)) == (mode != 3)
+        assert ("#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-9)) == (mode != 3 or opts is FAST)
 
 
 def test_one_observe_per_group_of_a_hierarchical_model_is_lifted_with_a_lookup():

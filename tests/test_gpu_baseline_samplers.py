@@ -120,3 +120,48 @@ def test_cfg5_hier_negbin_nuts10_at_full_size():
           "rhat of the 4 shared parameters %s, warm-up %.1f s, run %.1f s (%.2f ms per leapfrog step)" % (
               chains, warm, iters, lf, np.log2(lf + 1), wlf, np.mean([st.meanAcceptProb for st in stats]),
               ["%.3f" % r for r in rhat], tw, dt, dt / (lf * iters) * 1e3))
+
+
+def test_cfg5_centred_parameterisation_in_gather_mode():
+    """The same model with the group effects themselves as parameters, alpha_g ~ Normal(mu, e^s) (models.hier_negbin_centred: what
+    Real.parameter { a => Normal(mu, sigma).logDensity(a) } gives, compute/Real.scala:63-78): the prior ties every table entry to
+    the shared parameters, the reference hands d/d mu and d/d s of it over as sums over all 10 000 entries.  Fast builds lift the
+    prior into a row target over the group index (csrc/lift.cpp) and run in gather mode like the non-centred form.
+      * 10 000 groups x 10 observations: (logp, gradient) against the oracle evaluating the ORIGINAL program;
+      * 10 000 x 100, NUTS(10) + windowed diagonal mass, 64 chains: this is the form whose posterior NUTS can traverse -- tree
+        depth and R-hat are reported next to the non-centred run above."""
+    spec = models.hier_negbin_centred(10_000, 10)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    assert "#define RH_HAS_GATHER 1\n" in m.hip_source and "#define RH_BIGN 1" in m.hip_source and "#define RH_NSHARED 4\n" in m.hip_source
+    rng = np.random.default_rng(77)
+    q = rng.normal(size=(3, spec.n_params)) * 0.3
+    lp, g = m.density_batch(q)
+    d = O.OracleDensity(spec)
+    for c in range(2):
+        ref, ab = d.update_both(q[c])
+        got = np.concatenate([[lp[c]], g[c]])
+        err = np.abs(got - ref) / (1e-11 * ab + 1e-300)
+        assert np.all(err <= 1.0), (c, float(err.max()), int(np.argmax(err)))
+    m.close()
+    G, per, chains = 10_000, 100, 64
+    spec = models.hier_negbin_centred(G, per)
+    m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
+    warm, iters = 80, 20
+    cfg = R.make_config(iters, warm, R.NUTSSampler(10), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(15, 1.5, 15, 10))
+    s = R.Sampler(m, cfg, [9500 + c for c in range(chains)])
+    t0 = time.time(); s.warmup(); tw = time.time() - t0
+    t0 = time.time(); s.run(iters); dt = time.time() - t0
+    draws = s.draws()
+    stats, mass = s.stats()
+    s.close()
+    assert np.all(np.isfinite(draws)) and not np.allclose(mass, 1.0)
+    rhat = [r for r, _ in R.diagnostics(draws[:, :, :4])]
+    lf = sum(st.leapfrogSteps for st in stats) / (chains * iters)
+    wlf = sum(st.warmupLeapfrogSteps for st in stats) / (chains * warm)
+    post = draws[:, :, :4].reshape(-1, 4).mean(axis=0)
+    _note("cfg5 CENTRED NUTS(10) 10 000 x 100, %d chains x (%d + %d): mean leapfrog / iteration %.1f (tree depth ~%.1f; warm-up %.1f), accept %.3f, "
+          "rhat of (b0, b1, mu, s) %s, posterior means %s, warm-up %.1f s, run %.1f s (%.2f ms per leapfrog step)" % (
+              chains, warm, iters, lf, np.log2(lf + 1), wlf, np.mean([st.meanAcceptProb for st in stats]),
+              ["%.3f" % r for r in rhat], np.array2string(post, precision=3), tw, dt, dt / (lf * iters) * 1e3))
+    # the data were generated with b = (0.3, -0.2), alpha_g ~ N(1, 0.5): mu -> 1, s -> log 0.5
+    assert abs(post[0] - 0.3) < 0.05 and abs(post[1] + 0.2) < 0.05 and abs(post[2] - 1.0) < 0.1 and abs(post[3] - np.log(0.5)) < 0.1, post

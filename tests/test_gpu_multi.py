@@ -101,3 +101,42 @@ def test_bench_under_torch_distributed_run_one_rank():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["chains"] == 64
+
+
+@pytest.mark.parametrize("workload,extra", [
+    ("cfg1", ["--steps", "5", "--warmup", "5", "--chains-per-gpu", "64"]),
+    ("cfg3", ["--steps", "5", "--warmup", "20", "--chains-per-gpu", "64", "--sampler", "nuts"]),
+    ("cfg4", ["--steps", "2", "--warmup", "6", "--chains-per-gpu", "32", "--rows", "100000"]),
+    ("cfg5", ["--steps", "2", "--warmup", "4", "--chains-per-gpu", "16", "--rows", "20000"])])
+def test_side_workloads_under_torch_distributed_run_one_rank(workload, extra):
+    """the other BASELINE configurations through the same launch contract (`--workload cfgN --gpus N`), one rank: sharded seeds,
+    the engine's RCCL all-gather of the draws, max-over-ranks timing, ONE JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith(workload) and d["scaling"] == "weak"
+
+
+def test_a_missing_rank_is_a_clean_error_not_a_hang():
+    """rh_comm_create for a world of two with only one rank present: ncclCommInitRank would block for ever; the engine gives up after
+    RH_COMM_TIMEOUT_S and says which rank waited (run in a child process: the helper thread stays inside RCCL)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from rainier_amd import _capi, distributed as D\n"
+            "_capi.lib(); uid = D.Comm.unique_id(); t = time.time()\n"
+            "try:\n    D.Comm(uid, 2, 0, 0); print('NO ERROR')\n"
+            "except _capi.RainierHipError as e:\n    print('ERR', e.code, round(time.time() - t), str(e))\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, RH_COMM_TIMEOUT_S="4"))
+    assert "ERR %d" % _capi.RH_E_DEVICE in out.stdout and "never reached rh_comm_create" in out.stdout, out.stdout + out.stderr[-2000:]
