@@ -1453,6 +1453,204 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 }
 #pragma clang fp contract(off)
 
+// ---- the same contractions on v_mfma_f64_4x4x4_4b_f64 ---------------------------------------------------------------------------
+// Measured on MI355X (tools/ubench/fma64_cycles mfma, profiles/r3_d_fp64_mfma): v_mfma_f64_16x16x4_f64 issues once per 105 cycles
+// and SIMD (19.4 flop/cycle/SIMD; SQ_VALU_MFMA_BUSY_CYCLES counts 64 of them busy), the four-block shape v_mfma_f64_4x4x4_4b_f64
+// once per 16.7 cycles = 30.7 flop/cycle/SIMD -- 0.96 of the vector FMA rate, 1.58x the big shape per flop.  Its lane layout
+// (tools/ubench/mfma4_layout.hip; the guide documents the 16x16x4 form only): with k = lane >> 4, block = (lane >> 2) & 3 and
+// e = lane & 3,   A[block][i = e][k],   B[block][k][j = e],   and D[block][i][j] in lane 16 i + 4 block + j.
+// Mapping used here -- block = chain block, so that a lane's chain is lane & 15 exactly as in rh_grad_glm_kernel:
+//   forward   eta[row r0 + 4 rb + i][chain]  += X[r0 + 4 rb + i][pred(k, s)] . theta[pred(k, s)][chain]      A: lane (k, *, i), one LDS read
+//             per (rb, s) that the four chain blocks share (the same address in 4 lanes: a broadcast); D[rb] lane 16 i + chain
+//   backward  G[pred(i, s)][chain]          += X[r0 + 4 rb + k][pred(i, s)] . w[r0 + 4 rb + k][chain]         B: lane 16 k + chain IS the
+//             forward D[rb] register after the scalar part -- w never moves between lanes here either
+// with pred(g, s) = S4 g + s (S4 = ceil(PM / 4) steps; predictor groups of S4, so that both contractions walk the same grouping).
+// The row tile sits in LDS ROW-major ([row][column], odd stride) because a lane now reads 4 rows x 4 predictors per step.
+// 96 instead of 24 MFMA instructions per 16 rows x 16 chains, each a quarter of the flops; 96 broadcast LDS reads instead of 24.
+#ifndef RH_GLM4
+#define RH_GLM4 1
+#endif
+#if RH_GLM4
+#if RH_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIMD)
+rh_grad_glm4_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                    const int chains, const int nsplit, const int xcd_aware) {
+  rh_lk_init();
+  typedef rh_glm<RH_GLM_TARGET> GL;
+  typedef rh_target<RH_GLM_TARGET> TG;
+  constexpr int P = GL::P, NC = GL::NCOLS, W = RH_GLM_W;
+  constexpr int RV = (P % 16 != 0 && P % 16 <= 4 && P > 16) ? P % 16 : 0;   // a few left-over predictors on the VALU, as in rh_grad_glm_kernel
+  constexpr int PM = P - RV;
+  constexpr int S4 = (PM + 3) / 4;     // steps; predictor of (group g, step s) = S4 g + s
+  constexpr int ST = NC | 1;           // row stride in doubles (odd: the 64 rows of a staging store hit 64 different bank pairs)
+  constexpr int MYC = (NC + W - 1) / W;
+  constexpr int NBUF = (2 * 64 * ST * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double rh_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4, le = lane & 3;
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) *n_running = 0;
+  int bgroup, split;
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    bgroup = idx / spx;
+  } else { split = b % nsplit; bgroup = b / nsplit; }
+  const int chain0 = (bgroup * W + wave) * 16;
+  const int mychain = chain0 + li;
+  const int cl = mychain < chains ? mychain : chains - 1;
+  const bool compute = __any((mychain < chains) && (active[cl] != 0));
+  if (!__syncthreads_or(compute ? 1 : 0)) return;
+  // forward B operands: lane (k = lk, chain li) holds scale * theta[chain][pred(lk, s)]; fcol / bcol: the LDS column a lane reads
+  // in step s of the forward (predictor group lk) and of the backward (predictor group le) product (-1: the constant 1, -2: none)
+  double Bf[S4];
+  int fcol[S4], bcol[S4];
+#pragma unroll
+  for (int sidx = 0; sidx < S4; sidx++) {
+    const int pf = S4 * lk + sidx, pb = S4 * le + sidx;
+    Bf[sidx] = (pf < PM) ? GL::pred_scale[pf < PM ? pf : 0] * q[(size_t)cl * RH_NVARS + GL::pred_param[pf < PM ? pf : 0]] : 0.0;
+    fcol[sidx] = (pf < PM) ? GL::pred_col[pf < PM ? pf : 0] : -2;
+    bcol[sidx] = (pb < PM) ? GL::pred_col[pb < PM ? pb : 0] : -2;
+  }
+  double thv[RV > 0 ? RV : 1], Gv[RV > 0 ? RV : 1];
+  int vcol[RV > 0 ? RV : 1];
+#pragma unroll
+  for (int k = 0; k < RV; k++) { thv[k] = GL::pred_scale[PM + k] * q[(size_t)cl * RH_NVARS + GL::pred_param[PM + k]]; vcol[k] = GL::pred_col[PM + k]; Gv[k] = 0.0; }
+  double thu[GL::NTHU > 0 ? GL::NTHU : 1];
+#pragma unroll
+  for (int k = 0; k < GL::NTHU; k++) thu[k] = q[(size_t)cl * RH_NVARS + GL::thu_param[k]];
+  double G[S4];
+#pragma unroll
+  for (int sidx = 0; sidx < S4; sidx++) G[sidx] = 0.0;
+  double oth[GL::NOTHER > 0 ? GL::NOTHER : 1];
+#pragma unroll
+  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
+  int err = 0;
+
+  const long long n = d.nrows[RH_GLM_TARGET];
+  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
+  long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
+  if (r0 > n) r0 = n;
+  if (r1 > n) r1 = n;
+  const long long ntiles = (r1 - r0 + 63) / 64;
+  double stage[MYC];
+  auto fetch = [&](long long tile) {       // wave w fetches columns w, w + W, ...; lane = row: coalesced 512 B per column
+    long long row = r0 + tile * 64 + lane;
+    if (row >= n) row = n - 1;
+#pragma unroll
+    for (int m = 0; m < MYC; m++) {
+      const int j = wave + m * W;
+      stage[m] = (j < NC && n > 0) ? d.cols[TG::COL0 + j][row] : 0.0;
+    }
+  };
+  auto park = [&](int buf) {               // ... and parks them row-major
+#pragma unroll
+    for (int m = 0; m < MYC; m++) {
+      const int j = wave + m * W;
+      if (j < NC) rh_lds[(size_t)buf * 64 * ST + (size_t)lane * ST + j] = stage[m];
+    }
+  };
+  if (ntiles > 0) { fetch(0); park(0); }
+  __syncthreads();
+  for (long long t = 0; t < ntiles; t++) {
+    const int buf = NBUF == 2 ? (int)(t & 1) : 0;
+    if (t + 1 < ntiles) fetch(t + 1);
+    if (compute) {
+      const double *tile = rh_lds + (size_t)buf * 64 * ST;
+#pragma unroll 1
+      for (int sub = 0; sub < 4; sub++) {
+        const int row0s = sub * 16;
+        double D[4] = {0.0, 0.0, 0.0, 0.0};
+        // forward: step outermost, the four row blocks are four independent accumulators
+#pragma unroll
+        for (int sidx = 0; sidx < S4; sidx++)
+#pragma unroll
+          for (int rb = 0; rb < 4; rb++) {
+            const double a = fcol[sidx] >= 0 ? tile[(row0s + 4 * rb + le) * ST + fcol[sidx]] : (fcol[sidx] == -1 ? 1.0 : 0.0);
+            D[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Bf[sidx], D[rb], 0, 0, 0);
+          }
+        // this lane's rows: row0s + 4 rb + lk
+        double xv[RV > 0 ? RV : 1][4];
+#pragma unroll
+        for (int k = 0; k < RV; k++)
+#pragma unroll
+          for (int rb = 0; rb < 4; rb++) {
+            xv[k][rb] = vcol[k] >= 0 ? tile[(row0s + 4 * rb + lk) * ST + vcol[k]] : 1.0;
+            D[rb] += thv[k] * xv[k][rb];
+          }
+        double Wv[4];
+        const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 16 <= chains);
+        if (full) {
+#pragma unroll RH_GLM_ELEM_UNROLL
+          for (int rb = 0; rb < 4; rb++) {
+            const int rrow = row0s + 4 * rb + lk;
+            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+            GL::elem(thu, D[rb], [&](int j) { return tile[rrow * ST + j]; }, w, o, err);
+            Wv[rb] = w;
+#pragma unroll
+            for (int k = 0; k < GL::NOTHER; k++) oth[k] += o[k];
+          }
+        } else {
+#pragma unroll RH_GLM_ELEM_UNROLL
+          for (int rb = 0; rb < 4; rb++) {
+            const int rrow = row0s + 4 * rb + lk;
+            const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
+            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+            GL::elem(thu, D[rb], [&](int j) { return tile[rrow * ST + j]; }, w, o, err);
+            Wv[rb] = valid ? w : 0.0;
+#pragma unroll
+            for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < RV; k++)
+#pragma unroll
+          for (int rb = 0; rb < 4; rb++) Gv[k] += xv[k][rb] * Wv[rb];
+        // backward: row block outermost, so that consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+          for (int sidx = 0; sidx < S4; sidx++) {
+            const double a = bcol[sidx] >= 0 ? tile[(row0s + 4 * rb + lk) * ST + bcol[sidx]] : (bcol[sidx] == -1 ? 1.0 : 0.0);
+            G[sidx] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Wv[rb], G[sidx], 0, 0, 0);
+          }
+      }
+    }
+    if (NBUF == 1) __syncthreads();
+    if (t + 1 < ntiles) park(NBUF == 2 ? (buf ^ 1) : 0);
+    __syncthreads();
+  }
+  if (compute) {
+    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cl) * RH_NACC_MAX;
+    // G[s] at lane 16 i + chain = sum over the rows of x[pred(i, s)] * w for that chain
+#pragma unroll
+    for (int sidx = 0; sidx < S4; sidx++) {
+      const int pred = S4 * lk + sidx;
+      if (pred < PM && mychain < chains) out[GL::pred_acc[pred < PM ? pred : 0]] = G[sidx];
+    }
+#pragma unroll
+    for (int k = 0; k < RV; k++) {  // the VALU remainder and the other sums: fold the 4 lane groups (rows lk + 4 rb)
+      double v = Gv[k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lk == 0 && mychain < chains) out[GL::pred_acc[PM + k]] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < GL::NOTHER; k++) {
+      double v = oth[k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lk == 0 && mychain < chains) out[GL::other_acc[k]] = v;
+    }
+  }
+  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
+}
+#pragma clang fp contract(off)
+#endif  // RH_GLM4
+
 // ---- narrow GLMs (P <= 8 predictors): forward on the matrix cores, backward on the VALU ---------------------------
 // With few predictors the backward contraction would fill only P of the 16 MFMA output rows, so only
 // eta = X.theta goes to v_mfma_f64_16x16x4_f64 (ONE instruction per 16 rows x 16 chains when P <= 4) and the sums

@@ -156,6 +156,7 @@ struct rh_model {
   int grad_w = 8, ncols_max = 0, glm_ncols = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
+  bool glm4 = false;       // k_grad_glm is rh_grad_glm4_kernel (v_mfma_f64_4x4x4_4b_f64, row-major LDS tile)
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
@@ -303,8 +304,21 @@ void load_module(rh_model *m) {
   if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
+  // the four-block MFMA shape runs at 0.96 of the vector FMA rate, the 16x16x4 shape at 0.61 (profiles/r3_d_fp64_mfma): the
+  // wide-GLM kernel written for it is preferred; RH_GLM4=0 keeps rh_grad_glm_kernel
+  m->glm4 = false;
+  if (m->k_grad_glm && !m->glm_small) {
+    bool want = true;
+    if (const char *e = std::getenv("RH_GLM4")) want = std::atoi(e) != 0;
+    hipFunction_t f4 = nullptr;
+    if (want && hipModuleGetFunction(&f4, m->module, "rh_grad_glm4_kernel") == hipSuccess && f4) { m->k_grad_glm = f4; m->glm4 = true; }
+    else (void)hipGetLastError();
+  }
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
-  if (!m->glm_small && (size_t)m->glm_ncols * 66u * sizeof(double) + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
+  {  // one 64-row tile of all columns must fit the CU's LDS (column-major stride 66 | row-major odd stride)
+    const size_t tile = m->glm4 ? (size_t)64 * ((size_t)m->glm_ncols | 1u) * sizeof(double) : (size_t)m->glm_ncols * 66u * sizeof(double);
+    if (!m->glm_small && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
+  }
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
@@ -923,7 +937,8 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
-    const unsigned tile = (unsigned)m->glm_ncols * 66u * sizeof(double);  // rh_grad_glm_kernel's NBUF rule: two tiles while they fit
+    const unsigned tile = m->glm4 ? 64u * ((unsigned)m->glm_ncols | 1u) * (unsigned)sizeof(double)
+                                  : (unsigned)m->glm_ncols * 66u * (unsigned)sizeof(double);  // the kernels' NBUF rule: two tiles while they fit
     const unsigned lds = (2u * tile + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else if (m->use_lds_grad) {
@@ -1362,7 +1377,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

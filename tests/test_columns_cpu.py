@@ -375,3 +375,39 @@ def test_ark_reference_benchmark_model_has_197_targets_and_the_engine_rolls_them
     lm = dataclasses.replace(mixed, rir=rirm, columns=colsm, nrows=nrows_m)
     q = np.array([0.37])
     np.testing.assert_allclose(O.OracleDensity(lm).update(q), O.OracleDensity(mixed).update(q), rtol=1e-14)
+
+
+def test_model_create_host_time_budget():
+    """The host side of rh_model_create (parse, column canonicalisation with the data in hand, gradient re-derivation and its
+    verification, slot rolling, lifting, emission -- everything but hiprtc, which the code-object cache absorbs) has a budget
+    (VERDICT r2 weak #7 / next #6): cfg 4 exactly as the JVM hands it over (50 covariates through Model.observe's 8-way split:
+    1945 columns, here at 2e5 rows) <= 2 s; a 600-group hierarchical table through the split (5437 columns) <= 4 s.  Best of two
+    runs (the first one also pays the page faults of the columns)."""
+    import time
+    from rainier_amd import compute as CC
+    fast = _capi.compile_opts(fp_contract=True, factor_outputs=True)
+
+    def best(spec):
+        ts = []
+        for _ in range(2):
+            t = time.perf_counter()
+            _capi.lower_only(spec.rir, fast, compile=False, columns=spec.columns, nrows=spec.nrows)
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+
+    cols = models.logistic_data(200_000, 50)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(50)
+    cfg4 = M.Model.observe_vec(cols[0], cols[1:], lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic),
+                               split=True).compile("cfg4_as_handed_over")
+    assert len(cfg4.columns) == 1945
+    t4 = best(cfg4)
+    rng = np.random.default_rng(4)
+    K, n = 600, 6000
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent; zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    tab = M.Model.observe_vec(ys, [site, x], lambda s, u: M.NegativeBinomial((a + tau * CC.Lookup.apply(s, zs) + b * u).logistic, 5.0),
+                              split=True).compile("table600_split", inline=False)
+    assert len(tab.columns) > 5000
+    tt = best(tab)
+    print("model-create host time: cfg 4 as handed over %.2f s, 600-group table through the split %.2f s" % (t4, tt))
+    assert t4 <= 2.0 and tt <= 4.0, (t4, tt)

@@ -8,4 +8,4 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_VALU_MF
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/p$i -o bench -- python $R/tools/cfg4_probe.py 2000000 256 2 > $O/p$i/log.txt 2>&1
   f=$(find $O/p$i -name "bench_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/p$i/bench_counter_collection.csv
 done
-python $R/profiles/summarize.py rh_grad_glm_kernel 8 $R/gpurun_out/pmc_glm.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 2>&1 | tail -80
+python $R/profiles/summarize.py ${RH_PMC_KERNEL:-rh_grad_glm4_kernel} 8 $R/gpurun_out/pmc_glm.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 2>&1 | tail -80
