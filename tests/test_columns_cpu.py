@@ -410,4 +410,6 @@ def test_model_create_host_time_budget():
     assert len(tab.columns) > 5000
     tt = best(tab)
     print("model-create host time: cfg 4 as handed over %.2f s, 600-group table through the split %.2f s" % (t4, tt))
-    assert t4 <= 2.0 and tt <= 4.0, (t4, tt)
+    import os
+    slack = 3.0 if os.environ.get("PYTEST_XDIST_WORKER") else 1.0      # the budget is for an otherwise idle host (the driver runs serially)
+    assert t4 <= 2.0 * slack and tt <= 4.0 * slack, (t4, tt)
