@@ -21,6 +21,16 @@
 
 template <int T> struct rh_target;
 
+// Generic (non-gather) models with more than 512 parameters: the chain vectors live in HBM (big mode), and so do the things that
+// used to be per-wavefront register arrays of RH_NVARS elements -- theta is read in place from the chain's q (wave-uniform
+// addresses: scalar loads) and the n + 1 outputs are accumulated in a scratch area of the chain (`tot`: every lane executes the
+// same stores of the same values; the accumulation is sequential in program order).  The reference's back end has no parameter
+// limit (ir/Packer.scala:10-40); this is how a 2 000-parameter state-space model runs here: correct, not fast.
+#define RH_BIGTH (RH_BIGN && !RH_HAS_GATHER && RH_NVARS > 512)
+#if RH_BIGTH
+__shared__ double *rh_tot_base;   // the chain's (or the density call's) scratch for the outputs: RH_NOUT doubles
+#endif
+
 #if !RH_HAS_GATHER
 // ---- DataFunction.apply for one chain ------------------------------------------------------------
 #ifndef RH_ROWS_UNROLL
@@ -81,6 +91,16 @@ RH_DEV void rh_accumulate_all(const double (&th)[RH_NTH], const rh_model_data &d
 #pragma clang fp contract(off)
 
 // q (lane-distributed) -> logp (wave-uniform), grad (lane-distributed)
+#if RH_BIGTH
+RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, double &logp, wvec &grad, int &err) {
+  const double (&th)[RH_NTH] = *reinterpret_cast<const double (*)[RH_NTH]>(q.s.p);
+  double (&tot)[RH_NOUT] = *reinterpret_cast<double (*)[RH_NOUT]>(rh_tot_base);
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;   // (wave-uniform stores; every lane then reads back what the wavefront wrote)
+  rh_accumulate_all<0>(th, d, lane, tot, err);
+  logp = tot[0];
+  for (int i = lane; i < RH_NVARS; i += 64) grad.s.p[i] = tot[1 + i];
+}
+#else
 RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, double &logp, wvec &grad, int &err) {
   double th[RH_NTH];
 #pragma unroll
@@ -94,6 +114,7 @@ RH_DEV void rh_density(const wvec &q, const rh_model_data &d, const int lane, do
 #pragma unroll
   for (int i = 0; i < RH_NVARS; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
 }
+#endif  // RH_BIGTH
 
 #endif  // !RH_HAS_GATHER
 
@@ -189,7 +210,7 @@ enum {
 // u64 words of one chain's state image: lane-distributed vectors and the ring buffer take 64 words per slot,
 // wave-uniform scalars are stored once (lane 0 writes, every lane reads the same address -> scalar loads).
 #if RH_BIGN
-#define RH_STATE_NPOOL RH_POOL_VECS
+#define RH_STATE_NPOOL (RH_POOL_VECS + (RH_BIGTH ? 2 : 0))   /* + the outputs' scratch (RH_NOUT = RH_NVARS + 1 doubles: two vectors) */
 #else
 #define RH_STATE_NPOOL 0
 #endif
@@ -230,6 +251,9 @@ RH_DEV void rh_chain_load(rh_chain &c, rh_u64 *st, const int lane) {
   }
 #endif
   rh_pool_base = (double *)(st + w * 64); w += (size_t)RH_STATE_NPOOL * RH_SLOTS;
+#if RH_BIGTH
+  rh_tot_base = rh_pool_base + (size_t)RH_POOL_VECS * RH_SLOTS * 64;
+#endif
   rh_pool_depth[lane] = 0;
   const rh_u64 *sc = st + w * 64;
   int j = 0;
@@ -974,10 +998,18 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
+// the K parameter vectors of a wavefront's chain group: register arrays (SGPR pairs), or -- RH_BIGTH -- K pointers into q
+#if RH_BIGTH
+typedef const double *rh_thk_t[RH_GRAD_K];
+#define RH_THK(th, kk) (*reinterpret_cast<const double (*)[RH_NTH]>((th)[kk]))
+#else
+typedef double rh_thk_t[RH_GRAD_K][RH_NTH];
+#define RH_THK(th, kk) (th)[kk]
+#endif
 // COHERENT: the partial sums are stored with agent-scope (write-through) stores -- rh_grad_fused_kernel, whose epilogue reads them
 // from another XCD within the same launch
 template <int T, bool COHERENT>
-RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const int lane,
+RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
                             const int split, const int nsplit, const int chain0, const int chains,
                             double *__restrict__ partial, int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -986,7 +1018,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
       constexpr int NC = TG::NCOLS, U = RH_GRAD_U, K = RH_GRAD_K;
       double inv[K][TG::NINV > 0 ? TG::NINV : 1];
 #pragma unroll
-      for (int kk = 0; kk < K; kk++) TG::invariants(th[kk], inv[kk], err);
+      for (int kk = 0; kk < K; kk++) TG::invariants(RH_THK(th, kk), inv[kk], err);
       const long long n = d.nrows[T];
       const long long chunk = 64LL * U;
       const long long per = (((n + chunk - 1) / chunk) + nsplit - 1) / nsplit; // chunks per split
@@ -1028,7 +1060,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #pragma unroll
           for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c[u], acc[kk], err);
+            for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
           k = kn;
           if (!more) break;
         }
@@ -1043,7 +1075,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c[u], acc[kk], err);
+          for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
       }
 #endif
       for (; k < r1; k += 64) {
@@ -1051,7 +1083,7 @@ RH_DEV void rh_grad_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mode
 #pragma unroll
         for (int j = 0; j < NC; j++) c[j] = cp[j][k];
 #pragma unroll
-        for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c, acc[kk], err);
+        for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c, acc[kk], err);
       }
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
@@ -1093,13 +1125,17 @@ RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__re
   const int chain0 = group * RH_GRAD_K;
   if (chain0 >= chains) return -1;
   bool any = false;
-  double th[RH_GRAD_K][RH_NTH];
+  rh_thk_t th;
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
     any = any || (active[c] != 0);
+#if RH_BIGTH
+    th[kk] = q + (size_t)c * RH_NVARS;
+#else
 #pragma unroll
     for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i]; // wave-uniform address -> s_load
+#endif
   }
   if (!any) return -1;
   int err = 0;
@@ -1132,7 +1168,7 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 #pragma clang fp contract(fast)
 #endif
 template <int T>
-RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const int lane,
+RH_DEV void rh_grad_lds_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
                                 const int wave, const int split, const int nsplit, const int chain0, const int chains,
                                 const bool compute, double *__restrict__ partial, double *lds, int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -1142,7 +1178,7 @@ RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_
       constexpr int MYC = (NC + W - 1) / W; // columns this wave stages
       double inv[K][TG::NINV > 0 ? TG::NINV : 1];
 #pragma unroll
-      for (int kk = 0; kk < K; kk++) TG::invariants(th[kk], inv[kk], err);
+      for (int kk = 0; kk < K; kk++) TG::invariants(RH_THK(th, kk), inv[kk], err);
       const long long n = d.nrows[T];
       const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit; // tiles per split
       long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
@@ -1182,7 +1218,7 @@ RH_DEV void rh_grad_lds_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_
 #pragma unroll
           for (int j = 0; j < NC; j++) c[j] = lds[(buf * NC + j) * RH_LDS_TRP + lane];
 #pragma unroll
-          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], c, acc[kk], err);
+          for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c, acc[kk], err);
         }
         if (t + 1 < ntiles) park(buf ^ 1);
         __syncthreads();
@@ -1223,14 +1259,18 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const int group = __builtin_amdgcn_readfirstlane(bgroup * RH_GRAD_W + wave);
   const int chain0 = group * RH_GRAD_K;
   bool any = false;
-  double th[RH_GRAD_K][RH_NTH];
+  rh_thk_t th;
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     int c = chain0 + kk;
     if (c >= chains) c = chains - 1;
     any = any || (chain0 + kk < chains && active[c] != 0);
+#if RH_BIGTH
+    th[kk] = q + (size_t)c * RH_NVARS;
+#else
 #pragma unroll
     for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
+#endif
   }
   if (!__syncthreads_or(any ? 1 : 0)) return;
   int err = 0;
@@ -2062,6 +2102,15 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 #endif
                              const double *__restrict__ partial, const int nsplit, const int chain, const int chains,
                              const int lane, double &logp, wvec &grad, int &err) {
+#if RH_BIGTH
+  const double (&th)[RH_NTH] = *reinterpret_cast<const double (*)[RH_NTH]>(q.s.p);
+  double (&tot)[RH_NOUT] = *reinterpret_cast<double (*)[RH_NOUT]>(rh_tot_base);
+  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+  rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+  logp = tot[0];
+  for (int i = lane; i < RH_NVARS; i += 64) grad.s.p[i] = tot[1 + i];
+  return;
+#else
   double th[RH_NTH];
 #pragma unroll
   for (int i = 0; i < RH_NTH; i++) th[i] = wv_elem(q, i);
@@ -2096,6 +2145,7 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
     }
   }
 #endif
+#endif  // RH_BIGTH
 }
 
 #ifndef RH_TICK_FAST
@@ -2405,11 +2455,21 @@ RH_UNROLL_SLOTS
 // Seam 2: batched DensityFunction.  q [chains][nvars] -> logp [chains], grad [chains][nvars]; one wavefront per chain.
 extern "C" __global__ void __launch_bounds__(64)
 rh_density_kernel(const rh_model_data d, const double *__restrict__ q, double *__restrict__ logp,
-                  double *__restrict__ grad, int *__restrict__ err_out, const int chains) {
+                  double *__restrict__ grad, int *__restrict__ err_out, const int chains, double *tot_scratch) {
   rh_lk_init();
   const int chain = blockIdx.x * (64 / RH_LANES) + (int)(threadIdx.x / RH_LANES);  // RH_LANES lanes per chain (64 unless packed)
   const int lane = threadIdx.x & (RH_LANES - 1);
   if (chain >= chains) return;
+#if RH_BIGTH
+  rh_tot_base = tot_scratch + (size_t)chain * RH_NOUT;   // (one chain per workgroup in big mode; every lane stores the same value)
+  wvec qv, gv;                                            // views on the caller's arrays (element i at [i])
+  qv.s.p = const_cast<double *>(q) + (size_t)chain * RH_NVARS;
+  gv.s.p = grad + (size_t)chain * RH_NVARS;
+  double lp; int err = 0;
+  rh_density(qv, d, lane, lp, gv, err);
+  if (lane == 0) { logp[chain] = lp; if (err) atomicOr(err_out, 1); }
+#else
+  (void)tot_scratch;
   wvec qv, gv;
 RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++) qv.s[k] = (k * 64 + lane < RH_NVARS) ? q[(size_t)chain * RH_NVARS + k * 64 + lane] : 0.0;
@@ -2419,6 +2479,7 @@ RH_UNROLL_SLOTS
 RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++)
     if (k * 64 + lane < RH_NVARS) grad[(size_t)chain * RH_NVARS + k * 64 + lane] = gv.s[k];
+#endif
 }
 
 #endif  // !RH_HAS_GATHER
@@ -2432,10 +2493,15 @@ rh_density_fin_kernel(const rh_model_data d,
 #endif
                       const double *__restrict__ q,
                       const double *__restrict__ partial, double *__restrict__ logp, double *__restrict__ grad,
-                      int *__restrict__ err_out, const int chains, const int nsplit) {
+                      int *__restrict__ err_out, const int chains, const int nsplit, double *tot_scratch) {
   const int chain = blockIdx.x;
   const int lane = threadIdx.x;
   if (chain >= chains) return;
+#if RH_BIGTH
+  rh_tot_base = tot_scratch + (size_t)chain * RH_NOUT;
+#else
+  (void)tot_scratch;
+#endif
   double lp; int err = 0;
 #if RH_BIGN
   wvec qv, gv; // views on the caller's arrays (element i at [i])

@@ -1135,7 +1135,10 @@ struct TargetEmitter {
       os << "  }\n";
     } else {
       // data-free target: evaluated once, outputs(o) += f_o(theta)  (DataFunction.scala:73-83)
-      os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
+      // (a data-free target of a model with hundreds of parameters is thousands of statements: one copy per translation unit, not
+      //  one per kernel that evaluates it)
+      os << "  static " << (P.n_params > 512 ? "__device__ __attribute__((noinline))" : "RH_DEV")
+         << " void row(const double (&th)[RH_NTH], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
             "    (void)th; (void)inv; (void)c; (void)err;\n";
       if (!merged_away) {
         for (size_t n = 0; n < P.nodes.size(); n++) {
@@ -1207,7 +1210,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
     << "\n#define RH_NGATHER " << ngather << "\n";
   const int slots = (int)((P.n_params + 63) / 64);
   const bool bign = o.force_bign || slots > 8;
-  if (bign && !gmode) { err = "models with more than 512 parameters are supported in gather mode only (a parameter table indexed by a data column)"; return false; }
+  // (generic models beyond 512 parameters read theta in place and accumulate their outputs in a per-chain scratch area: RH_BIGTH)
   I.bign = bign;
   d << "#define RH_BIGN " << (bign ? 1 : 0) << "\n";
   // chain packing: without observation rows a chain only needs as many lanes as it has parameters

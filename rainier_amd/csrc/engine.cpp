@@ -304,11 +304,13 @@ void load_module(rh_model *m) {
   if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
     HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
-  // the four-block MFMA shape runs at 0.96 of the vector FMA rate, the 16x16x4 shape at 0.61 (profiles/r3_d_fp64_mfma): the
-  // wide-GLM kernel written for it is preferred; RH_GLM4=0 keeps rh_grad_glm_kernel
+  // The four-block MFMA shape issues at 0.96 of the vector FMA rate, the 16x16x4 shape at 0.61 (profiles/r3_d_fp64_mfma), but it
+  // carries a quarter of the flops per operand: the kernel written for it (rh_grad_glm4_kernel) needs 96 LDS operand reads per
+  // 16 rows x 16 chains instead of 24 and is LDS-latency-bound with the two wavefronts per SIMD its registers allow -- measured
+  // 24.9 vs 17.6 ms per cfg-4 gradient (profiles/r3_cfg4).  It is correct (the parity tests ran on it) and stays opt-in: RH_GLM4=1.
   m->glm4 = false;
   if (m->k_grad_glm && !m->glm_small) {
-    bool want = true;
+    bool want = false;
     if (const char *e = std::getenv("RH_GLM4")) want = std::atoi(e) != 0;
     hipFunction_t f4 = nullptr;
     if (want && hipModuleGetFunction(&f4, m->module, "rh_grad_glm4_kernel") == hipSuccess && f4) { m->k_grad_glm = f4; m->glm4 = true; }
@@ -968,7 +970,10 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
     HIPCHK(hipSetDevice(m->device));
     const int n = (int)m->prog.n_params;
     DevBuf bq(sizeof(double) * n * chains), bl(sizeof(double) * chains), bg(sizeof(double) * n * chains), be(sizeof(int));
-    void *dq = bq.p, *dl = bl.p, *dg = bg.p, *de = be.p;
+    // generic models beyond 512 parameters accumulate their n + 1 outputs in memory (RH_BIGTH): one scratch row per chain
+    const bool bigth = m->info.bign && !m->info.gather_mode && n > 512;
+    DevBuf btot(bigth ? sizeof(double) * (size_t)(n + 1) * chains : 8);
+    void *dq = bq.p, *dl = bl.p, *dg = bg.p, *de = be.p, *dtot = btot.p;
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(de, 0, sizeof(int), m->stream));
     int ch = chains;
@@ -989,10 +994,10 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       launch_grad(m, &gb, dq, bact.p, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
-        void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
+        void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit, &dtot};
         launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
       } else {
-        void *fa[] = {&m->data, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit};
+        void *fa[] = {&m->data, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit, &dtot};
         launch(m->k_density_fin, (unsigned)chains, 64, m->stream, fa);
       }
       HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
@@ -1001,7 +1006,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       HIPCHK(hipStreamSynchronize(m->stream));
       return;
     }
-    void *args[] = {&m->data, &dq, &dl, &dg, &de, &ch};
+    void *args[] = {&m->data, &dq, &dl, &dg, &de, &ch, &dtot};
     launch(m->k_density, (unsigned)((chains + 64 / m->info.pack_l - 1) / (64 / m->info.pack_l)), 64, m->stream, args);  // packed: 64 / pack_l chains per wavefront
     HIPCHK(hipMemcpyAsync(logp, dl, sizeof(double) * chains, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * n * chains, hipMemcpyDeviceToHost, m->stream));
@@ -1124,10 +1129,15 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
       HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
-      {  // the fused launch needs the base sampler-kernel variant (its state layout is compiled into the gradient module), the
-         // plain VALU gradient kernel and a lock-step sampler: static HMC.  RH_FUSE=0 keeps one tick launch per gradient.
+      {  // The fused launch (rh_grad_fused_kernel: static HMC's mid-trajectory update as the gradient launch's epilogue) needs the
+         // base sampler-kernel variant (its state layout is compiled into the gradient module), the plain VALU gradient kernel and
+         // a lock-step sampler.  It is OPT-IN (RH_FUSE=1): measured on cfg 2 the hand-off of the partial sums between XCDs --
+         // write-through stores, a device-scope counter, L2-bypassing loads: four dependent trips to memory at the tail of every
+         // launch -- costs 17.5 us per launch, as much as the tick launch and the gap it removes (11.68 vs 11.52 ms per
+         // iteration on one box; profiles/r3_a_cfg2).  Chains are bit-identical either way (tests/test_gpu_fused.py).
         bool fuse = m->k_grad_fused && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm && !m->use_lds_grad;
-        if (const char *e = std::getenv("RH_FUSE")) fuse = fuse && std::atoi(e) != 0;
+        const char *e = std::getenv("RH_FUSE");
+        fuse = fuse && e && std::atoi(e) != 0;
         if (fuse) {
           const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
           HIPCHK(hipMalloc(&s->d_groupcnt, sizeof(int) * ngroups));

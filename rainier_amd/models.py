@@ -268,6 +268,32 @@ def hier_negbin_centred(groups: int = 10_000, per_group: int = 100, seed: int = 
                      {"kind": "hier_negbin_centred", "groups": G})
 
 
+def random_walk(T: int = 2000, seed: int = 11, obs_sd: float = 0.5) -> ModelSpec:
+    """A local-level state-space model with T + 1 parameters -- theta = (s, x_1 .. x_T): x_1 ~ N(0, 1), x_t ~ N(x_{t-1}, e^s),
+    y_t ~ N(x_t, obs_sd), prior s - e^s on the log innovation scale -- written the way a Rainier user writes it with one
+    Model.observe per time point: everything is data-free.  The prior ties NEIGHBOURING states, so no part of it is a per-entry
+    table prior and nothing streams: the generic path with more than 512 parameters (big mode, RH_BIGTH)."""
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.normal(size=T) * 0.3)
+    y = x + rng.normal(size=T) * obs_sd
+    g = Graph(T + 1, [0, 0])
+    s = g.param(0)
+    xs = [g.param(1 + t) for t in range(T)]
+    inv_var = (s * -2.0).exp()
+    prior = (s - s.exp()) + std_normal_logpdf(xs[0]) + (s + HALF_LOG_2PI) * float(-(T - 1))
+    for t in range(1, T):
+        d = xs[t] - xs[t - 1]
+        prior = prior + (d * d) * inv_var * -0.5
+    lik = None
+    c = 1.0 / (obs_sd * obs_sd)
+    for t in range(T):
+        e = xs[t] - float(y[t])
+        term = (e * e) * (-0.5 * c)
+        lik = term if lik is None else lik + term
+    lik = lik + float(-T * (math.log(obs_sd) + HALF_LOG_2PI))
+    return ModelSpec("random_walk_%d" % T, g.compile([prior, lik]), [], [0, 0], T + 1, {"kind": "random_walk", "y": y})
+
+
 def negbin_glm(n: int = 100_000, k: int = 3, seed: int = 7, n_fail: float = 5.0) -> ModelSpec:
     """A negative-binomial GLM without group effects: theta = (a, b_0..b_{k-1}) ~ N(0,1), p = 1 / (1 + n e^{-eta}) so that the
     mean is e^eta, NegativeBinomial(p, n).logDensity(v) written as core/Discrete.scala:111-114 does (the data-only factorial
