@@ -7,14 +7,14 @@
 #      bench.py only quotes `roofline.traffic` from a profile of byte-identical code.
 # usage (from the repo root, via gpurun): bash tools/pmc_cfg2.sh <git-head> [outdir-name]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r2_a_cfg2}
+R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r3_a_cfg2}
 O=$R/gpurun_out/$NAME; mkdir -p $O
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ess --no-inlined"
 $BENCH > $O/bench_noprof.json 2> $O/bench_noprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $BENCH > $O/bench_stats_run.json 2> $O/stats.err
 f=$(find $O/stats -name "bench_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
 i=0
-for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1)); mkdir -p $O/p$i
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/p$i -o bench -- $BENCH > $O/p$i/log.txt 2>&1
   f=$(find $O/p$i -name "bench_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/p$i/bench_counter_collection.csv
@@ -23,5 +23,5 @@ SHA=$(python -c "import json;print(json.load(open('$O/bench_noprof.json'))['conf
 python $R/profiles/summarize.py rh_grad_kernel 256 $O/pmc_grad_kernel.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 \
   --meta git_head=$HEAD generated_source_sha16=$SHA rows=1000000 chains_per_gpu=1024 > $O/summary.txt 2>&1
 python $R/profiles/summarize.py rh_tick_kernel 256 $O/pmc_tick_kernel.json $O/p3 $O/p4 --meta git_head=$HEAD >> $O/summary.txt 2>&1
-rm -rf $O/stats $O/p?/[!bl]* 2>/dev/null
-tail -50 $O/summary.txt; cat $O/kernel_stats.csv | head -8; cat $O/bench_noprof.json
+rm -rf $O/stats $O/p?/[!bl]* $O/p? 2>/dev/null
+tail -30 $O/summary.txt | head -5; cat $O/kernel_stats.csv | head -6; cut -c1-300 $O/bench_noprof.json
