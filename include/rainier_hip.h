@@ -53,7 +53,7 @@ typedef struct rh_sampler rh_sampler; /* device-resident state of `chains` indep
 /* ---- seam 1: compile ------------------------------------------------------------------------ */
 
 enum rh_math_mode {
-  RH_MATH_FAST = 0,   /* exp/log nodes -> ROCm device libm / rh_fast_log (<= 1 ulp measured, like java.lang.Math's bound); the other
+  RH_MATH_FAST = 0,   /* exp/log nodes -> ROCm device libm / the prelude's fast log, <= 1 ulp measured, like java.lang.Math's bound; the other
                          device math functions measure 0.69-0.85 ulp except tan 1.07, atan 1.32, pow 1.29: inside the
                          stated fp64 tolerance, above java.lang.Math's 1-ulp specification */
   RH_MATH_STRICT = 1  /* exp/log nodes -> fdlibm (java.lang.StrictMath): bit-reproducible across machines */

@@ -1137,7 +1137,9 @@ struct TargetEmitter {
       // data-free target: evaluated once, outputs(o) += f_o(theta)  (DataFunction.scala:73-83)
       // (a data-free target of a model with hundreds of parameters is thousands of statements: one copy per translation unit, not
       //  one per kernel that evaluates it)
-      os << "  static " << (P.n_params > 512 ? "__device__ __attribute__((noinline))" : "RH_DEV")
+      if (P.n_params > 512)
+        os << "#ifndef RH_DEV_NOINLINE\n#define RH_DEV_NOINLINE __device__ __attribute__((noinline))\n#endif\n";
+      os << "  static " << (P.n_params > 512 ? "RH_DEV_NOINLINE" : "RH_DEV")
          << " void row(const double (&th)[RH_NTH], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
             "    (void)th; (void)inv; (void)c; (void)err;\n";
       if (!merged_away) {

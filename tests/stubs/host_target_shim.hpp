@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #define RH_DEV inline
+#define RH_DEV_NOINLINE
 #define RH_NAN (__builtin_nan(""))
 #define RH_INF (__builtin_inf())
 static inline double rh_one() { return 1.0; }
