@@ -232,9 +232,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
     ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
-    ap.add_argument("--ess-iters", type=int, default=1536,
-                    help="timed draws per chain of the ESS legs: static HMC with L=32 resonates on this posterior (autocorrelation time ~27 "
-                         "iterations), so R-hat only falls below 1.01 with > 1350 draws per chain")
+    ap.add_argument("--ess-iters", type=int, default=5120,
+                    help="timed draws per chain of the identity-mass ESS leg: static HMC with L=32 resonates on this posterior "
+                         "(autocorrelation time ~97 iterations for log sigma under identity mass, ~42 under the adapted diagonal "
+                         "mass), and R-hat = sqrt(1 + (tau - 1) / n) only falls below 1.01 with n > 4800 resp. 2050 draws per chain")
+    ap.add_argument("--ess-iters-mass", type=int, default=2560, help="timed draws per chain of the DefaultConfig-mass ESS leg")
     ap.add_argument("--ess-warmup", type=int, default=384)
     ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
                     help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC")
@@ -309,12 +311,13 @@ def main():
     total_steps = steps_local * world
     # ESS/s legs, independent of the driver's --steps/--warmup.  The chains start from N(0,1) draws and the posterior is 7e-4 wide:
     # they need a few hundred iterations to get there, and a static L=32 trajectory is ~5 periods of this posterior long, so a
-    # chain's draws are strongly autocorrelated (tau ~ 27 iterations, measured): R-hat = sqrt(1 + (tau - 1) / n) falls below 1.01
-    # only with n > 1350 draws per chain.  Trace.autocorrelation (core/Trace.scala:93-109) sums lags < min(n, 100).  Two configurations: the bench's (identity
+    # chain's draws are strongly autocorrelated (log sigma: tau ~ 97 iterations under identity mass, ~ 42 under the adapted mass,
+    # measured): R-hat = sqrt(1 + (tau - 1) / n) falls below 1.01 only with n > 4800 resp. 2050 draws per chain.  Trace.autocorrelation (core/Trace.scala:93-109) sums lags < min(n, 100).  Two configurations: the bench's (identity
     # mass) and DefaultConfig's windowed diagonal mass adaptation (sampler/Sampler.scala:24-25) with the same static L.
-    ess_iters, ess_warm = max(K, a.ess_iters), max(W, a.ess_warmup)
+    ess_warm = max(W, a.ess_warmup)
     ess_runs = {}
-    for name, mt in (("identity_mass", R.IdentityMassMatrixTuner()), ("default_diag_mass", R.DiagonalMassMatrixTuner(50, 1.5, 50, 50))):
+    for name, mt, ess_iters in (("identity_mass", R.IdentityMassMatrixTuner(), max(K, a.ess_iters)),
+                                ("default_diag_mass", R.DiagonalMassMatrixTuner(50, 1.5, 50, 50), max(K, a.ess_iters_mass))):
         if a.no_ess:
             break
         e_dt, e_draws, e_stats, _ = leg(ess_iters, ess_warm, mt)

@@ -1035,7 +1035,42 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
       long long k = r0 + lane;
-#if RH_GRAD_PIPELINE
+#if RH_GRAD_PIPELINE == 2
+      // rolling pipeline: tile u's registers are reloaded for the next chunk as soon as tile u has been consumed, so every load
+      // has the other U-1 tiles' arithmetic to land behind and no second buffer is needed.  The chunk loop runs on the
+      // wave-uniform base row (scalar branch, scalar base + lane offset addressing into the global address space).
+      {
+        typedef const double __attribute__((address_space(1))) *gcol_t;
+        gcol_t gp[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) gp[j] = (gcol_t)cp[j];
+        long long kb = r0;   // wave-uniform
+        if (kb + chunk <= r1) {
+          double c[U][NC];
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) c[u][j] = gp[j][kb + 64LL * u + lane];
+          for (;;) {
+            const long long kn = kb + chunk;
+            const bool more = kn + chunk <= r1;
+            const long long kl = (more ? kn : kb) + lane;   // the last chunk reloads itself: no branch around the loads
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+              for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < NC; j++) c[u][j] = gp[j][kl + 64LL * u];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            kb = kn;
+            if (!more) break;
+          }
+        }
+        k = kb + lane;
+      }
+#elif RH_GRAD_PIPELINE
       // software pipeline: the loads of tile i+1 are in flight while tile i is consumed
       if (k + 64LL * (U - 1) < r1) {
         double cn[U][NC];
@@ -1108,6 +1143,13 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
 #ifndef RH_GRAD_WAVES
 #define RH_GRAD_WAVES 1
 #endif
+RH_DEV void rh_grad_map(const int b, const int nsplit, const int xcd_aware, int &split, int &group) {
+  if (xcd_aware && (nsplit % 8) == 0) {
+    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
+    split = xcd + 8 * (idx % spx);
+    group = idx / spx;
+  } else { split = b % nsplit; group = b / nsplit; }
+}
 // returns the first chain of the workgroup's chain group, or -1 when there is nothing to do for it (no chain waits for a gradient)
 template <bool COHERENT>
 RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ active, double *partial,
@@ -1117,11 +1159,7 @@ RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__re
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0; // re-armed for the tick kernel that follows in stream order
   int split;
-  if (xcd_aware && (nsplit % 8) == 0) {
-    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
-    split = xcd + 8 * (idx % spx);
-    group = idx / spx;
-  } else { split = b % nsplit; group = b / nsplit; }
+  rh_grad_map(b, nsplit, xcd_aware, split, group);
   const int chain0 = group * RH_GRAD_K;
   if (chain0 >= chains) return -1;
   bool any = false;
@@ -1926,6 +1964,9 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
           for (int kk = 0; kk < K; kk++)
             if (lane == 0 && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + gdone] = accA[kk];
         };
+        // (A software-pipelined walk -- index column two tiles ahead, the other columns and the table entries one ahead -- was
+        //  measured in round 3: 162 VGPRs = three wavefronts per SIMD instead of four, 3.37 ms against 3.16-3.21 ms for cfg 5.  The
+        //  walk is bound by its arithmetic, not by the two trips to memory per tile; the plain loop stays.)
         for (int base = r0; base < r1; base += 64) {
           const int r = base + lane;
           const bool live = r < r1;
@@ -2156,35 +2197,24 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 // All but one of the L gradient requests of a static-HMC trajectory are followed by `twoFullSteps` (LeapFrog.scala:175-184):
 //   p += eps * grad;  q += eps * velocity(p)
 // -- a dozen flops per chain for which the tick engine paid a kernel launch (rh_tick_kernel's fast path: ~15 us + the gap, 6 % of a
-// cfg-2 leapfrog step).  rh_grad_fused_kernel is rh_grad_kernel plus an epilogue: every workgroup publishes its partial sums
-// (release fence), bumps its chain group's arrival counter, and the LAST of the group's nsplit workgroups combines the partials
-// and advances the group's RH_GRAD_K chains itself -- all of them at once, 64 / RH_GRAD_K lanes per chain -- and publishes the
-// next q.  The next gradient launch follows directly; the host issues a tick only where a trajectory ends (engine.cpp).
+// cfg-2 leapfrog step).  rh_grad_fused_kernel is rh_grad_kernel with that update as its PROLOGUE: every workgroup of a chain group
+// combines the partial sums the PREVIOUS launch left (visible at the kernel boundary: nothing crosses XCDs inside a launch, no
+// counter, no fence), advances the group's RH_GRAD_K chains itself -- all of them at once, 64 / RH_GRAD_K lanes per chain, each
+// workgroup of the group redundantly and identically -- and walks its row split at the NEW q, which never goes through memory.
+// The chains' advanced (q, p, g, logp, counters) go into a small per-chain RECORD (written by the group's split-0 workgroup); the
+// main state image is not touched, so no workgroup can read what another one of the same launch has written: launch n reads
+// partial sums and records of launch n-1 and writes its own (two buffers each, alternating).  Where the trajectory ends the host
+// issues rh_absorb_kernel (record -> state image) and the ordinary tick.  (Round 3 first tried the update as an EPILOGUE run by
+// the last workgroup of a group to arrive: the hand-off of the partial sums between XCDs cost what the launch cost)
 // Bit-identical chains by construction: the splits are summed in the very order rh_combine_targets uses (per-slot ascending sums,
 // then the 64-slot xor butterfly -- its upper levels happen between a lane's own registers here, the lower ones between the lanes
 // of the chain's group; IEEE addition commutes), the same generated finish() / data-free row() code runs on the sums, and the
 // update is spelled as wv_axpy / rh_velocity spell it (multiply, round, add, round; contraction off).  A chain that is not in
-// that state (or a Lookup error) is left alone: it stays `active`, its gradient is recomputed identically by the next launch
-// and consumed by the next tick.  Memory-side: agent-scope release / acquire fences around a relaxed atomic counter -- the
-// partials cross XCDs (each XCD has its own L2) through the Infinity Cache.
+// that state (or a Lookup error) is left alone: its q does not move, its gradient is recomputed identically and the next tick
+// consumes it.
 #if RH_NROWTARGETS > 0 && !RH_HAS_GATHER && !RH_BIGN && !RH_WITH_DENSE && !RH_WITH_NUTS && RH_PACK_L == 64 && RH_SLOTS == 1
-#if (RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8 || RH_GRAD_K == 16) && (RH_NVARS * RH_GRAD_K <= 64)
+#if (RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8 || RH_GRAD_K == 16) && (RH_NVARS * RH_GRAD_K <= 64) && !RH_BIGTH
 #define RH_HAVE_FUSED 1
-// How the partial sums cross from the workgroups that wrote them (any XCD, each with its own L2) to the group's last workgroup:
-//   RH_FUSE_SYNC 2 (default): agent-scope write-through stores / loads that bypass the XCD-local L2 (sc1), ordered by the counter
-//                 atomic and s_waitcnt -- no cache-wide operation at all;
-//   RH_FUSE_SYNC 1: plain stores, an agent-scope RELEASE fence (buffer_wbl2) per workgroup and an ACQUIRE fence (buffer_inv: the
-//                 whole L2 of that XCD) in the last workgroup of every chain group.
-#ifndef RH_FUSE_SYNC
-#define RH_FUSE_SYNC 2
-#endif
-RH_DEV double rh_fused_load(const double *p) {
-#if RH_FUSE_SYNC == 2
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  return *p;
-#endif
-}
 template <int T>
 RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *partial, const long long *nrows, const int nsplit,
                                       const int chain, const int chains, const int j, double (&tot)[RH_NOUT], int &err) {
@@ -2197,14 +2227,18 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
       constexpr int NA = TG::NACC > 0 ? TG::NACC : 1, M = RH_GRAD_K, LPC = 64 / RH_GRAD_K;
       double S[NA];
       double r[NA][M];  // r[o][m]: slot j + LPC * m of the 64-slot butterfly rh_combine_targets runs over the splits, output o
-      // splits 0..63: one address per slot (clamped: every lane loads, the surplus is masked after the load), the outputs at fixed
-      // offsets from it; all NA * M loads are in flight together
+      // splits 0..63: one address per slot (clamped: every lane of a slot row that has a split at all loads, the surplus is masked
+      // after the load), the outputs at fixed offsets from it; all the loads are in flight together
 #pragma unroll
       for (int m = 0; m < M; m++) {
         const int sp = j + LPC * m, spc = sp < nsplit ? sp : nsplit - 1;
         const double *pm = partial + (((size_t)TG::ROWT * nsplit + spc) * chains + chain) * RH_NACC_MAX;
 #pragma unroll
-        for (int o = 0; o < NA; o++) r[o][m] = rh_fused_load(pm + o);
+        for (int o = 0; o < NA; o++) r[o][m] = 0.0;
+        if (LPC * m < nsplit) {   // wave-uniform: with 16 splits and 8 lanes per chain only m = 0, 1 touch memory
+#pragma unroll
+          for (int o = 0; o < NA; o++) r[o][m] = pm[o];
+        }
       }
 #pragma unroll
       for (int m = 0; m < M; m++) {
@@ -2219,7 +2253,7 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
           if (sp < nsplit) {
             const double *pm = partial + (((size_t)TG::ROWT * nsplit + sp) * chains + chain) * RH_NACC_MAX;
 #pragma unroll
-            for (int o = 0; o < NA; o++) r[o][m] += rh_fused_load(pm + o);
+            for (int o = 0; o < NA; o++) r[o][m] += pm[o];
           }
         }
       }
@@ -2246,105 +2280,152 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
   }
 }
 
-// what the epilogue needs of the chains' state: loaded by EVERY workgroup right after its partial sums are stored, so that these
-// loads share the one memory round trip the stores need anyway and the group's last workgroup has a single dependent round
-// trip left after the counter -- the partial sums themselves (the tail of the launch is pure latency: every step counts)
-struct rh_fused_pre {
-  int pc, need, ts_i, ts_l, identity, sampling, cerr;
-  double eps, bq, bp, mm;
-  rh_i64 n_grad, n_leap, n_warm;
-};
-RH_DEV void rh_fused_prefetch(rh_fused_pre &f, const rh_u64 *state, const int chains, const int chain0, const int lane) {
-  constexpr int LPC = 64 / RH_GRAD_K;
-  const int kk = lane / LPC, j = lane & (LPC - 1);
-  const int chain = chain0 + kk < chains ? chain0 + kk : chains - 1;
-  const rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
-  const rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
-  const int jc = j < RH_NVARS ? j : 0;
-  f.pc = (int)(rh_i64)sc[RH_SI_pc]; f.need = (int)(rh_i64)sc[RH_SI_need_eval];
-  f.ts_i = (int)(rh_i64)sc[RH_SI_ts_i]; f.ts_l = (int)(rh_i64)sc[RH_SI_ts_l];
-  f.identity = (int)(rh_i64)sc[RH_SI_mass_identity]; f.sampling = (int)(rh_i64)sc[RH_SI_sampling_started];
-  f.cerr = (int)(rh_i64)sc[RH_SI_err];
-  f.eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
-  f.n_grad = (rh_i64)sc[RH_SI_n_grad]; f.n_leap = (rh_i64)sc[RH_SI_n_leapfrog]; f.n_warm = (rh_i64)sc[RH_SI_n_warm_leapfrog];
-  f.bq = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + jc]);
-  f.bp = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + jc]);
-  f.mm = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS) * 64 + jc]);
-}
-RH_DEV void rh_fused_epilogue(const rh_fused_pre &f, const rh_model_data &d, rh_u64 *state, double *qbuf, const double *partial,
-                              const int chains, const int nsplit, const int chain0, const int lane) {
+
+// the per-chain record of the fused launches, in 8-byte words: q, p, g (RH_NVARS each), then
+#define RH_REC_LOGP (3 * RH_NVARS)
+#define RH_REC_TSI (3 * RH_NVARS + 1)
+#define RH_REC_ERR (3 * RH_NVARS + 2)
+#define RH_REC_NGRAD (3 * RH_NVARS + 3)
+#define RH_REC_NLEAP (3 * RH_NVARS + 4)
+#define RH_REC_NWARM (3 * RH_NVARS + 5)
+#define RH_REC_VALID (3 * RH_NVARS + 6)
+#define RH_REC_U64 (3 * RH_NVARS + 8)
+
+// Prologue: the K chains' parameter vectors for this launch.  rec_in = the records of the previous launch (nullptr: the previous
+// launch was a plain one and the state image is current), partial_in = its partial sums.
+RH_DEV void rh_fused_prologue(double (&thk)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const double *__restrict__ q,
+                              const rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec_in, rh_u64 *__restrict__ rec_out, const double *__restrict__ partial_in,
+                              const int chains, const int nsplit, const int chain0, const int lane, const bool writer) {
   constexpr int LPC = 64 / RH_GRAD_K;
   const int kk = lane / LPC, j = lane & (LPC - 1), base = lane & ~(LPC - 1);
   const bool exists = chain0 + kk < chains;
   const int chain = exists ? chain0 + kk : chains - 1;
-  rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
-  rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
-  const bool fast = exists && f.pc == RH_S_TS_MID && f.need != 0 && f.ts_i < f.ts_l;
-  if (!__any(fast)) return;
-  const bool identity = f.identity != 0, live = j < RH_NVARS;
-  double bq = live ? f.bq : 0.0, bp = live ? f.bp : 0.0;
-  const double mm = live ? f.mm : 0.0, eps = f.eps;
-  double th[RH_NTH];
-#pragma unroll
-  for (int i = 0; i < RH_NTH; i++) th[i] = __shfl(bq, base + i, 64);
-  double tot[RH_NOUT];
-#pragma unroll
-  for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
-  int err = 0;
-  rh_combine_targets_packed<0>(th, partial, d.nrows, nsplit, chain, chains, j, tot, err);
-  const double logp = tot[0];
-  double g = 0.0;
-#pragma unroll
-  for (int i = 0; i < RH_NVARS; i++) g = (j == i) ? tot[1 + i] : g;
-  // RH_S_TS_MID with ts_i < ts_l:  BU = -logp; Bg = grad;  wv_axpy(Bp, eps, Bg);  rh_new_qs: wv_axpy(Bq, eps, velocity(Bp))
-  bp += eps * g;
-  const double vel = identity ? bp : bp * mm;
-  bq += eps * vel;
-#pragma unroll
-  for (int off = LPC / 2; off >= 1; off >>= 1) err |= __shfl_xor(err, off, 64);
-  if (fast && live) {
-    qbuf[(size_t)chain * RH_NVARS + j] = bq;
-    st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(bq);
-    st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(bp);
-    st[(size_t)(RH_VI_Bg * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(g);
-    st[(size_t)(RH_VI_pend_g * RH_SLOTS) * 64 + j] = (rh_u64)__double_as_longlong(g);
+  const rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
+  const rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+  const bool live = j < RH_NVARS;
+  const int jc = live ? j : 0;
+  // what never changes between two ticks
+  const int pc = (int)(rh_i64)sc[RH_SI_pc], need = (int)(rh_i64)sc[RH_SI_need_eval], ts_l = (int)(rh_i64)sc[RH_SI_ts_l];
+  const bool identity = (rh_i64)sc[RH_SI_mass_identity] != 0, sampling = (rh_i64)sc[RH_SI_sampling_started] != 0;
+  const double eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
+  const double mm = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_M * RH_SLOTS) * 64 + jc]);
+  // what the fused launches advance: from the previous launch's record if it left a valid one, else from the state image
+  const rh_u64 *ri = rec_in ? rec_in + (size_t)chain * RH_REC_U64 : nullptr;
+  const bool from_rec = ri != nullptr && ri[RH_REC_VALID] != 0;
+  double bq, bp, g_old, logp_old;
+  int ts_i, cerr;
+  rh_i64 n_grad, n_leap, n_warm;
+  if (from_rec) {
+    bq = __longlong_as_double((rh_i64)ri[jc]); bp = __longlong_as_double((rh_i64)ri[RH_NVARS + jc]);
+    g_old = __longlong_as_double((rh_i64)ri[2 * RH_NVARS + jc]); logp_old = __longlong_as_double((rh_i64)ri[RH_REC_LOGP]);
+    ts_i = (int)(rh_i64)ri[RH_REC_TSI]; cerr = (int)(rh_i64)ri[RH_REC_ERR];
+    n_grad = (rh_i64)ri[RH_REC_NGRAD]; n_leap = (rh_i64)ri[RH_REC_NLEAP]; n_warm = (rh_i64)ri[RH_REC_NWARM];
+  } else {
+    bq = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + jc]);
+    bp = __longlong_as_double((rh_i64)st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + jc]);
+    g_old = 0.0; logp_old = 0.0;
+    ts_i = (int)(rh_i64)sc[RH_SI_ts_i]; cerr = (int)(rh_i64)sc[RH_SI_err];
+    n_grad = (rh_i64)sc[RH_SI_n_grad]; n_leap = (rh_i64)sc[RH_SI_n_leapfrog]; n_warm = (rh_i64)sc[RH_SI_n_warm_leapfrog];
   }
-  if (fast && j == 0) {
-    sc[RH_SI_BU] = (rh_u64)__double_as_longlong(logp * -1); sc[RH_SI_pend_logp] = (rh_u64)__double_as_longlong(logp);
-    sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(f.ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)(f.cerr | err);
-    sc[RH_SI_n_grad] = (rh_u64)(f.n_grad + 1);
-    if (f.sampling) sc[RH_SI_n_leapfrog] = (rh_u64)(f.n_leap + 1); else sc[RH_SI_n_warm_leapfrog] = (rh_u64)(f.n_warm + 1);
+  if (!live) { bq = 0.0; bp = 0.0; }
+  const bool fast = exists && pc == RH_S_TS_MID && need != 0 && ts_i < ts_l;
+  bool valid = from_rec;
+  if (__any(fast)) {
+    double th[RH_NTH];
+#pragma unroll
+    for (int i = 0; i < RH_NTH; i++) th[i] = __shfl(bq, base + i, 64);
+    double tot[RH_NOUT];
+#pragma unroll
+    for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+    int err = 0;
+    rh_combine_targets_packed<0>(th, partial_in, d.nrows, nsplit, chain, chains, j, tot, err);
+    double g = 0.0;
+#pragma unroll
+    for (int i = 0; i < RH_NVARS; i++) g = (j == i) ? tot[1 + i] : g;
+#pragma unroll
+    for (int off = LPC / 2; off >= 1; off >>= 1) err |= __shfl_xor(err, off, 64);
+    if (fast) {
+      // RH_S_TS_MID with ts_i < ts_l:  BU = -logp; Bg = grad;  wv_axpy(Bp, eps, Bg);  rh_new_qs: wv_axpy(Bq, eps, velocity(Bp))
+      if (live) {
+        bp += eps * g;
+        const double vel = identity ? bp : bp * mm;
+        bq += eps * vel;
+      }
+      g_old = g; logp_old = tot[0];
+      ts_i += 1; cerr |= err; n_grad += 1;
+      if (sampling) n_leap += 1; else n_warm += 1;
+      valid = true;
+    }
   }
+  if (writer && exists) {
+    rh_u64 *ro = rec_out + (size_t)chain * RH_REC_U64;
+    if (live && valid) {
+      ro[j] = (rh_u64)__double_as_longlong(bq); ro[RH_NVARS + j] = (rh_u64)__double_as_longlong(bp);
+      ro[2 * RH_NVARS + j] = (rh_u64)__double_as_longlong(g_old);
+    }
+    if (j == 0) {
+      ro[RH_REC_LOGP] = (rh_u64)__double_as_longlong(logp_old);
+      ro[RH_REC_TSI] = (rh_u64)(rh_i64)ts_i; ro[RH_REC_ERR] = (rh_u64)(rh_i64)cerr;
+      ro[RH_REC_NGRAD] = (rh_u64)n_grad; ro[RH_REC_NLEAP] = (rh_u64)n_leap; ro[RH_REC_NWARM] = (rh_u64)n_warm;
+      ro[RH_REC_VALID] = valid ? 1 : 0;
+    }
+  }
+  // the row walk reads its parameters from scalar registers: lane `kk * LPC + i` holds chain kk's q[i].  A chain the fused launches
+  // have not advanced is evaluated where its last tick asked for it (qbuf), as rh_grad_kernel would.
+  if (!valid) bq = q[(size_t)chain * RH_NVARS + jc];
+#pragma unroll
+  for (int k2 = 0; k2 < RH_GRAD_K; k2++)
+#pragma unroll
+    for (int i = 0; i < RH_NTH; i++) thk[k2][i] = rh_readlane(bq, k2 * LPC + i);
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
-rh_grad_fused_kernel(const rh_model_data d, double *q, const int *__restrict__ active, double *partial,
-                     int *__restrict__ err_out, int *__restrict__ n_running, rh_u64 *state, int *group_cnt,
+rh_grad_fused_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active, const double *__restrict__ partial_in,
+                     double *__restrict__ partial_out, int *__restrict__ err_out, int *__restrict__ n_running,
+                     const rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec_in, rh_u64 *__restrict__ rec_out,
                      const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
-  int group;
-  const int chain0 = rh_grad_body<RH_FUSE_SYNC == 2>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
-  if (chain0 < 0) return;   // the same for every workgroup of the group: nobody counts
-  const int lane = threadIdx.x;
-  rh_fused_pre pre;
-  rh_fused_prefetch(pre, state, chains, chain0, lane);   // in flight together with the partial-sum stores
-#if RH_FUSE_SYNC == 2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's write-through partial sums have reached memory before it is counted
-#else
-  // release ONLY (L2 write-back of this workgroup's partial sums, no invalidate): an acquire here would drop the XCD's L2 -- the
-  // row tiles every other workgroup of the XCD is still streaming -- once per workgroup (measured: +95 us per launch)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-  int last = 0;
-  if (lane == 0) last = (__hip_atomic_fetch_add(&group_cnt[group], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1) ? 1 : 0;
-  if (!__builtin_amdgcn_readfirstlane(last)) return;
-  if (lane == 0) __hip_atomic_store(&group_cnt[group], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (nobody waits for it)
-#if RH_FUSE_SYNC == 2
-  asm volatile("" ::: "memory");   // the loads below bypass the local L2 (sc1) and follow the counter in program order
-#else
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' partial sums: only the group's last workgroup invalidates
-#endif
-  rh_fused_epilogue(pre, d, state, q, partial, chains, nsplit, chain0, lane);
+  const int lane = threadIdx.x, b = blockIdx.x;
+  if (b == 0 && lane == 0) *n_running = 0;
+  int split, group;
+  rh_grad_map(b, nsplit, xcd_aware, split, group);
+  const int chain0 = group * RH_GRAD_K;
+  if (chain0 >= chains) return;
+  bool any = false;
+#pragma unroll
+  for (int kk = 0; kk < RH_GRAD_K; kk++) any = any || (active[(chain0 + kk < chains) ? chain0 + kk : chains - 1] != 0);
+  if (!any) return;
+  double th[RH_GRAD_K][RH_NTH];
+  rh_fused_prologue(th, d, q, state, rec_in, rec_out, partial_in, chains, nsplit, chain0, lane, split == 0);
+  int err = 0;
+  rh_grad_targets<0, false>(th, d, lane, split, nsplit, chain0, chains, partial_out, err);
+  if (err && lane == 0) atomicOr(err_out, 1);
+}
+
+// records -> state image, before the tick that ends a trajectory (one wavefront per chain; a chain without a valid record is
+// left as it is).  What the ordinary tick would have stored after each of the fused updates (rh_tick_kernel, RH_S_TS_MID).
+extern "C" __global__ void __launch_bounds__(64)
+rh_absorb_kernel(rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec, double *__restrict__ qbuf, const int chains) {
+  const int chain = blockIdx.x, j = threadIdx.x;
+  if (chain >= chains) return;
+  const rh_u64 *ri = rec + (size_t)chain * RH_REC_U64;
+  if (ri[RH_REC_VALID] == 0) return;
+  rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
+  rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+  if (j < RH_NVARS) {
+    const rh_u64 q = ri[j], p = ri[RH_NVARS + j], g = ri[2 * RH_NVARS + j];
+    qbuf[(size_t)chain * RH_NVARS + j] = __longlong_as_double((rh_i64)q);
+    st[(size_t)(RH_VI_Bq * RH_SLOTS) * 64 + j] = q;
+    st[(size_t)(RH_VI_Bp * RH_SLOTS) * 64 + j] = p;
+    st[(size_t)(RH_VI_Bg * RH_SLOTS) * 64 + j] = g;
+    st[(size_t)(RH_VI_pend_g * RH_SLOTS) * 64 + j] = g;
+  }
+  if (j == 0) {
+    const double logp = __longlong_as_double((rh_i64)ri[RH_REC_LOGP]);
+    sc[RH_SI_BU] = (rh_u64)__double_as_longlong(logp * -1); sc[RH_SI_pend_logp] = ri[RH_REC_LOGP];
+    sc[RH_SI_ts_i] = ri[RH_REC_TSI]; sc[RH_SI_err] = ri[RH_REC_ERR];
+    sc[RH_SI_n_grad] = ri[RH_REC_NGRAD]; sc[RH_SI_n_leapfrog] = ri[RH_REC_NLEAP]; sc[RH_SI_n_warm_leapfrog] = ri[RH_REC_NWARM];
+  }
 }
 #endif
 #endif

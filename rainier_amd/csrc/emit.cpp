@@ -1228,7 +1228,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
   I.gather_mode = gmode; I.n_shared = (int)n_shared; I.grad_k = grad_k; I.nacc_max = nacc_max; I.glm_target = glm_target; I.glm_small = glm_small;
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << grad_k << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
-    << "\n#define RH_GRAD_PIPELINE " << (o.grad_pipeline ? 1 : 0) << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
+    << "\n#define RH_GRAD_PIPELINE " << o.grad_pipeline << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
   if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) " << (o.fast_log ? "rh_fast_log(x)" : "log(x)") << "\n";

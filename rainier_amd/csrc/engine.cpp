@@ -152,7 +152,8 @@ struct rh_model {
   bool loaded = false;
   hipModule_t module = nullptr;
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
-  hipFunction_t k_grad_fused = nullptr;  // rh_grad_kernel + the mid-trajectory leapfrog update as its epilogue (static HMC); absent when the model does not qualify
+  hipFunction_t k_grad_fused = nullptr;  // rh_grad_kernel + the mid-trajectory leapfrog update as its prologue (static HMC); absent when the model does not qualify
+  hipFunction_t k_absorb = nullptr;      // the fused launches' per-chain records -> state image, before the tick that ends a trajectory
   int grad_w = 8, ncols_max = 0, glm_ncols = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
@@ -198,7 +199,9 @@ struct rh_sampler {
   // tick engine
   bool tick_engine = false;
   int nsplit = 0, xcd_aware = 1;
-  void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr, *d_groupcnt = nullptr;
+  void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
+  void *d_partial2 = nullptr, *d_rec[2] = {nullptr, nullptr};  // fused launches: the second partial-sum buffer and the two record buffers (alternating)
+  int pp = 0;                                                   // which of the two the next launch writes
   bool fuse = false;  // static HMC on the plain gradient kernel: mid-trajectory updates run as the gradient launch's epilogue
   std::vector<hipEvent_t> ev;
   GatherBufs *gb = nullptr;
@@ -210,7 +213,7 @@ namespace {
 
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
-  if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e);
   if (const char *e = std::getenv("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
@@ -221,7 +224,10 @@ void assemble_source(rh_model *m) {
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
     int ncols_max = 1;
     for (auto &T : m->prog.targets) ncols_max = std::max<int>(ncols_max, (int)T.n_cols);
-    if (m->eopt.grad_unroll <= 0) m->eopt.grad_unroll = std::max(1, std::min(4, 16 / ncols_max));
+    // rolling pipeline: a load has the other U-1 tiles' arithmetic to land behind, so U is 8 where the row values fit
+    // (measured on cfg 2, profiles/r3_a_cfg2/sweep.txt: U 6..16 within 1 %, U = 4 is 4 % slower)
+    if (m->eopt.grad_unroll <= 0)
+      m->eopt.grad_unroll = m->eopt.grad_pipeline == 2 ? std::max(1, std::min(8, 32 / ncols_max)) : std::max(1, std::min(4, 16 / ncols_max));
   }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
   m->nacc_max = m->info.nacc_max;
@@ -291,6 +297,7 @@ void load_module(rh_model *m) {
     HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
     // compiled only for models whose chain group fits one wavefront's lanes (RH_HAVE_FUSED in rh_engine.hip.h)
     if (hipModuleGetFunction(&m->k_grad_fused, m->module, "rh_grad_fused_kernel") != hipSuccess) { m->k_grad_fused = nullptr; (void)hipGetLastError(); }
+    if (hipModuleGetFunction(&m->k_absorb, m->module, "rh_absorb_kernel") != hipSuccess) { m->k_absorb = nullptr; m->k_grad_fused = nullptr; (void)hipGetLastError(); }
   }
   m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
@@ -913,7 +920,9 @@ int default_nsplit(const rh_model *m, int chains) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   int64_t max_rows = 1;
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
-  int nsplit = (int)std::max<int64_t>(1, (4096 + ngroups - 1) / ngroups);
+  // the generic kernel with the rolling row loop hides its loads inside the wavefront: 2 wavefronts per SIMD in ONE round
+  // (2048) beat 4096 in 1.33 rounds of three (profiles/r3_a_cfg2/sweep.txt)
+  int nsplit = (int)std::max<int64_t>(1, ((m->eopt.grad_pipeline == 2 ? 2048 : 4096) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
   if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
@@ -1129,19 +1138,15 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       HIPCHK(hipMemset(s->d_qbuf, 0, sizeof(double) * n * chains));
       HIPCHK(hipMemset(s->d_active, 0, sizeof(int) * chains));
       HIPCHK(hipMemset(s->d_graderr, 0, sizeof(int)));
-      {  // The fused launch (rh_grad_fused_kernel: static HMC's mid-trajectory update as the gradient launch's epilogue) needs the
+      {  // The fused launch (rh_grad_fused_kernel: static HMC's mid-trajectory update as the gradient launch's prologue) needs the
          // base sampler-kernel variant (its state layout is compiled into the gradient module), the plain VALU gradient kernel and
-         // a lock-step sampler.  It is OPT-IN (RH_FUSE=1): measured on cfg 2 the hand-off of the partial sums between XCDs --
-         // write-through stores, a device-scope counter, L2-bypassing loads: four dependent trips to memory at the tail of every
-         // launch -- costs 17.5 us per launch, as much as the tick launch and the gap it removes (11.68 vs 11.52 ms per
-         // iteration on one box; profiles/r3_a_cfg2).  Chains are bit-identical either way (tests/test_gpu_fused.py).
-        bool fuse = m->k_grad_fused && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm && !m->use_lds_grad;
-        const char *e = std::getenv("RH_FUSE");
-        fuse = fuse && e && std::atoi(e) != 0;
+         // a lock-step sampler.  Chains are bit-identical with and without it (tests/test_gpu_fused.py); RH_FUSE=0 turns it off.
+        bool fuse = m->k_grad_fused && m->k_absorb && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm && !m->use_lds_grad;
+        if (const char *e = std::getenv("RH_FUSE")) fuse = fuse && std::atoi(e) != 0;
         if (fuse) {
-          const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
-          HIPCHK(hipMalloc(&s->d_groupcnt, sizeof(int) * ngroups));
-          HIPCHK(hipMemset(s->d_groupcnt, 0, sizeof(int) * ngroups));
+          const size_t rec_bytes = sizeof(uint64_t) * (size_t)(3 * n + 8) * chains;   // RH_REC_U64 (rh_engine.hip.h)
+          HIPCHK(hipMalloc(&s->d_partial2, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
+          for (int k = 0; k < 2; k++) { HIPCHK(hipMalloc(&s->d_rec[k], rec_bytes)); HIPCHK(hipMemset(s->d_rec[k], 0, rec_bytes)); }
           s->fuse = true;
         }
       }
@@ -1159,7 +1164,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
 extern "C" void rh_sampler_destroy(rh_sampler *s) {
   if (!s) return;
   if (s->m) hipSetDevice(s->m->device);
-  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_groupcnt})
+  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_partial2, s->d_rec[0], s->d_rec[1]})
     if (p) hipFree(p);
   for (hipEvent_t e : s->ev) hipEventDestroy(e);
   delete s->gb;
@@ -1174,26 +1179,33 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   rh_model *m = s->m;
   HIPCHK(hipSetDevice(m->device));
   int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
-  auto tick = [&](int fresh, bool reset_counter) {
+  void *pbuf[2] = {s->d_partial, s->d_partial2};
+  auto tick = [&](int fresh, bool reset_counter, void *partial) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     if (m->info.gather_mode) {
       void *args[] = {&m->data, &s->gb->gd, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
-                      &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+                      &s->d_active, &partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
       launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
       return;
     }
     void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
-                    &s->d_active, &s->d_partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+                    &s->d_active, &partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
     launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
   };
-  auto grad = [&]() { launch_grad(m, s->gb, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
-  auto grad_fused = [&]() {   // gradient + the mid-trajectory update of every chain that is in that state (no tick follows)
-    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &s->d_partial, &s->d_graderr, &s->d_running, &s->d_state, &s->d_groupcnt, &chains, &nsplit, &xcd};
+  auto grad = [&](void *partial) { launch_grad(m, s->gb, s->d_qbuf, s->d_active, partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
+  // gradient at the point the PREVIOUS launch's gradient moves every chain to (rh_fused_prologue); no tick between the two
+  auto grad_fused = [&](void *partial_in, void *partial_out, void *rec_in, void *rec_out) {
+    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &partial_in, &partial_out, &s->d_graderr, &s->d_running, &s->d_state, &rec_in, &rec_out,
+                    &chains, &nsplit, &xcd};
     launch(m->k_grad_fused, (unsigned)(((chains + m->grad_k - 1) / m->grad_k) * nsplit), 64, m->stream, args);
+  };
+  auto absorb = [&](void *rec) {
+    void *args[] = {&s->d_state, &rec, &s->d_qbuf, &chains};
+    launch(m->k_absorb, (unsigned)chains, 64, m->stream, args);
   };
   // Static HMC in the sampling phase runs in lock step: every chain was paused at the head of the same iteration, so gradient
   // request j of a trajectory is request j of every chain, and all but the L-th are followed by the plain update the fused
-  // launch performs itself.  (A chain that is out of step anyway is simply served by the next tick: rh_fused_epilogue.)
+  // launch that follows performs itself in its prologue.  (A chain that is out of step anyway is simply served by the next tick.)
   const int L = std::max(1, s->cfg.hmc_steps);
   const bool fuse_now = s->fuse && s->warmed && s->cfg.sampler == RH_SAMPLER_HMC && L > 1;
   long long pos = 0;  // gradient launches since the first tick of this call
@@ -1204,7 +1216,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     remaining_hint = std::max(1, iters * std::max(1, s->cfg.hmc_steps));
   }
   HIPCHK(hipEventRecord(s->e0, m->stream));
-  tick(s->started ? 0 : 1, true);
+  tick(s->started ? 0 : 1, true, s->d_partial);
   s->started = true;
   HIPCHK(hipEventRecord(s->e1, m->stream));
   for (;;) {
@@ -1218,13 +1230,22 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     const int B = std::min(remaining_hint, 256);
     while ((int)s->ev.size() < 2 * B) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev.push_back(e); }
     HIPCHK(hipEventRecord(s->e0, m->stream));
+    bool pending = false, prev_rec = false;   // the previous launch's gradient has not been consumed by a tick / it left records
     for (int i = 0; i < B; i++) {
       // the last launch of a batch is always followed by a tick: it is the tick that counts the chains still running
-      const bool fused = fuse_now && (int)(pos % L) + 1 < L && i != B - 1;
+      const bool ticked = !(fuse_now && (int)(pos % L) + 1 < L && i != B - 1);
+      const int cur = fuse_now ? s->pp : 0;
       HIPCHK(hipEventRecord(s->ev[2 * i], m->stream));
-      if (fused) grad_fused(); else grad();
+      if (pending) grad_fused(pbuf[cur ^ 1], pbuf[cur], prev_rec ? s->d_rec[cur ^ 1] : nullptr, s->d_rec[cur]);
+      else grad(pbuf[cur]);
       HIPCHK(hipEventRecord(s->ev[2 * i + 1], m->stream));
-      if (!fused) tick(0, false);
+      prev_rec = pending;
+      if (ticked) {
+        if (prev_rec) absorb(s->d_rec[cur]);
+        tick(0, false, pbuf[cur]);
+      }
+      pending = !ticked;
+      if (fuse_now) s->pp ^= 1;
       pos++;
     }
     HIPCHK(hipEventRecord(s->e1, m->stream));

@@ -121,7 +121,7 @@ struct EmitOptions {
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
-  bool grad_pipeline = false;  // software-pipelined row loop in the batched gradient kernel  // row-loop unroll of the batched gradient kernel (0 = default)
+  int grad_pipeline = 2;  // row loop of the batched gradient kernel: 0 plain, 1 double-buffered, 2 rolling (a tile's registers are reloaded as soon as it is consumed)
 };
 
 // What the engine needs to know about the lowered program (besides the source text)

@@ -1,9 +1,11 @@
 """The mid-trajectory leapfrog update fused into the gradient launch (rh_grad_fused_kernel, csrc/device/rh_engine.hip.h): static
-HMC in the sampling phase issues ONE launch per leapfrog step instead of gradient + tick (opt-in, RH_FUSE=1: measured, it does not
-pay on MI355X -- DESIGN 3.2).  The chains must not change by a bit against the default schedule -- the epilogue sums the row splits in the tick kernel's order and applies
-`twoFullSteps` (sampler/LeapFrog.scala:175-184) as the automaton spells it -- and, through it, against everything the tick
-engine is already checked against: tests/test_gpu_parity.py::test_tick_engine_matches_chain_engine_and_oracle runs static
-HMC on the tick engine, i.e. through this path, against the oracle's chains and the chain-per-wavefront engine."""
+HMC in the sampling phase issues ONE launch per leapfrog step instead of gradient + tick -- the update runs as the PROLOGUE of the
+next gradient launch, on the partial sums the previous launch left, and the advanced chains live in per-chain records until the
+tick that ends the trajectory.  The chains must not change by a bit against the two-launch schedule (RH_FUSE=0) --
+the prologue sums the row splits in the tick kernel's order and applies `twoFullSteps` (sampler/LeapFrog.scala:175-184) as the
+automaton spells it -- and, through it, against everything the tick engine is already checked against:
+tests/test_gpu_parity.py::test_tick_engine_matches_chain_engine_and_oracle runs static HMC on the tick engine, i.e. through this
+path, against the oracle's chains and the chain-per-wavefront engine."""
 import numpy as np
 import pytest
 
@@ -37,12 +39,12 @@ def test_fused_launches_leave_the_chains_bit_identical(build, tuner, monkeypatch
     mt = R.IdentityMassMatrixTuner() if tuner == "identity" else R.DiagonalMassMatrixTuner(10, 1.5, 5, 5)
     cfg = R.make_config(9, 40, R.HMCSampler(7), R.DualAvgTuner(0.8), mt, engine=_capi.ENGINE_TICK)
     seeds = [500 + c for c in range(21)]          # 21 chains: a ragged last chain group for every K
-    monkeypatch.setenv("RH_FUSE", "1")                # opt-in: it does not pay on MI355X (engine.cpp)
-    fused = _run(m, cfg, seeds)
+    fused = _run(m, cfg, seeds)                       # the default schedule
     assert fused[3] == "rh_grad_fused_kernel"
     pieces = _run(m, cfg, seeds, pieces=[2, 1, 6])    # rh_sampler_run called piecewise: every call starts a fresh lock-step schedule
-    monkeypatch.delenv("RH_FUSE")
+    monkeypatch.setenv("RH_FUSE", "0")
     plain = _run(m, cfg, seeds)
+    monkeypatch.delenv("RH_FUSE")
     assert plain[3] == "rh_grad_kernel"
     for got in (fused, pieces):
         assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1]) and got[2] == plain[2]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for the bench command (cfg 2, dominant kernel rh_grad_kernel) at the current HEAD:
+# rocprofv3 evidence for the bench command (cfg 2, dominant kernel rh_grad_fused_kernel) at the current HEAD:
 #   1. `--kernel-trace --stats` summary of `python bench.py --steps 20 --warmup 5`  -> kernel_stats.csv
 #   2. separate `--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ instruction mix | SQ busy/wait | TCC hit/miss), as the
 #      guide prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with runtime traces)
@@ -20,8 +20,8 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM
   f=$(find $O/p$i -name "bench_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/p$i/bench_counter_collection.csv
 done
 SHA=$(python -c "import json;print(json.load(open('$O/bench_noprof.json'))['config']['generated_source_sha16'])")
-python $R/profiles/summarize.py rh_grad_kernel 256 $O/pmc_grad_kernel.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 \
+python $R/profiles/summarize.py rh_grad_fused_kernel 256 $O/pmc_grad_kernel.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 \
   --meta git_head=$HEAD generated_source_sha16=$SHA rows=1000000 chains_per_gpu=1024 > $O/summary.txt 2>&1
-python $R/profiles/summarize.py rh_tick_kernel 256 $O/pmc_tick_kernel.json $O/p3 $O/p4 --meta git_head=$HEAD >> $O/summary.txt 2>&1
+python $R/profiles/summarize.py rh_tick_kernel 16 $O/pmc_tick_kernel.json $O/p3 $O/p4 --meta git_head=$HEAD >> $O/summary.txt 2>&1
 rm -rf $O/stats $O/p?/[!bl]* $O/p? 2>/dev/null
 tail -30 $O/summary.txt | head -5; cat $O/kernel_stats.csv | head -6; cut -c1-300 $O/bench_noprof.json
