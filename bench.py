@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # MI355X public FP64 vector peak (not in the local guide)
-TRAFFIC_PROFILE = "r3_a_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
+TRAFFIC_PROFILE = "r3_b_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
 
 
 def cpu_baseline(spec, L, seconds_budget=20.0):
@@ -232,10 +232,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
     ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
-    ap.add_argument("--ess-iters", type=int, default=5120,
+    ap.add_argument("--ess-iters", type=int, default=8192,
                     help="timed draws per chain of the identity-mass ESS leg: static HMC with L=32 resonates on this posterior "
-                         "(autocorrelation time ~97 iterations for log sigma under identity mass, ~42 under the adapted diagonal "
-                         "mass), and R-hat = sqrt(1 + (tau - 1) / n) only falls below 1.01 with n > 4800 resp. 2050 draws per chain")
+                         "(R-hat = sqrt(1 + (tau - 1) / n) with tau - 1 ~ 140 iterations under identity mass, ~ 42 under the "
+                         "adapted diagonal mass, measured), so R-hat only falls below 1.01 with n > 7000 resp. 2100 draws per chain")
+    ap.add_argument("--ess-multi", action="store_true", help="run the ESS legs on every rank at N > 1 too")
     ap.add_argument("--ess-iters-mass", type=int, default=2560, help="timed draws per chain of the DefaultConfig-mass ESS leg")
     ap.add_argument("--ess-warmup", type=int, default=384)
     ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
@@ -311,14 +312,15 @@ def main():
     total_steps = steps_local * world
     # ESS/s legs, independent of the driver's --steps/--warmup.  The chains start from N(0,1) draws and the posterior is 7e-4 wide:
     # they need a few hundred iterations to get there, and a static L=32 trajectory is ~5 periods of this posterior long, so a
-    # chain's draws are strongly autocorrelated (log sigma: tau ~ 97 iterations under identity mass, ~ 42 under the adapted mass,
-    # measured): R-hat = sqrt(1 + (tau - 1) / n) falls below 1.01 only with n > 4800 resp. 2050 draws per chain.  Trace.autocorrelation (core/Trace.scala:93-109) sums lags < min(n, 100).  Two configurations: the bench's (identity
+    # chain's draws are strongly autocorrelated (tau - 1 ~ 140 iterations under identity mass, ~ 42 under the adapted mass,
+    # measured): R-hat = sqrt(1 + (tau - 1) / n) falls below 1.01 only with n > 7000 resp. 2100 draws per chain.  The legs run at
+    # N = 1 only (every rank would repeat the same two minutes; --ess-multi forces them).  Trace.autocorrelation (core/Trace.scala:93-109) sums lags < min(n, 100).  Two configurations: the bench's (identity
     # mass) and DefaultConfig's windowed diagonal mass adaptation (sampler/Sampler.scala:24-25) with the same static L.
     ess_warm = max(W, a.ess_warmup)
     ess_runs = {}
     for name, mt, ess_iters in (("identity_mass", R.IdentityMassMatrixTuner(), max(K, a.ess_iters)),
                                 ("default_diag_mass", R.DiagonalMassMatrixTuner(50, 1.5, 50, 50), max(K, a.ess_iters_mass))):
-        if a.no_ess:
+        if a.no_ess or (world > 1 and not a.ess_multi):
             break
         e_dt, e_draws, e_stats, _ = leg(ess_iters, ess_warm, mt)
         if rank == 0:
