@@ -1531,108 +1531,6 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 }
 #pragma clang fp contract(off)
 
-// ---- the same model with ONE CHAIN PER LANE and the row values in SCALAR registers (rh_grad_glmv_kernel) ---------------------------
-// On MI355X the fp64 matrix instructions run on the fp64 vector datapath (profiles/r1_c: no overlap with fp64 VALU work) and
-// v_mfma_f64_16x16x4_f64 delivers 0.66 x the plain FMA rate (profiles/r3_d_fp64_mfma): the MFMA kernel above pays 670 cycles per 64
-// evaluations for its two contractions where 2 x 51 FMAs would pay 444.  What the matrix instruction buys is operand reuse -- any
-// layout that spreads (row, chain) pairs over the lanes needs an LDS read per FMA.  This kernel gets the reuse from the scalar
-// unit instead: a wavefront owns 64 chains, one per lane, with that chain's coefficients and gradient sums in vector registers
-// (2 x 51 doubles: exactly what two wavefronts per SIMD can hold), and walks the rows four at a time; a row's values are the same
-// for every lane, so they are scalar-loaded (s_load, one request per 4 rows x 1 column from a row-blocked copy of the columns,
-// x4[block][column][4]) and enter the FMAs as SGPR operands.  No LDS, no barrier, no cross-lane traffic until the final store.
-#ifndef RH_GLMV_R
-#define RH_GLMV_R 4
-#endif
-#if RH_FP_CONTRACT
-#pragma clang fp contract(fast)
-#endif
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-rh_grad_glmv_kernel(const rh_model_data d, const double *__restrict__ x4, const double *__restrict__ x4b, const double *__restrict__ q,
-                    const int *__restrict__ active, double *__restrict__ partial, int *__restrict__ err_out,
-                    int *__restrict__ n_running, const int chains, const int nsplit, const int xcd_aware) {
-  rh_lk_init();
-  typedef rh_glm<RH_GLM_TARGET> GL;
-  typedef rh_target<RH_GLM_TARGET> TG;
-  constexpr int P = GL::P, NC = GL::NCOLS, R = RH_GLMV_R;
-  const int lane = threadIdx.x, b = blockIdx.x;
-  if (b == 0 && lane == 0) *n_running = 0;
-  int split, group;
-  rh_grad_map(b, nsplit, xcd_aware, split, group);
-  const int chain0 = group * 64;
-  if (chain0 >= chains) return;
-  const int chain = chain0 + lane, cl = chain < chains ? chain : chains - 1;
-  const bool mine = chain < chains;
-  if (!__any(mine && active[cl] != 0)) return;
-  double beta[P], G[P];
-#pragma unroll
-  for (int p = 0; p < P; p++) { beta[p] = GL::pred_scale[p] * q[(size_t)cl * RH_NVARS + GL::pred_param[p]]; G[p] = 0.0; }
-  double thu[GL::NTHU > 0 ? GL::NTHU : 1], oth[GL::NOTHER > 0 ? GL::NOTHER : 1];
-#pragma unroll
-  for (int k = 0; k < GL::NTHU; k++) thu[k] = q[(size_t)cl * RH_NVARS + GL::thu_param[k]];
-#pragma unroll
-  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
-  int err = 0;
-  const long long n = d.nrows[RH_GLM_TARGET];
-  const long long nblk = (n + R - 1) / R, per = (nblk + nsplit - 1) / nsplit;
-  long long b0 = (long long)split * per, b1 = b0 + per;
-  if (b0 > nblk) b0 = nblk;
-  if (b1 > nblk) b1 = nblk;
-  for (long long blk = b0; blk < b1; blk++) {
-    const double *xf = x4 + blk * (long long)(NC * R);    // wave-uniform: the loads below are scalar loads
-    const double *xg = x4b + blk * (long long)(NC * R);   // the same block again through a second argument: the backward pass
-                                                          // reloads it (cache hit) instead of keeping 4 x 51 doubles in SGPRs
-    double eta[R], w[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) eta[r] = 0.0;
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      const int col = GL::pred_col[p];
-#pragma unroll
-      for (int r = 0; r < R; r++) eta[r] += (col >= 0 ? xf[col * R + r] : 1.0) * beta[p];
-    }
-    const bool full = (blk + 1) * R <= n;   // wave-uniform; the padding rows of the last block hold zeros
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      double ww = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-      GL::elem(thu, eta[r], [&](int j) { return xf[j * R + r]; }, ww, o, err);
-      const bool ok = full || blk * R + r < n;
-      w[r] = ok ? ww : 0.0;
-#pragma unroll
-      for (int k = 0; k < GL::NOTHER; k++) oth[k] += ok ? o[k] : 0.0;
-    }
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      const int col = GL::pred_col[p];
-#pragma unroll
-      for (int r = 0; r < R; r++) G[p] += (col >= 0 ? xg[col * R + r] : 1.0) * w[r];
-    }
-  }
-  if (mine) {
-    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + chain) * RH_NACC_MAX;
-#pragma unroll
-    for (int p = 0; p < P; p++) out[GL::pred_acc[p]] = G[p];
-#pragma unroll
-    for (int k = 0; k < GL::NOTHER; k++) out[GL::other_acc[k]] = oth[k];
-  }
-  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
-}
-#pragma clang fp contract(off)
-// columns -> x4[block][column][R] (rows past n: zeros); grid: any, one lane per (block, column) pair
-extern "C" __global__ void __launch_bounds__(256)
-rh_pack_rows_kernel(const rh_model_data d, double *__restrict__ x4) {
-  typedef rh_glm<RH_GLM_TARGET> GL;
-  typedef rh_target<RH_GLM_TARGET> TG;
-  constexpr int NC = GL::NCOLS, R = RH_GLMV_R;
-  const long long n = d.nrows[RH_GLM_TARGET], nblk = (n + R - 1) / R;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nblk * NC; i += (long long)gridDim.x * blockDim.x) {
-    // consecutive lanes take consecutive BLOCKS of one column: coalesced reads, 32-byte strided writes
-    const long long blk = i % nblk; const int j = (int)(i / nblk);
-    const double *c = d.cols[TG::COL0 + j];
-#pragma unroll
-    for (int r = 0; r < R; r++) x4[(blk * NC + j) * R + r] = (blk * R + r < n) ? c[blk * R + r] : 0.0;
-  }
-}
-
 // ---- the same contractions on v_mfma_f64_4x4x4_4b_f64 ---------------------------------------------------------------------------
 // Measured on MI355X (tools/ubench/fma64_cycles mfma, profiles/r3_d_fp64_mfma): v_mfma_f64_16x16x4_f64 issues once per 105 cycles
 // and SIMD (19.4 flop/cycle/SIMD; SQ_VALU_MFMA_BUSY_CYCLES counts 64 of them busy), the four-block shape v_mfma_f64_4x4x4_4b_f64

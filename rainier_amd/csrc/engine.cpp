@@ -158,9 +158,6 @@ struct rh_model {
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
   bool glm4 = false;       // k_grad_glm is rh_grad_glm4_kernel (v_mfma_f64_4x4x4_4b_f64, row-major LDS tile)
-  bool glmv = false;       // k_grad_glm is rh_grad_glmv_kernel (one chain per lane, row values in scalar registers; opt-in RH_GLMV=1)
-  hipFunction_t k_pack_rows = nullptr;
-  void *d_x4 = nullptr;    // glmv: the row-blocked copy of the GLM target's columns, x4[block][column][4] (built on first use)
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
@@ -326,20 +323,12 @@ void load_module(rh_model *m) {
     if (want && hipModuleGetFunction(&f4, m->module, "rh_grad_glm4_kernel") == hipSuccess && f4) { m->k_grad_glm = f4; m->glm4 = true; }
     else (void)hipGetLastError();
   }
-  // One chain per lane with the row values in scalar registers (rh_grad_glmv_kernel): opt-in, RH_GLMV=1
-  m->glmv = false;
-  if (m->k_grad_glm && !m->glm_small && !m->glm4) {
-    bool want = false;
-    if (const char *e = std::getenv("RH_GLMV")) want = std::atoi(e) != 0;
-    hipFunction_t fv = nullptr, fp = nullptr;
-    if (want && hipModuleGetFunction(&fv, m->module, "rh_grad_glmv_kernel") == hipSuccess && fv &&
-        hipModuleGetFunction(&fp, m->module, "rh_pack_rows_kernel") == hipSuccess && fp) { m->k_grad_glm = fv; m->k_pack_rows = fp; m->glmv = true; }
-    else (void)hipGetLastError();
-  }
+  // (Round 3 also measured the contractions OFF the matrix pipe -- one chain per lane, row values scalar-loaded as SGPR operands,
+  //  162 VALU instructions per 64 evaluations: 33.9 vs 17.5 ms, bound by scalar-load latency; git 28d5e00, profiles/r3_cfg4.)
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
   {  // one 64-row tile of all columns must fit the CU's LDS (column-major stride 66 | row-major odd stride)
     const size_t tile = m->glm4 ? (size_t)64 * ((size_t)m->glm_ncols | 1u) * sizeof(double) : (size_t)m->glm_ncols * 66u * sizeof(double);
-    if (!m->glm_small && !m->glmv && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
+    if (!m->glm_small && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   }
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   hipDeviceptr_t p; size_t sz;
@@ -758,7 +747,6 @@ extern "C" void rh_model_destroy(rh_model *m) {
     hipSetDevice(m->device);
     for (void *d : m->dev_cols) hipFree(d);
     if (m->d_coltab) hipFree(m->d_coltab);
-    if (m->d_x4) hipFree(m->d_x4);
     for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     for (int v = 1; v < 8; v++)  // [0] aliases the base module
@@ -939,7 +927,6 @@ int default_nsplit(const rh_model *m, int chains) {
   int nsplit = (int)std::max<int64_t>(1, ((m->eopt.grad_pipeline == 2 ? 2048 : 4096) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
-  if (m->k_grad_glm && m->glmv) { const int cg = (chains + 63) / 64; nsplit = (int)std::max<int64_t>(1, (2048 + cg - 1) / cg); }
   if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
   nsplit = ((nsplit + 7) / 8) * 8;
   const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);
@@ -960,15 +947,6 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
   if (m->k_grad_glm && m->glm_small) {
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
     launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
-  } else if (m->k_grad_glm && m->glmv) {
-    if (!m->d_x4) {   // first use: the row-blocked copy of the target's columns
-      const int64_t n = m->data.nrows[m->info.glm_target], nblk = (n + 3) / 4;
-      HIPCHK(hipMalloc(&m->d_x4, std::max<size_t>(8, (size_t)nblk * m->glm_ncols * 4 * sizeof(double))));
-      void *pa[] = {&m->data, &m->d_x4};
-      launch(m->k_pack_rows, 4096, 256, m->stream, pa);
-    }
-    void *va[] = {&m->data, &m->d_x4, &m->d_x4, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
-    launch(m->k_grad_glm, (unsigned)(((chains + 63) / 64) * nsplit), 64, m->stream, va);
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
@@ -1432,7 +1410,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : s->m->glmv ? "rh_grad_glmv_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }
