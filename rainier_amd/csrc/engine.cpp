@@ -162,6 +162,7 @@ struct rh_model {
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
+  bool unroll_auto = false;  // the row-loop unroll was the engine's choice (not the caller's): it may be reduced for a heavy row function
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   // gather mode: per row target (ROWT order) the host copy of the group offsets (rows sorted by table index)
@@ -226,10 +227,33 @@ void assemble_source(rh_model *m) {
     for (auto &T : m->prog.targets) ncols_max = std::max<int>(ncols_max, (int)T.n_cols);
     // rolling pipeline: a load has the other U-1 tiles' arithmetic to land behind, so U is 8 where the row values fit
     // (measured on cfg 2, profiles/r3_a_cfg2/sweep.txt: U 6..16 within 1 %, U = 4 is 4 % slower)
-    if (m->eopt.grad_unroll <= 0)
+    if (m->eopt.grad_unroll <= 0) {
       m->eopt.grad_unroll = m->eopt.grad_pipeline == 2 ? std::max(1, std::min(8, 32 / ncols_max)) : std::max(1, std::min(4, 16 / ncols_max));
+      m->unroll_auto = true;
+    }
   }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
+  if (m->unroll_auto && m->eopt.grad_unroll > 1) {
+    // ... and where the row function is light: the unrolled body is K x U copies of it (cfg 2: 8 x 8 x 9 operations); a heavy row
+    // function brings its own instruction-level parallelism and would only spill (build_code checks what the compiler did).
+    // The weight is read off the code just generated: the statements of the longest row() body.
+    size_t row_ops = 1;
+    for (size_t hr = targets.find("HAS_ROWS = true;"); hr != std::string::npos; hr = targets.find("HAS_ROWS = true;", hr + 1)) {
+      const size_t at = targets.find("void row(", hr);
+      if (at == std::string::npos) break;
+      const size_t end = targets.find("void finish(", at);
+      size_t c = 0;
+      for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
+      row_ops = std::max(row_ops, c);
+    }
+    int by_ops = (int)std::max<size_t>(1, 720 / ((size_t)std::max(1, m->info.grad_k) * row_ops));
+    while (by_ops & (by_ops - 1)) by_ops &= by_ops - 1;   // a power of two
+    if (by_ops < m->eopt.grad_unroll) {
+      m->eopt.grad_unroll = by_ops;
+      defines.clear(); targets.clear();
+      if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
+    }
+  }
   m->nacc_max = m->info.nacc_max;
   m->grad_k = m->info.grad_k;
   m->has_glm = m->info.glm_target >= 0;
@@ -271,9 +295,49 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
+// `.vgpr_spill_count` of kernel `name` from the code object's metadata note (msgpack; a kernel's keys are in alphabetical order, so
+// the first ".vgpr_spill_count" after the ".name" value belongs to the same kernel); -1 when it cannot be found.
+long kernel_vgpr_spills(const std::vector<char> &code, const std::string &name) {
+  auto find = [&](const std::string &needle, size_t from) -> size_t {
+    if (needle.size() > code.size()) return std::string::npos;
+    for (size_t i = from; i + needle.size() <= code.size(); i++)
+      if (std::memcmp(code.data() + i, needle.data(), needle.size()) == 0) return i;
+    return std::string::npos;
+  };
+  auto mstr = [](const std::string &v) {   // msgpack string header + bytes (fixstr | str8)
+    std::string o;
+    if (v.size() < 32) o.push_back((char)(0xa0 | v.size())); else { o.push_back((char)0xd9); o.push_back((char)v.size()); }
+    return o + v;
+  };
+  const size_t at = find(mstr(".name") + mstr(name), 0);
+  if (at == std::string::npos) return -1;
+  const std::string key = mstr(".vgpr_spill_count");
+  const size_t k = find(key, at);
+  if (k == std::string::npos || k + key.size() >= code.size()) return -1;
+  const unsigned char *p = (const unsigned char *)code.data() + k + key.size();
+  const size_t left = code.size() - (k + key.size());
+  if (p[0] <= 0x7f) return p[0];
+  if (p[0] == 0xcc && left >= 2) return p[1];
+  if (p[0] == 0xcd && left >= 3) return (long)p[1] << 8 | p[2];
+  if (p[0] == 0xce && left >= 5) return (long)p[1] << 24 | (long)p[2] << 16 | (long)p[3] << 8 | p[4];
+  return -1;
+}
+
+// A row loop unrolled beyond what the register file holds (a heavy row function x RH_GRAD_K chains x RH_GRAD_U tiles) makes the
+// compiler spill vector registers; such a kernel is slow, and at the extreme (506 VGPRs, 144 of them spilled, 179 scalar spills: a
+// fuzz model at K = U = 8) it was observed to return wrong sums.  The engine does not run a batched gradient kernel that spills:
+// the unroll is halved and the model lowered again until it does not (every variant is cached, so this costs a parse after the
+// first time).
 void build_code(rh_model *m) {
   const char *e = std::getenv("RH_HIPRTC_EXTRA");
-  m->code = build_source(m->arch, m->source, e ? e : "");
+  for (;;) {
+    m->code = build_source(m->arch, m->source, e ? e : "");
+    if (std::getenv("RH_KEEP_UNROLL") || m->eopt.grad_unroll <= 1) return;
+    const long a = kernel_vgpr_spills(m->code, "rh_grad_kernel"), b = kernel_vgpr_spills(m->code, "rh_grad_fused_kernel");
+    if (a <= 0 && b <= 0) return;
+    m->eopt.grad_unroll /= 2;
+    assemble_source(m);
+  }
 }
 
 void load_module(rh_model *m) {
@@ -794,10 +858,12 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
     if (all_cols && ((columns && nrows) || !m.synth_cols.empty())) { std::vector<int64_t> nrows_t; canonicalize(&m, colv.data(), nrows_in.data(), nrows_t); }
     assemble_source(&m);
     m.arch = arch && *arch ? arch : "gfx950";
+    if (code_size) {          // (nullptr: source only -- the CPU suite's host emulation of the generated code)
+      build_code(&m);         // may lower again with a smaller row-loop unroll: the source returned is the one that was compiled
+      *code_size = m.code.size();
+    }
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
-    if (!code_size) return;   // source only (the CPU suite's host emulation of the generated code)
-    build_code(&m);
-    *code_size = m.code.size();
+    if (!code_size) return;
     if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 7) + m.source);
   });
   return rc;

@@ -554,7 +554,7 @@ def test_gather_mode_beyond_the_generic_path_s_parameter_limit():
     assert "#define RH_HAS_GATHER 1\n" in src
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_table_priors(seed):
     """fuzz: a Lookup over 65-139 trailing parameters indexed by a column, with the table's prior folded into the data-free target the
     way the reference's front end leaves it -- standard, a random per-entry shape with per-entry constants (lifted as columns), two
@@ -745,7 +745,7 @@ def test_random_reference_text_models(seed):
         _check(spec, opts, qs, 1e-9)
 
 
-@pytest.mark.parametrize("kind,seed", [("table", s) for s in range(6)] + [("slots", s) for s in range(0, 24, 6)])
+@pytest.mark.parametrize("kind,seed", [("table", s) for s in range(12)] + [("slots", s) for s in range(24)])
 def test_the_gpu_fuzz_models_compile_for_gfx950(kind, seed):
     """tests/test_gpu_fuzz.py runs these seeded models through the kernels; here their generated code goes through hiprtc (which
     cross-compiles without a GPU), lowered WITH the data as rh_model_create would, so that the code objects are in the in-tree kernel
@@ -754,3 +754,19 @@ def test_the_gpu_fuzz_models_compile_for_gfx950(kind, seed):
     for opts in (STRICT, FAST):
         src, size = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), columns=spec.columns, nrows=spec.nrows)
         assert size > 0 and "rh_tick_kernel" in src
+
+
+def test_a_gradient_kernel_that_spills_is_lowered_again_with_a_smaller_unroll():
+    """found by the GPU fuzz (eight-slot model, seed 1): 8 chains x 8 tiles of a 45-statement row function compile to 506 VGPRs with
+    144 spilled, and that kernel returned wrong sums.  The engine (a) picks the unroll from the weight of the generated row function
+    and (b) reads `.vgpr_spill_count` of the batched gradient kernels out of the code object and lowers again with half the unroll
+    until nothing is spilled -- also when the caller asked for the unroll."""
+    import re
+    spec = eight_slot_model(1, n=4096)[0]
+    src, size = _capi.lower_only(spec.rir, _capi.compile_opts(**FAST), columns=spec.columns, nrows=spec.nrows)
+    assert size > 0 and int(re.search(r"#define RH_GRAD_U (\d+)", src).group(1)) <= 2
+    src, size = _capi.lower_only(spec.rir, _capi.compile_opts(grad_unroll=8, grad_chains=8, **FAST), columns=spec.columns, nrows=spec.nrows)
+    assert size > 0 and int(re.search(r"#define RH_GRAD_U (\d+)", src).group(1)) < 8
+    # the bench model keeps its measured shape: 8 chains x 8 tiles of the 11-statement factored row
+    src, _ = _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, **FAST), compile=False)
+    assert "#define RH_GRAD_U 8\n" in src and "#define RH_GRAD_K 8\n" in src
