@@ -187,12 +187,12 @@ def test_rir_header_overflow_is_rejected_before_allocation():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r3_a_cfg2/bench_default.json is the output of `python bench.py` on an MI355X: one JSON line with the keys the
+    """profiles/r3_b_cfg2/bench_default.json is the output of `python bench.py` on an MI355X: one JSON line with the keys the
     driver and the judge read (metric/value/...; roofline{bound, achieved, peak, unit, frac, traffic}; cpu_baseline{...}), the two
     ESS legs with their R-hat, and the inlined GPU figure beside the inlined CPU one."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lines = [l for l in open(os.path.join(root, "profiles", "r3_a_cfg2", "bench_default.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(root, "profiles", "r3_b_cfg2", "bench_default.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -209,7 +209,9 @@ def test_committed_bench_line_honours_the_contract():
     assert c["inlined_sufficient_statistics"]["value"] > 0 and c["nproc"] >= c["cores"]
     assert d["ess_leg"]["warmup"] >= 128 and d["ess_leg"]["iterations"] >= 64 and 0.6 < d["ess_leg"]["mean_accept_prob"] < 0.99
     assert abs(d["value"] - d["config"]["chains"] * d["config"]["leapfrog_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    for leg in ("ess_leg", "ess_leg_default_mass"):
+    assert d["ess_leg"]["converged"] and d["ess_leg"]["rhat_max"] < 1.01       # the leg ess_per_s quotes is a converged run
+    assert r["traffic_source"].startswith("measured in this run") and 0.5 * 32e6 < r["traffic"] < 2 * 32e6   # the 32 MB data set, about once
+    for leg in ("ess_leg", "ess_leg_identity_mass"):
         e = d[leg]
         assert len(e["rhat"]) == len(e["ess"]) == 5 and e["rhat_max"] == max(e["rhat"]) and e["ess_min"] == min(e["ess"])
         assert e["iterations"] >= 1024 and abs(e["ess_per_s"] - e["ess_min"] / e["seconds"]) < 1e-6 * e["ess_per_s"]
