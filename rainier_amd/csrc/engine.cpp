@@ -233,10 +233,11 @@ void assemble_source(rh_model *m) {
     }
   }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
-  if (m->unroll_auto && m->eopt.grad_unroll > 1) {
-    // ... and where the row function is light: the unrolled body is K x U copies of it (cfg 2: 8 x 8 x 9 operations); a heavy row
+  if ((m->unroll_auto && m->eopt.grad_unroll > 1) || (m->eopt.grad_chains == 0 && m->info.grad_k > 1 && !m->info.gather_mode)) {
+    // ... and where the row function is light: the unrolled body is K x U copies of it (cfg 2: 8 x 8 x 11 statements); a heavy row
     // function brings its own instruction-level parallelism and would only spill (build_code checks what the compiler did).
-    // The weight is read off the code just generated: the statements of the longest row() body.
+    // The weight is read off the code just generated: the statements of the longest row() body.  Budget: K x U x statements <= 720;
+    // tiles go first, then chains per wavefront (when the caller left them to the engine).
     size_t row_ops = 1;
     for (size_t hr = targets.find("HAS_ROWS = true;"); hr != std::string::npos; hr = targets.find("HAS_ROWS = true;", hr + 1)) {
       const size_t at = targets.find("void row(", hr);
@@ -246,10 +247,13 @@ void assemble_source(rh_model *m) {
       for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
       row_ops = std::max(row_ops, c);
     }
-    int by_ops = (int)std::max<size_t>(1, 720 / ((size_t)std::max(1, m->info.grad_k) * row_ops));
-    while (by_ops & (by_ops - 1)) by_ops &= by_ops - 1;   // a power of two
-    if (by_ops < m->eopt.grad_unroll) {
-      m->eopt.grad_unroll = by_ops;
+    auto pow2floor = [](size_t v) { size_t p = 1; while (p * 2 <= v) p *= 2; return (int)p; };
+    int k = std::max(1, m->info.grad_k), u = m->eopt.grad_unroll;
+    if (m->eopt.grad_chains == 0 && !m->info.gather_mode && (size_t)k * row_ops > 720) k = std::min(k, pow2floor(std::max<size_t>(1, 720 / row_ops)));
+    if (m->unroll_auto) u = std::min(u, pow2floor(std::max<size_t>(1, 720 / ((size_t)k * row_ops))));
+    if (k != m->info.grad_k || u != m->eopt.grad_unroll) {
+      if (k != m->info.grad_k) m->eopt.grad_chains = k;
+      m->eopt.grad_unroll = u;
       defines.clear(); targets.clear();
       if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
     }
@@ -325,17 +329,22 @@ long kernel_vgpr_spills(const std::vector<char> &code, const std::string &name) 
 
 // A row loop unrolled beyond what the register file holds (a heavy row function x RH_GRAD_K chains x RH_GRAD_U tiles) makes the
 // compiler spill vector registers; such a kernel is slow, and at the extreme (506 VGPRs, 144 of them spilled, 179 scalar spills: a
-// fuzz model at K = U = 8) it was observed to return wrong sums.  The engine does not run a batched gradient kernel that spills:
-// the unroll is halved and the model lowered again until it does not (every variant is cached, so this costs a parse after the
-// first time).
+// fuzz model at K = U = 8; 512 VGPRs, 768 spilled into scratch: another at K = 8, U = 1 in a strict build) the rolling row loop
+// was observed to return wrong sums.  The engine does not run a batched gradient kernel that spills: the unroll, then the number of
+// chains per wavefront, is halved and the model lowered again until it does not (every variant is cached, so this costs a parse
+// after the first time).
 void build_code(rh_model *m) {
   const char *e = std::getenv("RH_HIPRTC_EXTRA");
   for (;;) {
     m->code = build_source(m->arch, m->source, e ? e : "");
-    if (std::getenv("RH_KEEP_UNROLL") || m->eopt.grad_unroll <= 1) return;
+    if (std::getenv("RH_KEEP_UNROLL") || m->info.gather_mode) return;
     const long a = kernel_vgpr_spills(m->code, "rh_grad_kernel"), b = kernel_vgpr_spills(m->code, "rh_grad_fused_kernel");
     if (a <= 0 && b <= 0) return;
-    m->eopt.grad_unroll /= 2;
+    // first fewer tiles per chunk, then fewer chains per wavefront; a row function that spills even alone keeps the plain row loop
+    if (m->eopt.grad_unroll > 1) m->eopt.grad_unroll /= 2;
+    else if (m->info.grad_k > 1) m->eopt.grad_chains = m->info.grad_k / 2;
+    else if (m->eopt.grad_pipeline != 0) m->eopt.grad_pipeline = 0;
+    else return;
     assemble_source(m);
   }
 }

@@ -32,12 +32,12 @@ def _random_expr(rng, g, leaves, depth):
     return g.lookup(a.compare(b), [a, a + b, b * 0.5], -1)          # a select on a row-level compare
 
 
-def table_prior_model(seed):
+def table_prior_model(seed, npoints=2, per_range=(2, 6)):
     """a Lookup over 65-139 trailing parameters indexed by a column, with the table's prior folded into the data-free target the way
     the reference's front end leaves it (mode = seed % 4: standard | random per-entry shape with per-entry constants | two terms per
     entry | tied to a shared parameter, the centred parameterisation); returns (spec, finite evaluation points, mode)"""
     rng = np.random.default_rng(90000 + seed)
-    G, per = int(rng.integers(65, 140)), int(rng.integers(2, 6))
+    G, per = int(rng.integers(65, 140)), int(rng.integers(*per_range))
     n, nsh = G * per, int(rng.integers(2, 4))
     P = nsh + G
     site = rng.permutation(np.repeat(np.arange(G), per)).astype(float); x = rng.normal(size=n); y = rng.normal(size=n)
@@ -64,11 +64,11 @@ def table_prior_model(seed):
     r = g.col(1, 2) - (th[0] + th[1] * g.col(1, 1) + g.lookup(g.col(1, 0), th[nsh:], 0))
     spec = ModelSpec("fuzz_table_prior_%d" % seed, g.compile([prior, r * r * -0.5]), [site, x, y], [0, n], P, {})
     d = O.OracleDensity(spec)
-    qs = [q for q in rng.normal(size=(6, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:2]
+    qs = [q for q in rng.normal(size=(3 * npoints, P)) * 0.5 if np.all(np.isfinite(d.update(q)))][:npoints]
     return spec, qs, mode
 
 
-def eight_slot_model(seed, n=48):
+def eight_slot_model(seed, n=48, npoints=3):
     """a random expression as the per-observation term of an 8-slot Model.observe-shaped target (with a derived column per slot),
     gradient by the authoring DSL; returns (spec, finite evaluation points)"""
     rng = np.random.default_rng(1000 + seed)
@@ -89,5 +89,19 @@ def eight_slot_model(seed, n=48):
     val = val + th[0] * th[1] * 8.0                                     # a shared, parameter-only term (8 copies merged)
     spec = ModelSpec("fuzz_%d" % seed, g.compile([val]), cols, [n], P, {})
     d = O.OracleDensity(spec)
-    qs = [q for q in rng.normal(size=(6, P)) * 0.6 if np.all(np.isfinite(d.update(q)))][:3]
+    qs = [q for q in rng.normal(size=(2 * npoints, P)) * 0.6 if np.all(np.isfinite(d.update(q)))][:npoints]
     return spec, qs
+
+
+# the cases tests/test_gpu_fuzz.py runs through the kernels (tests/test_emitter_host.py cross-compiles the same ones for gfx950)
+GPU_FUZZ_CASES = ([("table", s, dict(npoints=5)) for s in range(8)] +                             # 2-5 rows per group: segmented scan
+                  [("table", s, dict(npoints=5, per_range=(64, 80))) for s in range(4)] +          # >= 64 rows per group: two-accumulator walk
+                  [("slots", s, dict(n=(4096, 1000, 70)[s % 3], npoints=11)) for s in range(12)])  # full / ragged / tiny row counts, ragged chain groups
+
+
+def gpu_fuzz_case(kind, seed, kw):
+    """-> (spec, evaluation points, mode | None)"""
+    if kind == "table":
+        return table_prior_model(seed, **kw)
+    spec, qs = eight_slot_model(seed, **kw)
+    return spec, qs, None

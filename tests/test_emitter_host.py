@@ -188,7 +188,7 @@ def test_gather_mode_row_code():
     assert "lk_g" in src
 
 
-from tests.fuzz_models import _random_expr, eight_slot_model, table_prior_model  # noqa: E402
+from tests.fuzz_models import GPU_FUZZ_CASES, _random_expr, eight_slot_model, gpu_fuzz_case, table_prior_model  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -745,12 +745,12 @@ def test_random_reference_text_models(seed):
         _check(spec, opts, qs, 1e-9)
 
 
-@pytest.mark.parametrize("kind,seed", [("table", s) for s in range(12)] + [("slots", s) for s in range(24)])
-def test_the_gpu_fuzz_models_compile_for_gfx950(kind, seed):
+@pytest.mark.parametrize("kind,seed,kw", GPU_FUZZ_CASES, ids=["%s-%d-%s" % (k, s, "-".join(str(v) for v in kw.values())) for k, s, kw in GPU_FUZZ_CASES])
+def test_the_gpu_fuzz_models_compile_for_gfx950(kind, seed, kw):
     """tests/test_gpu_fuzz.py runs these seeded models through the kernels; here their generated code goes through hiprtc (which
     cross-compiles without a GPU), lowered WITH the data as rh_model_create would, so that the code objects are in the in-tree kernel
     cache when the GPU tier runs"""
-    spec = table_prior_model(seed)[0] if kind == "table" else eight_slot_model(seed, n=4096)[0]
+    spec = gpu_fuzz_case(kind, seed, kw)[0]
     for opts in (STRICT, FAST):
         src, size = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), columns=spec.columns, nrows=spec.nrows)
         assert size > 0 and "rh_tick_kernel" in src
