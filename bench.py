@@ -160,7 +160,7 @@ def live_traffic(a, kernel):
              "--grad-unroll", str(a.grad_unroll), "--grad-splits", str(a.grad_splits)]
     child += (["--strict"] if a.strict else []) + (["--no-factor"] if a.no_factor else [])
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR"):
         env.pop(k, None)
     kb, n_used = {}, {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -442,7 +442,8 @@ def main():
     # for 16 B/lane loads and these are 8 B/lane, so the read side is 1-2x this figure).
     prof = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     live = None
-    if world == 1 and not a.no_live_traffic:
+    profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))   # this run is under rocprofv3 itself
+    if world == 1 and not a.no_live_traffic and not profiled:
         live, how = live_traffic(a, tim["dominant_kernel"])
         out["roofline"]["traffic_source"] = how
         if live is not None:
