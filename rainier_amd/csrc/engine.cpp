@@ -162,6 +162,7 @@ struct rh_model {
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
+  int n_row_targets_hint = 0; // row targets of the lowered program (known before the module is loaded)
   bool unroll_auto = false;  // the row-loop unroll was the engine's choice (not the caller's): it may be reduced for a heavy row function
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
@@ -233,6 +234,8 @@ void assemble_source(rh_model *m) {
     }
   }
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
+  m->n_row_targets_hint = 0;
+  for (const auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets_hint++;
   if ((m->unroll_auto && m->eopt.grad_unroll > 1) || (m->eopt.grad_chains == 0 && m->info.grad_k > 1 && !m->info.gather_mode)) {
     // ... and where the row function is light: the unrolled body is K x U copies of it (cfg 2: 8 x 8 x 11 statements); a heavy row
     // function brings its own instruction-level parallelism and would only spill (build_code checks what the compiler did).
@@ -338,6 +341,15 @@ void build_code(rh_model *m) {
   for (;;) {
     m->code = build_source(m->arch, m->source, e ? e : "");
     if (std::getenv("RH_KEEP_UNROLL") || m->info.gather_mode) return;
+    // the chain-per-wavefront kernels walk the rows with RH_ROWS_UNROLL copies of the row function per iteration: the same rule (a
+    // fuzz model whose rh_density_kernel held 459 VGPRs with 640 spilled faulted at unroll 4 and is right at 2 and 1; the unroll
+    // does not change a lane's summation order, so the results are the same bits)
+    if (m->n_row_targets_hint > 0 && m->eopt.rows_unroll > 1 &&
+        (kernel_vgpr_spills(m->code, "rh_density_kernel") > 0 || kernel_vgpr_spills(m->code, "rh_chain_kernel") > 0)) {
+      m->eopt.rows_unroll /= 2;
+      assemble_source(m);
+      continue;
+    }
     const long a = kernel_vgpr_spills(m->code, "rh_grad_kernel"), b = kernel_vgpr_spills(m->code, "rh_grad_fused_kernel");
     if (a <= 0 && b <= 0) return;
     // first fewer tiles per chunk, then fewer chains per wavefront; a row function that spills even alone keeps the plain row loop
