@@ -7,7 +7,7 @@
 #      bench.py only quotes `roofline.traffic` from a profile of byte-identical code.
 # usage (from the repo root, via gpurun): bash tools/pmc_cfg2.sh <git-head> [outdir-name]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r3_a_cfg2}
+R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r3_b_cfg2}
 O=$R/gpurun_out/$NAME; mkdir -p $O
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ess --no-inlined --no-live-traffic"
 $BENCH > $O/bench_noprof.json 2> $O/bench_noprof.err
