@@ -14,6 +14,7 @@
 // For the README regression this turns 6 outputs x ~20 fp64 ops per row into 5 basis sums (r*r, r, r*x_k) x 9 ops.
 // Rows are still streamed for every evaluation (no data-only sums are hoisted: every basis term involves the
 // parameters or is consumed as a product with one that does); only rounding changes, so it is a fast-mode option.
+#include <stdexcept>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -387,7 +388,11 @@ struct TargetEmitter {
       }
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n]) continue;
-        if (P.nodes[n].dep == 0) { const std::vector<uint32_t> rr = row_roots(); if (std::find(rr.begin(), rr.end(), (uint32_t)n) != rr.end()) want((uint32_t)n); continue; }
+        if (P.nodes[n].dep == 0) {   // a parameter-only row root: a basis term, or the scatter value of a table that enters with a parameter-only adjoint
+          const std::vector<uint32_t> rr = row_roots();
+          if (std::find(rr.begin(), rr.end(), (uint32_t)n) != rr.end() || (gather.ok && n == gather.sv)) want((uint32_t)n);
+          continue;
+        }
         operands(P.nodes[n], ops);
         for (uint32_t o : ops) want(o);
       }
@@ -660,7 +665,12 @@ struct TargetEmitter {
       if (nd.input < P.n_params) return "th[" + std::to_string(nd.input) + "]";
       return "c[" + std::to_string(nd.input - P.targets[t].input_start) + "]";
     }
-    if (ctx != 0 && has_rows() && nd.dep == 0) return "inv[" + std::to_string(inv_slot.at(id)) + "]";
+    if (ctx != 0 && has_rows() && nd.dep == 0) {
+      auto it = inv_slot.find(id);
+      if (it == inv_slot.end()) throw std::out_of_range("emit: parameter-only node " + std::to_string(id) + " (op " + std::to_string((int)nd.op) +
+                                                         ") of target " + std::to_string(t) + " is used in context " + std::to_string(ctx) + " but has no invariant slot");
+      return "inv[" + std::to_string(it->second) + "]";
+    }
     return "n" + std::to_string(id);
   }
   // fast mode only: division by a finite non-zero constant becomes a multiplication by its reciprocal (<= 1 ulp apart)

@@ -19,6 +19,7 @@
 // data-free expression over one entry -- Model.observe's one-row initial chunk -- becomes a one-row target).  Everything here
 // runs in rh_model_create's loader (engine.cpp load_program), before the data-dependent passes; synthesised columns follow the
 // caller's.
+#include <stdexcept>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,17 @@
 #include "../../include/rainier_hip_rir.h"
 #include "device/rh_shared.h"
 #include "rir.hpp"
+
+namespace {
+// std::map::at with the caller's line in the message (an internal invariant that did not hold: the model is then loaded without the lift)
+template <class M, class K>
+auto &map_at(M &m, const K &k, int line) {
+  auto it = m.find(k);
+  if (it == m.end()) throw std::out_of_range("lift.cpp:" + std::to_string(line) + ": node is not in the member's map");
+  return it->second;
+}
+}  // namespace
+#define MAP_AT(m, k) map_at(m, k, __LINE__)
 
 namespace rh {
 namespace {
@@ -179,7 +191,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
       bool differs = false;
       const double v0 = P.nodes[kv.first].cval;
       for (size_t g = 1; g < members.size() && !differs; g++) {
-        const double v = P.nodes[maps[g].at(kv.first)].cval;
+        const double v = P.nodes[MAP_AT(maps[g], kv.first)].cval;
         differs = std::memcmp(&v, &v0, 8) != 0;
       }
       if (differs) slots.push_back(kv.first);
@@ -235,7 +247,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
       for (auto &kv : m1[0]) {   // (a parameter may have several INPUT nodes)
         if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
         for (size_t g = 1; g < ok1.size() && !varies[P.nodes[kv.first].input]; g++)
-          varies[P.nodes[kv.first].input] = P.nodes[m1[g].at(kv.first)].input != P.nodes[kv.first].input;
+          varies[P.nodes[kv.first].input] = P.nodes[MAP_AT(m1[g], kv.first)].input != P.nodes[kv.first].input;
       }
       for (auto &kv : m1[0]) {
         if (P.nodes[kv.first].op != RH_RIR_INPUT) continue;
@@ -258,13 +270,13 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
         std::vector<char> in_sg(np, 0);
         bool ok = true;
         for (size_t j = 0; j < pslots.size() && ok; j++) {
-          const uint32_t q = P.nodes[memo.at(pslots[j])].input;
+          const uint32_t q = P.nodes[MAP_AT(memo, pslots[j])].input;
           if (in_sg[q] || fixed_param[q]) { ok = false; break; }   // one parameter in two roles: its gradient is a sum, not a slot
-          for (uint32_t x : pnodes[j]) if (P.nodes[memo.at(x)].input != q) ok = false;
+          for (uint32_t x : pnodes[j]) if (P.nodes[MAP_AT(memo, x)].input != q) ok = false;
           in_sg[q] = 1;
         }
         for (size_t j = 0; j < pslots.size() && ok; j++)
-          ok = match(P, to[1 + P.nodes[pslots[j]].input], go[1 + P.nodes[memo.at(pslots[j])].input], memo, true);
+          ok = match(P, to[1 + P.nodes[pslots[j]].input], go[1 + P.nodes[MAP_AT(memo, pslots[j])].input], memo, true);
         for (uint32_t q = 0; q < np && ok; q++) {
           if (in_sg[q]) { if (!in_s0[q]) ok = is_zero(to[1 + q]); continue; }
           if (in_s0[q]) ok = is_zero(go[1 + q]);
@@ -274,7 +286,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
         for (auto &kv : memo) if (ok && P.nodes[kv.first].op == RH_RIR_INPUT && P.nodes[kv.second].input != P.nodes[kv.first].input) {
           size_t j = 0;
           while (j < pslots.size() && P.nodes[pslots[j]].input != P.nodes[kv.first].input) j++;
-          if (j == pslots.size() || P.nodes[kv.second].input != P.nodes[memo.at(pslots[j])].input) ok = false;
+          if (j == pslots.size() || P.nodes[kv.second].input != P.nodes[MAP_AT(memo, pslots[j])].input) ok = false;
         }
         if (ok) { members.push_back(ok1[k]); maps.push_back(std::move(memo)); }
       }
@@ -295,7 +307,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
       if (slots.size() > 4096) continue;
       ptable.assign(pslots.size(), {});
       for (size_t j = 0; j < pslots.size(); j++) {
-        for (size_t g = 0; g < members.size(); g++) ptable[j].push_back(P.nodes[maps[g].at(pslots[j])].input);
+        for (size_t g = 0; g < members.size(); g++) ptable[j].push_back(P.nodes[MAP_AT(maps[g], pslots[j])].input);
         std::sort(ptable[j].begin(), ptable[j].end());
         ptable[j].erase(std::unique(ptable[j].begin(), ptable[j].end()), ptable[j].end());
       }
@@ -312,7 +324,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
   for (size_t j = 0; j < pslots.size(); j++) {   // index columns: the position of the member's parameter in the slot's table
     std::vector<double> col;
     for (size_t g = 0; g < members.size(); g++)
-      col.push_back((double)(std::lower_bound(ptable[j].begin(), ptable[j].end(), P.nodes[maps[g].at(pslots[j])].input) - ptable[j].begin()));
+      col.push_back((double)(std::lower_bound(ptable[j].begin(), ptable[j].end(), P.nodes[MAP_AT(maps[g], pslots[j])].input) - ptable[j].begin()));
     synth.push_back(col);
   }
   // the new row target: the template's expression with the slot constants replaced by column reads (and the varying parameters by
@@ -477,11 +489,11 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
     if (P.nodes[kv.first].op != RH_RIR_CONST) continue;
     const double v0 = P.nodes[kv.first].cval;
     bool differs = false;
-    for (uint32_t g = 1; g < G && !differs; g++) { const double v = P.nodes[maps[g].at(kv.first)].cval; differs = std::memcmp(&v, &v0, 8) != 0; }
+    for (uint32_t g = 1; g < G && !differs; g++) { const double v = P.nodes[MAP_AT(maps[g], kv.first)].cval; differs = std::memcmp(&v, &v0, 8) != 0; }
     if (differs) slots.push_back(kv.first);
   }
   if (slots.size() > 4096) return no(11);
-  for (uint32_t s : slots) { std::vector<double> col; for (uint32_t g = 0; g < G; g++) col.push_back(P.nodes[maps[g].at(s)].cval); synth.push_back(col); }
+  for (uint32_t s : slots) { std::vector<double> col; for (uint32_t g = 0; g < G; g++) col.push_back(P.nodes[MAP_AT(maps[g], s)].cval); synth.push_back(col); }
   { std::vector<double> col; for (uint32_t g = 0; g < G; g++) col.push_back((double)g); synth.push_back(col); }
   // the row target
   const uint32_t in0 = P.n_inputs;

@@ -770,3 +770,25 @@ def test_a_gradient_kernel_that_spills_is_lowered_again_with_a_smaller_unroll():
     # the bench model keeps its measured shape: 8 chains x 8 tiles of the 11-statement factored row
     src, _ = _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, **FAST), compile=False)
     assert "#define RH_GRAD_U 8\n" in src and "#define RH_GRAD_K 8\n" in src
+
+
+def test_gather_mode_with_a_parameter_only_scatter_value():
+    """found by extended fuzzing (families seed 2039): a table that enters the row term LINEARLY with a parameter-only coefficient has a
+    parameter-only adjoint -- every eq-lookup of its gradient family carries the same invariant g = f(theta), no data in it.  The
+    emitter used to refuse such a model (`map::at`: the scatter value had no invariant slot); it is an ordinary invariant."""
+    rng = np.random.default_rng(12)
+    G, per = 70, 3
+    n = G * per
+    site = rng.permutation(np.repeat(np.arange(G), per)).astype(float); x = rng.normal(size=n)
+    P = 2 + G
+    g = Graph(P, [0, 2])
+    th = [g.param(i) for i in range(P)]
+    prior = th[0] * th[0] * -0.5 + th[1] * th[1] * -0.5
+    for k in range(G):
+        prior = prior + th[2 + k] * th[2 + k] * -0.5
+    coef = (th[0] * 0.3).exp() + th[1] * th[1]                      # parameter-only, not trivial
+    row = coef * g.lookup(g.col(1, 0), th[2:], 0) + th[1] * g.col(1, 1)
+    spec = ModelSpec("gather_param_only_adjoint", g.compile([prior, row]), [site, x], [0, n], P, {})
+    qs = rng.normal(size=(2, P)) * 0.4
+    for opts in (STRICT, FAST):
+        assert "#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-10)
