@@ -2,8 +2,7 @@
 takes a seed, run on [LO, HI) in this process; failures are printed and counted, nothing stops.  No GPU needed (the generated code is
 compiled for the host and compared with the oracle on the original program).
     python tools/host_fuzz_more.py 2000 2100
-Known non-failures: `test_random_families_that_differ_in_a_parameter` reports "the program lifts constants into columns of its own" for
-~3 % of the seeds -- the harness re-loads an already lifted program, which lifts a few more single-entry targets; the product lifts once."""
+(The harness lifts once, as rh_model_create does: an already lifted program is lowered with the loader's lifting passes off.)
 import os
 import sys
 
