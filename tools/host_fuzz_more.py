@@ -2,7 +2,7 @@
 takes a seed, run on [LO, HI) in this process; failures are printed and counted, nothing stops.  No GPU needed (the generated code is
 compiled for the host and compared with the oracle on the original program).
     python tools/host_fuzz_more.py 2000 2100
-(The harness lifts once, as rh_model_create does: an already lifted program is lowered with the loader's lifting passes off.)
+(The harness lifts once, as rh_model_create does: an already lifted program is lowered with the loader's lifting passes off.)"""
 import os
 import sys
 
