@@ -330,3 +330,78 @@ def test_a_row_target_behind_more_than_255_data_free_targets(lib):
     bad = g.compile([g.col(0, 0) * a] + [a * a * -0.5 for _ in range(ntar - 2)] + [g.col(0, 1) * a + g.col(ntar - 1, 0)])
     with pytest.raises(_capi.RainierHipError, match="two targets|another target"):
         _capi.lower_only(bad, compile=False)
+
+
+def _kernel_meta(code: bytes, kernel: str, key: str) -> int:
+    """one integer field of a kernel's metadata in a gfx950 code object (msgpack note; a kernel's keys are in alphabetical order)"""
+    def mstr(v):
+        v = v.encode()
+        return (bytes([0xa0 | len(v)]) if len(v) < 32 else bytes([0xd9, len(v)])) + v
+    at = code.find(mstr(".name") + mstr(kernel))
+    assert at >= 0, kernel
+    # .name sorts before .private_segment_fixed_size / .sgpr_* / .vgpr_*; keys that sort before it belong to the NEXT kernel's map
+    k = code.find(mstr(key), at)
+    assert k >= 0, key
+    p = code[k + len(mstr(key)):]
+    if p[0] <= 0x7f:
+        return p[0]
+    return {0xcc: lambda: p[1], 0xcd: lambda: (p[1] << 8) | p[2], 0xce: lambda: int.from_bytes(p[1:5], "big")}[p[0]]()
+
+
+def test_the_bench_models_gradient_kernels_keep_their_register_budget(tmp_path, monkeypatch):
+    """a guard on what the compiler makes of the cfg-2 build: both batched gradient kernels fit two wavefronts per SIMD with
+    room to spare (<= 200 of 256 VGPRs), spill nothing, use no scratch -- a toolchain or source change that breaks this costs the
+    headline number before any test notices"""
+    import glob
+    monkeypatch.setenv("RH_KERNEL_CACHE", str(tmp_path))
+    from rainier_amd import models
+    src, size = _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, fp_contract=True, factor_outputs=True))
+    assert "#define RH_GRAD_U 8\n" in src and "#define RH_GRAD_PIPELINE 2\n" in src
+    files = glob.glob(str(tmp_path / "*.hsaco"))
+    assert len(files) == 1
+    code = open(files[0], "rb").read()
+    for kernel in ("rh_grad_kernel", "rh_grad_fused_kernel"):
+        assert _kernel_meta(code, kernel, ".vgpr_spill_count") == 0 and _kernel_meta(code, kernel, ".sgpr_spill_count") == 0
+        assert _kernel_meta(code, kernel, ".private_segment_fixed_size") == 0
+        assert 128 < _kernel_meta(code, kernel, ".vgpr_count") <= 200
+    assert _kernel_meta(code, "rh_absorb_kernel", ".vgpr_count") <= 32
+
+
+def test_the_bench_models_row_loop_is_nine_fp64_instructions_per_evaluation(tmp_path, monkeypatch):
+    """the hot loop of cfg 2 at ISA level: per chunk of 8 tiles x 8 chains, 9 fp64 instructions per 64 row-chain
+    evaluations (3 fma for the predictor, the residual, 5 accumulations) and 32 global -- not flat -- loads, no spill traffic"""
+    import glob
+    import re
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    monkeypatch.setenv("RH_KERNEL_CACHE", str(tmp_path))
+    from rainier_amd import models
+    _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, fp_contract=True, factor_outputs=True))
+    dis = subprocess.check_output([objdump, "-d", "--mcpu=gfx950", glob.glob(str(tmp_path / "*.hsaco"))[0]]).decode()
+    body = dis[dis.index("<rh_grad_fused_kernel>:"):]
+    body = body[:body.index("\n\n", 10)] if "\n\n" in body[10:] else body
+    ins = []
+    for line in body.splitlines():
+        m = re.match(r"\s+(\S+)\s+(.*?)\s*//\s*([0-9A-F]+):", line)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    addr = {a: i for i, (a, _, _) in enumerate(ins)}
+    loops = []
+    for i, (a, op, args) in enumerate(ins):
+        if not (op.startswith("s_cbranch") or op == "s_branch"):
+            continue
+        tok = args.split()[-1] if args.split() else ""
+        if not tok.isdigit():
+            continue
+        off = int(tok) - (65536 if int(tok) >= 32768 else 0)
+        tgt = a + 4 + 4 * off
+        if tgt < a and tgt in addr:
+            loops.append([o for _, o, _ in ins[addr[tgt]:i + 1]])
+    fp64 = lambda ops: sum(o.startswith(("v_fma_f64", "v_fmac_f64", "v_add_f64", "v_mul_f64")) for o in ops)   # noqa: E731
+    hot = [ops for ops in loops if fp64(ops) == 8 * 8 * 9]                    # K x U x 9: the chunk loop (innermost: nothing nests in it)
+    assert hot, sorted(fp64(ops) for ops in loops)
+    ops = min(hot, key=len)
+    assert sum(o == "global_load_dwordx2" for o in ops) == 8 * 4 and not any(o.startswith(("flat_load", "scratch_")) for o in ops)
+    assert sum(o.startswith("v_accvgpr") for o in ops) == 0 and len(ops) <= 1.15 * 8 * 8 * 9   # <= 15 % of the loop is not arithmetic
