@@ -126,8 +126,9 @@ def test_headers_are_c_and_library_links_from_c(tmp_path):
     assert "abi 4 header 4" in out
     assert "sizeof rh_config %d rh_chain_stats %d" % (C.sizeof(_capi.Config), C.sizeof(_capi.ChainStats)) in out
     assert "default 1000 1000 sampler 1 ehmc 1024 mass 1 50 1.5" in out          # DefaultConfig, sampler/Sampler.scala:17-27
-    import torch
-    if not torch.cuda.is_available():
+    # (no `import torch` in this process: torch brings its own bundled comgr / LLVM under the system library's soname, and every model
+    #  this process compiled afterwards would be built by that other compiler and land in the shared kernel cache)
+    if not os.path.exists("/dev/kfd"):
         assert "create rc %d devices" % _capi.RH_E_DEVICE in out and "no CPU fallback" in out
 
 
@@ -347,19 +348,29 @@ def _kernel_meta(code: bytes, kernel: str, key: str) -> int:
         return p[0]
     return {0xcc: lambda: p[1], 0xcd: lambda: (p[1] << 8) | p[2], 0xce: lambda: int.from_bytes(p[1:5], "big")}[p[0]]()
 
+def _lower_bench_model_in_a_fresh_process(cache_dir) -> bytes:
+    """the cfg-2 build's code object, compiled by a python process that has loaded nothing but the engine: a process that imported
+    torch first compiles with torch's BUNDLED comgr / LLVM (another ROCm version, loaded under the same soname) and gets different
+    code -- the in-tree cache is filled by build(), which runs without torch"""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "from rainier_amd import _capi, models\n"
+            "src, size = _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, fp_contract=True, factor_outputs=True))\n"
+            "assert '#define RH_GRAD_U 8\\n' in src and '#define RH_GRAD_PIPELINE 2\\n' in src and 'torch' not in sys.modules\n") % root
+    subprocess.check_call([sys.executable, "-c", prog], env=dict(os.environ, RH_KERNEL_CACHE=str(cache_dir)))
+    files = glob.glob(os.path.join(str(cache_dir), "*.hsaco"))
+    assert len(files) == 1
+    return files[0]
+
 
 def test_the_bench_models_gradient_kernels_keep_their_register_budget(tmp_path, monkeypatch):
     """a guard on what the compiler makes of the cfg-2 build: both batched gradient kernels fit two wavefronts per SIMD with
     room to spare (<= 200 of 256 VGPRs), spill nothing, use no scratch -- a toolchain or source change that breaks this costs the
     headline number before any test notices"""
-    import glob
-    monkeypatch.setenv("RH_KERNEL_CACHE", str(tmp_path))
-    from rainier_amd import models
-    src, size = _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, fp_contract=True, factor_outputs=True))
-    assert "#define RH_GRAD_U 8\n" in src and "#define RH_GRAD_PIPELINE 2\n" in src
-    files = glob.glob(str(tmp_path / "*.hsaco"))
-    assert len(files) == 1
-    code = open(files[0], "rb").read()
+    code = open(_lower_bench_model_in_a_fresh_process(tmp_path), "rb").read()
     for kernel in ("rh_grad_kernel", "rh_grad_fused_kernel"):
         assert _kernel_meta(code, kernel, ".vgpr_spill_count") == 0 and _kernel_meta(code, kernel, ".sgpr_spill_count") == 0
         assert _kernel_meta(code, kernel, ".private_segment_fixed_size") == 0
@@ -376,10 +387,7 @@ def test_the_bench_models_row_loop_is_nine_fp64_instructions_per_evaluation(tmp_
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump")
-    monkeypatch.setenv("RH_KERNEL_CACHE", str(tmp_path))
-    from rainier_amd import models
-    _capi.lower_only(models.linreg(n=8, k=3).rir, _capi.compile_opts(grad_chains=8, fp_contract=True, factor_outputs=True))
-    dis = subprocess.check_output([objdump, "-d", "--mcpu=gfx950", glob.glob(str(tmp_path / "*.hsaco"))[0]]).decode()
+    dis = subprocess.check_output([objdump, "-d", "--mcpu=gfx950", _lower_bench_model_in_a_fresh_process(tmp_path)]).decode()
     body = dis[dis.index("<rh_grad_fused_kernel>:"):]
     body = body[:body.index("\n\n", 10)] if "\n\n" in body[10:] else body
     ins = []
