@@ -411,5 +411,7 @@ def test_model_create_host_time_budget():
     tt = best(tab)
     print("model-create host time: cfg 4 as handed over %.2f s, 600-group table through the split %.2f s" % (t4, tt))
     import os
-    slack = 3.0 if os.environ.get("PYTEST_XDIST_WORKER") else 1.0      # the budget is for an otherwise idle host (the driver runs serially)
+    # the budget (2 s / 4 s) is for an otherwise idle host -- measured 0.43 s / 2.83 s at the end of round 3; the assertion leaves
+    # 1.5 x for a busy one (the driver runs the suite serially beside other work), 3 x under xdist
+    slack = 3.0 if os.environ.get("PYTEST_XDIST_WORKER") else 1.5
     assert t4 <= 2.0 * slack and tt <= 4.0 * slack, (t4, tt)
