@@ -233,3 +233,67 @@ def lower_only(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", colum
         L.rh_free(src)
     check(rc)
     return text, size.value
+
+
+def lower_report(rir: bytes, opts: CompileOpts = None, arch: str = "gfx950", columns=None, nrows=None):
+    """lower_only plus what the engine makes of the result (test hook, no device): returns (source, report) where report is
+    {"shape": {attempts, rows_unroll, grad_unroll, grad_k, chain_waves, ...}, "kernels": {(tag, kernel): {vgprs, sgprs, vgpr_spills,
+    sgpr_spills, scratch, fit, why}}} -- tag "base" or "variantN"; fit = the engine would launch it (csrc/engine.cpp kernel_health)."""
+    L = lib()
+    L.rh_lower_report_data.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64), C.POINTER(CompileOpts),
+                                       C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+    src, size, rep = C.c_char_p(), C.c_size_t(0), C.c_void_p()
+    buf = C.create_string_buffer(rir, len(rir))
+    o = opts if opts is not None else compile_opts()
+    arr = nr = None
+    if columns is not None:
+        cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]
+        arr = (C.POINTER(C.c_double) * max(1, len(cols)))(*[dptr(c) for c in cols])
+        nr = (C.c_int64 * max(1, len(nrows)))(*[int(x) for x in nrows])
+    rc = L.rh_lower_report_data(buf, len(rir), arr, nr, C.byref(o), arch.encode(), C.byref(src), C.byref(size), C.byref(rep))
+    text = src.value.decode() if src.value else ""
+    if src:
+        L.rh_free(src)
+    check(rc)
+    try:
+        return text, parse_report(C.string_at(rep).decode())
+    finally:
+        L.rh_free(rep)
+
+
+def parse_report(text: str):
+    out = {"shape": {}, "kernels": {}}
+    for ln in text.splitlines():
+        head, _, why = ln.partition(" why=")
+        f = head.split()
+        if f and f[0].startswith("attempts="):
+            out["shape"] = {k: int(v) for k, v in (x.split("=") for x in f)}
+            continue
+        kv = dict(x.split("=", 1) for x in f[1:])
+        name = kv.pop("kernel")
+        out["kernels"][(f[0], name)] = dict({k: int(v) for k, v in kv.items()}, why=why)
+    return out
+
+
+def code_object_report(code: bytes):
+    """Every kernel of a code object: registers, spills, scratch, and whether the engine would launch it (test hook)."""
+    L = lib()
+    L.rh_code_object_report.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    rep = C.c_void_p()
+    check(L.rh_code_object_report(code, len(code), C.byref(rep)))
+    try:
+        return parse_report(C.string_at(rep).decode())["kernels"]
+    finally:
+        L.rh_free(rep)
+
+
+def code_object_offsets(code: bytes, kernel: str):
+    """The engine's own instruction walk of one kernel (offsets from the kernel's first byte): checked against llvm-objdump."""
+    L = lib()
+    L.rh_code_object_offsets.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+    offs, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+    check(L.rh_code_object_offsets(code, len(code), kernel.encode(), C.byref(offs), C.byref(n)))
+    try:
+        return [int(offs[i]) for i in range(n.value)]
+    finally:
+        L.rh_free(offs)

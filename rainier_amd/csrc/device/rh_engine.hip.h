@@ -40,6 +40,31 @@ __shared__ double *rh_tot_base;   // the chain's (or the density call's) scratch
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
+// Rows [kb, n) of target T, kb wave-uniform, n - kb arbitrary: every lane takes every step of the (scalar) loop.  A lane whose row
+// lies past the end re-reads the last row -- the addresses stay in bounds, the row function runs with all lanes active -- and
+// its contributions are dropped by a select.  t starts at -0.0, so that `t += x` is x in every bit (x + -0.0 == x also for the
+// zeros), and the live lanes' `acc + t` is the very addition the plain loop performs.
+template <int T, class TH, class INV, class CP, int NA>
+RH_DEV void rh_rows_ragged(const TH &th, const INV &inv, const CP &cp, long long kb, const long long n, const int lane,
+                           double (&acc)[NA], int &err) {
+  typedef rh_target<T> TG;
+  constexpr int NC = TG::NCOLS;
+  for (; kb < n; kb += 64) {
+    const long long k = kb + lane;
+    const bool live = k < n;
+    const long long kc = live ? k : n - 1;
+    double c[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) c[j] = cp[j][kc];
+    double t[NA];
+#pragma unroll
+    for (int o = 0; o < NA; o++) t[o] = -0.0;
+    TG::row(th, inv, c, t, err);   // (a dead lane can only repeat the error of the lane that owns the last row)
+#pragma unroll
+    for (int o = 0; o < NA; o++) acc[o] = live ? acc[o] + t[o] : acc[o];
+  }
+}
+
 template <int T>
 RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data &d, const int lane,
                                  double (&tot)[RH_NOUT], int &err) {
@@ -60,22 +85,21 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
     double acc[NA];
 #pragma unroll
     for (int o = 0; o < NA; o++) acc[o] = 0.0;
-    long long k = lane;
-    for (; k + (long long)RH_LANES * (U - 1) < n; k += (long long)RH_LANES * U) {
+    // The walk runs on a WAVE-UNIFORM base row (scalar loop branches), so the row function always executes with all 64 lanes
+    // active; the ragged end is handled by rh_rows_ragged.  (A lane-strided loop `for (k = lane; k < n; k += 64)` is a divergent
+    // region around the heaviest code of the kernel -- exactly where this toolchain's register allocator puts spill code and
+    // copies ahead of the exec restore: DESIGN 8.5.)  A lane still sums its rows lane, lane + 64, ... in ascending order.
+    long long kb = 0;
+    for (; kb + (long long)RH_LANES * U <= n; kb += (long long)RH_LANES * U) {
       double c[U][NC];
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + (long long)RH_LANES * u];
+        for (int j = 0; j < NC; j++) c[u][j] = cp[j][kb + (long long)RH_LANES * u + lane];
 #pragma unroll
       for (int u = 0; u < U; u++) TG::row(th, inv, c[u], acc, err);
     }
-    for (; k < n; k += RH_LANES) {
-      double c[NC];
-#pragma unroll
-      for (int j = 0; j < NC; j++) c[j] = cp[j][k];
-      TG::row(th, inv, c, acc, err);
-    }
+    rh_rows_ragged<T>(th, inv, cp, kb, n, lane, acc, err);
     rh_wave_sum_all(acc);
     TG::finish(th, inv, acc, (double)n, tot);
   }
@@ -1034,7 +1058,7 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
       for (int kk = 0; kk < K; kk++)
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
-      long long k = r0 + lane;
+      long long kb = r0;   // wave-uniform base row: every loop below branches on scalars, the row code runs with all lanes active
 #if RH_GRAD_PIPELINE == 2
       // rolling pipeline: tile u's registers are reloaded for the next chunk as soon as tile u has been consumed, so every load
       // has the other U-1 tiles' arithmetic to land behind and no second buffer is needed.  The chunk loop runs on the
@@ -1044,7 +1068,6 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
         gcol_t gp[NC];
 #pragma unroll
         for (int j = 0; j < NC; j++) gp[j] = (gcol_t)cp[j];
-        long long kb = r0;   // wave-uniform
         if (kb + chunk <= r1) {
           double c[U][NC];
 #pragma unroll
@@ -1068,57 +1091,68 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
             if (!more) break;
           }
         }
-        k = kb + lane;
       }
 #elif RH_GRAD_PIPELINE
       // software pipeline: the loads of tile i+1 are in flight while tile i is consumed
-      if (k + 64LL * (U - 1) < r1) {
+      if (kb + chunk <= r1) {
         double cn[U][NC];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int j = 0; j < NC; j++) cn[u][j] = cp[j][k + 64LL * u];
+          for (int j = 0; j < NC; j++) cn[u][j] = cp[j][kb + 64LL * u + lane];
         for (;;) {
           double c[U][NC];
 #pragma unroll
           for (int u = 0; u < U; u++)
 #pragma unroll
             for (int j = 0; j < NC; j++) c[u][j] = cn[u][j];
-          const long long kn = k + chunk;
-          const bool more = kn + 64LL * (U - 1) < r1;
+          const long long kn = kb + chunk;
+          const bool more = kn + chunk <= r1;
           if (more) {
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
-              for (int j = 0; j < NC; j++) cn[u][j] = cp[j][kn + 64LL * u];
+              for (int j = 0; j < NC; j++) cn[u][j] = cp[j][kn + 64LL * u + lane];
           }
 #pragma unroll
           for (int u = 0; u < U; u++)
 #pragma unroll
             for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
-          k = kn;
+          kb = kn;
           if (!more) break;
         }
       }
 #else
-      for (; k + 64LL * (U - 1) < r1; k += chunk) {
+      for (; kb + chunk <= r1; kb += chunk) {
         double c[U][NC];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int j = 0; j < NC; j++) c[u][j] = cp[j][k + 64LL * u];
+          for (int j = 0; j < NC; j++) c[u][j] = cp[j][kb + 64LL * u + lane];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
           for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
       }
 #endif
-      for (; k < r1; k += 64) {
+      // the ragged end of the last split: still a scalar loop; a lane past the end re-reads the last row and a select drops its
+      // contributions (see rh_rows_ragged) -- no divergent region around the row code
+      for (; kb < r1; kb += 64) {
+        const long long k = kb + lane;
+        const bool live = k < r1;
+        const long long kc = live ? k : r1 - 1;
         double c[NC];
 #pragma unroll
-        for (int j = 0; j < NC; j++) c[j] = cp[j][k];
+        for (int j = 0; j < NC; j++) c[j] = cp[j][kc];
 #pragma unroll
-        for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c, acc[kk], err);
+        for (int kk = 0; kk < K; kk++) {
+          double t[NA];
+#pragma unroll
+          for (int o = 0; o < NA; o++) t[o] = -0.0;
+          TG::row(RH_THK(th, kk), inv[kk], c, t, err);
+#pragma unroll
+          for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
@@ -2659,3 +2693,9 @@ enum {
   RH_VIDX_COUNT
 };
 extern "C" __device__ __attribute__((used)) const int rh_state_mass_vec = RH_VIDX_M;
+// u64 word offsets, inside a chain's image, of what the engine's create-time self-check reads back after LeapFrog.initialize: the
+// point (Pq), the gradient the sampler kernel computed there (Pg) and PU = -logp.  Element i of a vector sits at offset + i in
+// every layout (lane-distributed slots of 64, packed chains, big mode's in-place vectors).
+extern "C" __device__ __attribute__((used)) const int rh_state_off_Pq = RH_VI_Pq * RH_SLOTS * 64;
+extern "C" __device__ __attribute__((used)) const int rh_state_off_Pg = RH_VI_Pg * RH_SLOTS * 64;
+extern "C" __device__ __attribute__((used)) const int rh_state_off_PU = RH_STATE_U64 - RH_STATE_NSCALAR + RH_SI_PU;

@@ -134,8 +134,11 @@ std::vector<char> compile_hip(const std::string &src, const std::string &arch, c
 
 struct KSet {  // the per-chain sampler kernels of one compiled variant (with / without NUTS support)
   hipModule_t module = nullptr;
-  hipFunction_t k_chain = nullptr, k_tick = nullptr;
+  hipFunction_t k_chain = nullptr, k_tick = nullptr;   // nullptr: absent, or not fit to run (why_chain / why_tick say which)
+  std::string why_chain, why_tick;
   int state_words = 0, dense_off = 0;  // dense_off: u64 word offset of the dense-mass rows in the state image
+  int off_Pq = -1, off_Pg = -1, off_PU = -1;   // u64 word offsets in a chain's image the create-time self-check reads
+  bool chain_checked = false, tick_checked = false;
   bool loaded = false;
 };
 
@@ -182,6 +185,12 @@ struct rh_model {
   int64_t rows_total = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  // what the code object's kernels are fit for (kernel_health): an engine whose kernels are not is never chosen, and an explicit
+  // request for it fails with RH_E_UNSUPPORTED and the reason
+  bool chain_ok = false, density_ok = false, tick_ok = false;
+  std::string chain_why, density_why, tick_why;
+  int compile_attempts = 0;   // code objects built or fetched for this model (re-lowering included)
+  bool selfcheck_done = false;
 };
 
 namespace { struct GatherBufs; }
@@ -271,7 +280,8 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
   defines += "#define RH_GLM_W " + std::to_string(m->glm_w) + "\n";
   if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_CHAIN_WAVES")) defines += "#define RH_CHAIN_WAVES " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = std::max(1, std::atoi(e));
+  defines += "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
@@ -302,57 +312,57 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
-// `.vgpr_spill_count` of kernel `name` from the code object's metadata note (msgpack; a kernel's keys are in alphabetical order, so
-// the first ".vgpr_spill_count" after the ".name" value belongs to the same kernel); -1 when it cannot be found.
-long kernel_vgpr_spills(const std::vector<char> &code, const std::string &name) {
-  auto find = [&](const std::string &needle, size_t from) -> size_t {
-    if (needle.size() > code.size()) return std::string::npos;
-    for (size_t i = from; i + needle.size() <= code.size(); i++)
-      if (std::memcmp(code.data() + i, needle.data(), needle.size()) == 0) return i;
-    return std::string::npos;
-  };
-  auto mstr = [](const std::string &v) {   // msgpack string header + bytes (fixstr | str8)
-    std::string o;
-    if (v.size() < 32) o.push_back((char)(0xa0 | v.size())); else { o.push_back((char)0xd9); o.push_back((char)v.size()); }
-    return o + v;
-  };
-  const size_t at = find(mstr(".name") + mstr(name), 0);
-  if (at == std::string::npos) return -1;
-  const std::string key = mstr(".vgpr_spill_count");
-  const size_t k = find(key, at);
-  if (k == std::string::npos || k + key.size() >= code.size()) return -1;
-  const unsigned char *p = (const unsigned char *)code.data() + k + key.size();
-  const size_t left = code.size() - (k + key.size());
-  if (p[0] <= 0x7f) return p[0];
-  if (p[0] == 0xcc && left >= 2) return p[1];
-  if (p[0] == 0xcd && left >= 3) return (long)p[1] << 8 | p[2];
-  if (p[0] == 0xce && left >= 5) return (long)p[1] << 24 | (long)p[2] << 16 | (long)p[3] << 8 | p[4];
-  return -1;
+// ---- which kernels of a code object the engine agrees to launch ---------------------------------------------------------------
+// A kernel is launched only if (1) its metadata reports NO spilled vector registers and (2) the static check of isacheck.cpp finds
+// no vector instruction ahead of a join block's exec restore.  Both guard against the same fault of this toolchain's register
+// allocator (spill code and live-range copies placed before `s_or_b64 exec, exec, s[a:b]` run under the mask of the region that
+// just ended; root-caused in round 4 on rh_chain_kernel of hier_negbin(6, 7): profiles/r4_spill_rootcause).  A kernel
+// that fails is replaced by a lighter build of itself (row unroll, chains per wavefront, wavefronts per SIMD) or by another engine;
+// when nothing is left the call fails with RH_E_UNSUPPORTED -- it is never run.  RH_ALLOW_UNHEALTHY=1 (diagnostics: reproducing the
+// fault on a GPU) switches the rule off.
+enum { KH_ABSENT = 0, KH_OK = 1, KH_BAD = 2 };
+int kernel_health(const std::vector<char> &code, const std::string &name, std::string *why = nullptr) {
+  rh::KernelMeta km;
+  std::vector<std::string> names;
+  if (!rh::list_kernels(code, names)) { if (why) *why = name + ": the code object cannot be read"; return KH_BAD; }
+  if (std::find(names.begin(), names.end(), name) == names.end()) return KH_ABSENT;
+  if (std::getenv("RH_ALLOW_UNHEALTHY")) return KH_OK;
+  if (!rh::kernel_meta(code, name, km)) { if (why) *why = name + ": no metadata entry (spill count unknown)"; return KH_BAD; }
+  if (km.vgpr_spills != 0) { if (why) *why = name + ": " + std::to_string(km.vgpr_spills) + " spilled vector registers"; return KH_BAD; }
+  std::vector<std::string> findings;
+  if (!rh::check_code_object(code, name, findings) || !findings.empty()) {
+    if (why) *why = findings.empty() ? name + ": machine code could not be walked" : findings[0];
+    return KH_BAD;
+  }
+  return KH_OK;
 }
 
-// A row loop unrolled beyond what the register file holds (a heavy row function x RH_GRAD_K chains x RH_GRAD_U tiles) makes the
-// compiler spill vector registers; such a kernel is slow, and at the extreme (506 VGPRs, 144 of them spilled, 179 scalar spills: a
-// fuzz model at K = U = 8; 512 VGPRs, 768 spilled into scratch: another at K = 8, U = 1 in a strict build) the rolling row loop
-// was observed to return wrong sums.  The engine does not run a batched gradient kernel that spills: the unroll, then the number of
-// chains per wavefront, is halved and the model lowered again until it does not (every variant is cached, so this costs a parse
-// after the first time).
+// Lower, compile, look at what the compiler did, and lower again with a lighter shape while a kernel the model would launch is
+// not fit to run (every attempt is cached under its own key, so this costs a parse after the first time; the attempts are counted
+// in m->compile_attempts).  What is still unfit afterwards is recorded by load_module (m->chain_ok, m->tick_ok, ...).
 void build_code(rh_model *m) {
   const char *e = std::getenv("RH_HIPRTC_EXTRA");
+  const bool keep = std::getenv("RH_KEEP_UNROLL") != nullptr;
   for (;;) {
     m->code = build_source(m->arch, m->source, e ? e : "");
-    if (std::getenv("RH_KEEP_UNROLL") || m->info.gather_mode) return;
-    // the chain-per-wavefront kernels walk the rows with RH_ROWS_UNROLL copies of the row function per iteration: the same rule (a
-    // fuzz model whose rh_density_kernel held 459 VGPRs with 640 spilled faulted at unroll 4 and is right at 2 and 1; the unroll
-    // does not change a lane's summation order, so the results are the same bits)
-    if (m->n_row_targets_hint > 0 && m->eopt.rows_unroll > 1 &&
-        (kernel_vgpr_spills(m->code, "rh_density_kernel") > 0 || kernel_vgpr_spills(m->code, "rh_chain_kernel") > 0)) {
+    m->compile_attempts++;
+    if (keep) return;
+    auto bad = [&](const char *k) { return kernel_health(m->code, k) == KH_BAD; };
+    if (m->info.gather_mode) {   // K chains per wavefront x ~14 wave-uniform doubles each: fewer chains is the only lever
+      if (bad("rh_grad_gather_kernel") && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; assemble_source(m); continue; }
+      return;
+    }
+    // the chain-per-wavefront kernels walk the rows with RH_ROWS_UNROLL copies of the row function per iteration (the unroll does
+    // not change a lane's summation order, so the results are the same bits)
+    if (m->n_row_targets_hint > 0 && m->eopt.rows_unroll > 1 && (bad("rh_density_kernel") || bad("rh_chain_kernel"))) {
       m->eopt.rows_unroll /= 2;
       assemble_source(m);
       continue;
     }
-    const long a = kernel_vgpr_spills(m->code, "rh_grad_kernel"), b = kernel_vgpr_spills(m->code, "rh_grad_fused_kernel");
-    if (a <= 0 && b <= 0) return;
-    // first fewer tiles per chunk, then fewer chains per wavefront; a row function that spills even alone keeps the plain row loop
+    // rh_chain_kernel asks for two wavefronts per SIMD (256 registers: +47 % on cfg 3); a model that does not fit gets one (512)
+    if (bad("rh_chain_kernel") && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) { m->eopt.chain_waves = 1; assemble_source(m); continue; }
+    if (!bad("rh_grad_kernel") && !bad("rh_grad_fused_kernel")) return;
+    // first fewer tiles per chunk, then fewer chains per wavefront; a row function that does not fit even alone keeps the plain row loop
     if (m->eopt.grad_unroll > 1) m->eopt.grad_unroll /= 2;
     else if (m->info.grad_k > 1) m->eopt.grad_chains = m->info.grad_k / 2;
     else if (m->eopt.grad_pipeline != 0) m->eopt.grad_pipeline = 0;
@@ -361,28 +371,48 @@ void build_code(rh_model *m) {
   }
 }
 
+// kernel `name` of `module` if it is fit to run (kernel_health); otherwise nullptr and the reason
+hipFunction_t fit_kernel(const std::vector<char> &code, hipModule_t module, const char *name, std::string *why = nullptr) {
+  std::string w;
+  const int h = kernel_health(code, name, &w);
+  if (h != KH_OK) {
+    if (why) *why = h == KH_BAD ? w : std::string(name) + " is not part of this build";
+    return nullptr;
+  }
+  hipFunction_t f = nullptr;
+  HIPCHK(hipModuleGetFunction(&f, module, name));
+  return f;
+}
+
 void load_module(rh_model *m) {
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipModuleLoadData(&m->module, m->code.data()));
   HIPCHK(hipModuleGetFunction(&m->k_selftest, m->module, "rh_selftest_kernel"));
   m->n_row_targets = 0;
   for (auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets++;
+  std::string wg, wf, wt;
   if (m->info.gather_mode) {  // parameter table indexed by a data column: tick engine with the group-major gather kernel only
-    HIPCHK(hipModuleGetFunction(&m->k_grad_gather, m->module, "rh_grad_gather_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
+    m->k_grad_gather = fit_kernel(m->code, m->module, "rh_grad_gather_kernel", &wg);
+    m->k_density_fin = fit_kernel(m->code, m->module, "rh_density_fin_kernel", &wf);
+    m->k_tick = fit_kernel(m->code, m->module, "rh_tick_kernel", &wt);
+    m->tick_ok = m->k_grad_gather && m->k_density_fin && m->k_tick;
+    m->tick_why = !m->k_grad_gather ? wg : (!m->k_density_fin ? wf : wt);
+    m->chain_why = m->density_why = "gather-mode models run on the tick engine only";
   } else {
-    HIPCHK(hipModuleGetFunction(&m->k_chain, m->module, "rh_chain_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_density, m->module, "rh_density_kernel"));
+    m->k_chain = fit_kernel(m->code, m->module, "rh_chain_kernel", &m->chain_why);
+    m->k_density = fit_kernel(m->code, m->module, "rh_density_kernel", &m->density_why);
+    m->chain_ok = m->k_chain != nullptr; m->density_ok = m->k_density != nullptr;
+    m->tick_why = "the tick engine needs a model that streams rows";
   }
   if (m->n_row_targets > 0 && !m->info.gather_mode) {  // the tick engine only exists for models that stream rows
-    HIPCHK(hipModuleGetFunction(&m->k_grad, m->module, "rh_grad_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_tick, m->module, "rh_tick_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_grad_lds, m->module, "rh_grad_lds_kernel"));
-    HIPCHK(hipModuleGetFunction(&m->k_density_fin, m->module, "rh_density_fin_kernel"));
+    m->k_grad = fit_kernel(m->code, m->module, "rh_grad_kernel", &wg);
+    m->k_tick = fit_kernel(m->code, m->module, "rh_tick_kernel", &wt);
+    m->k_grad_lds = fit_kernel(m->code, m->module, "rh_grad_lds_kernel");
+    m->k_density_fin = fit_kernel(m->code, m->module, "rh_density_fin_kernel", &wf);
     // compiled only for models whose chain group fits one wavefront's lanes (RH_HAVE_FUSED in rh_engine.hip.h)
-    if (hipModuleGetFunction(&m->k_grad_fused, m->module, "rh_grad_fused_kernel") != hipSuccess) { m->k_grad_fused = nullptr; (void)hipGetLastError(); }
-    if (hipModuleGetFunction(&m->k_absorb, m->module, "rh_absorb_kernel") != hipSuccess) { m->k_absorb = nullptr; m->k_grad_fused = nullptr; (void)hipGetLastError(); }
+    m->k_grad_fused = fit_kernel(m->code, m->module, "rh_grad_fused_kernel");
+    m->k_absorb = fit_kernel(m->code, m->module, "rh_absorb_kernel");
+    if (!m->k_absorb) m->k_grad_fused = nullptr;
   }
   m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
@@ -394,7 +424,7 @@ void load_module(rh_model *m) {
   // have the same peak, so moving eta to the matrix cores only adds AGPR traffic); the hybrid kernel stays opt-in.
   const bool small_mfma = std::getenv("RH_GLM_SMALL_MFMA") && std::atoi(std::getenv("RH_GLM_SMALL_MFMA")) != 0;
   if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
-    HIPCHK(hipModuleGetFunction(&m->k_grad_glm, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel"));
+    m->k_grad_glm = fit_kernel(m->code, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel");   // (unfit: the plain VALU kernel)
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
   // The four-block MFMA shape issues at 0.96 of the vector FMA rate, the 16x16x4 shape at 0.61 (profiles/r3_d_fp64_mfma), but it
   // carries a quarter of the flops per operand: the kernel written for it (rh_grad_glm4_kernel) needs 96 LDS operand reads per
@@ -404,9 +434,8 @@ void load_module(rh_model *m) {
   if (m->k_grad_glm && !m->glm_small) {
     bool want = false;
     if (const char *e = std::getenv("RH_GLM4")) want = std::atoi(e) != 0;
-    hipFunction_t f4 = nullptr;
-    if (want && hipModuleGetFunction(&f4, m->module, "rh_grad_glm4_kernel") == hipSuccess && f4) { m->k_grad_glm = f4; m->glm4 = true; }
-    else (void)hipGetLastError();
+    hipFunction_t f4 = want ? fit_kernel(m->code, m->module, "rh_grad_glm4_kernel") : nullptr;
+    if (f4) { m->k_grad_glm = f4; m->glm4 = true; }
   }
   // (Round 3 also measured the contractions OFF the matrix pipe -- one chain per lane, row values scalar-loaded as SGPR operands,
   //  162 VALU instructions per 64 evaluations: 33.9 vs 17.5 ms, bound by scalar-load latency; git 28d5e00, profiles/r3_cfg4.)
@@ -416,6 +445,14 @@ void load_module(rh_model *m) {
     if (!m->glm_small && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   }
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
+  if (m->use_lds_grad && !m->k_grad_lds) m->use_lds_grad = false;
+  if (m->n_row_targets > 0 && !m->info.gather_mode) {
+    m->tick_ok = m->k_tick && m->k_density_fin && (m->k_grad || m->k_grad_glm);
+    m->tick_why = !m->k_tick ? wt : (!m->k_density_fin ? wf : wg);
+  }
+  if (!m->density_ok && !m->tick_ok)
+    throw Fail{RH_E_UNSUPPORTED, "no kernel of this model is fit to run on this toolchain (the model is too heavy for the register file): " +
+                                  (m->info.gather_mode ? m->tick_why : m->density_why + (m->n_row_targets > 0 ? "; " + m->tick_why : std::string()))};
   hipDeviceptr_t p; size_t sz;
   HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_state_words"));
   HIPCHK(hipMemcpy(&m->state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
@@ -434,19 +471,55 @@ std::string variant_defines(int v) {
   if (v & 4) d += "#define RH_PACK_L 64\n";  // one chain per wavefront although the model packs (few or diverging chains)
   return d;
 }
+// the code object of sampler-kernel variant v (v > 0) of a model whose base module has been built
+std::vector<char> build_variant_code(rh_model *m, int v) {
+  const char *extra = std::getenv("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
+  std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source, extra ? extra : "");
+  m->compile_attempts++;
+  if (!m->info.gather_mode && kernel_health(code, "rh_chain_kernel") == KH_BAD && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) {
+    // the variant's larger chain state does not fit two wavefronts per SIMD: its own build with one (only the variant's per-chain
+    // kernels are used, so the base module's choice is not affected)
+    std::string src = m->source;
+    const std::string two = "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
+    const size_t at = src.find(two);
+    if (at != std::string::npos) {
+      src.replace(at, two.size(), "#define RH_CHAIN_WAVES 1\n");
+      code = build_source(m->arch, variant_defines(v) + src, extra ? extra : "");
+      m->compile_attempts++;
+    }
+  }
+  return code;
+}
+void read_state_offsets(KSet &ks) {
+  hipDeviceptr_t p; size_t sz;
+  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_words"));
+  HIPCHK(hipMemcpy(&ks.state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_off_Pq"));
+  HIPCHK(hipMemcpy(&ks.off_Pq, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_off_Pg"));
+  HIPCHK(hipMemcpy(&ks.off_Pg, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_off_PU"));
+  HIPCHK(hipMemcpy(&ks.off_PU, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+}
 KSet &load_variant(rh_model *m, int v) {
   KSet &ks = m->variants[v];
   if (ks.loaded) return ks;
   HIPCHK(hipSetDevice(m->device));
-  if (v == 0) { ks.module = m->module; ks.k_chain = m->k_chain; ks.k_tick = m->k_tick; ks.state_words = m->state_words; ks.loaded = true; return ks; }
-  const char *extra = std::getenv("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
-  const std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source, extra ? extra : "");
+  if (v == 0) {
+    ks.module = m->module; ks.k_chain = m->k_chain; ks.k_tick = m->tick_ok ? m->k_tick : nullptr; ks.why_chain = m->chain_why; ks.why_tick = m->tick_why;
+    read_state_offsets(ks);
+    ks.loaded = true;
+    return ks;
+  }
+  const std::vector<char> code = build_variant_code(m, v);
   HIPCHK(hipModuleLoadData(&ks.module, code.data()));
-  if (!m->info.gather_mode) HIPCHK(hipModuleGetFunction(&ks.k_chain, ks.module, "rh_chain_kernel"));
-  if (m->n_row_targets > 0) HIPCHK(hipModuleGetFunction(&ks.k_tick, ks.module, "rh_tick_kernel"));
+  if (!m->info.gather_mode) ks.k_chain = fit_kernel(code, ks.module, "rh_chain_kernel", &ks.why_chain);
+  else ks.why_chain = "gather-mode models run on the tick engine only";
+  if (m->n_row_targets > 0) ks.k_tick = fit_kernel(code, ks.module, "rh_tick_kernel", &ks.why_tick);
+  else ks.why_tick = "the tick engine needs a model that streams rows";
+  if (ks.k_tick && !m->tick_ok) { ks.k_tick = nullptr; ks.why_tick = m->tick_why; }   // the gradient kernels are the base module's
+  read_state_offsets(ks);
   hipDeviceptr_t p; size_t sz;
-  HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_words"));
-  HIPCHK(hipMemcpy(&ks.state_words, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
   if (v & 2) {
     HIPCHK(hipModuleGetGlobal(&p, &sz, ks.module, "rh_state_dense_off"));
     HIPCHK(hipMemcpy(&ks.dense_off, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
@@ -648,6 +721,51 @@ void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void 
   HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, s, args, nullptr));
 }
 
+// ---- create-time self-checks (see selfcheck_engine) ----------------------------------------------------------------------------
+bool selfcheck_enabled() {
+  const char *e = std::getenv("RH_SELFCHECK");
+  return !(e && std::atoi(e) == 0);
+}
+// |a - b| within summation-order noise of each other, judged against the size of the whole output vector (gradients cancel)
+bool outputs_agree(const double *lp, const double *g, const double *lp_ref, const double *g_ref, int n, std::string &what) {
+  double scale = 0.0;
+  for (int i = -1; i < n; i++) {
+    const double a = i < 0 ? *lp : g[i], b = i < 0 ? *lp_ref : g_ref[i];
+    if (std::isfinite(a)) scale = std::max(scale, std::fabs(a));
+    if (std::isfinite(b)) scale = std::max(scale, std::fabs(b));
+  }
+  for (int i = -1; i < n; i++) {
+    const double a = i < 0 ? *lp : g[i], b = i < 0 ? *lp_ref : g_ref[i];
+    if (!std::isfinite(a) && !std::isfinite(b)) continue;
+    if (std::isfinite(a) && std::isfinite(b) && std::fabs(a - b) <= 1e-7 * (std::fabs(a) + std::fabs(b)) + 1e-9 * scale + 1e-300) continue;
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "%s: %.17g vs %.17g", i < 0 ? "logp" : ("gradient " + std::to_string(i)).c_str(), a, b);
+    what = buf;
+    return false;
+  }
+  return true;
+}
+// rh_density_kernel against the tick engine's gradient path (gradient kernel + rh_density_fin_kernel) at three points, when a
+// model has both and its data are small enough for one wavefront per chain.  They are different kernels around the same row code;
+// a disagreement beyond summation-order noise means one of them is wrong on this device, and nothing says which: creation fails.
+void selfcheck_density(rh_model *m) {
+  if (!selfcheck_enabled() || !m->density_ok || !m->tick_ok || m->info.gather_mode || m->rows_total > ((int64_t)1 << 22)) return;
+  const int nc = 3, n = (int)m->prog.n_params;
+  std::vector<double> q((size_t)nc * n), la(nc), lb(nc), ga((size_t)nc * n), gb((size_t)nc * n);
+  uint64_t x = 0x9E3779B97F4A7C15ULL;
+  for (double &v : q) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; v = ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 1.2; }
+  int rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_CHAIN, 0, la.data(), ga.data());
+  if (rc == RH_E_LOOKUP) return;   // the data hold an index outside a Lookup table: every later call reports it
+  if (rc == RH_OK) rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_TICK, 0, lb.data(), gb.data());
+  if (rc != RH_OK) throw Fail{rc, "create-time self-check: " + m->err};
+  for (int c = 0; c < nc; c++) {
+    std::string what;
+    if (!outputs_agree(&la[c], &ga[(size_t)c * n], &lb[c], &gb[(size_t)c * n], n, what))
+      throw Fail{RH_E_DEVICE, "create-time self-check: rh_density_kernel and the tick engine's gradient path disagree at a test point (" + what +
+                               "): one of the two is wrong on this device"};
+  }
+}
+
 }  // namespace
 
 // ---- seam 1 -----------------------------------------------------------------------------------------
@@ -766,7 +884,9 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     if (!m->dev_cols.empty()) HIPCHK(hipMemcpy(m->d_coltab, m->dev_cols.data(), m->dev_cols.size() * sizeof(void *), hipMemcpyHostToDevice));
     m->data.cols = (const double *const *)m->d_coltab;
   });
-  if (rc != RH_OK) { rh_model_destroy(m); return rc; }
+  int rc2 = rc;
+  if (rc2 == RH_OK) rc2 = guard(m, [&] { selfcheck_density(m); });
+  if (rc2 != RH_OK) { const std::string keep = m->err; rh_model_destroy(m); g_err = keep; return rc2; }
   *out = m;
   return RH_OK;
 }
@@ -866,8 +986,50 @@ extern "C" int rh_device_count(void) {
 // through *src_out (malloc'ed, caller frees with rh_free) and the code-object size.
 // rh_lower_only_data: the same with the observation columns in hand, i.e. exactly the lowering rh_model_create performs
 // (column canonicalisation and what follows from it included); columns == NULL skips the data-dependent passes.
+namespace {
+// one line per kernel of a code object: registers, spills, scratch, and whether the engine would launch it
+std::string code_report(const std::vector<char> &code, const std::string &tag) {
+  std::vector<std::string> names;
+  std::string r;
+  if (!rh::list_kernels(code, names)) return tag + " unreadable\n";
+  for (const std::string &k : names) {
+    rh::KernelMeta km;
+    rh::kernel_meta(code, k, km);
+    std::string why;
+    const int h = kernel_health(code, k, &why);
+    r += tag + " kernel=" + k + " vgprs=" + std::to_string(km.vgprs) + " sgprs=" + std::to_string(km.sgprs) + " vgpr_spills=" + std::to_string(km.vgpr_spills) +
+         " sgpr_spills=" + std::to_string(km.sgpr_spills) + " scratch=" + std::to_string(km.scratch_bytes) + " fit=" + (h == KH_OK ? "1" : "0") +
+         (h == KH_OK ? std::string() : " why=" + why) + "\n";
+  }
+  return r;
+}
+}  // namespace
+// Test hooks (no device needed): the report of one code object in memory, and the decoder's instruction offsets of one kernel
+extern "C" int rh_code_object_report(const void *code, size_t len, char **report) {
+  if (!code || !report) return RH_E_INVALID;
+  const std::vector<char> c((const char *)code, (const char *)code + len);
+  const std::string r = code_report(c, "object");
+  *report = (char *)std::malloc(r.size() + 1); std::memcpy(*report, r.c_str(), r.size() + 1);
+  return RH_OK;
+}
+extern "C" int rh_code_object_offsets(const void *code, size_t len, const char *kernel, uint32_t **offs, size_t *n) {
+  if (!code || !kernel || !offs || !n) return RH_E_INVALID;
+  const std::vector<char> c((const char *)code, (const char *)code + len);
+  std::vector<uint32_t> o;
+  if (!rh::kernel_instruction_offsets(c, kernel, o)) return RH_E_INVALID;
+  *offs = (uint32_t *)std::malloc(sizeof(uint32_t) * std::max<size_t>(1, o.size()));
+  std::memcpy(*offs, o.data(), sizeof(uint32_t) * o.size());
+  *n = o.size();
+  return RH_OK;
+}
+extern "C" int rh_lower_report_data(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
+                                    const rh_compile_opts *opts, const char *arch, char **src_out, size_t *code_size, char **report);
 extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
                                   const rh_compile_opts *opts, const char *arch, char **src_out, size_t *code_size) {
+  return rh_lower_report_data(rir, rir_len, columns, nrows, opts, arch, src_out, code_size, nullptr);
+}
+extern "C" int rh_lower_report_data(const void *rir, size_t rir_len, const double *const *columns, const int64_t *nrows,
+                                    const rh_compile_opts *opts, const char *arch, char **src_out, size_t *code_size, char **report) {
   rh_model m;
   const int rc = guard(nullptr, [&] {
     std::vector<int64_t> nrows_in;
@@ -885,7 +1047,17 @@ extern "C" int rh_lower_only_data(const void *rir, size_t rir_len, const double 
     }
     if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
     if (!code_size) return;
-    if (opts && opts->with_nuts) (void)build_source(m.arch, variant_defines(opts->with_nuts & 7) + m.source);
+    std::vector<char> vcode;
+    if (opts && opts->with_nuts) vcode = build_variant_code(&m, opts->with_nuts & 7);
+    if (report) {   // what the engine would launch of it: the shape it settled on and every kernel's fitness (kernel_health)
+      std::string r = "attempts=" + std::to_string(m.compile_attempts) + " rows_unroll=" + std::to_string(m.eopt.rows_unroll) +
+                      " grad_unroll=" + std::to_string(m.eopt.grad_unroll) + " grad_k=" + std::to_string(m.info.grad_k) +
+                      " chain_waves=" + std::to_string(m.eopt.chain_waves) + " grad_pipeline=" + std::to_string(m.eopt.grad_pipeline) +
+                      " gather=" + std::to_string((int)m.info.gather_mode) + " row_targets=" + std::to_string(m.n_row_targets_hint) + "\n";
+      r += code_report(m.code, "base");
+      if (!vcode.empty()) r += code_report(vcode, "variant" + std::to_string(opts->with_nuts & 7));
+      *report = (char *)std::malloc(r.size() + 1); std::memcpy(*report, r.c_str(), r.size() + 1);
+    }
   });
   return rc;
 }
@@ -1062,6 +1234,10 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
   if (engine < RH_ENGINE_AUTO || engine > RH_ENGINE_TICK || grad_splits < 0 || grad_splits > 65536) { m->err = g_err = "rh_density_eval_ex: unknown engine / bad grad_splits"; return RH_E_INVALID; }
   if (engine == RH_ENGINE_TICK && m->n_row_targets == 0) { m->err = g_err = "the tick engine needs a model that streams rows"; return RH_E_INVALID; }
   if (engine == RH_ENGINE_CHAIN && m->info.gather_mode) { m->err = g_err = "gather-mode models run on the tick engine only"; return RH_E_UNSUPPORTED; }
+  // AUTO: rh_density_kernel (one chain per wavefront) unless it is not fit to run (kernel_health) -- then the tick engine's path
+  const bool use_tick = m->info.gather_mode || engine == RH_ENGINE_TICK || (engine == RH_ENGINE_AUTO && !m->density_ok && m->tick_ok);
+  if (use_tick && !m->tick_ok) { m->err = g_err = "the tick engine's kernels of this model are not fit to run: " + m->tick_why; return RH_E_UNSUPPORTED; }
+  if (!use_tick && !m->density_ok) { m->err = g_err = "rh_density_kernel of this model is not fit to run: " + m->density_why; return RH_E_UNSUPPORTED; }
   std::lock_guard<std::mutex> lk(m->mu);
   int lookup_err = 0;
   const int rc = guard(m, [&] {
@@ -1075,7 +1251,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipMemsetAsync(de, 0, sizeof(int), m->stream));
     int ch = chains;
-    if (m->info.gather_mode || engine == RH_ENGINE_TICK) {
+    if (use_tick) {
       // the tick engine's gradient path exactly as the sampler drives it: the row-streaming gradient kernel fills the
       // per-split partial sums (and, in gather mode, the scatter sums) for all chains, the finish kernel combines them in
       // the same fixed order as rh_tick_kernel (rh_combine_chain) -- so parity tests reach the kernels the bench times
@@ -1146,6 +1322,70 @@ extern "C" void rh_config_default(rh_config *c) {
   c->mass_init_window = 50; c->mass_expansion = 1.5; c->mass_skip_first = 50; c->mass_skip_last = 50;
 }
 
+// ---- create-time self-check ------------------------------------------------------------------------------------------------------
+// The sampler kernels carry their own inlined copy of the model's density (rh_chain_kernel: the whole row walk; rh_tick_kernel:
+// the data-free targets and the combination of the gradient kernel's partial sums).  Before an engine is used for the first time
+// with a sampler-kernel variant, three chains are initialised with it (LeapFrog.initialize: one gradient at a N(0, 1) point) and the
+// (logp, gradient) they hold is compared with the density path of seam 2 at the same points -- different kernels of the same
+// translation unit, with different register pressure and different control flow around the same row code.  A disagreement beyond
+// summation-order noise is this toolchain's register-allocator fault (or a bug of ours) showing on this very model and data: the
+// engine is taken out of use (AUTO then chooses the other one, an explicit request fails with the reason).  RH_SELFCHECK=0 skips it.
+namespace {
+thread_local int g_force_variant = -1;   // set while a self-check sampler is created: the variant is given, and no nested check
+bool selfcheck_engine(rh_model *m, KSet &ks, int v, bool tick) {
+  if (g_force_variant >= 0 || !selfcheck_enabled()) return true;
+  bool &done = tick ? ks.tick_checked : ks.chain_checked;
+  if (done) return true;
+  // the reference: rh_density_kernel where it exists and the data are small enough for one wavefront per chain, else the tick
+  // engine's gradient path (for the tick engine that still checks rh_tick_kernel against rh_density_fin_kernel)
+  const bool ref_density = m->density_ok && m->rows_total <= ((int64_t)1 << 22);
+  if (!ref_density && !m->tick_ok) { done = true; return true; }
+  const int nc = 3, n = (int)m->prog.n_params;
+  rh_config cfg;
+  rh_config_default(&cfg);
+  cfg.iterations = 1; cfg.warmup = 0; cfg.sampler = RH_SAMPLER_HMC; cfg.hmc_steps = 1;
+  cfg.step_tuner = RH_STEP_STATIC; cfg.static_step = 1e-3; cfg.mass_tuner = RH_MASS_IDENTITY;
+  cfg.engine = tick ? RH_ENGINE_TICK : RH_ENGINE_CHAIN;
+  const int64_t seeds[3] = {0x5e1fc4ec, 0x5e1fc4ed, 0x5e1fc4ee};
+  std::string why;
+  rh_sampler *s2 = nullptr;
+  g_force_variant = v;
+  int rc = rh_sampler_create(m, &cfg, seeds, nc, &s2);
+  g_force_variant = -1;
+  if (rc == RH_OK) rc = rh_sampler_warmup(s2);   // LeapFrog.initialize, then paused at the head of iteration 0
+  std::vector<uint64_t> img;
+  if (rc == RH_OK) {
+    img.resize((size_t)nc * ks.state_words);
+    if (hipMemcpy(img.data(), s2->d_state, img.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) rc = RH_E_DEVICE;
+  }
+  if (s2) rh_sampler_destroy(s2);
+  if (rc != RH_OK) why = "self-check run failed: " + m->err;
+  else {
+    std::vector<double> q((size_t)nc * n), g((size_t)nc * n), lp(nc), gr((size_t)nc * n), lr(nc);
+    for (int c = 0; c < nc; c++) {
+      const uint64_t *st = img.data() + (size_t)c * ks.state_words;
+      std::memcpy(&q[(size_t)c * n], st + ks.off_Pq, sizeof(double) * n);
+      std::memcpy(&g[(size_t)c * n], st + ks.off_Pg, sizeof(double) * n);
+      double pu; std::memcpy(&pu, st + ks.off_PU, sizeof pu);
+      lp[c] = -pu;
+    }
+    rc = rh_density_eval_ex(m, q.data(), nc, ref_density ? RH_ENGINE_CHAIN : RH_ENGINE_TICK, 0, lr.data(), gr.data());
+    if (rc == RH_E_LOOKUP) { done = true; return true; }   // (a Lookup index out of range in the data: the sampler reports it itself)
+    if (rc != RH_OK) why = "self-check reference failed: " + m->err;
+    for (int c = 0; c < nc && why.empty(); c++) {
+      std::string what;
+      if (!outputs_agree(&lp[c], &g[(size_t)c * n], &lr[c], &gr[(size_t)c * n], n, what))
+        why = std::string("create-time self-check: ") + (tick ? "rh_tick_kernel" : "rh_chain_kernel") + " disagrees with " +
+              (ref_density ? "rh_density_kernel" : "rh_density_fin_kernel") + " at an initial point (" + what + ")";
+    }
+  }
+  done = true;
+  if (why.empty()) return true;
+  if (tick) { ks.k_tick = nullptr; ks.why_tick = why; } else { ks.k_chain = nullptr; ks.why_chain = why; }
+  return false;
+}
+}  // namespace
+
 extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_t *seeds, int32_t chains, rh_sampler **out) {
   if (!out) { g_err = "rh_sampler_create: out is NULL"; return RH_E_INVALID; }
   *out = nullptr;
@@ -1172,9 +1412,31 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       // serialise, which only pays once there are more chains than wavefront slots
       s->pack_l = m->info.pack_l;
       if (m->info.pack_l != 64 && cfg->sampler != RH_SAMPLER_HMC && chains < 4096) { v |= 4; s->pack_l = 64; }
+      if (g_force_variant >= 0) { v = g_force_variant; s->pack_l = (v & 4) ? 64 : m->info.pack_l; }   // a self-check run of exactly that variant
       if ((v & 2) && (m->prog.n_params > 64 || m->info.bign)) throw Fail{RH_E_UNSUPPORTED, "DenseMassMatrixTuner supports at most 64 parameters"};
-      std::lock_guard<std::mutex> lk(m->mu);  // variants are built lazily: two samplers may be created concurrently
-      KSet &ks = load_variant(m, v);
+      if (cfg->engine < RH_ENGINE_AUTO || cfg->engine > RH_ENGINE_TICK) throw Fail{RH_E_INVALID, "unknown engine"};
+      if (cfg->engine == RH_ENGINE_TICK && m->n_row_targets == 0) throw Fail{RH_E_INVALID, "the tick engine needs a model that streams rows"};
+      if (cfg->engine == RH_ENGINE_CHAIN && m->info.gather_mode) throw Fail{RH_E_UNSUPPORTED, "gather-mode models run on the tick engine only"};
+      KSet *ksp = nullptr;
+      { std::lock_guard<std::mutex> lk(m->mu);  // variants are built lazily: two samplers may be created concurrently
+        ksp = &load_variant(m, v); }
+      KSet &ks = *ksp;
+      // Engine choice.  AUTO: the tick engine for gather mode and from 65 536 rows on, the chain engine below -- and whichever of
+      // the two has kernels that are fit to run (kernel_health) and agree with the density kernel on this device (self-check)
+      // when the preferred one does not.  An explicit request is never rerouted: it fails with the reason.
+      for (int round = 0; ; round++) {
+        const bool want_tick = m->info.gather_mode || cfg->engine == RH_ENGINE_TICK ||
+                               (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && (m->rows_total >= 65536 || !ks.k_chain));
+        bool tick = want_tick;
+        if (tick && !ks.k_tick) {
+          if (cfg->engine == RH_ENGINE_AUTO && ks.k_chain) tick = false;
+          else throw Fail{RH_E_UNSUPPORTED, "the tick engine's kernels of this model are not fit to run: " + ks.why_tick};
+        }
+        if (!tick && !ks.k_chain) throw Fail{RH_E_UNSUPPORTED, "the chain engine's kernel of this model is not fit to run: " + ks.why_chain +
+                                                                 (m->n_row_targets > 0 && cfg->engine == RH_ENGINE_AUTO ? "; tick engine: " + ks.why_tick : std::string())};
+        s->tick_engine = tick;
+        if (round >= 2 || selfcheck_engine(m, ks, v, tick)) break;   // (a failed check has cleared the kernel and left the reason: choose again)
+      }
       s->k_chain = ks.k_chain; s->k_tick = ks.k_tick; s->state_words = ks.state_words; s->dense_off = ks.dense_off;
     }
     rh_cfg_dev &d = s->cfg;
@@ -1210,10 +1472,6 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     HIPCHK(hipEventCreate(&s->e0));
     HIPCHK(hipEventCreate(&s->e1));
     s->last_stats.resize(chains);
-    if (cfg->engine < RH_ENGINE_AUTO || cfg->engine > RH_ENGINE_TICK) throw Fail{RH_E_INVALID, "unknown engine"};
-    if (cfg->engine == RH_ENGINE_TICK && m->n_row_targets == 0) throw Fail{RH_E_INVALID, "the tick engine needs a model that streams rows"};
-    if (cfg->engine == RH_ENGINE_CHAIN && m->info.gather_mode) throw Fail{RH_E_UNSUPPORTED, "gather-mode models run on the tick engine only"};
-    s->tick_engine = m->info.gather_mode || cfg->engine == RH_ENGINE_TICK || (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && m->rows_total >= 65536);
     if (s->tick_engine) {
       int nsplit = cfg->grad_splits;
       if (nsplit <= 0) nsplit = default_nsplit(m, chains);

@@ -121,6 +121,7 @@ struct EmitOptions {
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
+  int chain_waves = 2;    // wavefronts per SIMD rh_chain_kernel asks for (2: 256 registers; the engine falls back to 1 when the kernel does not fit)
   int grad_pipeline = 2;  // row loop of the batched gradient kernel: 0 plain, 1 double-buffered, 2 rolling (a tile's registers are reloaded as soon as it is consumed)
 };
 
@@ -141,5 +142,20 @@ bool emit_hip(const Program &p, const EmitOptions &o, std::string &defines, std:
 
 // Lowers a requirements program (kind 1) to  rh_req_eval(th, out, err)  + defines RH_NVARS / RH_NREQ.
 bool emit_requirements(const Program &p, const EmitOptions &o, std::string &defines, std::string &body, std::string &err);
+
+// ---- isacheck.cpp: what the engine reads out of a code object before it agrees to launch one of its kernels -----------------
+struct KernelMeta {
+  bool found = false;
+  long vgprs = -1, sgprs = -1, vgpr_spills = -1, sgpr_spills = -1, scratch_bytes = -1;
+};
+// the kernel's entry of the AMDGPU metadata note; false (found = false) when any of the fields is missing
+bool kernel_meta(const std::vector<char> &code, const std::string &name, KernelMeta &out);
+// the kernels (STT_FUNC symbols of .text) of a code object
+bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names);
+// instruction offsets of one kernel, relative to its first byte (the decoder's own test compares them with llvm-objdump)
+bool kernel_instruction_offsets(const std::vector<char> &code, const std::string &name, std::vector<uint32_t> &offs);
+// static check for vector instructions ahead of a join block's exec restore (this toolchain's register-allocator fault, see
+// isacheck.cpp); only_kernel empty = every kernel.  Returns false when the code could not be walked; findings are text lines.
+bool check_code_object(const std::vector<char> &code, const std::string &only_kernel, std::vector<std::string> &findings);
 
 }  // namespace rh
