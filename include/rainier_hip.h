@@ -34,9 +34,10 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 4  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
+#define RH_ABI_VERSION 5  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
                              3: rh_density_eval_ex, rh_sample_multi, rh_comm_* (RCCL all-gather of the draws);
-                             4: rh_model_clone */
+                             4: rh_model_clone;
+                             5: rh_model_engines, rh_compile_count */
 
 enum rh_status {
   RH_OK = 0,
@@ -92,6 +93,18 @@ void rh_model_destroy(rh_model *m);
 int rh_model_nvars(const rh_model *m);
 /* the generated HIP source (the analogue of rainier-decompile's view of the generated bytecode) */
 const char *rh_model_hip_source(const rh_model *m);
+/* Which of the model's engines can run, and why not.  Before a kernel is launched its code object is inspected (no spilled vector
+ * registers; no vector instruction ahead of a control-flow join's exec restore -- a fault of the ROCm 7.2 register allocator that
+ * produced silent wrong sums) and, at creation, checked against another kernel of the same model on the device.  A
+ * kernel that fails is replaced by a lighter build or by the other engine (RH_ENGINE_AUTO); an explicit request for an engine
+ * that is out of use returns RH_E_UNSUPPORTED.  The reference has no counterpart: its back end splits any method that is too
+ * heavy (ir/Packer.scala:10-71) instead of meeting a register file.
+ * *chain_engine / *tick_engine / *density: 1 = usable (rh_sample with that engine / rh_density_eval); why: the reasons of the
+ * unusable ones, text (may be NULL); compile_attempts: code objects built or fetched while lowering this model. */
+int rh_model_engines(const rh_model *m, int32_t *chain_engine, int32_t *tick_engine, int32_t *density, int32_t *compile_attempts,
+                     char *why, size_t why_cap);
+/* hiprtc compilations this process has performed so far (kernel-cache misses; model creation costs seconds each) */
+int64_t rh_compile_count(void);
 /* last error message: of this model, or of the calling thread when m == NULL */
 const char *rh_last_error(const rh_model *m);
 

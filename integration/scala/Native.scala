@@ -13,6 +13,7 @@ object Native {
                           copts: Array[Int]): Long                                                // rh_model_create
   /** the same compiled model on another device: no second lowering, columns copied device to device */
   @native def modelClone(model: Long, device: Int): Long                                          // rh_model_clone
+  @native def modelEngines(model: Long): Int                                                      // rh_model_engines: bit 0 chain, 1 tick, 2 density; >> 8 = compile attempts
   @native def modelDestroy(model: Long): Unit                                                     // rh_model_destroy
   @native def modelNVars(model: Long): Int                                                        // rh_model_nvars
   /** engine / gradSplits: 0, 0 = the engine's choice (rh_density_eval) */

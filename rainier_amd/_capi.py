@@ -25,6 +25,7 @@ ENGINE_AUTO, ENGINE_CHAIN, ENGINE_TICK = 0, 1, 2
 # every symbol include/rainier_hip.h declares (checked by tests/test_capi_cpu.py)
 EXPORTS = [
     "rh_model_create", "rh_model_clone", "rh_model_destroy", "rh_model_nvars", "rh_model_hip_source", "rh_last_error",
+    "rh_model_engines", "rh_compile_count",
     "rh_density_eval", "rh_density_eval_ex", "rh_config_default", "rh_sample", "rh_sample_multi", "rh_sampler_create", "rh_sampler_destroy",
     "rh_sampler_warmup", "rh_sampler_run", "rh_sampler_draws", "rh_sampler_draws_device", "rh_sampler_stats",
     "rh_sampler_timing", "rh_sampler_progress", "rh_sampler_mass_dense", "rh_optimize", "rh_diagnostics", "rh_abi_version", "rh_device_count", "rh_requirements_eval",
@@ -87,6 +88,8 @@ def lib():
     L.rh_model_nvars.argtypes = [vp]
     L.rh_model_hip_source.restype = C.c_char_p; L.rh_model_hip_source.argtypes = [vp]
     L.rh_last_error.restype = C.c_char_p; L.rh_last_error.argtypes = [vp]
+    L.rh_model_engines.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
+    L.rh_compile_count.restype = C.c_int64; L.rh_compile_count.argtypes = []
     L.rh_density_eval.argtypes = [vp, dp, C.c_int32, dp, dp]
     L.rh_density_eval_ex.argtypes = [vp, dp, C.c_int32, C.c_int32, C.c_int32, dp, dp]
     L.rh_config_default.argtypes = [C.POINTER(Config)]

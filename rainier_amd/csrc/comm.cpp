@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <future>
 #include <memory>
@@ -33,6 +34,7 @@ struct Rccl {
   int (*GetUniqueId)(nccl_uid *) = nullptr;
   int (*CommInitRank)(nccl_comm *, int, nccl_uid, int) = nullptr;
   int (*CommDestroy)(nccl_comm) = nullptr;
+  int (*CommAbort)(nccl_comm) = nullptr;   // optional
   int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -48,6 +50,7 @@ struct Rccl {
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllGather, "ncclAllGather") SYM(AllReduce, "ncclAllReduce") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
     return true;
   }
 };
@@ -88,6 +91,10 @@ struct rh_comm {
   hipStream_t stream = nullptr;
   void *d_gather = nullptr; size_t gather_bytes = 0;
   void *d_scalar = nullptr;
+  // a collective that missed its deadline is still enqueued on `stream` and may still touch d_gather / d_scalar: the communicator
+  // refuses every further call, and rh_comm_destroy aborts it (ncclCommAbort) and LEAVES the buffers and the stream alone -- the
+  // process is expected to report the failure and exit
+  bool poisoned = false;
 };
 
 extern "C" int rh_comm_unique_id(unsigned char id[RH_COMM_ID_BYTES]) {
@@ -119,14 +126,17 @@ extern "C" int rh_comm_create(const unsigned char id[RH_COMM_ID_BYTES], int32_t 
   std::memcpy(u.internal, id, RH_COMM_ID_BYTES);
   // ncclCommInitRank blocks until all `world` ranks have called it: run it on a helper thread and give up after the deadline
   // (the helper then stays blocked inside RCCL; the caller is about to report the failure and exit)
-  struct Init { nccl_comm comm = nullptr; std::promise<int> done; };
+  struct Init { nccl_comm comm = nullptr; std::promise<int> done; std::atomic<bool> abandoned{false}; };
   auto st = std::make_shared<Init>();
   std::future<int> fut = st->done.get_future();
   std::thread([st, world, u, rank, device] {
     (void)hipSetDevice(device);
-    st->done.set_value(g_rccl.CommInitRank(&st->comm, world, u, rank));
+    const int rc = g_rccl.CommInitRank(&st->comm, world, u, rank);
+    if (st->abandoned.load() && rc == 0 && st->comm && g_rccl.CommAbort) g_rccl.CommAbort(st->comm);   // nobody is waiting any more
+    st->done.set_value(rc);
   }).detach();
   if (fut.wait_for(std::chrono::duration<double>(comm_timeout_s())) != std::future_status::ready) {
+    st->abandoned.store(true);   // should the helper ever get its communicator, it aborts it instead of leaking it
     delete c;
     return fail(RH_E_DEVICE, "ncclCommInitRank: rank " + std::to_string(rank) + " of " + std::to_string(world) + " waited " +
                              std::to_string((int)comm_timeout_s()) + " s (RH_COMM_TIMEOUT_S) for the other ranks -- one of them never reached rh_comm_create");
@@ -145,6 +155,11 @@ extern "C" int rh_comm_create(const unsigned char id[RH_COMM_ID_BYTES], int32_t 
 extern "C" void rh_comm_destroy(rh_comm *c) {
   if (!c) return;
   hipSetDevice(c->device);
+  if (c->poisoned) {
+    if (c->comm && g_rccl.CommAbort) g_rccl.CommAbort(c->comm);
+    delete c;   // (the device buffers and the stream stay: work that cannot be recalled may still use them)
+    return;
+  }
   if (c->comm) g_rccl.CommDestroy(c->comm);
   if (c->d_gather) hipFree(c->d_gather);
   if (c->d_scalar) hipFree(c->d_scalar);
@@ -157,6 +172,7 @@ extern "C" void rh_comm_destroy(rh_comm *c) {
 // pointer of the gathered buffer (owned by the communicator, valid until the next gather / destroy).
 extern "C" int rh_comm_allgather_draws(rh_comm *c, rh_sampler *s, double *host_out, void **dev_out) {
   if (!c || !s) return fail(RH_E_INVALID, "rh_comm_allgather_draws: NULL");
+  if (c->poisoned) return fail(RH_E_DEVICE, "rh_comm_allgather_draws: an earlier collective of this communicator timed out; it accepts no further work");
   int dev = 0; void *sstream = nullptr; int64_t count = 0; void *d_draws = nullptr;
   if (rh_sampler_geometry_(s, &dev, &sstream, &count) != RH_OK || rh_sampler_draws_device(s, &d_draws) != RH_OK)
     return fail(RH_E_INVALID, "rh_comm_allgather_draws: bad sampler handle");
@@ -172,7 +188,7 @@ extern "C" int rh_comm_allgather_draws(rh_comm *c, rh_sampler *s, double *host_o
   // the sampler's launches are complete when rh_sampler_run returns (it synchronises its stream): no cross-stream event needed
   const int rc = g_rccl.AllGather(d_draws, c->d_gather, (size_t)count, kNcclFloat64, c->comm, c->stream);
   if (rc) return nccl_fail("ncclAllGather", rc);
-  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allgather_draws (ncclAllGather)", werr)) return fail(RH_E_DEVICE, werr); }
+  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allgather_draws (ncclAllGather)", werr)) { c->poisoned = true; return fail(RH_E_DEVICE, werr); } }
   if (host_out && hipMemcpy(host_out, c->d_gather, bytes, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(RH_E_DEVICE, "rh_comm_allgather_draws: copy to host failed");
   if (dev_out) *dev_out = c->d_gather;
@@ -182,11 +198,12 @@ extern "C" int rh_comm_allgather_draws(rh_comm *c, rh_sampler *s, double *host_o
 // max over ranks of one double (the timing reduction of a benchmark) -- also a device-side barrier
 extern "C" int rh_comm_allreduce_max(rh_comm *c, double *value) {
   if (!c || !value) return fail(RH_E_INVALID, "rh_comm_allreduce_max: NULL");
+  if (c->poisoned) return fail(RH_E_DEVICE, "rh_comm_allreduce_max: an earlier collective of this communicator timed out; it accepts no further work");
   if (hipSetDevice(c->device) != hipSuccess) return fail(RH_E_DEVICE, "hipSetDevice failed");
   if (hipMemcpy(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(RH_E_DEVICE, "copy failed");
   const int rc = g_rccl.AllReduce(c->d_scalar, (char *)c->d_scalar + sizeof(double), 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
   if (rc) return nccl_fail("ncclAllReduce", rc);
-  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allreduce_max (ncclAllReduce)", werr)) return fail(RH_E_DEVICE, werr); }
+  { std::string werr; if (!wait_stream(c->stream, "rh_comm_allreduce_max (ncclAllReduce)", werr)) { c->poisoned = true; return fail(RH_E_DEVICE, werr); } }
   if (hipMemcpy(value, (char *)c->d_scalar + sizeof(double), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(RH_E_DEVICE, "copy failed");
   return RH_OK;
 }

@@ -26,7 +26,7 @@ template <int T> struct rh_target;
 // addresses: scalar loads) and the n + 1 outputs are accumulated in a scratch area of the chain (`tot`: every lane executes the
 // same stores of the same values; the accumulation is sequential in program order).  The reference's back end has no parameter
 // limit (ir/Packer.scala:10-40); this is how a 2 000-parameter state-space model runs here: correct, not fast.
-#define RH_BIGTH (RH_BIGN && !RH_HAS_GATHER && RH_NVARS > 512)
+#define RH_BIGTH (RH_BIGN && !RH_HAS_GATHER && (RH_NVARS > 512 || RH_HEAVY))
 #if RH_BIGTH
 __shared__ double *rh_tot_base;   // the chain's (or the density call's) scratch for the outputs: RH_NOUT doubles
 #endif
@@ -54,13 +54,13 @@ RH_DEV void rh_rows_ragged(const TH &th, const INV &inv, const CP &cp, long long
     const bool live = k < n;
     const long long kc = live ? k : n - 1;
     double c[NC];
-#pragma unroll
+RH_UNROLL_ACC
     for (int j = 0; j < NC; j++) c[j] = cp[j][kc];
     double t[NA];
-#pragma unroll
+RH_UNROLL_ACC
     for (int o = 0; o < NA; o++) t[o] = -0.0;
     TG::row(th, inv, c, t, err);   // (a dead lane can only repeat the error of the lane that owns the last row)
-#pragma unroll
+RH_UNROLL_ACC
     for (int o = 0; o < NA; o++) acc[o] = live ? acc[o] + t[o] : acc[o];
   }
 }
@@ -83,7 +83,7 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
     for (int j = 0; j < NC; j++) cp[j] = d.cols[TG::COL0 + j];
     constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
     double acc[NA];
-#pragma unroll
+RH_UNROLL_ACC
     for (int o = 0; o < NA; o++) acc[o] = 0.0;
     // The walk runs on a WAVE-UNIFORM base row (scalar loop branches), so the row function always executes with all 64 lanes
     // active; the ragged end is handled by rh_rows_ragged.  (A lane-strided loop `for (k = lane; k < n; k += 64)` is a divergent
@@ -94,7 +94,7 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
       double c[U][NC];
 #pragma unroll
       for (int u = 0; u < U; u++)
-#pragma unroll
+RH_UNROLL_ACC
         for (int j = 0; j < NC; j++) c[u][j] = cp[j][kb + (long long)RH_LANES * u + lane];
 #pragma unroll
       for (int u = 0; u < U; u++) TG::row(th, inv, c[u], acc, err);
@@ -1056,7 +1056,7 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
       double acc[K][NA];
 #pragma unroll
       for (int kk = 0; kk < K; kk++)
-#pragma unroll
+RH_UNROLL_ACC
         for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
       long long kb = r0;   // wave-uniform base row: every loop below branches on scalars, the row code runs with all lanes active
 #if RH_GRAD_PIPELINE == 2
@@ -1127,7 +1127,7 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
         double c[U][NC];
 #pragma unroll
         for (int u = 0; u < U; u++)
-#pragma unroll
+RH_UNROLL_ACC
           for (int j = 0; j < NC; j++) c[u][j] = cp[j][kb + 64LL * u + lane];
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -1142,15 +1142,15 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
         const bool live = k < r1;
         const long long kc = live ? k : r1 - 1;
         double c[NC];
-#pragma unroll
+RH_UNROLL_ACC
         for (int j = 0; j < NC; j++) c[j] = cp[j][kc];
 #pragma unroll
         for (int kk = 0; kk < K; kk++) {
           double t[NA];
-#pragma unroll
+RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) t[o] = -0.0;
           TG::row(RH_THK(th, kk), inv[kk], c, t, err);
-#pragma unroll
+RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
         }
       }
@@ -1159,7 +1159,7 @@ RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const in
         rh_wave_sum_all(acc[kk]);   // a chain's NA sums level by level: their exchanges overlap
         double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
         if (lane == 0 && chain0 + kk < chains) {
-#pragma unroll
+RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) {
             if constexpr (COHERENT) __hip_atomic_store(out + o, acc[kk][o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else out[o] = acc[kk][o];
@@ -1951,6 +1951,30 @@ RH_DEV double rh_segmented_scan(double v, const int start, const int lane) {
   }
   return v;
 }
+// One 64-row tile of a gather-mode target for the K chains of the wavefront.  `full` is wave-uniform (a scalar branch): a full tile
+// runs the row function as it is; in the ragged last tile of a split every lane still runs it -- a lane past the end on the last
+// row, which it re-read -- and a select drops its contributions (see rh_rows_ragged): the row code has no divergent region around it.
+template <int T, class INV, int NC, int NA>
+RH_DEV void rh_gather_rows(const double (&th)[RH_GRAD_K][RH_NTH], const INV &inv, const double (&cc)[NC], const double (&gz)[RH_GRAD_K],
+                           double (&acc)[RH_GRAD_K][NA], double (&sv)[RH_GRAD_K], int &err, const bool full, const bool live) {
+  typedef rh_target<T> TG;
+  constexpr int K = RH_GRAD_K;
+  if (full) {
+#pragma unroll
+    for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < K; kk++) {
+      double t[NA], s1 = -0.0;
+#pragma unroll
+      for (int o = 0; o < NA; o++) t[o] = -0.0;
+      TG::row(th[kk], inv[kk], cc, gz[kk], t, s1, err);
+#pragma unroll
+      for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
+      sv[kk] = live ? sv[kk] + s1 : sv[kk];
+    }
+  }
+}
 template <int T>
 RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
                               const double *__restrict__ q, const int lane, const int split, const int nsplit,
@@ -2006,7 +2030,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
           const bool live = r < r1;
           const int rr = live ? r : r1 - 1;
           double cc[NC];
-#pragma unroll
+RH_UNROLL_ACC
           for (int j = 0; j < NC; j++) cc[j] = cp[j][rr];
           int g = 0;
           if constexpr (TG::HAS_GATHER) g = (int)cc[TG::G_COL] - TG::G_LOW;
@@ -2016,10 +2040,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
             gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
             sv[kk] = 0.0;
           }
-          if (live) {
-#pragma unroll
-            for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
-          }
+          rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
           if constexpr (TG::HAS_GATHER) {
             if (g == gA) {
 #pragma unroll
@@ -2048,7 +2069,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
         const bool live = r < r1;
         const int rr = live ? r : r1 - 1;
         double cc[NC];
-#pragma unroll
+RH_UNROLL_ACC
         for (int j = 0; j < NC; j++) cc[j] = cp[j][rr];
         int g = g0, gbeg = base, gend = r1;   // a target without a gather: one segment, nothing is stored per group
         if constexpr (TG::HAS_GATHER) {
@@ -2061,10 +2082,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
           gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
           sv[kk] = 0.0;
         }
-        if (live) {
-#pragma unroll
-          for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
-        }
+        rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
         if constexpr (TG::HAS_GATHER) {
           const int start = gbeg - base;                      // first lane of this lane's group (<= 0: it began earlier)
           const bool tail = live && (r == gend - 1);          // last row of its group
@@ -2137,11 +2155,11 @@ RH_DEV void rh_combine_targets(const double (&th)[RH_NTH], const double *__restr
       // lane l sums the splits l, l+64, ... (ascending), then the fixed-order butterfly: deterministic, and the
       // nsplit loads are issued in parallel instead of as one dependent chain
       double S[NA];
-#pragma unroll
+RH_UNROLL_ACC
       for (int o = 0; o < NA; o++) S[o] = 0.0;
       for (int s = lane; s < nsplit; s += 64) {
         const double *p = partial + (((size_t)TG::ROWT * nsplit + s) * chains + chain) * RH_NACC_MAX;
-#pragma unroll
+RH_UNROLL_ACC
         for (int o = 0; o < NA; o++) S[o] += p[o];
       }
       rh_wave_sum_all(S);
@@ -2428,7 +2446,10 @@ rh_grad_fused_kernel(const rh_model_data d, const double *__restrict__ q, const 
   bool any = false;
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) any = any || (active[(chain0 + kk < chains) ? chain0 + kk : chains - 1] != 0);
-  if (!any) return;
+  if (!any) {   // nothing of this group is advanced by this launch: its records must not look as if something had been
+    if (split == 0 && lane < RH_GRAD_K && chain0 + lane < chains) rec_out[(size_t)(chain0 + lane) * RH_REC_U64 + RH_REC_VALID] = 0;
+    return;
+  }
   double th[RH_GRAD_K][RH_NTH];
   rh_fused_prologue(th, d, q, state, rec_in, rec_out, partial_in, chains, nsplit, chain0, lane, split == 0);
   int err = 0;
@@ -2439,11 +2460,14 @@ rh_grad_fused_kernel(const rh_model_data d, const double *__restrict__ q, const 
 // records -> state image, before the tick that ends a trajectory (one wavefront per chain; a chain without a valid record is
 // left as it is).  What the ordinary tick would have stored after each of the fused updates (rh_tick_kernel, RH_S_TS_MID).
 extern "C" __global__ void __launch_bounds__(64)
-rh_absorb_kernel(rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec, double *__restrict__ qbuf, const int chains) {
+rh_absorb_kernel(rh_u64 *__restrict__ state, rh_u64 *__restrict__ rec, double *__restrict__ qbuf, const int *__restrict__ active,
+                 const int chains) {
   const int chain = blockIdx.x, j = threadIdx.x;
   if (chain >= chains) return;
-  const rh_u64 *ri = rec + (size_t)chain * RH_REC_U64;
-  if (ri[RH_REC_VALID] == 0) return;
+  rh_u64 *ri = rec + (size_t)chain * RH_REC_U64;
+  // only a chain that is waiting for a gradient can have been advanced by the launch that wrote this record; a record is consumed
+  // once (a paused chain must never be overwritten with what an earlier trajectory left in the buffer)
+  if (ri[RH_REC_VALID] == 0 || active[chain] == 0) return;
   rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
   if (j < RH_NVARS) {
@@ -2459,6 +2483,7 @@ rh_absorb_kernel(rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec, dou
     sc[RH_SI_BU] = (rh_u64)__double_as_longlong(logp * -1); sc[RH_SI_pend_logp] = ri[RH_REC_LOGP];
     sc[RH_SI_ts_i] = ri[RH_REC_TSI]; sc[RH_SI_err] = ri[RH_REC_ERR];
     sc[RH_SI_n_grad] = ri[RH_REC_NGRAD]; sc[RH_SI_n_leapfrog] = ri[RH_REC_NLEAP]; sc[RH_SI_n_warm_leapfrog] = ri[RH_REC_NWARM];
+    ri[RH_REC_VALID] = 0;   // (one wavefront per chain: every lane has read its part of the record by now)
   }
 }
 #endif

@@ -409,8 +409,33 @@ RH_DEV double rh_wave_sum(double v) {
 // it (bit-identical), but the N cross-lane exchanges of a level are in flight together.  One after the other they cost a
 // ds_bpermute round trip per level and value -- 40 sums at the end of rh_grad_kernel's row walk were 240 serial round trips
 // (~11 us of pure latency per workgroup, at the tail of the launch where nothing else hides it).
+// The memory-resident lowering (RH_HEAVY: emit.cpp chunk_body, the engine's last resort for models that do not fit the register
+// file): the generated functions reach their accumulators and invariants through an opaque index (rh_oz), so those arrays stay in
+// scratch memory by design, and the loops over them here stay rolled -- the live state is a few elements, not the array.
+#ifndef RH_HEAVY
+#define RH_HEAVY 0
+#endif
+typedef double rh_acc_t;
+#if RH_HEAVY
+#define RH_UNROLL_ACC _Pragma("unroll 2")   /* loops over a target's accumulators: a few elements in flight, not all of them */
+// an index the compiler cannot see through: `a[j + rh_oz()]` keeps `a` in memory (no splitting into registers), and no load of it is
+// forwarded from a store, merged with another or hoisted out of a loop -- the asm is volatile and yields 0
+RH_DEV int rh_oz() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
+#else
+#define RH_UNROLL_ACC _Pragma("unroll")
+#endif
 template <int N>
 RH_DEV void rh_wave_sum_all(double (&v)[N]) {
+#if RH_HEAVY
+  // one element at a time: the same fixed-order butterfly per element, hence the same bits
+  _Pragma("unroll 1") for (int i = 0; i < N; i++) {
+    double x = v[i];
+#pragma unroll
+    for (int off = RH_LANES / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    v[i] = x;
+  }
+  return;
+#endif
 #pragma unroll
   for (int off = RH_LANES / 2; off >= 1; off >>= 1) {
     double t[N];

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <map>
 #include <sstream>
 #include <tuple>
@@ -47,6 +48,96 @@ struct Lin {  // alpha * term + beta
   uint32_t term = NONE, alpha = ONE, beta = ZERO;
 };
 
+// ---- bounded live state (the analogue of the reference's method splitting, ir/Packer.scala:10-71) --------------------------------
+// The reference's back end cuts every expression tree into methods of at most 200 nodes whose results travel through the JVM's
+// locals and fields, so no model is too heavy for it.  Here a straight-line function of thousands of statements meets a register
+// file: what does not fit is spilled by the compiler, and this toolchain's spill placement is not to be trusted.  In
+// the memory-resident lowering (EmitOptions.chunk > 0) the body of a generated function is cut into CHUNKS of at most `chunk`
+// statement groups, each in its own scope; a value that is used in a later chunk than the one that defines it is stored to a slot
+// of a per-lane scratch array when it is defined and loaded from there -- under a fresh name -- by every later chunk that uses it.
+// Every access goes through an opaque index (rh_oz(): a volatile asm that yields 0), so the array cannot be split into registers,
+// nothing is forwarded from a store to a load, and a value's register dies with its chunk.  (A volatile array would say the same,
+// but this toolchain mis-selects the flat accesses volatile private memory is left with: "Illegal instruction detected".)  The arithmetic and its order are untouched (the results are the same bits); the
+// live state of the function is one chunk's temporaries, whatever the size of the model.  Slots are reused when a value's last
+// reader has passed.
+static std::string chunk_body(const std::string &body, int chunk, const std::string &indent = "    ") {
+  std::vector<std::string> lines;
+  { std::istringstream is(body); std::string ln; while (std::getline(is, ln)) lines.push_back(ln); }
+  struct Group { std::vector<std::string> text; std::vector<long> defs, uses; };
+  std::vector<Group> groups;
+  std::string head;   // declarations that stay at function scope (casts to void, rh1)
+  auto ids_of = [](const std::string &ln, std::vector<long> &out) {
+    for (size_t i = 0; i + 1 < ln.size(); i++) {
+      if (ln[i] != 'n' || !std::isdigit((unsigned char)ln[i + 1])) continue;
+      if (i > 0 && (std::isalnum((unsigned char)ln[i - 1]) || ln[i - 1] == '_')) continue;
+      size_t j = i + 1; long v = 0;
+      while (j < ln.size() && std::isdigit((unsigned char)ln[j])) { v = v * 10 + (ln[j] - '0'); j++; }
+      if (j < ln.size() && (std::isalnum((unsigned char)ln[j]) || ln[j] == '_')) continue;
+      out.push_back(v);
+      i = j - 1;
+    }
+  };
+  for (size_t i = 0; i < lines.size(); i++) {
+    const std::string &ln = lines[i];
+    if (ln.find("(void)") != std::string::npos || ln.find("const double rh1 = ") != std::string::npos) { head += ln + "\n"; continue; }
+    Group g;
+    g.text.push_back(ln);
+    if (ln.find("const int k") != std::string::npos) {            // a Lookup: index, (table,) select, range check
+      while (i + 1 < lines.size() && lines[i].find("err = 1;") == std::string::npos) g.text.push_back(lines[++i]);
+    } else if (ln.find("{ const double ix") != std::string::npos) {   // an eq-family accumulation: two lines inside braces
+      while (i + 1 < lines.size() && lines[i].find('}') == std::string::npos) g.text.push_back(lines[++i]);
+    }
+    for (const std::string &t : g.text) {
+      const size_t d = t.find("const double n");
+      std::vector<long> all;
+      ids_of(t, all);
+      long def = -1;
+      if (d != std::string::npos && t.find(" = ", d) != std::string::npos) { std::vector<long> dd; ids_of(t.substr(d, t.find(" = ", d) - d), dd); if (!dd.empty()) def = dd[0]; }
+      if (def >= 0) g.defs.push_back(def);
+      for (long v : all) if (v != def) g.uses.push_back(v);
+    }
+    groups.push_back(g);
+  }
+  const size_t nch = (groups.size() + (size_t)chunk - 1) / (size_t)chunk;
+  if (nch <= 1) return body;
+  std::map<long, size_t> def_chunk, last_use;
+  for (size_t gi = 0; gi < groups.size(); gi++) {
+    const size_t c = gi / (size_t)chunk;
+    for (long v : groups[gi].defs) def_chunk[v] = c;
+    for (long v : groups[gi].uses) { auto it = last_use.find(v); if (it == last_use.end() || it->second < c) last_use[v] = c; }
+  }
+  std::map<long, int> slot;
+  std::vector<int> free_slots;
+  int nslots = 0;
+  std::vector<std::vector<long>> dies(nch);
+  for (auto &kv : last_use) if (def_chunk.count(kv.first) && kv.second > def_chunk[kv.first]) dies[kv.second].push_back(kv.first);
+  std::ostringstream os, out;
+  for (size_t c = 0; c < nch; c++) {
+    os << indent << "{\n";
+    std::vector<long> loads, stores;
+    std::map<long, char> seen;
+    for (size_t gi = c * (size_t)chunk; gi < std::min(groups.size(), (c + 1) * (size_t)chunk); gi++) {
+      for (long v : groups[gi].uses) if (def_chunk.count(v) && def_chunk[v] < c && !seen[v]) { seen[v] = 1; loads.push_back(v); }
+      for (long v : groups[gi].defs) if (last_use.count(v) && last_use[v] > c) stores.push_back(v);
+    }
+    for (long v : loads) os << indent << "const double n" << v << " = rh_sp[" << slot.at(v) << " + rh_oz()];\n";
+    for (size_t gi = c * (size_t)chunk; gi < std::min(groups.size(), (c + 1) * (size_t)chunk); gi++) {
+      for (const std::string &t : groups[gi].text) os << t << "\n";
+      for (long v : groups[gi].defs)
+        if (last_use.count(v) && last_use[v] > c) {
+          int sl;
+          if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); } else sl = nslots++;
+          slot[v] = sl;
+          os << indent << "rh_sp[" << sl << " + rh_oz()] = n" << v << ";\n";
+        }
+    }
+    os << indent << "}\n";
+    for (long v : dies[c]) free_slots.push_back(slot.at(v));
+  }
+  out << head << indent << "double rh_sp[" << std::max(1, nslots) << "];\n" << os.str();
+  return out.str();
+}
+
 struct TargetEmitter {
   Program P;  // private copy: factoring appends synthesized nodes
   uint32_t t;
@@ -55,6 +146,10 @@ struct TargetEmitter {
   bool fma_adds = false;       // per-row code: adds/subs as fma(x, +-1.0, y); with fast_div (= contraction allowed) mul+add is fused here
   uint32_t run_end = 0;        // data-free targets t..run_end are emitted together (shared sub-expressions once)
   bool merged_away = false;    // this data-free target was emitted by an earlier one of its run
+  int chunk = 0;               // > 0: memory-resident lowering, at most this many statement groups per chunk (chunk_body)
+  // memory-resident lowering: the accumulators and invariants are reached through an OPAQUE index (rh_oz() is a volatile asm that
+  // yields 0), so the arrays cannot be split into registers and no load is forwarded from a store or hoisted out of the row loop
+  std::string oz() const { return chunk > 0 ? " + rh_oz()" : ""; }
   // gather mode (models with a big parameter table indexed by a data column -- cfg 5):
   //   value side   : LOOKUP(index column, [theta_first .. theta_first+count-1], low)   -> `gz`, the gathered parameter
   //   gradient side: output(1 + first + k) = eq(index, low + k, Gv, 0) for every k (compute/Gradient.scala:148-152) -> one
@@ -663,13 +758,13 @@ struct TargetEmitter {
     if (nd.op == RH_RIR_CONST) return lit(nd.cval);
     if (nd.op == RH_RIR_INPUT) {
       if (nd.input < P.n_params) return "th[" + std::to_string(nd.input) + "]";
-      return "c[" + std::to_string(nd.input - P.targets[t].input_start) + "]";
+      return "c[" + std::to_string(nd.input - P.targets[t].input_start) + oz() + "]";   // (memory-resident lowering: the row's values stay in scratch too)
     }
     if (ctx != 0 && has_rows() && nd.dep == 0) {
       auto it = inv_slot.find(id);
       if (it == inv_slot.end()) throw std::out_of_range("emit: parameter-only node " + std::to_string(id) + " (op " + std::to_string((int)nd.op) +
                                                          ") of target " + std::to_string(t) + " is used in context " + std::to_string(ctx) + " but has no invariant slot");
-      return "inv[" + std::to_string(it->second) + "]";
+      return "inv[" + std::to_string(it->second) + oz() + "]";
     }
     return "n" + std::to_string(id);
   }
@@ -700,9 +795,15 @@ struct TargetEmitter {
     // every use below compares or indexes k as unsigned
     os << "    const int " << k << " = (int)((unsigned)rh_d2i(" << R(nd.a) << ") - (unsigned)(" << nd.low << "));\n";
     auto it_tab = use_inv ? inv_table.find(id) : inv_table.end();   // (the GLM scalar part has no inv[]: it keeps its own copies)
+    bool all_params = chunk > 0 && nd.table.size() > 2;   // memory-resident lowering: theta is in memory (RH_BIGTH), so a table of parameters is ONE indexed load
+    for (uint32_t e : nd.table) all_params = all_params && P.nodes[e].op == RH_RIR_INPUT && P.nodes[e].input < P.n_params && !(gather.ok && e == gather.node);
     if (it_tab != inv_table.end()) {
       os << lhs << "((unsigned)" << k << " < " << nd.table.size() << "u) ? inv[" << it_tab->second << " + " << k << "] : RH_NAN;\n";
-    } else if (nd.table.size() <= 64) {
+    } else if (all_params) {
+      os << "    static const int p" << id << "[" << nd.table.size() << "] = {";
+      for (size_t e = 0; e < nd.table.size(); e++) os << (e ? ", " : "") << P.nodes[nd.table[e]].input;
+      os << "};\n" << lhs << "((unsigned)" << k << " < " << nd.table.size() << "u) ? th[p" << id << "[" << k << "]] : RH_NAN;\n";
+    } else if (nd.table.size() <= (chunk > 0 ? 4u : 64u)) {
       os << lhs;
       for (size_t e = 0; e + 1 < nd.table.size(); e++) os << "(" << k << " == " << e << ") ? " << R(nd.table[e]) << " : ";
       os << R(nd.table.back()) << ";\n";
@@ -1092,55 +1193,59 @@ struct TargetEmitter {
     os << "  static constexpr bool HAS_GATHER = " << (gather.ok ? "true" : "false") << ";\n  static constexpr int G_COL = " << gather.col
        << ", G_FIRST = " << gather.first << ", G_COUNT = " << gather.count << ", G_LOW = " << gather.low << ";\n";
     // ---- invariants
-    os << "  static RH_DEV void invariants(const double (&th)[RH_NTH], double *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
+    os << "  static RH_DEV void invariants(const double (&th)[RH_NTH], rh_acc_t *inv, int &err) {\n    (void)th; (void)inv; (void)err;\n";
     if (rows) {
+      std::ostringstream b;
       for (size_t n = 0; n < P.nodes.size(); n++)
         if (reach_inv[n] && P.nodes[n].dep == 0 && !trivial((uint32_t)n))
-          if (!emit_node(os, (uint32_t)n, 0, err)) return false;
-      for (auto &kv : inv_slot) os << "    inv[" << kv.second << "] = n" << kv.first << ";\n";
+          if (!emit_node(b, (uint32_t)n, 0, err)) return false;
+      for (auto &kv : inv_slot) b << "    inv[" << kv.second << oz() << "] = n" << kv.first << ";\n";
+      os << (chunk > 0 ? chunk_body(b.str(), chunk) : b.str());
     }
     os << "  }\n";
     // ---- row
     if (rows) {
       if (gmode)
-        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, const double gz, double *acc, double &sv, int &err) {\n"
+        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, const double gz, rh_acc_t *acc, double &sv, int &err) {\n"
               "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       else
-        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const double *inv, const double *c, double *acc, int &err) {\n"
+        os << "  static RH_DEV void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, rh_acc_t *acc, int &err) {\n"
               "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       bool link_open = false;
+      std::ostringstream b;
       for (size_t n = 0; n < P.nodes.size(); n++) {
         if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
         if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
         if (link.ok && (n == link.V || link.cores.count((uint32_t)n))) {   // verified closed forms (detect_link)
-          if (!link_open) { emit_link_prelude(os); link_open = true; }
-          if (n == link.V) os << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
-          else os << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
+          if (!link_open) { emit_link_prelude(b); link_open = true; }
+          if (n == link.V) b << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
+          else b << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
           continue;
         }
-        if (!emit_node(os, (uint32_t)n, 1, err)) return false;
+        if (!emit_node(b, (uint32_t)n, 1, err)) return false;
       }
       for (size_t j = 0; j < basis.size(); j++)
-        if (basis[j] != NONE && !in_family[j]) os << accumulate("acc[" + std::to_string(j) + "]", basis[j], 1);
+        if (basis[j] != NONE && !in_family[j]) b << accumulate("acc[" + std::to_string(j) + oz() + "]", basis[j], 1);
       for (const Family &f : families) {   // eq(column, k, g, 0) for every k of the block: the column's value picks the one accumulator
-        os << "    { const double ix = " << ref(f.col, 1) << "; const int kk = (int)ix - (" << f.kmin << ");\n"
-           << "      if (ix == (double)(int)ix && (unsigned)kk < " << f.size << "u) acc[" << f.base << " + kk] += " << ref(f.g, 1) << "; }\n";
+        b << "    { const double ix = " << ref(f.col, 1) << "; const int kk = (int)ix - (" << f.kmin << ");\n"
+          << "      if (ix == (double)(int)ix && (unsigned)kk < " << f.size << "u) acc[" << f.base << " + kk] += " << ref(f.g, 1) << "; }\n";
       }
-      if (gather.ok) os << accumulate("sv", gather.sv, 1);
+      if (gather.ok) b << accumulate("sv", gather.sv, 1);
+      os << (chunk > 0 && !link_open ? chunk_body(b.str(), chunk) : b.str());   // (the closed-form link is a light row by construction)
       os << "  }\n";
       // ---- finish: tot[o] += alpha * S[j] + nrows * beta
-      os << "  static RH_DEV void finish(const double (&th)[RH_NTH], const double *inv, const double *S, const double nrows, double (&tot)[RH_NOUT]) {\n"
-            "    (void)th; (void)inv; (void)S; (void)nrows;\n";
+      os << "  static RH_DEV void finish(const double (&th)[RH_NTH], const rh_acc_t *inv, const rh_acc_t *S, const double nrows, double (&tot_)[RH_NOUT]) {\n"
+            "    (void)th; (void)inv; (void)S; (void)nrows; rh_acc_t *const tot = tot_; (void)tot;\n";
       for (size_t o = 0; o < outs.size(); o++) {
         const Lin &l = outs[o];
         std::string e;
-        if (l.term != NONE && l.alpha != ZERO) e = l.alpha == ONE ? "S[" + std::to_string(l.term) + "]" : ref(l.alpha, 2) + " * S[" + std::to_string(l.term) + "]";
+        if (l.term != NONE && l.alpha != ZERO) e = l.alpha == ONE ? "S[" + std::to_string(l.term) + oz() + "]" : ref(l.alpha, 2) + " * S[" + std::to_string(l.term) + oz() + "]";
         for (auto &tm : outs_multi[o]) {
           if (tm.second == ZERO) continue;
-          e += (e.empty() ? "" : " + ") + (tm.second == ONE ? "S[" + std::to_string(tm.first) + "]" : ref(tm.second, 2) + " * S[" + std::to_string(tm.first) + "]");
+          e += (e.empty() ? "" : " + ") + (tm.second == ONE ? "S[" + std::to_string(tm.first) + oz() + "]" : ref(tm.second, 2) + " * S[" + std::to_string(tm.first) + oz() + "]");
         }
         if (l.beta != ZERO) e += (e.empty() ? "" : " + ") + ("nrows * " + ref(l.beta, 2));
-        if (!e.empty()) os << "    tot[" << o << "] += " << e << ";\n";
+        if (!e.empty()) os << "    tot[" << o << oz() << "] += " << e << ";\n";
       }
       os << "  }\n";
     } else {
@@ -1150,20 +1255,22 @@ struct TargetEmitter {
       if (P.n_params > 512)
         os << "#ifndef RH_DEV_NOINLINE\n#define RH_DEV_NOINLINE __device__ __attribute__((noinline))\n#endif\n";
       os << "  static " << (P.n_params > 512 ? "RH_DEV_NOINLINE" : "RH_DEV")
-         << " void row(const double (&th)[RH_NTH], const double *inv, const double *c, double (&acc)[RH_NOUT], int &err) {\n"
-            "    (void)th; (void)inv; (void)c; (void)err;\n";
+         << " void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, double (&acc_)[RH_NOUT], int &err) {\n"
+            "    (void)th; (void)inv; (void)c; (void)err; rh_acc_t *const acc = acc_; (void)acc;\n";
       if (!merged_away) {
+        std::ostringstream b;
         for (size_t n = 0; n < P.nodes.size(); n++) {
           if (!reach_row[n] || trivial((uint32_t)n)) continue;
-          if (!emit_node(os, (uint32_t)n, 1, err)) return false;
+          if (!emit_node(b, (uint32_t)n, 1, err)) return false;
         }
         // accumulate target by target, in DataFunction order; every node above was evaluated exactly once
         for (uint32_t tt = t; tt <= run_end; tt++)
           for (size_t o = 0; o < (gmode ? (size_t)n_shared + 1 : P.targets[tt].outputs.size()); o++) {
             const Node &on = P.nodes[P.targets[tt].outputs[o]];
             if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
-            os << "    acc[" << o << "] += " << ref(P.targets[tt].outputs[o], 1) << ";\n";
+            b << "    acc[" << o << oz() << "] += " << ref(P.targets[tt].outputs[o], 1) << ";\n";
           }
+        os << (chunk > 0 ? chunk_body(b.str(), chunk) : b.str());
       }
       os << "  }\n";
     }
@@ -1196,6 +1303,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
     te.fma_adds = o.fma_adds;
+    te.chunk = o.chunk;
     if (P.targets[t].n_cols == 0) {  // runs of consecutive data-free targets share one evaluation
       if (t > 0 && P.targets[t - 1].n_cols == 0) te.merged_away = true;
       else { uint32_t e = t; while (e + 1 < P.targets.size() && P.targets[e + 1].n_cols == 0) e++; te.run_end = e; }
@@ -1221,10 +1329,10 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
   d << "#define RH_HAS_GATHER " << (gmode ? 1 : 0) << "\n#define RH_NSHARED " << n_shared << "\n#define RH_NTH " << n_shared
     << "\n#define RH_NGATHER " << ngather << "\n";
   const int slots = (int)((P.n_params + 63) / 64);
-  const bool bign = o.force_bign || slots > 8;
+  const bool bign = o.force_bign || slots > 8 || o.chunk > 0;   // (the memory-resident lowering keeps the chain vectors in HBM, theta and the outputs in memory: RH_BIGTH)
   // (generic models beyond 512 parameters read theta in place and accumulate their outputs in a per-chain scratch area: RH_BIGTH)
   I.bign = bign;
-  d << "#define RH_BIGN " << (bign ? 1 : 0) << "\n";
+  d << "#define RH_BIGN " << (bign ? 1 : 0) << "\n#define RH_HEAVY " << (o.chunk > 0 ? 1 : 0) << "\n#define RH_BIGU " << o.big_unroll << "\n";
   // chain packing: without observation rows a chain only needs as many lanes as it has parameters
   if (o.pack && nrowt == 0 && !bign && !gmode && P.n_params <= 32) I.pack_l = P.n_params <= 8 ? 8 : (P.n_params <= 16 ? 16 : 32);
   d << "#ifndef RH_PACK_L\n#define RH_PACK_L " << I.pack_l << "\n#endif\n";

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <fstream>
 #include <functional>
 #include <mutex>
@@ -42,6 +43,7 @@ static const char *kEngineSrc =
 
 namespace {
 thread_local std::string g_err;
+std::atomic<long> g_compiles{0};   // hiprtc compilations of this process (cache misses): rh_compile_count
 
 struct Fail {
   int code;
@@ -231,6 +233,11 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
   if (const char *e = std::getenv("RH_LOGIT_LINK")) m->eopt.logit_link = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RH_CHUNK")) if (m->eopt.chunk == 0) m->eopt.chunk = std::max(0, std::atoi(e));   // tests: the memory-resident lowering for any model
+  if (m->eopt.chunk > 0) {   // the memory-resident lowering comes with the lightest kernel shapes and without the special-cased rows
+    m->eopt.rows_unroll = 1; m->eopt.grad_unroll = 1; m->eopt.grad_pipeline = 0; m->unroll_auto = false;
+    m->eopt.grad_chains = 1;
+  }
   if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
     int ncols_max = 1;
@@ -296,19 +303,70 @@ void assemble_source(rh_model *m) {
               kEngineSrc;
 }
 
-std::vector<char> build_source(const std::string &arch, const std::string &source, const std::string &extra = std::string()) {
+// Which compiler hiprtc dispatches to is a property of the PROCESS, not of the hiprtc version number: a process that imported
+// torch first runs torch's bundled libhiprtc / comgr (another LLVM under the same API version), which produces different code for
+// the same source.  The cache key therefore carries the identity of the hiprtc library actually bound -- the file behind
+// hiprtcCompileProgram (name of the resolved file + its size) -- and, when one is already loaded, of the comgr library next to it.
+std::string compiler_identity() {
+  static const std::string id = [] {
+    auto ident = [](const char *path) {
+      std::string out = "?";
+      if (!path) return out;
+      char real[4096];
+      const char *rp = realpath(path, real) ? real : path;
+      struct stat st;
+      const char *slash = std::strrchr(rp, '/');
+      out = slash ? slash + 1 : rp;
+      if (stat(rp, &st) == 0) out += ":" + std::to_string((long long)st.st_size);
+      return out;
+    };
+    std::string r;
+    Dl_info info;
+    if (dladdr((void *)&hiprtcCompileProgram, &info) && info.dli_fname) r = ident(info.dli_fname);
+    for (const char *soname : {"libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"}) {
+      void *h = dlopen(soname, RTLD_NOLOAD | RTLD_LAZY);
+      if (!h) continue;
+      void *sym = dlsym(h, "amd_comgr_get_version");
+      if (sym && dladdr(sym, &info) && info.dli_fname) r += "+" + ident(info.dli_fname);
+      dlclose(h);
+      break;
+    }
+    return r;
+  }();
+  return id;
+}
+std::string cache_path(const std::string &arch, const std::string &source, const std::string &extra) {
   int hv = 0;
   hiprtcVersion(&hv, &hv);
-  const uint64_t h = fnv1a(arch + "|" + std::to_string(hv) + "|" + extra + "|" + source);
+  const uint64_t h = fnv1a(arch + "|" + std::to_string(hv) + "|" + compiler_identity() + "|" + extra + "|" + source);
   char name[64];
-  std::snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
-  const std::string path = cache_dir() + name;
+  std::snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
+  return cache_dir() + name;
+}
+std::vector<char> build_source(const std::string &arch, const std::string &source, const std::string &extra = std::string()) {
+  const std::string path = cache_path(arch, source, extra) + ".hsaco";
   std::vector<char> code;
   if (!std::getenv("RH_NO_KERNEL_CACHE") && read_file(path, code)) return code;
   std::string log;
   code = compile_hip(source, arch, extra, log);
+  g_compiles++;
   if (!std::getenv("RH_NO_KERNEL_CACHE")) write_file(path, code);
   return code;
+}
+// An attempt the engine abandons (build_code lowers the model again with a lighter shape) is not kept as a code object: a small
+// marker with the kernels that were unfit takes its place, so that the next process takes the same decision without compiling.
+void abandon_attempt(const std::string &arch, const std::string &source, const std::string &extra, const std::string &unfit) {
+  if (std::getenv("RH_NO_KERNEL_CACHE")) return;
+  const std::string base = cache_path(arch, source, extra);
+  std::remove((base + ".hsaco").c_str());
+  write_file(base + ".unfit", std::vector<char>(unfit.begin(), unfit.end()));
+}
+bool abandoned_attempt(const std::string &arch, const std::string &source, const std::string &extra, std::string &unfit) {
+  if (std::getenv("RH_NO_KERNEL_CACHE")) return false;
+  std::vector<char> b;
+  if (!read_file(cache_path(arch, source, extra) + ".unfit", b)) return false;
+  unfit.assign(b.begin(), b.end());
+  return true;
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
 
@@ -342,32 +400,76 @@ int kernel_health(const std::vector<char> &code, const std::string &name, std::s
 // in m->compile_attempts).  What is still unfit afterwards is recorded by load_module (m->chain_ok, m->tick_ok, ...).
 void build_code(rh_model *m) {
   const char *e = std::getenv("RH_HIPRTC_EXTRA");
+  const std::string extra = e ? e : "";
   const bool keep = std::getenv("RH_KEEP_UNROLL") != nullptr;
   for (;;) {
-    m->code = build_source(m->arch, m->source, e ? e : "");
     m->compile_attempts++;
+    std::string unfit;   // "\n"-separated names of the unfit kernels of an attempt that was abandoned before
+    const bool marker = !keep && abandoned_attempt(m->arch, m->source, extra, unfit);
+    if (!marker) m->code = build_source(m->arch, m->source, extra);
     if (keep) return;
-    auto bad = [&](const char *k) { return kernel_health(m->code, k) == KH_BAD; };
+    auto bad = [&](const char *k) {
+      if (marker) return unfit.find(std::string("\n") + k + "\n") != std::string::npos;
+      return kernel_health(m->code, k) == KH_BAD;
+    };
+    auto again = [&] {   // this attempt is abandoned: leave the marker, lower again
+      if (!marker) {
+        std::string names = "\n";
+        for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel",
+                              "rh_density_fin_kernel"})
+          if (kernel_health(m->code, k) == KH_BAD) names += std::string(k) + "\n";
+        abandon_attempt(m->arch, m->source, extra, names);
+      }
+      assemble_source(m);
+    };
+    // The last resort: when what has been built leaves the model without a sampling engine or without a density path, it is
+    // lowered again in the memory-resident form (emit.cpp chunk_body: the generated functions cut into chunks, values travelling
+    // through a per-lane scratch array -- the analogue of the reference's method splitting, ir/Packer.scala:10-71), with smaller
+    // chunks while that does not fit either.  Slower, same bits, any size.
+    auto usable = [&] {
+      if (m->info.gather_mode) return !bad("rh_grad_gather_kernel") && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
+      // (a dense linear predictor's gradients come from the MFMA kernel: load_module prefers it, so it can stand in for rh_grad_kernel)
+      const bool glm = m->has_glm && m->n_row_targets_hint == 1 && !m->glm_small && !marker && kernel_health(m->code, "rh_grad_glm_kernel") == KH_OK;
+      const bool tick = m->n_row_targets_hint > 0 && (!bad("rh_grad_kernel") || glm) && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
+      return tick || (!bad("rh_chain_kernel") && !bad("rh_density_kernel"));
+    };
+    auto heavier = [&] {
+      if (std::getenv("RH_NO_CHUNKS")) return false;
+      if (m->eopt.chunk == 0) { m->eopt.chunk = 48; return true; }   // (assemble_source sets what goes with it)
+      if (m->eopt.chunk > 12) { m->eopt.chunk /= 2; return true; }
+      return false;
+    };
+    // big mode (chain vectors in HBM): the vector loops keep RH_BIGU slots in flight per lane; fewer while a sampler kernel does not fit
+    if (m->info.bign && m->eopt.chunk == 0 && m->eopt.big_unroll > 2 && (bad("rh_tick_kernel") || bad("rh_chain_kernel"))) {
+      m->eopt.big_unroll /= 2; again(); continue;
+    }
     if (m->info.gather_mode) {   // K chains per wavefront x ~14 wave-uniform doubles each: fewer chains is the only lever
-      if (bad("rh_grad_gather_kernel") && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; assemble_source(m); continue; }
+      if (bad("rh_grad_gather_kernel") && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; again(); continue; }
+      if (!usable() && heavier()) { again(); continue; }
+      if (marker) m->code = build_source(m->arch, m->source, extra);   // (abandoned under other settings: it is the last shape now)
       return;
     }
     // the chain-per-wavefront kernels walk the rows with RH_ROWS_UNROLL copies of the row function per iteration (the unroll does
     // not change a lane's summation order, so the results are the same bits)
     if (m->n_row_targets_hint > 0 && m->eopt.rows_unroll > 1 && (bad("rh_density_kernel") || bad("rh_chain_kernel"))) {
       m->eopt.rows_unroll /= 2;
-      assemble_source(m);
+      again();
       continue;
     }
     // rh_chain_kernel asks for two wavefronts per SIMD (256 registers: +47 % on cfg 3); a model that does not fit gets one (512)
-    if (bad("rh_chain_kernel") && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) { m->eopt.chain_waves = 1; assemble_source(m); continue; }
-    if (!bad("rh_grad_kernel") && !bad("rh_grad_fused_kernel")) return;
-    // first fewer tiles per chunk, then fewer chains per wavefront; a row function that does not fit even alone keeps the plain row loop
-    if (m->eopt.grad_unroll > 1) m->eopt.grad_unroll /= 2;
-    else if (m->info.grad_k > 1) m->eopt.grad_chains = m->info.grad_k / 2;
-    else if (m->eopt.grad_pipeline != 0) m->eopt.grad_pipeline = 0;
-    else return;
-    assemble_source(m);
+    if (bad("rh_chain_kernel") && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) { m->eopt.chain_waves = 1; again(); continue; }
+    if (bad("rh_grad_kernel") || bad("rh_grad_fused_kernel")) {
+      // first fewer tiles per chunk, then fewer chains per wavefront; a row function that does not fit even alone keeps the plain row loop
+      bool lighter = true;
+      if (m->eopt.grad_unroll > 1) m->eopt.grad_unroll /= 2;
+      else if (m->info.grad_k > 1) m->eopt.grad_chains = m->info.grad_k / 2;
+      else if (m->eopt.grad_pipeline != 0) m->eopt.grad_pipeline = 0;
+      else lighter = false;
+      if (lighter) { again(); continue; }
+    }
+    if (!usable() && heavier()) { again(); continue; }
+    if (marker) m->code = build_source(m->arch, m->source, extra);   // (abandoned under other settings: it is the last shape now)
+    return;
   }
 }
 
@@ -471,24 +573,44 @@ std::string variant_defines(int v) {
   if (v & 4) d += "#define RH_PACK_L 64\n";  // one chain per wavefront although the model packs (few or diverging chains)
   return d;
 }
-// the code object of sampler-kernel variant v (v > 0) of a model whose base module has been built
+// the code object of sampler-kernel variant v (v > 0) of a model whose base module has been built.  A variant's chain state is
+// larger than the base module's (NUTS: seven more vectors, the tree's scalars), so its per-chain kernels may not fit where the base
+// module's do: it is then built with one wavefront per SIMD for rh_chain_kernel and / or fewer slots in flight in big mode's vector
+// loops (only the variant's per-chain kernels are used, so the base module's choices are not affected).  The first build whose
+// sampler kernels are all fit is taken; otherwise the one with the most.
 std::vector<char> build_variant_code(rh_model *m, int v) {
   const char *extra = std::getenv("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
-  std::vector<char> code = build_source(m->arch, variant_defines(v) + m->source, extra ? extra : "");
-  m->compile_attempts++;
-  if (!m->info.gather_mode && kernel_health(code, "rh_chain_kernel") == KH_BAD && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) {
-    // the variant's larger chain state does not fit two wavefronts per SIMD: its own build with one (only the variant's per-chain
-    // kernels are used, so the base module's choice is not affected)
+  auto with = [&](int waves, int bigu) {
     std::string src = m->source;
-    const std::string two = "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
-    const size_t at = src.find(two);
-    if (at != std::string::npos) {
-      src.replace(at, two.size(), "#define RH_CHAIN_WAVES 1\n");
-      code = build_source(m->arch, variant_defines(v) + src, extra ? extra : "");
-      m->compile_attempts++;
-    }
+    auto swap = [&](const std::string &name, int from, int to) {
+      const std::string a = "#define " + name + " " + std::to_string(from) + "\n";
+      const size_t at = src.find(a);
+      if (at != std::string::npos && from != to) src.replace(at, a.size(), "#define " + name + " " + std::to_string(to) + "\n");
+    };
+    swap("RH_CHAIN_WAVES", m->eopt.chain_waves, waves);
+    swap("RH_BIGU", m->eopt.big_unroll, bigu);
+    m->compile_attempts++;
+    return build_source(m->arch, variant_defines(v) + src, extra ? extra : "");
+  };
+  auto nfit = [&](const std::vector<char> &code) {
+    int n = 0;
+    if (!m->info.gather_mode && kernel_health(code, "rh_chain_kernel") != KH_BAD) n++;
+    if (m->n_row_targets_hint > 0 && kernel_health(code, "rh_tick_kernel") != KH_BAD) n++;
+    return n;
+  };
+  const int want = (m->info.gather_mode ? 0 : 1) + (m->n_row_targets_hint > 0 ? 1 : 0);
+  std::vector<std::pair<int, int>> shapes = {{m->eopt.chain_waves, m->eopt.big_unroll}};
+  if (!std::getenv("RH_CHAIN_WAVES") && m->eopt.chain_waves != 1 && !m->info.gather_mode) shapes.push_back({1, m->eopt.big_unroll});
+  if (m->info.bign) for (int u = m->eopt.big_unroll / 2; u >= 2; u /= 2) shapes.push_back({1, u});
+  std::vector<char> best;
+  int best_n = -1;
+  for (auto &sh : shapes) {
+    std::vector<char> code = with(m->info.gather_mode ? m->eopt.chain_waves : sh.first, sh.second);
+    const int n = nfit(code);
+    if (n > best_n) { best_n = n; best.swap(code); }
+    if (best_n >= want) break;
   }
-  return code;
+  return best;
 }
 void read_state_offsets(KSet &ks) {
   hipDeviceptr_t p; size_t sz;
@@ -974,6 +1096,24 @@ extern "C" int rh_optimize(rh_model *m, const double *x0, int32_t starts, int32_
   return rc;
 }
 
+extern "C" int rh_model_engines(const rh_model *m, int32_t *chain_engine, int32_t *tick_engine, int32_t *density, int32_t *compile_attempts,
+                                char *why, size_t why_cap) {
+  if (!m || !m->loaded) { g_err = "rh_model_engines: model not loaded"; return RH_E_INVALID; }
+  // (the base sampler-kernel variant; a NUTS / dense-mass variant is inspected when a sampler first asks for it)
+  if (chain_engine) *chain_engine = m->chain_ok ? 1 : 0;
+  if (tick_engine) *tick_engine = m->tick_ok ? 1 : 0;
+  if (density) *density = (m->density_ok || m->tick_ok) ? 1 : 0;
+  if (compile_attempts) *compile_attempts = m->compile_attempts;
+  if (why && why_cap) {
+    std::string w;
+    if (!m->chain_ok) w += "chain engine: " + m->chain_why + "\n";
+    if (!m->tick_ok) w += "tick engine: " + m->tick_why + "\n";
+    if (!m->density_ok) w += "rh_density_kernel: " + m->density_why + "\n";
+    std::snprintf(why, why_cap, "%s", w.c_str());
+  }
+  return RH_OK;
+}
+extern "C" int64_t rh_compile_count(void) { return (int64_t)g_compiles.load(); }
 extern "C" const char *rh_last_error(const rh_model *m) { return m ? m->err.c_str() : g_err.c_str(); }
 extern "C" int rh_abi_version(void) { return RH_ABI_VERSION; }
 extern "C" int rh_device_count(void) {
@@ -1053,7 +1193,7 @@ extern "C" int rh_lower_report_data(const void *rir, size_t rir_len, const doubl
       std::string r = "attempts=" + std::to_string(m.compile_attempts) + " rows_unroll=" + std::to_string(m.eopt.rows_unroll) +
                       " grad_unroll=" + std::to_string(m.eopt.grad_unroll) + " grad_k=" + std::to_string(m.info.grad_k) +
                       " chain_waves=" + std::to_string(m.eopt.chain_waves) + " grad_pipeline=" + std::to_string(m.eopt.grad_pipeline) +
-                      " gather=" + std::to_string((int)m.info.gather_mode) + " row_targets=" + std::to_string(m.n_row_targets_hint) + "\n";
+                      " chunk=" + std::to_string(m.eopt.chunk) + " bigu=" + std::to_string(m.eopt.big_unroll) + " gather=" + std::to_string((int)m.info.gather_mode) + " row_targets=" + std::to_string(m.n_row_targets_hint) + "\n";
       r += code_report(m.code, "base");
       if (!vcode.empty()) r += code_report(vcode, "variant" + std::to_string(opts->with_nuts & 7));
       *report = (char *)std::malloc(r.size() + 1); std::memcpy(*report, r.c_str(), r.size() + 1);
@@ -1245,7 +1385,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
     const int n = (int)m->prog.n_params;
     DevBuf bq(sizeof(double) * n * chains), bl(sizeof(double) * chains), bg(sizeof(double) * n * chains), be(sizeof(int));
     // generic models beyond 512 parameters accumulate their n + 1 outputs in memory (RH_BIGTH): one scratch row per chain
-    const bool bigth = m->info.bign && !m->info.gather_mode && n > 512;
+    const bool bigth = m->info.bign && !m->info.gather_mode && (n > 512 || m->eopt.chunk > 0);
     DevBuf btot(bigth ? sizeof(double) * (size_t)(n + 1) * chains : 8);
     void *dq = bq.p, *dl = bl.p, *dg = bg.p, *de = be.p, *dtot = btot.p;
     HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * n * chains, hipMemcpyHostToDevice, m->stream));
@@ -1547,7 +1687,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     launch(m->k_grad_fused, (unsigned)(((chains + m->grad_k - 1) / m->grad_k) * nsplit), 64, m->stream, args);
   };
   auto absorb = [&](void *rec) {
-    void *args[] = {&s->d_state, &rec, &s->d_qbuf, &chains};
+    void *args[] = {&s->d_state, &rec, &s->d_qbuf, &s->d_active, &chains};
     launch(m->k_absorb, (unsigned)chains, 64, m->stream, args);
   };
   // Static HMC in the sampling phase runs in lock step: every chain was paused at the head of the same iteration, so gradient

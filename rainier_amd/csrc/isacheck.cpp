@@ -13,11 +13,13 @@
 //     instruction inserted afterwards runs under the mask of the region that just ended.  Lanes that skipped the region keep a
 //     stale register, or their spill slot is never written.
 //
-//     What is flagged: an exec restore that is preceded, in its basic block, by an EXEC-honouring vector instruction with no
-//     other write of EXEC in between -- unless the block is the first body block of the very region the restore closes (its
-//     layout predecessor ends with the saveexec into the same SGPR pair and a branch: a then/else arm whose join block was merged
-//     into it).  The instruction walk needs only instruction LENGTHS and a handful of opcodes of the GFX9 encodings; the CPU suite
-//     checks the walk against llvm-objdump on every code object build() leaves in the kernel cache.
+//     What is flagged: an exec restore that is preceded, in its basic block, by a vector instruction that writes vector
+//     registers or memory, with no other write of EXEC in between -- when the block is PROVEN to be the region's join block by
+//     the way it is entered (the target of the header's s_cbranch_execz, or the fall-through of a divergent loop's back edge).
+//     Seen in the wild as scratch stores (spills), v_accvgpr_write (the allocator's register-to-AGPR copies, which the metadata
+//     does not count as spills) and v_mov (live-range splits).  The instruction walk needs only instruction LENGTHS and a handful
+//     of opcodes of the GFX9 encodings; the CPU suite checks the walk against llvm-objdump on every code object build() leaves
+//     in the kernel cache.
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
@@ -63,6 +65,8 @@ bool sections(const std::vector<char> &b, std::vector<Sec> &out, std::vector<std
 }
 
 // ---- GFX9 (gfx940 / gfx950) instruction walk --------------------------------------------------------------
+// K_VEC: a vector instruction that writes vector registers or memory under EXEC; K_VEC_NOEXEC: one that does not (lane access
+// instructions, compares into VCC / an SGPR pair -- the structurizer's own loop-exit conditions legitimately precede a restore)
 enum Kind : uint8_t { K_SALU, K_SMEM, K_VEC, K_VEC_NOEXEC, K_BRANCH, K_CBRANCH, K_END, K_INDIRECT };
 struct Ins {
   uint32_t off; uint8_t len; Kind kind;
@@ -71,6 +75,7 @@ struct Ins {
   bool reads_exec = false;      // scalar instruction with EXEC among its sources
   int sdst = -1;                // scalar destination register (first of a pair)
   int pair = -1;                // end_cf: the SGPR pair a
+  int src_pair = -1;            // SOP2 with EXEC as destination and as one source: the other source (an SGPR pair)
   int64_t target = -1;          // branch target (byte offset in the section)
   uint8_t bop = 0;              // SOPP opcode of a branch (8 = s_cbranch_execz, 9 = s_cbranch_execnz)
 };
@@ -105,7 +110,8 @@ bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
     const bool saveexec = (op >= 32 && op <= 39) || (op >= 51 && op <= 54);   // s_*_saveexec_b64, s_andn1/orn1_saveexec, s_andn{1,2}_wrexec
     if (saveexec) { I.writes_exec = true; I.reads_exec = true; }
     if (sdst == 126 || sdst == 127) I.writes_exec = true;
-    if (op == 29 || op == 30 || op == 31) I.kind = K_INDIRECT;   // s_setpc_b64, s_swappc_b64, s_rfe_b64
+    if (op == 29 || op == 31) I.kind = K_END;      // s_setpc_b64 (a function's return; a computed jump is never emitted inside our kernels), s_rfe_b64
+    // (op 30, s_swappc_b64, is a CALL: control comes back to the next instruction; the callee is walked as a function of its own)
     return true;
   }
   if ((w >> 28) == 0xB) {                         // SOPK
@@ -122,6 +128,7 @@ bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
     I.sdst = (int)sdst;
     I.reads_exec = s0 == 126 || s1 == 126 || s0 == 127 || s1 == 127;
     if (sdst == 126 || sdst == 127) I.writes_exec = true;
+    if (sdst == 126 && (s0 == 126 || s1 == 126)) { const unsigned other = s0 == 126 ? s1 : s0; if (other <= 107) I.src_pair = (int)other; }
     if (op == 15 && sdst == 126) {                // s_or_b64 exec, ...
       const unsigned other = s0 == 126 ? s1 : (s1 == 126 ? s0 : 999);
       if (other <= 107) { I.end_cf = true; I.pair = (int)other; }   // exec | an SGPR pair (or vcc): the SI_END_CF form
@@ -136,8 +143,9 @@ bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
     if ((w >> 25) == 0x3F) {                      // VOP1
       const unsigned op = (w >> 9) & 0xFF;
       if (op == 2) { I.kind = K_VEC_NOEXEC; I.sdst = (int)((w >> 17) & 0xFF); }  // v_readfirstlane_b32 (writes an SGPR)
-    } else if ((w >> 25) == 0x3E) {               // VOPC
+    } else if ((w >> 25) == 0x3E) {               // VOPC: writes VCC / EXEC only -- the structurizer's own loop-exit conditions sit ahead of a restore
       const unsigned op = (w >> 17) & 0xFF;
+      I.kind = K_VEC_NOEXEC;
       // v_cmpx_* write EXEC: class ops 0x11/0x13 (f32/f64 cmpx_class), 0x15 f16; compare ops with bit 4 set in each 0x20 block
       if (op == 0x11 || op == 0x13 || op == 0x15 || (op >= 0x30 && op <= 0x3F) || (op >= 0x50 && op <= 0x5F) || (op >= 0x70 && op <= 0x7F) ||
           (op >= 0xB0 && op <= 0xBF) || (op >= 0xD0 && op <= 0xDF) || (op >= 0xF0 && op <= 0xFF))
@@ -157,6 +165,7 @@ bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
       if (op == 0x142) I.kind = K_VEC_NOEXEC;                                   // v_readfirstlane_b32, VOP3 form
       if (op < 0x100) {                           // VOPC in VOP3 form: sdst in [7:0]
         const unsigned sd = w & 0xFF;
+        I.kind = K_VEC_NOEXEC;
         if (sd == 126 || sd == 127) I.writes_exec = true;
         if (op == 0x11 || op == 0x13 || op == 0x15 || (op >= 0x30 && op <= 0x3F) || (op >= 0x50 && op <= 0x5F) || (op >= 0x70 && op <= 0x7F) ||
             (op >= 0xB0 && op <= 0xBF) || (op >= 0xD0 && op <= 0xDF) || (op >= 0xF0 && op <= 0xFF))
@@ -214,7 +223,7 @@ bool kernel_meta(const std::vector<char> &code, const std::string &name, KernelM
   return out.found;
 }
 
-bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names) {
+bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names, bool kernels_only) {
   std::vector<Sec> secs; std::vector<std::string> sn;
   names.clear();
   if (!sections(code, secs, sn)) return false;
@@ -230,6 +239,23 @@ bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names
       names.push_back(n);
     }
   }
+  if (!kernels_only) return true;
+  // a kernel has a descriptor object "<name>.kd"; the other functions are device functions the kernels call (noinline)
+  std::set<std::string> kd;
+  for (size_t i = 0; i < secs.size(); i++) {
+    if (secs[i].type != 2 || secs[i].link >= secs.size()) continue;
+    const Sec &str = secs[secs[i].link];
+    for (uint64_t o = secs[i].off; o + 24 <= secs[i].off + secs[i].size; o += 24) {
+      uint32_t nm;
+      if (!rd(code, o, nm)) return false;
+      std::string n;
+      for (uint64_t p = str.off + nm; p < code.size() && code[p]; p++) n.push_back(code[p]);
+      if (n.size() > 3 && n.compare(n.size() - 3, 3, ".kd") == 0) kd.insert(n.substr(0, n.size() - 3));
+    }
+  }
+  std::vector<std::string> out;
+  for (const std::string &n : names) if (kd.count(n)) out.push_back(n);
+  names.swap(out);
   return true;
 }
 
@@ -269,6 +295,8 @@ bool check_code_object(const std::vector<char> &code, const std::string &only_ke
   std::vector<Sec> secs; std::vector<std::string> sn;
   if (!sections(code, secs, sn)) { findings.push_back("not an ELF64 code object"); return false; }
   std::vector<Func> funcs;
+  std::set<std::string> kernel_names;
+  { std::vector<std::string> kn; if (list_kernels(code, kn, true)) kernel_names.insert(kn.begin(), kn.end()); }
   for (size_t i = 0; i < secs.size(); i++) {
     if (secs[i].type != 2 || secs[i].link >= secs.size()) continue;
     const Sec &str = secs[secs[i].link];
@@ -278,12 +306,13 @@ bool check_code_object(const std::vector<char> &code, const std::string &only_ke
       if ((info & 0xF) != 2 || shndx >= secs.size() || sn[shndx] != ".text") continue;
       std::string n;
       for (uint64_t p = str.off + nm; p < code.size() && code[p]; p++) n.push_back(code[p]);
-      if (!only_kernel.empty() && n != only_kernel) continue;
+      if (!only_kernel.empty() && n != only_kernel && kernel_names.count(n)) continue;   // (device functions: possible callees of any kernel)
       const Sec &tx = secs[shndx];
       funcs.push_back({n, tx.off + (value - tx.addr), size});
     }
   }
-  if (funcs.empty()) { findings.push_back(only_kernel.empty() ? "no kernels in the code object" : "kernel " + only_kernel + " not found"); return false; }
+  if (funcs.empty() || (!only_kernel.empty() && !kernel_names.count(only_kernel))) {
+    findings.push_back(only_kernel.empty() ? "no kernels in the code object" : "kernel " + only_kernel + " not found"); return false; }
   bool walked = true;
   char buf[256];
   for (const Func &f : funcs) {
@@ -329,11 +358,15 @@ bool check_code_object(const std::vector<char> &code, const std::string &only_ke
         if (ins[j].kind == K_VEC) { seen_vec = true; first_vec = ins[j].off; }
       }
       if (closed || !seen_vec) continue;
-      // j = the block's first instruction.  Is this block the first BODY block of the region the restore closes (a then / else arm
-      // the join block was merged into, or duplicated into)?  A body block is entered from the region's header -- [saveexec into the
-      // same pair | s_xor / s_mov of that pair with EXEC], then the branch -- by falling through an s_cbranch_execz (or no branch
-      // at all) or by an s_cbranch_execnz; the JOIN block is entered the other way round (target of the execz, fall-through of the
-      // execnz), and there the instructions ahead of the restore are the fault.
+      // j = the block's first instruction.  The instructions ahead of the restore ran under the mask of the region that ends here;
+      // that is a fault exactly when this block is the region's JOIN block -- where every lane is supposed to be back -- and not
+      // a piece of the region's body that happens to end in the restore (a then / else arm the join block was merged or
+      // duplicated into, the tail of a region that contains uniform loops).  The join block is proven by how it is entered:
+      //   (a) it is the target of the s_cbranch_execz that follows the region's header -- [saveexec into the same pair | an
+      //       s_xor / s_mov of that pair with EXEC], then the branch: the lanes that skip the region land here;
+      //   (b) it is what an s_cbranch_execnz back edge falls through to whose loop mask -- `s_andn2_b64 exec, exec, s[a:b]` just
+      //       ahead of the branch -- is the pair: the exit of a divergent loop.
+      // (A region whose skip branch was removed -- a few instructions, no memory access -- has no such witness and is not seen.)
       auto opens_region = [&](size_t br) {   // do the (at most four) instructions ahead of ins[br] write the pair from EXEC?
         size_t k = br;
         for (int n = 0; n < 4 && k > 0; n++) {
@@ -343,15 +376,14 @@ bool check_code_object(const std::vector<char> &code, const std::string &only_ke
         }
         return false;
       };
-      bool region_body = false;
-      if (j > 0) {
-        const Ins &pv = ins[j - 1];
-        if (pv.kind == K_CBRANCH && pv.bop == 8) region_body = opens_region(j - 1);
-        else if (pv.kind != K_BRANCH && pv.kind != K_CBRANCH && pv.kind != K_END) region_body = opens_region(j);
+      bool join = false;
+      for (size_t bk = 0; bk < ins.size() && !join; bk++)
+        if (ins[bk].kind == K_CBRANCH && ins[bk].bop == 8 && ins[bk].target == (int64_t)ins[j].off) join = opens_region(bk);
+      if (!join && j > 0 && ins[j - 1].kind == K_CBRANCH && ins[j - 1].bop == 9 && j >= 2) {
+        const Ins &lm = ins[j - 2];   // s_andn2_b64 exec, exec, s[a:b]
+        join = lm.writes_exec && lm.reads_exec && lm.src_pair == ins[i].pair;
       }
-      for (size_t b = 0; b < ins.size() && !region_body; b++)
-        if (ins[b].kind == K_CBRANCH && ins[b].bop == 9 && ins[b].target == (int64_t)ins[j].off) region_body = opens_region(b);
-      if (region_body) continue;
+      if (!join) continue;
       std::snprintf(buf, sizeof buf, "%s+0x%x: exec restore (s[%d:%d]) behind vector instructions of its own block (first at +0x%x): "
                     "they ran under the mask of the region that ended", f.name.c_str(), ins[i].off, ins[i].pair, ins[i].pair + 1, first_vec);
       findings.push_back(buf);

@@ -646,7 +646,9 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
         }
       }
     }
-    if (!ok && !std::getenv("RH_LIFT_NOVERIFY")) { synth.resize(synth0); return no(12); }   // (the variable is a debugging aid)
+    // (the variable is a debugging aid.)  Nothing of the attempt is left behind: the row target's nodes were appended to P itself,
+    // among them INPUT nodes beyond P.n_inputs that a later lift would hand the same indices to
+    if (!ok && !std::getenv("RH_LIFT_NOVERIFY")) { synth.resize(synth0); P.nodes.resize(n_old); return no(12); }
   }
   P = std::move(Q);
   return true;

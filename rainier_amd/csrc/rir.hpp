@@ -121,6 +121,9 @@ struct EmitOptions {
   int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
+  int chunk = 0;          // > 0: memory-resident lowering (emit.cpp chunk_body): generated functions are cut into chunks of at most this many
+                          // statement groups and values travel between chunks through a per-lane scratch array; the engine's last resort for heavy models
+  int big_unroll = 16;    // big mode (chain vectors in HBM): slots in flight per lane in the vector loops (RH_BIGU); halved by the engine while a sampler kernel does not fit
   int chain_waves = 2;    // wavefronts per SIMD rh_chain_kernel asks for (2: 256 registers; the engine falls back to 1 when the kernel does not fit)
   int grad_pipeline = 2;  // row loop of the batched gradient kernel: 0 plain, 1 double-buffered, 2 rolling (a tile's registers are reloaded as soon as it is consumed)
 };
@@ -150,8 +153,8 @@ struct KernelMeta {
 };
 // the kernel's entry of the AMDGPU metadata note; false (found = false) when any of the fields is missing
 bool kernel_meta(const std::vector<char> &code, const std::string &name, KernelMeta &out);
-// the kernels (STT_FUNC symbols of .text) of a code object
-bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names);
+// the kernels of a code object (STT_FUNC symbols of .text with a kernel descriptor; kernels_only = false: device functions too)
+bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names, bool kernels_only = true);
 // instruction offsets of one kernel, relative to its first byte (the decoder's own test compares them with llvm-objdump)
 bool kernel_instruction_offsets(const std::vector<char> &code, const std::string &name, std::vector<uint32_t> &offs);
 // static check for vector instructions ahead of a join block's exec restore (this toolchain's register-allocator fault, see

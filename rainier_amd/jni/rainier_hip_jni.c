@@ -87,6 +87,16 @@ JNIEXPORT jlong JNICALL Java_com_stripe_rainier_hip_Native_00024_modelClone(JNIE
   return (jlong)(intptr_t)m;
 }
 
+/* int modelEngines(long model): which engines the model can use on this toolchain (rh_model_engines, ABI 5):
+ * bit 0 chain engine, bit 1 tick engine, bit 2 density seam; bits 8.. = code objects built or fetched while lowering it */
+JNIEXPORT jint JNICALL Java_com_stripe_rainier_hip_Native_00024_modelEngines(JNIEnv *env, jobject self, jlong h) {
+  (void)self;
+  int32_t chain = 0, tick = 0, density = 0, attempts = 0;
+  const int rc = rh_model_engines((const rh_model *)(intptr_t)h, &chain, &tick, &density, &attempts, NULL, 0);
+  if (rc != RH_OK) { throw_rh(env, NULL, rc); return 0; }
+  return (jint)((chain ? 1 : 0) | (tick ? 2 : 0) | (density ? 4 : 0) | (attempts << 8));
+}
+
 JNIEXPORT void JNICALL Java_com_stripe_rainier_hip_Native_00024_modelDestroy(JNIEnv *env, jobject self, jlong h) {
   (void)env; (void)self;
   rh_model_destroy((rh_model *)(intptr_t)h);

@@ -348,6 +348,15 @@ class Model:
     @property
     def hip_source(self) -> str: return _capi.lib().rh_model_hip_source(self._h).decode()
 
+    def engines(self) -> dict:
+        """rh_model_engines: which engines the engine agrees to run for this model on this toolchain and why not
+        ({"chain": bool, "tick": bool, "density": bool, "compile_attempts": int, "why": str})."""
+        c, t, d, a = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        why = C.create_string_buffer(2048)
+        _capi.check(_capi.lib().rh_model_engines(self._h, C.byref(c), C.byref(t), C.byref(d), C.byref(a), why, len(why)), self._h)
+        return {"chain": bool(c.value), "tick": bool(t.value), "density": bool(d.value), "compile_attempts": a.value,
+                "why": why.value.decode(errors="replace")}
+
     def density(self) -> DensityFunction: return DensityFunction(self)
 
     def density_batch(self, q: np.ndarray, engine: int = _capi.ENGINE_AUTO, grad_splits: int = 0):

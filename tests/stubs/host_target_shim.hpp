@@ -7,6 +7,12 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+// the generated functions' accumulator / invariant element type
+#ifndef RH_HEAVY
+#define RH_HEAVY 0
+#endif
+typedef double rh_acc_t;
+static inline int rh_oz() { return 0; }   // device: a volatile asm that yields 0 (an index the compiler cannot see through)
 #define RH_DEV inline
 #define RH_DEV_NOINLINE
 #define RH_NAN (__builtin_nan(""))

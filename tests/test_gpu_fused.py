@@ -49,3 +49,19 @@ def test_fused_launches_leave_the_chains_bit_identical(build, tuner, monkeypatch
     for got in (fused, pieces):
         assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1]) and got[2] == plain[2]
     assert all(st[0] == 9 * 7 for st in fused[2])
+
+
+def test_fused_schedule_against_the_oracle():
+    # the fused launches themselves against the ORACLE's chains (tame dynamics: static step, identity mass, so that rounding does
+    # not grow), before anything is compared product against product
+    from tests import oracle_lib as O
+    from tests.test_gpu_parity import _oracle_cfg
+    spec = models.linreg(n=70_001, k=3)
+    cfg = R.make_config(3, 0, R.HMCSampler(5), R.StaticStepSize(2e-3), R.IdentityMassMatrixTuner(), engine=_capi.ENGINE_TICK)
+    seeds = [900 + c for c in range(9)]
+    for build in (dict(math_mode=_capi.MATH_STRICT, grad_chains=4), dict(fp_contract=True, factor_outputs=True, grad_chains=8)):
+        got = _run(R.Model(spec, device=0, **build), cfg, seeds)
+        assert got[3] == "rh_grad_fused_kernel"
+        for c in (0, 8):
+            want, _, _ = O.sample_model(spec, _oracle_cfg(cfg, O.JM_DET), seeds[c])
+            np.testing.assert_allclose(got[0][c], want, rtol=1e-9, atol=1e-11, err_msg="fused schedule differs from the ORACLE (%s, chain %d)" % (build, c))

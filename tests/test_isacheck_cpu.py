@@ -1,0 +1,182 @@
+"""What the engine reads out of a code object before it launches one of its kernels (csrc/isacheck.cpp, csrc/engine.cpp
+kernel_health) -- no GPU needed.
+
+The reference never meets this problem: its back end cuts every expression tree into methods of at most 200 nodes
+(rainier-compute/.../ir/Packer.scala:10-71, compute/Compiler.scala:33-35), so no model is too heavy for the JVM.  Here a heavy row
+function meets a register file, and this toolchain's register allocator can place spill code, AGPR copies and live-range copies
+AHEAD of a join block's exec restore (profiles/r4_spill_rootcause): silent wrong sums.  The engine therefore launches a kernel only
+if it has no spilled vector register and its machine code shows no such join block."""
+import glob
+import lzma
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rainier_amd import _capi, models
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+KCACHE = os.path.join(ROOT, "rainier_amd", "kcache")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _cache_objects():
+    files = sorted(glob.glob(os.path.join(KCACHE, "*.hsaco")))
+    if not files:
+        pytest.skip("the kernel cache is empty: run __graft_entry__.build() first")
+    return files
+
+
+def _fault_fixture():
+    return lzma.decompress(open(os.path.join(HERE, "golden", "r4_join_fault.hsaco.xz"), "rb").read())
+
+
+def test_the_code_object_that_returned_wrong_draws_is_rejected(tmp_path):
+    # rh_chain_kernel of hier_negbin(6, 7) as round 3 ran it on the driver's box: 58 spilled VGPRs, chain-state vectors saved with
+    # 6 of 64 lanes active at the exit of the 6-row target's loop
+    code = _fault_fixture()
+    rep = _capi.code_object_report(code)
+    ck = rep[("object", "rh_chain_kernel")]
+    assert ck["fit"] == 0 and ck["vgpr_spills"] == 58 and ck["scratch"] == 236
+    assert rep[("object", "rh_density_kernel")]["fit"] == 1 and rep[("object", "rh_grad_kernel")]["fit"] == 1
+    # ... and by the machine-code walk alone, whatever the metadata says (the same fault shows with zero spills as v_accvgpr_write)
+    import isa_check
+    f = tmp_path / "fault.hsaco"
+    f.write_bytes(code)
+    bad = isa_check.check_file(str(f))
+    assert [(k, r) for k, _, _, r in bad] == [("rh_chain_kernel", "s_or_b64 exec, exec, s[12:13]")]
+    assert bad[0][2].startswith("scratch_store_dwordx2 off, v[136:137]")
+
+
+def test_instruction_walk_agrees_with_llvm_objdump_on_every_cached_kernel():
+    # the engine's own decoder only needs instruction LENGTHS and a handful of opcodes; every instruction boundary of every kernel
+    # build() left in the cache must be where llvm-objdump puts it
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    files = _cache_objects()
+    step = max(1, len(files) // 24)            # ~24 code objects spread over the cache (each one: 6..10 kernels)
+    nk = 0
+    for f in files[::step]:
+        code = open(f, "rb").read()
+        out = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", f], capture_output=True, text=True, check=True).stdout
+        cur, addrs, base = None, {}, {}
+        for ln in out.splitlines():
+            m = re.match(r"^([0-9a-f]+) <([^>]+)>:", ln)
+            if m:
+                cur = m.group(2); addrs[cur] = []; base[cur] = int(m.group(1), 16); continue
+            m = re.search(r"// ([0-9A-F]{12}):", ln)
+            if m and cur:
+                addrs[cur].append(int(m.group(1), 16) - base[cur])
+        for k, a in addrs.items():
+            mine = _capi.code_object_offsets(code, k)
+            assert mine and mine == a[:len(mine)], (os.path.basename(f), k)     # (objdump also prints the padding behind the symbol)
+            nk += 1
+    assert nk >= 50
+
+
+def test_engine_and_objdump_rule_agree_on_every_cached_kernel():
+    # two statements of the join-block rule: the engine's walk of the machine code and tools/isa_check.py over objdump's text
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    import isa_check
+    files = _cache_objects()
+    step = max(1, len(files) // 30)
+    for f in files[::step]:
+        code = open(f, "rb").read()
+        rep = _capi.code_object_report(code)
+        flagged_py = {k for k, _, _, _ in isa_check.check_file(f)}
+        flagged_engine = {k for (_, k), v in rep.items() if not v["fit"] and "exec restore" in v["why"]}
+        spilled = {k for (_, k), v in rep.items() if v["vgpr_spills"] > 0}
+        assert flagged_engine == flagged_py - spilled or flagged_engine | spilled >= flagged_py, (os.path.basename(f), flagged_engine, flagged_py)
+
+
+def test_no_cached_code_object_is_an_abandoned_attempt():
+    # an attempt the engine abandoned (it lowered the model again with a lighter shape) leaves a small marker, not a code object: what
+    # ships in the cache is what can be launched, and the next process takes the same decision without compiling
+    files = _cache_objects()
+    markers = glob.glob(os.path.join(KCACHE, "*.unfit"))
+    stems = {os.path.basename(f)[:-6] for f in files}
+    assert not stems & {os.path.basename(m)[:-6] for m in markers}
+    for m in markers:
+        names = open(m).read().split()
+        assert names and all(n.startswith("rh_") for n in names), m
+
+
+def test_every_model_of_build_keeps_a_usable_engine():
+    # walks what build() lowered (cache hits): every model keeps a density path and a sampling engine whose kernels the engine
+    # agrees to launch; no kernel it would launch reports a spilled vector register
+    import __graft_entry__ as G
+    n = 0
+    for name, rir, opts, check, kw in G.build_jobs():
+        _, rep = _capi.lower_report(rir, opts, **kw)
+        assert G._usable(rep), (name, {k: v["why"] for k, v in rep["kernels"].items() if not v["fit"]})
+        for (tag, k), v in rep["kernels"].items():
+            if v["fit"]:
+                assert v["vgpr_spills"] == 0, (name, tag, k)
+        n += 1
+    assert n >= 80
+
+
+def test_heavy_model_is_lowered_memory_resident_and_light_models_are_not():
+    # a 134-parameter table-prior model with 134 accumulators per lane does not fit the register file in any shape: the engine
+    # ends at the memory-resident lowering (chunks, volatile scratch arrays, theta and the outputs in memory) and keeps the tick
+    # engine; the README model keeps its bench shape
+    from tests.fuzz_models import GPU_FUZZ_CASES, gpu_fuzz_case
+    kind, seed, kw = next(c for c in GPU_FUZZ_CASES if c[0] == "table" and c[1] == 3)
+    spec = gpu_fuzz_case(kind, seed, dict(kw, npoints=0))[0]
+    src, rep = _capi.lower_report(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), columns=spec.columns, nrows=spec.nrows)
+    assert rep["shape"]["chunk"] > 0 and "#define RH_HEAVY 1" in src and "double rh_sp[" in src and "rh_oz()" in src and "#define RH_BIGN 1" in src
+    fit = {k: v["fit"] for (tag, k), v in rep["kernels"].items()}
+    assert fit["rh_grad_kernel"] and fit["rh_tick_kernel"] and fit["rh_density_fin_kernel"] and fit["rh_density_kernel"]
+    spec = models.linreg(n=8, k=3)
+    src, rep = _capi.lower_report(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True, grad_chains=8))
+    assert rep["shape"]["chunk"] == 0 and rep["shape"]["grad_k"] == 8 and rep["shape"]["grad_unroll"] == 8 and rep["shape"]["chain_waves"] == 2
+    assert all(v["fit"] for v in rep["kernels"].values())
+
+
+def test_memory_resident_lowering_is_bit_identical_on_the_host(monkeypatch):
+    # the chunked form of the generated functions (values through a volatile scratch array) computes the same bits as the plain
+    # form: checked with the host compiler on the generated code itself (tests/host_emulation.py)
+    from tests.host_emulation import HostTargets
+    from tests.fuzz_models import GPU_FUZZ_CASES, gpu_fuzz_case
+    cases = [c for c in GPU_FUZZ_CASES if c[0] == "table"][:2] + [c for c in GPU_FUZZ_CASES if c[0] != "table"][:2]
+    for kind, seed, kw in cases:
+        spec, qs = gpu_fuzz_case(kind, seed, dict(kw, npoints=3))[:2]
+        outs = []
+        for chunk in ("0", "5", "40"):
+            monkeypatch.setenv("RH_CHUNK", chunk)
+            src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), columns=spec.columns, nrows=spec.nrows, compile=False)
+            assert ("#define RH_HEAVY 1" in src) == (chunk != "0")
+            if chunk == "5":
+                assert "double rh_sp[" in src and "rh_oz()" in src       # values do travel through the scratch array
+            h = HostTargets(src)
+            outs.append([h.eval(q, spec.columns, spec.nrows) for q in qs])
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert np.array_equal(a[0], b[0], equal_nan=True) and a[1] == b[1], (kind, seed)
+
+
+def test_cache_key_carries_the_compiler_identity(tmp_path):
+    # a process that imported torch first binds torch's bundled hiprtc / comgr (another LLVM under the same hiprtc version number):
+    # its code objects must not share keys with the ROCm compiler's.  Same model, same options, two fresh processes, two temp caches.
+    prog = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "%s"
+            "from rainier_amd import _capi, models\n"
+            "spec = models.normal_1d()\n"
+            "_capi.lower_only(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT))\n"
+            "print(sorted(os.listdir(os.environ['RH_KERNEL_CACHE'])))\n")
+    keys = []
+    for tag, pre in (("plain", ""), ("torch", "import torch\n")):
+        d = tmp_path / tag
+        d.mkdir()
+        env = dict(os.environ, RH_KERNEL_CACHE=str(d))
+        out = subprocess.run([sys.executable, "-c", prog % (ROOT, pre)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        keys.append(eval(out.stdout.strip().splitlines()[-1]))
+    assert keys[0] and keys[1] and not set(keys[0]) & set(keys[1]), keys

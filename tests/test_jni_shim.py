@@ -43,7 +43,7 @@ def fj(tmp_path_factory):
     for name, res, args in [
             ("abiVersion", C.c_int32, []), ("deviceCount", C.c_int32, []),
             ("modelCreate", C.c_int64, [vp, vp, vp, vp]), ("modelDestroy", None, [C.c_int64]), ("modelNVars", C.c_int32, [C.c_int64]),
-            ("modelClone", C.c_int64, [C.c_int64, C.c_int32]),
+            ("modelClone", C.c_int64, [C.c_int64, C.c_int32]), ("modelEngines", C.c_int32, [C.c_int64]),
             ("densityEval", None, [C.c_int64, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
             ("optimize", None, [C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, vp]),
             ("sample", None, [vp] * 9), ("requirementsEval", None, [vp, vp, vp, C.c_int64, vp]),
@@ -131,7 +131,7 @@ def test_scala_flat_array_layouts_match_the_shim():
     native = open(os.path.join(ROOT, "integration", "scala", "Native.scala")).read()
     methods = re.findall(r"@native def (\w+)\(", native)
     symbols = re.findall(r"Java_com_stripe_rainier_hip_Native_00024_(\w+)\(", shim)
-    assert sorted(methods) == sorted(symbols) and len(methods) == 11
+    assert sorted(methods) == sorted(symbols) and len(methods) == 12
     # argument counts agree (JNIEnv*, jobject + the Scala parameters)
     for mth in methods:
         sc = re.search(r"@native def %s\((.*?)\)\s*:" % mth, native, re.S).group(1)
@@ -230,6 +230,8 @@ def test_shim_sample_is_bit_identical_to_the_ctypes_path(jvm):
         # two handles = rh_sample_multi: same trace
         h2 = call(fj, "modelClone", h, -1)                 # what hipSample(devices = ...) does: lowered once, cloned per device
         assert h2 != 0 and h2 != h and call(fj, "modelNVars", h2) == spec.n_params
+        eng = call(fj, "modelEngines", h)                  # rh_model_engines: a light model has every engine it could have
+        assert eng & 4 and eng & (1 | 2) and (eng >> 8) >= 1
         d2, m2, _ = _sample(fj, [h, h2], cfg, seeds, spec.n_params)
         assert np.array_equal(d2, d) and np.array_equal(m2, m)
         call(fj, "modelDestroy", h); call(fj, "modelDestroy", h2)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# The GPU tier in one call: every -m gpu test (no -x: a failure must not hide the rest; the row representatives of tests/conftest.py
+# run first), smoke(), and the default bench line.  usage, from the repo root:
+#   gpurun --timeout 1500 -- "bash tools/gpu_suite.sh NAME [pytest args]"      -> gpurun_out/NAME/{tests.log,smoke.log,bench.json}
+cd "$GRAFT_REPO_ROOT" || exit 1
+NAME=${1:-suite}; shift
+O=gpurun_out/$NAME; mkdir -p "$O"
+( time timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=15 "$@" ) > "$O/tests.log" 2>&1
+tail -25 "$O/tests.log"
+( time timeout 120 python -c "import __graft_entry__ as G; G.smoke()" ) > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log"
+( time timeout 400 python bench.py ) > "$O/bench.json" 2> "$O/bench.err"; cut -c1-600 "$O/bench.json"; tail -3 "$O/bench.err"

@@ -10,9 +10,11 @@ and runs under the mask of the region that just ended: lanes that skipped the re
 lanes are never written.  Seen in rh_chain_kernel of hier_negbin(6, 7): the 6-row prior target's loop exit spills four chain-state
 vectors with 6 lanes active (profiles/r4_spill_rootcause/).
 
-What is flagged, per basic block (label to label, labels = branch targets): a vector instruction (VALU / VMEM / DS / scratch /
-flat / global, anything that honours EXEC) that precedes an `s_or_b64 exec, exec, <sgpr pair>` with no other write of EXEC in
-between in that block.  `strict` flags it even when an earlier exec restore opened the block.
+What is flagged, per basic block (label to label, labels = branch targets): a vector instruction that writes vector registers or
+memory and precedes an `s_or_b64 exec, exec, <sgpr pair>` with no other write of EXEC in between in that block -- when the block is
+proven to be the join block of the region that restore closes (see check_lines).  The engine applies the same rule to the machine
+code itself before it launches a kernel (csrc/isacheck.cpp); this tool is the independent second statement of it, over
+llvm-objdump's text, that the CPU suite compares the engine's verdicts with.
 
 usage: python tools/isa_check.py [--strict] file.hsaco ... | --cache DIR
 """
@@ -42,36 +44,53 @@ def writes_exec(ins):
 
 
 def check_lines(lines, strict=False):
-    """-> list of (kernel, label, first vector instruction, the exec restore it precedes)"""
-    bad = []
-    kernel, label = None, None
-    first_vec, restored = None, False
-    scanning = False
+    """-> list of (kernel, label, first vector instruction, the exec restore it precedes).  A second statement of the rule
+    csrc/isacheck.cpp applies (that one walks the machine code itself): the block must be PROVEN the join block of the region the
+    restore closes -- the target of the s_cbranch_execz behind the saveexec into the same pair, or the fall-through of an
+    s_cbranch_execnz back edge behind `s_andn2_b64 exec, exec, <pair>`; strict = every block (many false positives: region
+    bodies that end in the restore)."""
+    blocks = []          # (kernel, label, [instructions])
+    kernel = None
     for ln in lines:
         m = _LABEL.match(ln)
         if m:
             name = m.group(1)
             if not re.match(r"^L\d+$", name):
                 kernel = name
-            label = name
-            first_vec, restored, scanning = None, False, True
+            blocks.append((kernel, name, []))
             continue
-        if not ln.startswith("\t") or not scanning:
-            continue
-        ins = ln.strip().split("//")[0].strip()
-        if not ins:
-            continue
-        if _END_CF.match(ins):
-            if first_vec is not None and (strict or not restored):
-                bad.append((kernel, label, first_vec, ins))
-                scanning = False
-            restored = True
-            continue
-        if writes_exec(ins):
-            scanning = False      # a region opens here: later restores in this block belong to it
-            continue
-        if _VECTOR.match(ins) and not _EXEC_IGNORING.match(ins) and first_vec is None:
-            first_vec = ins
+        if ln.startswith("\t") and blocks:
+            ins = ln.strip().split("//")[0].strip()
+            if ins:
+                blocks[-1][2].append(ins)
+    # witnesses: label -> set of pairs for which the label is a proven join block
+    joins = {}
+    for bi, (kern, lab, body) in enumerate(blocks):
+        for k, ins in enumerate(body):
+            m = re.match(r"^s_cbranch_execz (\S+)", ins)
+            if m:
+                for back in body[max(0, k - 4):k]:
+                    w = re.match(r"^s_\w+ (s\[\d+:\d+\]), .*", back)
+                    if w and ("exec" in back or "saveexec" in back):
+                        joins.setdefault((kern, m.group(1)), set()).add(w.group(1))
+            if re.match(r"^s_cbranch_execnz ", ins) and k == len(body) - 1 and k >= 1 and bi + 1 < len(blocks):
+                w = re.match(r"^s_andn2_b64 exec, exec, (s\[\d+:\d+\])", body[k - 1])
+                if w:
+                    joins.setdefault((kern, blocks[bi + 1][1]), set()).add(w.group(1))
+    bad = []
+    for kern, lab, body in blocks:
+        first_vec = None
+        for ins in body:
+            m = re.match(r"^s_or_b64 exec, exec, (s\[\d+:\d+\])", ins)
+            if m:
+                if first_vec is not None and (strict or m.group(1) in joins.get((kern, lab), ())):
+                    bad.append((kern, lab, first_vec, ins))
+                    break
+                continue
+            if writes_exec(ins):
+                break
+            if _VECTOR.match(ins) and not _EXEC_IGNORING.match(ins) and not ins.startswith("v_cmp") and first_vec is None:
+                first_vec = ins
     return bad
 
 
