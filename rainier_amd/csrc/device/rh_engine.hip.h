@@ -1951,28 +1951,18 @@ RH_DEV double rh_segmented_scan(double v, const int start, const int lane) {
   }
   return v;
 }
-// One 64-row tile of a gather-mode target for the K chains of the wavefront.  `full` is wave-uniform (a scalar branch): a full tile
-// runs the row function as it is; in the ragged last tile of a split every lane still runs it -- a lane past the end on the last
-// row, which it re-read -- and a select drops its contributions (see rh_rows_ragged): the row code has no divergent region around it.
+// One 64-row tile of a gather-mode target for the K chains of the wavefront.  The ragged last tile of a split is the one place where a
+// row function still runs inside a divergent region (`if (live)`): the select-masked form of rh_rows_ragged keeps K x (NACC + 1)
+// temporaries alive next to the accumulators -- 163-175 VGPRs instead of 123 for cfg 5, i.e. two wavefronts per SIMD instead of four
+// and 3.8 ms per launch instead of 3.2 (measured, profiles/r4_cfg5) -- for a tile that occurs once per split.  The join block behind
+// this region is what csrc/isacheck.cpp looks at before the kernel may be launched.
 template <int T, class INV, int NC, int NA>
 RH_DEV void rh_gather_rows(const double (&th)[RH_GRAD_K][RH_NTH], const INV &inv, const double (&cc)[NC], const double (&gz)[RH_GRAD_K],
-                           double (&acc)[RH_GRAD_K][NA], double (&sv)[RH_GRAD_K], int &err, const bool full, const bool live) {
+                           double (&acc)[RH_GRAD_K][NA], double (&sv)[RH_GRAD_K], int &err, const bool live) {
   typedef rh_target<T> TG;
-  constexpr int K = RH_GRAD_K;
-  if (full) {
+  if (live) {
 #pragma unroll
-    for (int kk = 0; kk < K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
-  } else {
-#pragma unroll
-    for (int kk = 0; kk < K; kk++) {
-      double t[NA], s1 = -0.0;
-#pragma unroll
-      for (int o = 0; o < NA; o++) t[o] = -0.0;
-      TG::row(th[kk], inv[kk], cc, gz[kk], t, s1, err);
-#pragma unroll
-      for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
-      sv[kk] = live ? sv[kk] + s1 : sv[kk];
-    }
+    for (int kk = 0; kk < RH_GRAD_K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
   }
 }
 template <int T>
@@ -2040,7 +2030,7 @@ RH_UNROLL_ACC
             gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
             sv[kk] = 0.0;
           }
-          rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
+          rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, live);
           if constexpr (TG::HAS_GATHER) {
             if (g == gA) {
 #pragma unroll
@@ -2082,7 +2072,7 @@ RH_UNROLL_ACC
           gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
           sv[kk] = 0.0;
         }
-        rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
+        rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, live);
         if constexpr (TG::HAS_GATHER) {
           const int start = gbeg - base;                      // first lane of this lane's group (<= 0: it began earlier)
           const bool tail = live && (r == gend - 1);          // last row of its group
@@ -2216,11 +2206,17 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
   RH_UNROLL_SLOTS
   for (int k = 0; k < RH_SLOTS; k++)
     if (k * 64 + lane < RH_NVARS) grad.s[k] = 0.0; // `grad` may be a view on an exactly-sized array
+  // ... so only the lane that owns element i touches it.  (The select form below reads and writes back EVERY lane's element of the
+  // slot: through a view on the caller's [chains][nVars] array the lanes past nVars did that to the first elements of the NEXT
+  // chain's gradient, racing with the workgroup that computes them -- found by the round-4 create-time self-check.)
+#pragma unroll
+  for (int i = 0; i < RH_NTH; i++)
+    if ((i & 63) == lane) grad.s[i >> 6] = tot[1 + i];
 #else
   wv_zero(grad);
-#endif
 #pragma unroll
   for (int i = 0; i < RH_NTH; i++) grad.s[i >> 6] = ((i & 63) == lane) ? tot[1 + i] : grad.s[i >> 6];
+#endif
 #if RH_HAS_GATHER
   // the table parameters' gradients: 8 slots' scatter sums are loaded before the first store (see RH_BIG2)
   for (int k0 = 0; k0 < RH_SLOTS; k0 += 8) {

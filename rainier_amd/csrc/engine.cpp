@@ -168,6 +168,7 @@ struct rh_model {
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int n_row_targets_hint = 0; // row targets of the lowered program (known before the module is loaded)
+  bool rows_unroll_auto = true;  // the chain-per-wavefront kernels' row unroll is the engine's choice (rh_compile_opts.rows_unroll == 0)
   bool unroll_auto = false;  // the row-loop unroll was the engine's choice (not the caller's): it may be reduced for a heavy row function
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
@@ -252,6 +253,24 @@ void assemble_source(rh_model *m) {
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
   m->n_row_targets_hint = 0;
   for (const auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets_hint++;
+  if (m->rows_unroll_auto && m->eopt.rows_unroll > 1 && m->n_row_targets_hint > 0) {
+    // the chain-per-wavefront kernels' row unroll: four copies of a light row function hide the loads; a heavier one brings its own
+    // parallelism and would only be lowered again after the compiler has spilled (build_code) -- start where those models end up
+    size_t row_ops = 1;
+    for (size_t hr = targets.find("HAS_ROWS = true;"); hr != std::string::npos; hr = targets.find("HAS_ROWS = true;", hr + 1)) {
+      const size_t at = targets.find("void row(", hr);
+      if (at == std::string::npos) break;
+      const size_t end = targets.find("void finish(", at);
+      size_t c = 0;
+      for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
+      row_ops = std::max(row_ops, c);
+    }
+    if (row_ops > 24) {
+      m->eopt.rows_unroll = 1;
+      defines.clear(); targets.clear();
+      if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
+    }
+  }
   if ((m->unroll_auto && m->eopt.grad_unroll > 1) || (m->eopt.grad_chains == 0 && m->info.grad_k > 1 && !m->info.gather_mode)) {
     // ... and where the row function is light: the unrolled body is K x U copies of it (cfg 2: 8 x 8 x 11 statements); a heavy row
     // function brings its own instruction-level parallelism and would only spill (build_code checks what the compiler did).
@@ -664,7 +683,7 @@ int apply_compile_opts(rh_model *m, const rh_compile_opts *opts) {
   m->eopt.strict_math = opts->math_mode == RH_MATH_STRICT;
   m->eopt.fp_contract = opts->fp_contract != 0;
   if (opts->rows_unroll < 0 || opts->rows_unroll > 64) throw Fail{RH_E_INVALID, "rows_unroll out of range [0,64]"};
-  if (opts->rows_unroll > 0) m->eopt.rows_unroll = opts->rows_unroll;
+  if (opts->rows_unroll > 0) { m->eopt.rows_unroll = opts->rows_unroll; m->rows_unroll_auto = false; }
   if (opts->grad_chains < 0 || opts->grad_chains > 16 || opts->grad_unroll < 0 || opts->grad_unroll > 16)
     throw Fail{RH_E_INVALID, "grad_chains / grad_unroll out of range [0,16]"};
   m->eopt.grad_chains = opts->grad_chains; m->eopt.grad_unroll = opts->grad_unroll;

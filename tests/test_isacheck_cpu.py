@@ -113,7 +113,7 @@ def test_every_model_of_build_keeps_a_usable_engine():
     import __graft_entry__ as G
     n = 0
     for name, rir, opts, check, kw in G.build_jobs():
-        _, rep = _capi.lower_report(rir, opts, **kw)
+        _, rep = G.lower_job(rir, opts, kw)
         assert G._usable(rep), (name, {k: v["why"] for k, v in rep["kernels"].items() if not v["fit"]})
         for (tag, k), v in rep["kernels"].items():
             if v["fit"]:

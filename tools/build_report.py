@@ -17,7 +17,7 @@ def main():
     show_all = "--all" in sys.argv
     n = nbad = 0
     for name, rir, opts, check, kw in G.build_jobs():
-        _, rep = _capi.lower_report(rir, opts, **kw)
+        _, rep = G.lower_job(rir, opts, kw)
         n += 1
         unfit = {k: v for k, v in rep["kernels"].items() if not v["fit"]}
         sh = rep["shape"]

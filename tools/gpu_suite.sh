@@ -5,7 +5,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 NAME=${1:-suite}; shift
 O=gpurun_out/$NAME; mkdir -p "$O"
-( time timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=15 "$@" ) > "$O/tests.log" 2>&1
-tail -25 "$O/tests.log"
+( time RH_HARVEST=$O/kcache_new timeout -s INT --kill-after=60 ${SUITE_TIMEOUT:-1200} python -m pytest tests -m gpu -v --tb=short -rf -p no:cacheprovider --durations=25 "$@" ) > "$O/tests.log" 2>&1
+grep -E "FAILED|ERROR|passed|failed" "$O/tests.log" | tail -30
+[ -n "$SUITE_ONLY" ] && exit 0
 ( time timeout 120 python -c "import __graft_entry__ as G; G.smoke()" ) > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log"
 ( time timeout 400 python bench.py ) > "$O/bench.json" 2> "$O/bench.err"; cut -c1-600 "$O/bench.json"; tail -3 "$O/bench.err"
