@@ -168,6 +168,7 @@ struct rh_model {
   int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int n_row_targets_hint = 0; // row targets of the lowered program (known before the module is loaded)
+  bool shape_guessed = false;    // assemble_source has made its first guesses from the size of the generated code
   bool rows_unroll_auto = true;  // the chain-per-wavefront kernels' row unroll is the engine's choice (rh_compile_opts.rows_unroll == 0)
   bool unroll_auto = false;  // the row-loop unroll was the engine's choice (not the caller's): it may be reduced for a heavy row function
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
@@ -253,6 +254,27 @@ void assemble_source(rh_model *m) {
   if (!rh::emit_hip(m->prog, m->eopt, defines, targets, err, &m->info)) throw Fail{RH_E_UNSUPPORTED, err};
   m->n_row_targets_hint = 0;
   for (const auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets_hint++;
+  if (!m->shape_guessed) {
+    // First guesses that spare a heavy model the attempts it is known to lose (each one a compilation of tens of seconds): a
+    // generated function of more than 1200 statements goes to the memory-resident lowering at once, and a generic model beyond 512
+    // parameters (theta and the outputs in memory, chain vectors in HBM) starts big mode's vector loops at 4 slots in flight --
+    // where the 601- and 701-parameter state-space models of the tests end up after five attempts otherwise.
+    m->shape_guessed = true;
+    size_t longest = 0;
+    for (size_t at = targets.find("void row("); at != std::string::npos; at = targets.find("void row(", at + 1)) {
+      const size_t end = targets.find("\n  }\n", at);
+      size_t c = 0;
+      for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
+      longest = std::max(longest, c);
+    }
+    bool again = false;
+    if (longest > 1200 && m->eopt.chunk == 0 && !std::getenv("RH_NO_CHUNKS")) {
+      m->eopt.chunk = 48; again = true;
+      if (!std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = 1;   // (such a model's chain kernel has never fitted two wavefronts per SIMD)
+    }
+    if (m->info.bign && !m->info.gather_mode && m->prog.n_params > 512 && m->eopt.big_unroll > 4) { m->eopt.big_unroll = 4; again = true; }
+    if (again) { assemble_source(m); return; }
+  }
   if (m->rows_unroll_auto && m->eopt.rows_unroll > 1 && m->n_row_targets_hint > 0) {
     // the chain-per-wavefront kernels' row unroll: four copies of a light row function hide the loads; a heavier one brings its own
     // parallelism and would only be lowered again after the compiler has spilled (build_code) -- start where those models end up
@@ -1578,7 +1600,13 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       if (cfg->engine == RH_ENGINE_CHAIN && m->info.gather_mode) throw Fail{RH_E_UNSUPPORTED, "gather-mode models run on the tick engine only"};
       KSet *ksp = nullptr;
       { std::lock_guard<std::mutex> lk(m->mu);  // variants are built lazily: two samplers may be created concurrently
-        ksp = &load_variant(m, v); }
+        ksp = &load_variant(m, v);
+        // a packed variant (several chains per wavefront) whose chain kernel is not fit to run: the one-chain-per-wavefront variant
+        // of the same sampler kernels takes its place (same chains, bit for bit; eight-schools' packed NUTS kernel is the case)
+        if (!ksp->k_chain && !m->info.gather_mode && !(v & 4) && m->info.pack_l != 64 && g_force_variant < 0) {
+          KSet &alt = load_variant(m, v | 4);
+          if (alt.k_chain) { v |= 4; s->pack_l = 64; ksp = &alt; }
+        } }
       KSet &ks = *ksp;
       // Engine choice.  AUTO: the tick engine for gather mode and from 65 536 rows on, the chain engine below -- and whichever of
       // the two has kernels that are fit to run (kernel_health) and agree with the density kernel on this device (self-check)
