@@ -427,7 +427,11 @@ int kernel_health(const std::vector<char> &code, const std::string &name, std::s
   if (std::find(names.begin(), names.end(), name) == names.end()) return KH_ABSENT;
   if (std::getenv("RH_ALLOW_UNHEALTHY")) return KH_OK;
   if (!rh::kernel_meta(code, name, km)) { if (why) *why = name + ": no metadata entry (spill count unknown)"; return KH_BAD; }
-  if (km.vgpr_spills != 0) { if (why) *why = name + ": " + std::to_string(km.vgpr_spills) + " spilled vector registers"; return KH_BAD; }
+  // (the count includes the allocator's VGPR -> AGPR copies; without a single scratch instruction in the kernel nothing went to memory)
+  if (km.vgpr_spills != 0 && rh::kernel_touches_scratch(code, name) != 0) {
+    if (why) *why = name + ": " + std::to_string(km.vgpr_spills) + " spilled vector registers";
+    return KH_BAD;
+  }
   std::vector<std::string> findings;
   if (!rh::check_code_object(code, name, findings) || !findings.empty()) {
     if (why) *why = findings.empty() ? name + ": machine code could not be walked" : findings[0];

@@ -78,6 +78,7 @@ struct Ins {
   int src_pair = -1;            // SOP2 with EXEC as destination and as one source: the other source (an SGPR pair)
   int64_t target = -1;          // branch target (byte offset in the section)
   uint8_t bop = 0;              // SOPP opcode of a branch (8 = s_cbranch_execz, 9 = s_cbranch_execnz)
+  bool scratch = false;         // an access to private (scratch) memory
 };
 
 bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
@@ -176,6 +177,8 @@ bool decode(const unsigned char *p, size_t left, uint32_t off, Ins &I) {
   }
   if (enc == 0x36 || enc == 0x37 || enc == 0x38 || enc == 0x3A || enc == 0x3C || enc == 0x31) {   // DS, FLAT, MUBUF, MTBUF, MIMG, EXP
     I.len = 8; I.kind = K_VEC;
+    if (enc == 0x37 && ((w >> 14) & 3) == 1) I.scratch = true;   // FLAT encoding, SEG = scratch: private memory (spills, local arrays)
+    if (enc == 0x38) I.scratch = true;                            // MUBUF: the other way private memory is reached
     return true;
   }
   if (enc == 0x35) { I.kind = K_VEC; return true; }                              // VINTRP (not in compute code)
@@ -288,6 +291,38 @@ bool kernel_instruction_offsets(const std::vector<char> &code, const std::string
     }
   }
   return false;
+}
+
+// Does the kernel's own code touch private (scratch) memory at all?  `.vgpr_spill_count` also counts the allocator's VGPR -> AGPR
+// copies (they start life as spills and are turned into v_accvgpr_write later), so a non-zero count on a kernel WITHOUT a single
+// scratch instruction is not a spill to memory -- and the copies themselves are what the join-block walk looks at.
+// returns -1 when the kernel cannot be walked
+int kernel_touches_scratch(const std::vector<char> &code, const std::string &name) {
+  std::vector<Sec> secs; std::vector<std::string> sn;
+  if (!sections(code, secs, sn)) return -1;
+  for (size_t i = 0; i < secs.size(); i++) {
+    if (secs[i].type != 2 || secs[i].link >= secs.size()) continue;
+    const Sec &str = secs[secs[i].link];
+    for (uint64_t o = secs[i].off; o + 24 <= secs[i].off + secs[i].size; o += 24) {
+      uint32_t nm; unsigned char info; uint16_t shndx; uint64_t value, size;
+      if (!rd(code, o, nm) || !rd(code, o + 4, info) || !rd(code, o + 6, shndx) || !rd(code, o + 8, value) || !rd(code, o + 16, size)) return -1;
+      if ((info & 0xF) != 2 || shndx >= secs.size()) continue;
+      std::string n;
+      for (uint64_t p = str.off + nm; p < code.size() && code[p]; p++) n.push_back(code[p]);
+      if (n != name) continue;
+      const Sec &tx = secs[shndx];
+      const uint64_t foff = tx.off + (value - tx.addr);
+      if (foff + size > code.size()) return -1;
+      for (uint64_t p = 0; p < size;) {
+        Ins I;
+        if (!decode((const unsigned char *)code.data() + foff + p, size - p, (uint32_t)p, I)) return -1;
+        if (I.scratch) return 1;
+        p += I.len;
+      }
+      return 0;
+    }
+  }
+  return -1;
 }
 
 // -> findings, one line each: "<kernel>+0x<offset>: ..."; returns false when the code object cannot be walked at all

@@ -155,6 +155,8 @@ struct KernelMeta {
 bool kernel_meta(const std::vector<char> &code, const std::string &name, KernelMeta &out);
 // the kernels of a code object (STT_FUNC symbols of .text with a kernel descriptor; kernels_only = false: device functions too)
 bool list_kernels(const std::vector<char> &code, std::vector<std::string> &names, bool kernels_only = true);
+// 1 / 0: the kernel's own code does / does not access private (scratch) memory; -1: it cannot be walked
+int kernel_touches_scratch(const std::vector<char> &code, const std::string &name);
 // instruction offsets of one kernel, relative to its first byte (the decoder's own test compares them with llvm-objdump)
 bool kernel_instruction_offsets(const std::vector<char> &code, const std::string &name, std::vector<uint32_t> &offs);
 // static check for vector instructions ahead of a join block's exec restore (this toolchain's register-allocator fault, see

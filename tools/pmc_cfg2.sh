@@ -7,7 +7,7 @@
 #      bench.py only quotes `roofline.traffic` from a profile of byte-identical code.
 # usage (from the repo root, via gpurun): bash tools/pmc_cfg2.sh <git-head> [outdir-name]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r3_b_cfg2}
+R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r4_cfg2}
 O=$R/gpurun_out/$NAME; mkdir -p $O
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ess --no-inlined --no-live-traffic"
 $BENCH > $O/bench_noprof.json 2> $O/bench_noprof.err
@@ -19,6 +19,12 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/p$i -o bench -- $BENCH > $O/p$i/log.txt 2>&1
   f=$(find $O/p$i -name "bench_counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/p$i/bench_counter_collection.csv
 done
+python - "$O/p1/bench_counter_collection.csv" > $O/p1_kernels.txt 2>&1 <<'PY'
+import csv, sys, collections
+c = collections.Counter(r["Kernel_Name"] for r in csv.DictReader(open(sys.argv[1])))
+for k, n in c.most_common(): print(n, k)
+PY
+tail -3 $O/p1/log.txt > $O/p1_log_tail.txt 2>/dev/null
 SHA=$(python -c "import json;print(json.load(open('$O/bench_noprof.json'))['config']['generated_source_sha16'])")
 python $R/profiles/summarize.py rh_grad_fused_kernel 256 $O/pmc_grad_kernel.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 \
   --meta git_head=$HEAD generated_source_sha16=$SHA rows=1000000 chains_per_gpu=1024 > $O/summary.txt 2>&1
