@@ -1356,6 +1356,9 @@ struct GatherBufs {
         gd.sbuf[rt] = (double *)sb;
       }
     }
+    // hipMemset on device memory is a fill KERNEL on the null stream and returns before it has run; the engine's own stream is
+    // non-blocking, so nothing orders its first launch behind these fills but this
+    HIPCHK(hipDeviceSynchronize());
   }
   ~GatherBufs() { for (void *p : owned) (void)hipFree(p); }
 };
@@ -1567,6 +1570,7 @@ bool selfcheck_engine(rh_model *m, KSet &ks, int v, bool tick) {
   done = true;
   if (why.empty()) return true;
   if (tick) { ks.k_tick = nullptr; ks.why_tick = why; } else { ks.k_chain = nullptr; ks.why_chain = why; }
+  std::fprintf(stderr, "rainier-hip: the %s engine is taken out of use for this model: %s\n", tick ? "tick" : "chain", why.c_str());   // never silently
   return false;
 }
 }  // namespace
@@ -1693,6 +1697,11 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
         s->gb = new GatherBufs(); s->gb->build(m, chains, nsplit);
       }
     }
+    // The buffers above were cleared with hipMemset: fill KERNELS on the null stream that return before they have run, while the
+    // sampler's launches go to the model's non-blocking stream -- a late fill of `active` / `qbuf` would wipe what the first tick has
+    // published (seen under `rocprofv3 --pmc`, where dispatches are serialised: the round-4 self-check caught the first gradient
+    // of a 3-chain sampler summing 29 of its 488 row splits).  Everything is in place before the handle leaves this function.
+    HIPCHK(hipDeviceSynchronize());
   });
   if (rc != RH_OK) { rh_sampler_destroy(s); return rc; }
   *out = s;
