@@ -116,11 +116,11 @@ def test_every_model_of_build_keeps_a_usable_engine():
         _, rep = G.lower_job(rir, opts, kw)
         assert G._usable(rep), (name, {k: v["why"] for k, v in rep["kernels"].items() if not v["fit"]})
         for (tag, k), v in rep["kernels"].items():
-            # (`.vgpr_spill_count` also counts the allocator's VGPR -> AGPR copies: a kernel is only held to it when its own code
-            #  touches scratch memory at all -- csrc/isacheck.cpp kernel_touches_scratch; a kernel without scratch has scratch 0
-            #  unless it calls a device function that owns a frame)
+            # `.vgpr_spill_count` also counts the allocator's VGPR -> AGPR copies; a non-zero count is accepted for the two sampler
+            # kernels only, and only when their own code has no scratch instruction (csrc/engine.cpp kernel_health): the
+            # row-streaming and density kernels are held to the plain rule
             if v["fit"] and v["vgpr_spills"] != 0:
-                assert v["scratch"] == 0 or "_ZN" in "".join(kk for (_, kk) in rep["kernels"]), (name, tag, k, v)
+                assert k in ("rh_chain_kernel", "rh_tick_kernel"), (name, tag, k, v)
         n += 1
     assert n >= 80
 
