@@ -65,6 +65,9 @@ typedef struct rh_compile_opts {
   int32_t device;        /* HIP device ordinal; -1 = current device */
   int32_t math_mode;     /* rh_math_mode */
   int32_t fp_contract;   /* 0 = never fuse a*b+c in model code (JVM semantics, default); 1 = allow FMA */
+  /* The three shape fields are UPPER BOUNDS: the engine lowers a model again with a smaller value while a kernel of the requested
+     shape is not fit to run on this toolchain (spilled registers / vector code ahead of a join's exec restore: rh_model_engines),
+     so a caller never gets a kernel the engine would not launch; the generated source (rh_model_hip_source) says what was built. */
   int32_t rows_unroll;   /* row-loop unroll factor of the chain-per-wavefront kernel; 0 = engine default */
   int32_t grad_chains;   /* tick engine: chains that share one pass over the rows per wavefront; 0 = default (4) */
   int32_t grad_unroll;   /* tick engine: row-loop unroll; 0 = default (2) */

@@ -95,6 +95,14 @@ object HipModel {
       Native.modelCreate(rir.bytes, rir.columns, rir.rows, opts.copts)
     }
 
+    /** Which engines the model can use on this toolchain (rh_model_engines, ABI 5): (chain engine, tick engine, density seam,
+      * code objects built or fetched while lowering).  The engine inspects every kernel before it launches it and replaces what is
+      * not fit to run (INTEGRATION.md section 5); RH_ENGINE_AUTO never needs this, an explicit engine request should look first. */
+    def hipEngines(opts: HipOptions = HipOptions.fast): (Boolean, Boolean, Boolean, Int) = {
+      val h = create(opts)
+      try { val e = Native.modelEngines(h); ((e & 1) != 0, (e & 2) != 0, (e & 4) != 0, e >> 8) } finally Native.modelDestroy(h)
+    }
+
     /** Model.density() on the device; the caller owns the handle through `close`. */
     def hipDensity(opts: HipOptions = HipOptions.fast): (DensityFunction, () => Unit) = {
       val h = create(opts)
