@@ -329,6 +329,7 @@ def main():
     cpg = a.chains_per_gpu
     seeds = D.shard_seeds(1000, cpg, rank)     # seeds by GLOBAL chain id: results independent of the GPU count
     engine = {"auto": 0, "chain": 1, "tick": 2}[a.engine]
+    engines = model.engines()                  # which engines the engine agrees to run for this build on this toolchain (rh_model_engines)
 
     def leg(iters, warm, mass_tuner=None):
         """One sampler run: `warm` untimed warm-up iterations, then `iters` timed ones + (N > 1) the ONE collective.
@@ -408,7 +409,10 @@ def main():
                                "%d chains/GPU, DualAvgTuner(0.8), identity mass" % (rows, L, cpg),
                    "chains": cpg * world, "rows": rows, "leapfrog_per_step": L, "fp_contract": not a.strict, "factor_outputs": not (a.strict or a.no_factor),
                    "engine": tim["dominant_kernel"], "grad_chains": a.grad_chains, "grad_unroll": a.grad_unroll,
-                   "grad_splits": a.grad_splits, "generated_source_sha16": src_sha},
+                   "grad_splits": a.grad_splits, "generated_source_sha16": src_sha,
+                   # (ABI 5: kernels the engine found unfit to run are replaced, never launched; empty `why` = nothing was)
+                   "engines_usable": {k: engines[k] for k in ("chain", "tick", "density")}, "engines_why": engines["why"].strip(),
+                   "compile_attempts": engines["compile_attempts"]},
         "row_chain_evals_per_s": rce, "grad_element_evals_per_s": rce * spec.n_params,
         # ESS/s = min over parameters of Trace.diagnostics' ESS, over the leg's wall time; quoted for the leg that converges: the
         # bench's model, chains, kernels and static L with DefaultConfig's windowed diagonal mass adaptation (Sampler.scala:24-25).
