@@ -107,39 +107,48 @@ def test_no_cached_code_object_is_an_abandoned_attempt():
         assert names and all(n.startswith("rh_") for n in names), m
 
 
+def _build_report():
+    import json
+    path = os.path.join(KCACHE, "build_report.json")
+    if not os.path.exists(path):
+        pytest.skip("no build report: run __graft_entry__.build() first")
+    return json.load(open(path))
+
+
 def test_every_model_of_build_keeps_a_usable_engine():
-    # walks what build() lowered (cache hits): every model keeps a density path and a sampling engine whose kernels the engine
-    # agrees to launch; no kernel it would launch reports a spilled vector register
-    import __graft_entry__ as G
-    n = 0
-    for name, rir, opts, check, kw in G.build_jobs():
-        _, rep = G.lower_job(rir, opts, kw)
-        assert G._usable(rep), (name, {k: v["why"] for k, v in rep["kernels"].items() if not v["fit"]})
-        for (tag, k), v in rep["kernels"].items():
-            # `.vgpr_spill_count` also counts the allocator's VGPR -> AGPR copies; a non-zero count is accepted for the two sampler
-            # kernels only, and only when their own code has no scratch instruction (csrc/engine.cpp kernel_health): the
-            # row-streaming and density kernels are held to the plain rule
+    # build() lowers ~100 models (the BASELINE configurations, the reference's own lowerings, the GPU fuzz cases, sampler-kernel
+    # variants) and asserts for each that it keeps a density path and a sampling engine; what the engine settled on is in the
+    # build report beside the code objects.  Here: no kernel the engine would launch reports a spilled vector register -- but
+    # for the two sampler kernels, whose count may be the allocator's VGPR -> AGPR copies (csrc/engine.cpp kernel_health)
+    rep = _build_report()
+    assert len(rep) >= 80
+    for name, r in rep.items():
+        ks = {k.split(":", 1)[1]: v for k, v in r["kernels"].items() if k.startswith("base:")}
+        gather = "rh_grad_gather_kernel" in ks
+        tick = ks.get("rh_tick_kernel", {}).get("fit") and ks.get("rh_density_fin_kernel", {}).get("fit") and \
+            (ks.get("rh_grad_gather_kernel" if gather else "rh_grad_kernel", {}).get("fit") or ks.get("rh_grad_glm_kernel", {}).get("fit"))
+        chain = ks.get("rh_chain_kernel", {}).get("fit") and ks.get("rh_density_kernel", {}).get("fit")
+        assert tick or chain, name
+        for k, v in r["kernels"].items():
             if v["fit"] and v["vgpr_spills"] != 0:
-                assert k in ("rh_chain_kernel", "rh_tick_kernel"), (name, tag, k, v)
-        n += 1
-    assert n >= 80
+                assert k.split(":", 1)[1] in ("rh_chain_kernel", "rh_tick_kernel"), (name, k, v)
 
 
 def test_heavy_model_is_lowered_memory_resident_and_light_models_are_not():
     # a 134-parameter table-prior model with 134 accumulators per lane does not fit the register file in any shape: the engine
-    # ends at the memory-resident lowering (chunks, volatile scratch arrays, theta and the outputs in memory) and keeps the tick
-    # engine; the README model keeps its bench shape
-    from tests.fuzz_models import GPU_FUZZ_CASES, gpu_fuzz_case
-    kind, seed, kw = next(c for c in GPU_FUZZ_CASES if c[0] == "table" and c[1] == 3)
-    spec = gpu_fuzz_case(kind, seed, dict(kw, npoints=0))[0]
-    src, rep = _capi.lower_report(spec.rir, _capi.compile_opts(math_mode=_capi.MATH_STRICT), columns=spec.columns, nrows=spec.nrows)
-    assert rep["shape"]["chunk"] > 0 and "#define RH_HEAVY 1" in src and "double rh_sp[" in src and "rh_oz()" in src and "#define RH_BIGN 1" in src
-    fit = {k: v["fit"] for (tag, k), v in rep["kernels"].items()}
-    assert fit["rh_grad_kernel"] and fit["rh_tick_kernel"] and fit["rh_density_fin_kernel"] and fit["rh_density_kernel"]
+    # ends at the memory-resident lowering (chunks, opaque-index scratch arrays, theta and the outputs in memory) and keeps the tick
+    # engine; the README model keeps its bench shape.  (From build()'s report: lowering the heavy one is minutes of compilation.)
+    rep = _build_report()
+    heavy = [r for n, r in rep.items() if "fuzz_table_3[strict]" in n]
+    assert heavy and all(r["heavy"] and r["shape"]["chunk"] > 0 for r in heavy)
+    for r in heavy:
+        fit = {k.split(":", 1)[1]: v["fit"] for k, v in r["kernels"].items()}
+        assert fit["rh_grad_kernel"] and fit["rh_tick_kernel"] and fit["rh_density_fin_kernel"] and fit["rh_density_kernel"]
+    assert sum(r["heavy"] for r in rep.values()) < len(rep) // 3        # the last resort, not the rule
     spec = models.linreg(n=8, k=3)
-    src, rep = _capi.lower_report(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True, grad_chains=8))
-    assert rep["shape"]["chunk"] == 0 and rep["shape"]["grad_k"] == 8 and rep["shape"]["grad_unroll"] == 8 and rep["shape"]["chain_waves"] == 2
-    assert all(v["fit"] for v in rep["kernels"].values())
+    src, rep1 = _capi.lower_report(spec.rir, _capi.compile_opts(fp_contract=True, factor_outputs=True, grad_chains=8))
+    assert rep1["shape"]["chunk"] == 0 and rep1["shape"]["grad_k"] == 8 and rep1["shape"]["grad_unroll"] == 8 and rep1["shape"]["chain_waves"] == 2
+    assert all(v["fit"] for v in rep1["kernels"].values()) and "#define RH_HEAVY 0" in src
 
 
 def test_memory_resident_lowering_is_bit_identical_on_the_host(monkeypatch):
