@@ -760,13 +760,20 @@ def test_random_reference_text_models(seed):
 
 @pytest.mark.parametrize("kind,seed,kw", GPU_FUZZ_CASES, ids=["%s-%d-%s" % (k, s, "-".join(str(v) for v in kw.values())) for k, s, kw in GPU_FUZZ_CASES])
 def test_the_gpu_fuzz_models_compile_for_gfx950(kind, seed, kw):
-    """tests/test_gpu_fuzz.py runs these seeded models through the kernels; here their generated code goes through hiprtc (which
+    """tests/test_gpu_fuzz.py runs these seeded models through the kernels; build() puts their generated code through hiprtc (which
     cross-compiles without a GPU), lowered WITH the data as rh_model_create would, so that the code objects are in the in-tree kernel
-    cache when the GPU tier runs"""
-    spec = gpu_fuzz_case(kind, seed, kw)[0]
-    for opts in (STRICT, FAST):
-        src, size = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), columns=spec.columns, nrows=spec.nrows)
-        assert size > 0 and "rh_tick_kernel" in src
+    cache when the GPU tier runs -- and leaves what the engine settled on in its report.  (Round 4: read from that report; lowering
+    the heavy ones again here would be minutes of compilation each on a cold cache.)"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rainier_amd", "kcache", "build_report.json")
+    if not os.path.exists(path):
+        pytest.skip("no build report: run __graft_entry__.build() first")
+    rep = json.load(open(path))
+    mine = [r for name, r in rep.items() if "fuzz_%s_%d[" % (kind, seed) in name]
+    assert len(mine) >= 2, (kind, seed)                  # both math modes
+    for r in mine:
+        fit = {k.split(":", 1)[1]: v["fit"] for k, v in r["kernels"].items() if k.startswith("base:")}
+        assert fit.get("rh_tick_kernel") and fit.get("rh_density_fin_kernel") and (fit.get("rh_grad_kernel") or fit.get("rh_grad_gather_kernel")), (kind, seed, fit)
 
 
 def test_a_gradient_kernel_that_spills_is_lowered_again_with_a_smaller_unroll():
