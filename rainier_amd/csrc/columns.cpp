@@ -12,6 +12,7 @@
 //      c_a + alpha, alpha - c_a, beta * c_a   (an affine image -- beta = -0.0 is how the signed zeros of x_k * (-0.0) survive
 //                                              strict mode --; kept atomic -- wrapped in NOOP -- so that later algebra never
 //                                              distributes over it: (y - 1) * S must stay a masked term, not S*y - S)
+//      compare(c_a, k)              (strict builds, RH_INDEX_MASKS: the per-entry mask of a Lookup's index column, see index_masks below)
 // its INPUT node is replaced by that expression over the BASE columns, which alone are uploaded.  Every relation is
 // verified on ALL rows (candidates are pre-filtered on 32 sample rows).  In strict mode "equal" means bit-identical, so the
 // recomputed value is the very double the reference stored (IEEE negation / multiplication / addition are deterministic);
@@ -24,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -37,7 +39,7 @@ namespace rh {
 namespace {
 
 struct CExpr {  // expression of one original column over base columns
-  enum Kind { BASE, ALIAS, CONST, NEG, MUL, ADDC, SUBC, MULC } kind = BASE;
+  enum Kind { BASE, ALIAS, CONST, NEG, MUL, ADDC, SUBC, MULC, CMPK } kind = BASE;
   int a = -1, b = -1;   // operand original-column indices (local to the target)
   double c = 0.0;
 };
@@ -49,7 +51,93 @@ struct Same {
   bool operator()(double x, double y) const { return fast ? x == y : bits(x) == bits(y); }
 };
 
+// Strict builds, after the masks of a Lookup's index column have been recognised (index masks, below): the gradient of table entry k
+// is a sum of eq(index_s, low + k, g_s, 0) terms, one per Lookup of the target that reads the table (8 in a target written by
+// Model.observe's split) -- except where the front end has folded one away: a mask that is -1 or +1 on every row of its slot is a
+// constant to it, and Lookup(constant, [0, g, 0]) is 0.  Gather mode reads every entry's gradient as THE scatter of one value
+// (emit.cpp detect_gather) and the strict roll needs the 8 slots to be the same expression (rollstrict.cpp), so the folded terms
+// are written back where the data confirms the folding: no row of that index column selects the entry, hence the term adds
+// +0.0 on every row.
+void complete_scatter_terms(Program &P, const double *const *columns, const int64_t *nrows, const std::vector<uint32_t> &kept) {
+  for (size_t t = 0; t < P.targets.size(); t++) {
+    Target &T = P.targets[t];
+    if (!T.n_cols) continue;
+    auto local_col = [&](uint32_t id) { const Node &x = P.nodes[id]; return (x.op == RH_RIR_INPUT && x.input >= P.n_params && x.dep == t + 1) ? (int)(x.input - T.input_start) : -1; };
+    struct Slot { uint32_t ix; int col; uint32_t g; bool have_g, bad; std::vector<char> present; };
+    std::vector<Slot> slots;
+    uint32_t first = 0; int32_t low = 0; size_t cnt = 0;
+    bool consistent = true;
+    const size_t n0 = P.nodes.size();
+    for (size_t i = 0; i < n0; i++) {
+      const Node &nd = P.nodes[i];
+      if (nd.op != RH_RIR_LOOKUP || nd.table.size() <= 3 || local_col(nd.a) < 0) continue;
+      const Node &t0 = P.nodes[nd.table[0]];
+      if (!(t0.op == RH_RIR_INPUT && t0.input < P.n_params && t0.input + nd.table.size() == P.n_params)) continue;
+      bool run = true;
+      for (size_t k = 0; k < nd.table.size() && run; k++) { const Node &tk = P.nodes[nd.table[k]]; run = tk.op == RH_RIR_INPUT && tk.input == t0.input + k; }
+      if (!run) continue;
+      if (cnt && (first != t0.input || low != nd.low)) consistent = false;
+      first = t0.input; low = nd.low; cnt = nd.table.size();
+      bool known = false;
+      for (const Slot &sl : slots) known = known || sl.ix == nd.a;
+      if (!known) slots.push_back({nd.a, local_col(nd.a), 0, false, false, std::vector<char>(cnt, 0)});
+    }
+    if (slots.empty() || !consistent) continue;
+    // the eq terms that are there: output of entry k, cut along its top-level additions
+    std::vector<uint32_t> stack;
+    for (size_t k = 0; k < cnt; k++) {
+      stack.assign(1, T.outputs[1 + first + k]);
+      for (int steps = 0; !stack.empty() && steps < 4096; steps++) {
+        const Node &x = P.nodes[stack.back()]; stack.pop_back();
+        if (x.op == RH_RIR_ADD) { stack.push_back(x.a); stack.push_back(x.b); continue; }
+        if (x.op == RH_RIR_NOOP) { stack.push_back(x.a); continue; }
+        if (x.op == RH_RIR_SEQ) { stack.push_back(x.b); continue; }
+        if (x.op != RH_RIR_LOOKUP || x.low != -1 || x.table.size() != 3) continue;
+        const Node &cm = P.nodes[x.a];
+        if (cm.op != RH_RIR_COMPARE || P.nodes[cm.b].op != RH_RIR_CONST || P.nodes[cm.b].cval != (double)low + (double)k) continue;
+        const Node &z0 = P.nodes[x.table[0]], &z2 = P.nodes[x.table[2]];
+        if (!(z0.op == RH_RIR_CONST && z0.cval == 0.0 && z2.op == RH_RIR_CONST && z2.cval == 0.0)) continue;
+        for (Slot &sl : slots) {
+          if (sl.ix != cm.a) continue;
+          sl.present[k] = 1;
+          if (!sl.have_g) { sl.g = x.table[1]; sl.have_g = true; } else if (sl.g != x.table[1]) sl.bad = true;
+        }
+      }
+    }
+    uint32_t zero = 0xFFFFFFFFu;
+    for (Slot &sl : slots) {
+      if (!sl.have_g || sl.bad) continue;
+      // which entries do the rows of this index column select?
+      std::vector<char> selected(cnt, 0);
+      const double *c = columns[kept[T.col0 + (uint32_t)sl.col]];
+      for (int64_t r = 0; r < nrows[t]; r++) {
+        const double v = c[r];
+        const double kk = v - (double)low;
+        if (kk >= 0.0 && kk < (double)cnt && kk == std::floor(kk)) selected[(size_t)kk] = 1;
+        else if (!(v == v)) selected[0] = selected[0];   // (a NaN index compares as -1 with everything: selects nothing)
+      }
+      for (size_t k = 0; k < cnt; k++) {
+        if (sl.present[k] || selected[k]) continue;
+        if (zero == 0xFFFFFFFFu) { Node z; z.op = RH_RIR_CONST; z.cval = 0.0; P.nodes.push_back(z); zero = (uint32_t)P.nodes.size() - 1; }
+        Node kc; kc.op = RH_RIR_CONST; kc.cval = (double)low + (double)k; P.nodes.push_back(kc);
+        Node cm; cm.op = RH_RIR_COMPARE; cm.a = sl.ix; cm.b = (uint32_t)P.nodes.size() - 1; cm.dep = (uint32_t)t + 1; P.nodes.push_back(cm);
+        Node lk; lk.op = RH_RIR_LOOKUP; lk.a = (uint32_t)P.nodes.size() - 1; lk.low = -1; lk.table = {zero, sl.g, zero}; lk.dep = (uint32_t)t + 1; P.nodes.push_back(lk);
+        const uint32_t term = (uint32_t)P.nodes.size() - 1;
+        uint32_t &out = T.outputs[1 + first + k];
+        const Node &o = P.nodes[out];
+        if (o.op == RH_RIR_CONST && o.cval == 0.0) out = term;
+        else { Node ad; ad.op = RH_RIR_ADD; ad.a = out; ad.b = term; ad.dep = (uint32_t)t + 1; P.nodes.push_back(ad); out = (uint32_t)P.nodes.size() - 1; }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+bool index_masks_on() {
+  const char *e = std::getenv("RH_INDEX_MASKS");
+  return e ? std::atoi(e) != 0 : false;
+}
 
 bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,
                           std::string &err, bool allow_unroll) {
@@ -94,6 +182,79 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       for (char o : ok) if (!o) return false;
       return true;
     };
+    // Strict builds: the per-entry masks of a Lookup's index column.  The reference's gradient of Lookup(index, table) with respect to
+    // entry k is eq(index, low + k, g, 0) = Lookup(Compare(index, low + k), [0, g, 0], -1) (compute/Gradient.scala:146-152,
+    // compute/Real.scala:42), and with `index` a data column its front end evaluates Compare(index, low + k) ahead of time: one column
+    // of -1 / 0 / +1 per entry (and per slot of Model.observe's split).  Fast builds get the natural form back by deriving the gradient
+    // again (rederive.cpp); strict builds keep the reference's expression, so here the columns themselves are recognised: column j IS
+    // compare(c_a, k) on every row, c_a the index column of a Lookup of this target.  k comes from a row where the mask is 0; a mask
+    // without such a row (an entry no row of this target selects) takes the k of the table entry whose gradient output reads it --
+    // any k that reproduces the column is exact on this data, that one keeps the shape gather mode reads (emit.cpp detect_gather).
+    std::vector<int> ix_cols;                                   // index columns of this target's Lookups (local indices)
+    std::vector<char> hinted((size_t)nc, 0);                    // 1: hint_k valid, 2: contradictory hints
+    std::vector<double> hint_k((size_t)nc, 0.0);
+    if (index_masks_on() && !fast) {
+      auto local_col = [&](uint32_t id) { const Node &x = P.nodes[id]; return (x.op == RH_RIR_INPUT && x.input >= P.n_params && x.dep == t + 1) ? (int)(x.input - T.input_start) : -1; };
+      bool shaped = false, consistent = true;
+      uint32_t first = 0; int32_t low = 0;
+      for (const Node &nd : P.nodes) {
+        if (nd.op != RH_RIR_LOOKUP || nd.table.size() <= 3) continue;
+        const int a = local_col(nd.a);
+        if (a < 0) continue;
+        if (std::find(ix_cols.begin(), ix_cols.end(), a) == ix_cols.end()) ix_cols.push_back(a);
+        // a table that is the run of trailing parameters (the shape of gather mode): its entries' gradient outputs name their masks
+        const Node &t0 = P.nodes[nd.table[0]];
+        if (!(t0.op == RH_RIR_INPUT && t0.input < P.n_params && t0.input + nd.table.size() == P.n_params)) continue;
+        bool run = true;
+        for (size_t k = 0; k < nd.table.size() && run; k++) { const Node &tk = P.nodes[nd.table[k]]; run = tk.op == RH_RIR_INPUT && tk.input == t0.input + k; }
+        if (!run) continue;
+        if (shaped && (first != t0.input || low != nd.low)) consistent = false;
+        shaped = true; first = t0.input; low = nd.low;
+      }
+      if (shaped && consistent) {
+        std::vector<uint32_t> stack;
+        for (uint32_t p = first; p < P.n_params; p++) {
+          stack.assign(1, T.outputs[1 + p]);
+          for (int steps = 0; !stack.empty() && steps < 4096; steps++) {   // the output cut along its top-level additions
+            const Node &x = P.nodes[stack.back()]; stack.pop_back();
+            if (x.op == RH_RIR_ADD) { stack.push_back(x.a); stack.push_back(x.b); continue; }
+            if (x.op == RH_RIR_NOOP) { stack.push_back(x.a); continue; }
+            if (x.op == RH_RIR_SEQ) { stack.push_back(x.b); continue; }     // (the Translator's SEQ(definition, use): the value is `use`)
+            if (x.op != RH_RIR_LOOKUP || x.low != -1 || x.table.size() != 3) continue;
+            const int j = local_col(x.a);
+            if (j < 0) continue;
+            const double k = (double)low + (double)(p - first);
+            if (hinted[(size_t)j] == 1 && hint_k[(size_t)j] != k) hinted[(size_t)j] = 2;
+            else if (!hinted[(size_t)j]) { hinted[(size_t)j] = 1; hint_k[(size_t)j] = k; }
+          }
+        }
+      }
+    }
+    auto cmp3 = [](double l, double r) { return l > r ? 1.0 : (l == r ? 0.0 : -1.0); };   // DCMPL; I2D (ir/MethodGenerator.scala:56-94)
+    auto try_mask = [&](int j, CExpr &e) {
+      const double *c = col[(size_t)j];
+      for (int64_t r : sr) if (!(bits(c[r]) == bits(1.0) || bits(c[r]) == bits(0.0) || bits(c[r]) == bits(-1.0))) return false;
+      for (int a : ix_cols) {
+        if (a >= j) continue;
+        const double *ca = col[(size_t)a];
+        double k = 0.0;
+        bool have = false;
+        if (hinted[(size_t)j] == 1) { k = hint_k[(size_t)j]; have = true; }
+        else {
+          double lo = -HUGE_VAL, hi = HUGE_VAL;
+          for (int64_t r = 0; r < nr && !have; r++) {
+            if (c[r] == 0.0) { k = ca[r]; have = true; }
+            else if (c[r] < 0.0) { if (ca[r] > lo) lo = ca[r]; }
+            else if (ca[r] < hi) hi = ca[r];
+          }
+          // no row selects the entry: the smallest integer above every "-1" row, if it is below every "+1" row (a column that is
+          // the same on every row is left to the constant rule)
+          if (!have && std::isfinite(lo) && std::isfinite(hi)) { k = std::floor(lo) + 1.0; have = lo < k && k < hi; }
+        }
+        if (have && k == k && verify(j, [&](int64_t r) { return cmp3(ca[r], k); })) { e.kind = CExpr::CMPK; e.a = a; e.c = k; return true; }
+      }
+      return false;
+    };
     // on a handful of rows every column is an affine image of every other: a small target (Model.observe's initial chunk, when it
     // is not unrolled) is only searched for copies, negations and products -- the relations its big sibling's slots have too
     const bool small = nr < 16;
@@ -110,6 +271,8 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       const double *c = col[(size_t)j];
       CExpr e;
       bool found = false;
+      if (!ix_cols.empty() && try_mask(j, e)) { ex[(size_t)j] = e; return true; }
+      if (!search) return false;
       if (is_const[(size_t)j]) { e.kind = CExpr::CONST; e.c = c[0]; found = true; }
       for (int a = 0; a < j && !found; a++) {
         const double *ca = col[(size_t)a];
@@ -148,7 +311,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       if (found) ex[(size_t)j] = e;
       return found;
     };
-    if (search) {
+    if (search || !ix_cols.empty()) {
       const int nth = (nr < 400000 && nc >= 64) ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
       if (nth <= 1) {
         for (int j = 0; j < nc; j++) if (process(j)) changed = true;
@@ -270,6 +433,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
       case CExpr::ADDC: id = op1(RH_RIR_NOOP, op2(RH_RIR_ADD, column(t, e.a), constant(e.c), dep), dep); break;
       case CExpr::SUBC: id = op1(RH_RIR_NOOP, op2(RH_RIR_SUB, constant(e.c), column(t, e.a), dep), dep); break;
       case CExpr::MULC: id = op1(RH_RIR_NOOP, op2(RH_RIR_MUL, constant(e.c), column(t, e.a), dep), dep); break;
+      case CExpr::CMPK: id = op2(RH_RIR_COMPARE, column(t, e.a), constant(e.c), dep); break;
     }
     return col_node[t][j] = id;
   };
@@ -358,6 +522,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     Q.targets[t].outputs = acc;
   }
   P = std::move(Q);
+  if (index_masks_on() && !fast) complete_scatter_terms(P, columns, nrows, kept);
   return true;
 }
 
