@@ -373,9 +373,7 @@ struct TargetEmitter {
              P.nodes[cmp.b].cval == (double)(gather.low + (int)k);
       }
       if (ok) { if (!have_sv) { gather.sv = on.table[1]; have_sv = true; } else ok = on.table[1] == gather.sv; }
-      if (!ok) {
-        if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: target %u table output %u: op %u low %d table %zu index op %u\n", t, k, on.op, on.low, on.table.size(), on.op == RH_RIR_LOOKUP ? P.nodes[on.a].op : 999u);
-        err = "gather mode: gradient output of table parameter " + std::to_string(k) + " is not eq(index, k, g, 0)"; return false; }
+      if (!ok) { err = "gather mode: gradient output of table parameter " + std::to_string(k) + " is not eq(index, k, g, 0)"; return false; }
     }
     if (gather.ok && !have_sv) { err = "gather mode: no table gradient in a target that reads the table"; return false; }
     return true;

@@ -289,7 +289,6 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
   if (left_a > 0 && index_masks_on()) {   // a target kept its slots: once more with every sum's addends in one canonical order
     SumNormaliser N(P);
     for (Target &T : N.Q.targets) for (uint32_t &o : T.outputs) o = N.norm(o);
-    for (Node &n : N.Q.nodes) (void)n;
     std::vector<std::vector<uint32_t>> pb;
     int left_b = 0;
     Program B = N.Q;
@@ -392,7 +391,6 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
       if (!c.empty()) find(c[0]);
     }
     for (auto &to : terms) for (const Term &tm : to) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty() && R.hasp[tm.node]) param_comp[find(c[0])] = 1; }
-    if (std::getenv("RH_ROLL_WHY")) for (size_t o = 0; o < no; o++) for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (c.size() > 6) { const Node &n = P.nodes[tm.node]; std::fprintf(stderr, "rainier-hip:   target %zu output %zu: a term (op %u, operands' ops %u %u) reads %zu columns\n", t, o, n.op, P.nodes[n.a].op, P.nodes[n.b].op, c.size()); } }
     std::map<uint32_t, std::vector<uint32_t>> comp;
     for (auto &kv : parent) comp[find(kv.first)].push_back(kv.first);
     // every component gets a structural class; classes that parameters reach fix the slot count S; a parameter-free class with S
@@ -443,32 +441,6 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
     }
     std::map<uint64_t, std::vector<size_t>> classes;
     for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
-    if (say && classes.size() > 2) {
-      for (auto &kv : classes) { std::fprintf(stderr, "rainier-hip:   class:"); for (size_t c : kv.second) std::fprintf(stderr, " %zu", c); std::fprintf(stderr, "\n"); }
-      // the first output on which two parameter-reaching groups differ
-      std::vector<uint64_t> h2(comps.size(), 0x5107);
-      for (size_t o = 0; o < no; o++) {
-        std::vector<std::vector<uint64_t>> hs(comps.size());
-        for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty()) hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg)); }
-        bool diff = false;
-        size_t c0 = comps.size();
-        for (size_t c = 0; c < comps.size(); c++) { if (!comp_param[c]) continue; std::sort(hs[c].begin(), hs[c].end()); if (c0 == comps.size()) c0 = c; else if (hs[c] != hs[c0]) diff = true; }
-        if (diff) {
-          std::function<void(uint32_t, int)> dump = [&](uint32_t id, int d) {
-            const Node &n = P.nodes[id];
-            if (d > 4) { std::fprintf(stderr, "."); return; }
-            if (n.op == RH_RIR_CONST) { std::fprintf(stderr, "%g", n.cval); return; }
-            if (n.op == RH_RIR_INPUT) { std::fprintf(stderr, n.input < P.n_params ? "th%u" : "c%u", n.input < P.n_params ? n.input : n.input - P.targets[t].input_start); return; }
-            std::fprintf(stderr, "(%u ", n.op); dump(n.a, d + 1);
-            if (n.op == RH_RIR_LOOKUP) { std::fprintf(stderr, " low%d [", n.low); for (uint32_t e : n.table) { dump(e, d + 1); std::fprintf(stderr, ","); } std::fprintf(stderr, "]"); }
-            else if (binary_op(n.op)) { std::fprintf(stderr, " "); dump(n.b, d + 1); }
-            std::fprintf(stderr, ")");
-          };
-          for (const Term &tm : terms[o]) { std::fprintf(stderr, "rainier-hip:     term%s ", tm.neg ? " (-)" : ""); dump(tm.node, 0); std::fprintf(stderr, "\n"); }
-        }
-        if (diff) { std::fprintf(stderr, "rainier-hip:   output %zu: terms per group:", o); for (size_t c = 0; c < comps.size(); c++) std::fprintf(stderr, " %zu", hs[c].size()); std::fprintf(stderr, "\n"); break; }
-      }
-    }
     size_t S = 0; bool ok = true;
     for (auto &kv : classes) {
       if (!comp_param[kv.second[0]]) continue;
@@ -476,7 +448,6 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
       if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false;
     }
     if (!ok || S < 2 || (S & (S - 1)) != 0) {                     // 1 / S must be exact
-      if (say) for (size_t c = 0; c < comps.size(); c++) { std::fprintf(stderr, "rainier-hip:   group %zu (param %d):", c, (int)comp_param[c]); for (uint32_t col : comps[c]) std::fprintf(stderr, " %u", col - P.targets[t].input_start); std::fprintf(stderr, "\n"); }
       if (say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: %zu column groups in %zu structural classes, no common slot count (S = %zu)\n", t, comps.size(), classes.size(), S);
       continue;
     }
@@ -517,22 +488,6 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
         std::sort(got.begin(), got.end());
         ok = got == want;
         if (!ok && say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: output %zu, slot %zu has %zu terms, slot 0 %zu, and they differ after renaming\n", t, o, s, got.size(), want.size());
-        if (!ok && say) {
-          std::function<void(uint32_t, int)> dump = [&](uint32_t id, int d) {
-            const Node &n = P.nodes[id];
-            if (d > 6) { std::fprintf(stderr, "."); return; }
-            if (n.op == RH_RIR_CONST) { std::fprintf(stderr, "%g", n.cval); return; }
-            if (n.op == RH_RIR_INPUT) { std::fprintf(stderr, n.input < P.n_params ? "th%u" : "c%u", n.input < P.n_params ? n.input : n.input - P.targets[t].input_start); return; }
-            std::fprintf(stderr, "(%u ", n.op); dump(n.a, d + 1);
-            if (n.op == RH_RIR_LOOKUP) { std::fprintf(stderr, " low%d [%zu]", n.low, n.table.size()); }
-            else if (binary_op(n.op)) { std::fprintf(stderr, " "); dump(n.b, d + 1); }
-            std::fprintf(stderr, ")");
-          };
-          for (auto &x : st[0]) { std::fprintf(stderr, "rainier-hip:     slot 0 term "); dump(x.first, 0); std::fprintf(stderr, "\n"); }
-          for (auto &x : st[s]) { std::fprintf(stderr, "rainier-hip:     slot %zu term ", s); dump(x.first, 0); std::fprintf(stderr, "\n"); }
-          std::fprintf(stderr, "rainier-hip:     columns slot 0:"); for (uint32_t c : order[0]) std::fprintf(stderr, " %u", c - P.targets[t].input_start);
-          std::fprintf(stderr, "  slot %zu:", s); for (uint32_t c : order[s]) std::fprintf(stderr, " %u", c - P.targets[t].input_start); std::fprintf(stderr, "\n");
-        }
       }
     }
     if (!ok) continue;
