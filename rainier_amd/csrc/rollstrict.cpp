@@ -370,6 +370,9 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
           if (split_of(tm, sum, chain)) {
             const std::vector<uint32_t> c = R.cols(tm.node);
             for (size_t i = 1; i < c.size() && !spans; i++) spans = find(c[i]) != find(c[0]);
+            // (x + x) * f, the Translator's 2 x f: written x f + x f for an entry whose rows straddle two slots -- the same double
+            // either way (a doubling is exact), so it is brought to the second form everywhere
+            if (!spans && P.nodes[sum].op == RH_RIR_ADD && P.nodes[sum].a == P.nodes[sum].b) spans = true;
           }
           if (!spans) { out.push_back(tm); continue; }
           std::vector<Term> addends;
@@ -441,6 +444,18 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
     }
     std::map<uint64_t, std::vector<size_t>> classes;
     for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
+    if (say && classes.size() > 2)     // which output tells the column groups apart: the first one on which two of them differ
+      for (size_t o = 0; o < no; o++) {
+        std::vector<std::vector<uint64_t>> hs(comps.size());
+        for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty()) hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg)); }
+        size_t c0 = comps.size(), cd = comps.size();
+        for (size_t c = 0; c < comps.size() && cd == comps.size(); c++) {
+          if (!comp_param[c] || comps[c].size() < 2) continue;
+          std::sort(hs[c].begin(), hs[c].end());
+          if (c0 == comps.size()) c0 = c; else if (hs[c] != hs[c0]) cd = c;
+        }
+        if (cd != comps.size()) { std::fprintf(stderr, "rainier-hip: strict roll, target %zu: output %zu tells column group %zu (%zu terms) from group %zu (%zu terms)\n", t, o, c0, hs[c0].size(), cd, hs[cd].size()); break; }
+      }
     size_t S = 0; bool ok = true;
     for (auto &kv : classes) {
       if (!comp_param[kv.second[0]]) continue;

@@ -458,6 +458,7 @@ def test_strict_glmm_poisson2_streams_25_columns_instead_of_452(monkeypatch):
     data = json.load(open(os.path.join(G, "glmm_poisson2.json")))
     spec = models.glmm_poisson2_reference(100, 40, data)
     qs = np.random.default_rng(23).normal(size=(2, 146)) * 0.3
+    monkeypatch.delenv("RH_INDEX_MASKS", raising=False)
     src = _check(spec, STRICT, qs, 1e-12)
     assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 452
     monkeypatch.setenv("RH_INDEX_MASKS", "1")
