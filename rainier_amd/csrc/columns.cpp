@@ -121,6 +121,35 @@ struct SelectSumFolder {
     if (pa >= 0 && pb >= 0) memo[key] = r ? 1 : 0;       // (only once the pair is fixed is the answer final)
     return r;
   }
+  // a with parameter pa replaced by node `by`, following the walk that found a = b but for pa -> pb: parts where the two are the SAME
+  // node are shared by every entry (the row's own Lookup over the table holds pa as an entry -- it must stay) and are kept
+  uint32_t substitute_along(uint32_t a, uint32_t b, long pa, long pb, uint32_t by, uint32_t dep, std::map<std::pair<uint32_t, uint32_t>, uint32_t> &memo) {
+    while (N[a].op == RH_RIR_SEQ) a = N[a].b;
+    while (N[b].op == RH_RIR_SEQ) b = N[b].b;
+    if (a == b) return a;
+    auto key = std::make_pair(a, b);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    const Node x = N[a], y = N[b];
+    uint32_t r = a;
+    if (x.op == RH_RIR_INPUT) r = (x.dep == 0 && (long)x.input == pa) ? by : a;
+    else if (x.op != RH_RIR_CONST) {
+      Node q = x;
+      if (x.op == RH_RIR_MUL) {
+        long qa = pa, qb = pb;
+        std::map<std::pair<uint32_t, uint32_t>, char> m1;
+        const bool straight = same_but(x.a, y.a, qa, qb, m1) && same_but(x.b, y.b, qa, qb, m1);
+        q.a = substitute_along(x.a, straight ? y.a : y.b, pa, pb, by, dep, memo);
+        q.b = substitute_along(x.b, straight ? y.b : y.a, pa, pb, by, dep, memo);
+      } else {
+        q.a = substitute_along(x.a, y.a, pa, pb, by, dep, memo);
+        if (x.op == RH_RIR_LOOKUP) { for (size_t i = 0; i < x.table.size(); i++) q.table[i] = substitute_along(x.table[i], y.table[i], pa, pb, by, dep, memo); }
+        else if (binary(x.op)) q.b = substitute_along(x.b, y.b, pa, pb, by, dep, memo);
+      }
+      q.dep = dep; N.push_back(q); r = (uint32_t)N.size() - 1;
+    }
+    return memo[key] = r;
+  }
   // `id` with parameter p replaced by node `by` (new nodes appended; parts that do not reach p are shared)
   uint32_t substitute(uint32_t id, long p, uint32_t by, uint32_t dep, std::map<uint32_t, uint32_t> &memo) {
     auto it = memo.find(id);
@@ -257,6 +286,46 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
         const Node &o = P.nodes[out];
         if (o.op == RH_RIR_CONST && o.cval == 0.0) out = term;
         else { Node ad; ad.op = RH_RIR_ADD; ad.a = out; ad.b = term; ad.dep = (uint32_t)t + 1; P.nodes.push_back(ad); out = (uint32_t)P.nodes.size() - 1; }
+      }
+    }
+    // The mask carried as a select, not as a product: w(eq(index, k, T, 0)) with parameter-only factors w around the select becomes
+    // eq(index, k, w(T), 0) -- on the selected row the same operations on the same values, elsewhere 0 instead of 0 * factors (equal
+    // unless a factor is not finite).  The entries of a slot share ONE w(T): the scatter value gather mode reads.
+    for (Slot &sl : slots) {
+      if (!sl.have || sl.bad || sl.chain.empty()) continue;
+      if (zero == 0xFFFFFFFFu) { Node z; z.op = RH_RIR_CONST; z.cval = 0.0; P.nodes.push_back(z); zero = (uint32_t)P.nodes.size() - 1; }
+      uint32_t v = sl.value;
+      for (size_t w = sl.chain.size(); w-- > 0;) {
+        Node mu; mu.op = RH_RIR_MUL; mu.dep = (uint32_t)t + 1;
+        if (sl.chain[w].fac == 0xFFFFFFFFu) { mu.op = RH_RIR_ADD; mu.a = v; mu.b = v; }
+        else if (sl.chain[w].inner_left) { mu.a = v; mu.b = sl.chain[w].fac; } else { mu.a = sl.chain[w].fac; mu.b = v; }
+        P.nodes.push_back(mu); v = (uint32_t)P.nodes.size() - 1;
+      }
+      for (size_t k = 0; k < sl.param.size(); k++) {
+        std::vector<uint32_t> terms;
+        stack.assign(1, T.outputs[1 + (size_t)sl.param[k]]);
+        while (!stack.empty() && terms.size() < 65536) {
+          const uint32_t y = stack.back(); stack.pop_back();
+          const Node &x = P.nodes[y];
+          if (x.dep != 0 && x.op == RH_RIR_ADD) { stack.push_back(x.b); stack.push_back(x.a); continue; }
+          if (x.op == RH_RIR_NOOP && P.nodes[x.a].op == RH_RIR_ADD) { stack.push_back(x.a); continue; }
+          if (x.op == RH_RIR_SEQ) { stack.push_back(x.b); continue; }
+          terms.push_back(y);
+        }
+        bool touched = false;
+        for (uint32_t &y : terms) {
+          uint32_t lk = 0;
+          if (!peel(y, chain, lk) || chain.empty()) continue;
+          const Node cm = P.nodes[P.nodes[lk].a];
+          if (cm.a != sl.ix || P.nodes[cm.b].cval != (double)sl.low + (double)k) continue;
+          Node nl; nl.op = RH_RIR_LOOKUP; nl.a = P.nodes[lk].a; nl.low = -1; nl.table = {zero, v, zero}; nl.dep = (uint32_t)t + 1;
+          P.nodes.push_back(nl); y = (uint32_t)P.nodes.size() - 1;
+          touched = true;
+        }
+        if (!touched) continue;
+        uint32_t acc = terms[0];
+        for (size_t i = 1; i < terms.size(); i++) { Node ad; ad.op = RH_RIR_ADD; ad.a = acc; ad.b = terms[i]; ad.dep = (uint32_t)t + 1; P.nodes.push_back(ad); acc = (uint32_t)P.nodes.size() - 1; }
+        T.outputs[1 + (size_t)sl.param[k]] = acc;
       }
     }
   }
@@ -422,9 +491,11 @@ void fold_select_sums(Program &P, const double *const *columns, const int64_t *n
         for (uint32_t q = 0; q < Q.size() && lnew == 0xFFFFFFFFu; q++)      // the program's own Lookup when it already is that table
           if (Q[q].op == RH_RIR_LOOKUP && Q[q].a == nl.a && Q[q].low == nl.low && Q[q].table == nl.table) lnew = q;
         if (lnew == 0xFFFFFFFFu) { Q.push_back(nl); lnew = (uint32_t)Q.size() - 1; }
-        std::map<uint32_t, uint32_t> smemo;
-        value = F.substitute(cands[i].T, ref_param, lnew, (uint32_t)t + 1, smemo);
-        for (Wrap &w : cands[i].chain) w.fac = F.substitute(w.fac, ref_param, lnew, (uint32_t)t + 1, smemo);
+        const Cand &other = cands[grp[1]];          // any other member: its tree shows where the entry's parameter stands
+        const long other_param = entry_param[other.c];
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> smemo;
+        value = F.substitute_along(cands[i].T, other.T, ref_param, other_param, lnew, (uint32_t)t + 1, smemo);
+        for (size_t w = 0; w < cands[i].chain.size(); w++) cands[i].chain[w].fac = F.substitute_along(cands[i].chain[w].fac, other.chain[w].fac, ref_param, other_param, lnew, (uint32_t)t + 1, smemo);
       }
       for (size_t g : grp) drop[cands[g].pos] = 1;
       std::vector<uint32_t> folded;

@@ -58,3 +58,28 @@ def test_strict_cfg5_shape_beyond_the_generic_path_s_parameter_limit(monkeypatch
         got = np.concatenate([[lp[c]], g[c]])
         assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300)
     m.close()
+
+
+def test_strict_location_scale_table_in_gather_mode_on_the_device(monkeypatch):
+    """alphas = Normal(mu, sd).latentVec(100): select sums folded, factors carried inside the selects (tests/test_emitter_host.py,
+    test_strict_location_scale_table_in_gather_mode, is the host half)"""
+    from rainier_amd import compute as CC
+    from rainier_amd import modeling as M
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    b = M.Normal(0, 1).latent
+    alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("centred_table_100", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
+    refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]
+    m = R.Model(spec, device=0, **STRICT)
+    assert "#define RH_HAS_GATHER 1\n" in m.hip_source
+    lp, g = m.density_batch(np.asarray(qs), engine=_capi.ENGINE_TICK)
+    for c, (ref, ab) in enumerate(refs):
+        got = np.concatenate([[lp[c]], g[c]])
+        assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300)
+    m.close()

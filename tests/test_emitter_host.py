@@ -451,6 +451,27 @@ def test_strict_builds_read_the_reference_s_mask_columns_as_a_scatter(family, n,
     assert max(ncols) <= 6 and sum(ncols) <= 13, ncols          # (x, site, y, constant terms) per row target + the lifted prior's index
 
 
+def test_strict_location_scale_table_in_gather_mode(monkeypatch):
+    """alphas = Normal(mu, sd).latentVec(K), eta = alphas(site) + b x (the idiomatic form; entries z_k sd + mu, hoisted behind the
+    lookup by the loader).  The reference writes d/d mu as sum_k (e_k + e_k) and d/d sd as sum_k e_k z_k ... with e_k = eq(site, k, g, 0)
+    -- one select per entry and row -- and d/d z_k as e_k * sd.  With RH_INDEX_MASKS=1 strict builds fold the select sums (exactly one
+    select is non-zero on a row: the sum IS g + g, resp. g * Lookup(site, z) ...) and carry the factor of d/d z_k inside the select,
+    so that the model runs in gather mode.  (Not yet through Model.observe's split: the slots are not rolled.)"""
+    from rainier_amd import compute as CC
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    b = M.Normal(0, 1).latent
+    alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("centred_table_100", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
+    src = _check(spec, STRICT, qs, 1e-12)
+    assert "#define RH_HAS_GATHER 1\n" in src and "#define RH_NSHARED 3\n" in src
+
+
 def test_strict_glmm_poisson2_streams_25_columns_instead_of_452(monkeypatch):
     """bench/stan/GLMMPoisson2.scala in the reference's text, strict build: two Lookups over index columns, neither table a run of
     trailing parameters (generic path).  With the masks recognised the row target reads 8 x (y, site, year) + 1 columns"""
