@@ -78,7 +78,7 @@ struct SelectSumFolder {
       else if (x.op == RH_RIR_LOOKUP) {
         r = x.low == y.low && x.table.size() == y.table.size() && same(x.a, y.a);
         for (size_t i = 0; r && i < x.table.size(); i++) r = same(x.table[i], y.table[i]);
-      } else if (x.op == RH_RIR_MUL) r = (same(x.a, y.a) && same(x.b, y.b)) || (same(x.a, y.b) && same(x.b, y.a));
+      } else if (x.op == RH_RIR_MUL || x.op == RH_RIR_ADD) r = (same(x.a, y.a) && same(x.b, y.b)) || (same(x.a, y.b) && same(x.b, y.a));   // (a op b = b op a, bit for bit)
       else if (binary(x.op)) r = same(x.a, y.a) && same(x.b, y.b);
       else r = same(x.a, y.a);
     }
@@ -110,7 +110,7 @@ struct SelectSumFolder {
       } else if (x.op == RH_RIR_LOOKUP) {
         r = x.low == y.low && x.table.size() == y.table.size() && same_but(x.a, y.a, pa, pb, memo);
         for (size_t i = 0; r && i < x.table.size(); i++) r = same_but(x.table[i], y.table[i], pa, pb, memo);
-      } else if (x.op == RH_RIR_MUL) {
+      } else if (x.op == RH_RIR_MUL || x.op == RH_RIR_ADD) {
         long qa = pa, qb = pb;
         r = same_but(x.a, y.a, qa, qb, memo) && same_but(x.b, y.b, qa, qb, memo);
         if (r) { pa = qa; pb = qb; }
@@ -135,7 +135,7 @@ struct SelectSumFolder {
     if (x.op == RH_RIR_INPUT) r = (x.dep == 0 && (long)x.input == pa) ? by : a;
     else if (x.op != RH_RIR_CONST) {
       Node q = x;
-      if (x.op == RH_RIR_MUL) {
+      if (x.op == RH_RIR_MUL || x.op == RH_RIR_ADD) {
         long qa = pa, qb = pb;
         std::map<std::pair<uint32_t, uint32_t>, char> m1;
         const bool straight = same_but(x.a, y.a, qa, qb, m1) && same_but(x.b, y.b, qa, qb, m1);
@@ -617,6 +617,10 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
             if (x.op == RH_RIR_ADD) { stack.push_back(x.a); stack.push_back(x.b); continue; }
             if (x.op == RH_RIR_NOOP) { stack.push_back(x.a); continue; }
             if (x.op == RH_RIR_SEQ) { stack.push_back(x.b); continue; }     // (the Translator's SEQ(definition, use): the value is `use`)
+            if (x.op == RH_RIR_MUL && x.dep != 0 && (P.nodes[x.a].dep == 0) != (P.nodes[x.b].dep == 0)) {   // a parameter-only factor around the select
+              stack.push_back(P.nodes[x.a].dep == 0 ? x.b : x.a);
+              continue;
+            }
             if (x.op != RH_RIR_LOOKUP || x.low != -1 || x.table.size() != 3) continue;
             const int j = local_col(x.a);
             if (j < 0) continue;

@@ -58,7 +58,20 @@ struct Roller {
     else if (n.op == RH_RIR_LOOKUP) lookups.emplace(std::make_tuple(n.a, n.low, n.table), i);
     else cons.emplace(std::make_tuple(n.op, n.a, binary_op(n.op) ? n.b : 0xffffffffu), i);
   }
-  uint32_t push(const Node &n) { P.nodes.push_back(n); const uint32_t i = (uint32_t)P.nodes.size() - 1; index(i); return i; }
+  uint32_t push(const Node &n) {
+    P.nodes.push_back(n);
+    const uint32_t i = (uint32_t)P.nodes.size() - 1;
+    index(i);
+    if (!hasp.empty()) {      // (nodes made after the constructor: renamed trees, distributed products)
+      char h = 0;
+      if (n.op == RH_RIR_INPUT) h = n.input < P.n_params;
+      else if (n.op == RH_RIR_LOOKUP) { h = hasp[n.a]; for (uint32_t e : n.table) h = h || hasp[e]; }
+      else if (n.op != RH_RIR_CONST) h = hasp[n.a] || (binary_op(n.op) && hasp[n.b]);
+      hasp.resize(P.nodes.size(), 0);
+      hasp[i] = h;
+    }
+    return i;
+  }
   uint32_t constant(double v) {
     uint64_t b; std::memcpy(&b, &v, 8);
     auto it = consts.find(b);
