@@ -19,6 +19,14 @@
 // fast mode also accepts value equality (+0 == -0).  The pass also records, for every base column with at most 8 distinct
 // values, that set (Program::col_domain): the emitter may verify a closed form on the values that actually occur.
 //
+// Strict builds with RH_INDEX_MASKS=1 (off until it has run on the device) also undo, with the data in hand, what the reference's
+// front end did to the gradient of Lookup(index column, table) -- index_masks (the per-entry Compare columns recognised),
+// complete_scatter_terms (terms folded for entries no row selects written back; parameter-only factors carried inside the select),
+// fold_select_sums (sum_k eq(index, k, T, 0) = T, sum_k eq(index, k, F(z_k), 0) = F(Lookup(index, z))) -- so that hierarchical
+// models reach gather mode (emit.cpp detect_gather) and the strict roll (rollstrict.cpp) with the reference's own arithmetic on
+// every row.  Each rewrite is exact on the data it was verified on: the selected row computes the same operations on the same
+// values, every other row contributes +0.0 either way (a factor that is not finite would have made it NaN: the one difference).
+//
 // Second job, for programs recognised this way as the reference's lowering: Model.observe's INITIAL CHUNK (1-8 observations in a
 // row target of its own, core/Model.scala:84-96) is unrolled -- its rows substituted as constants and summed in row order -- so
 // that the model is left with one streamed target.

@@ -11,6 +11,20 @@
 // over S x the rows.  1 / S is exact for S = 8 and the shared terms are the only arithmetic that changes (by a power of two);
 // the order in which the rows are added up changes as it does in any parallel reduction.  Anything that does not match keeps the
 // 8-slot expression.
+//
+// With RH_INDEX_MASKS=1 (rir.hpp index_masks_on: the strict lowering of hierarchical models, off until it has run on the device) the
+// roll also reads through what keeps the reference's 8 slots from being ONE expression although they are one function:
+//   * SEQ(definition, use) -- the Translator's sequencing of a shared sub-expression, placed inside whichever slot used it first --
+//     is read as `use` (what the emitter evaluates anyway);
+//   * a term (sum over the slots) * (parameter-only factors) -- the chain rule through a transformed parameter -- has the factors
+//     distributed over the addends of different column groups: ONE extra rounding per addend;  (x + x) * f is written x f + x f
+//     (the same double: a doubling is exact);
+//   * if the slots still differ, once more with the addends of every data-dependent sum in ONE canonical order (SumNormaliser: the
+//     reference's Line is a map, its addends are folded in a different order in every slot): the ORDER of the additions inside a
+//     row's expression changes, nothing is merged or cancelled;  a * b and b * a are one node (the same double);
+//   * a loose column times parameter-only factors (a * (y_1 + ... + y_8) arrives as one pre-summed column) is kept on the first
+//     slot's rows and zero-padded for the others, like a bare loose column.
+// These are the only places where the per-row arithmetic of a rolled strict target is not the reference's operation for operation.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
