@@ -192,7 +192,7 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
     if (!T.n_cols) continue;
     auto local_col = [&](uint32_t id) { const Node &x = P.nodes[id]; return (x.op == RH_RIR_INPUT && x.input >= P.n_params && x.dep == t + 1) ? (int)(x.input - T.input_start) : -1; };
     struct Wrap { uint32_t fac; bool inner_left; };
-    struct Slot { uint32_t ix; int col; int32_t low; std::vector<long> param; bool have = false, bad = false; uint32_t value = 0; std::vector<Wrap> chain; std::vector<char> present; };
+    struct Slot { uint32_t ix; int col; int32_t low; std::vector<long> param; bool have = false, bad = false, nested = false; uint32_t value = 0; std::vector<Wrap> chain; std::vector<char> present; };
     std::vector<Slot> slots;
     const size_t n0 = P.nodes.size();
     for (size_t i = 0; i < n0; i++) {
@@ -242,21 +242,36 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
     };
     std::vector<uint32_t> stack;
     std::vector<Wrap> chain;
+    // (the selects may sit below a sum that a parameter-only factor multiplies -- (sum over the slots of eq(site_s, k, g_s, 0)) * sd --:
+    //  the walk goes through sums and such products alike and keeps the factors met on the way, outermost first; `nested` = a
+    //  select was found below a product of a sum, where its term cannot be rewritten in place)
     for (Slot &sl : slots) {
       for (size_t k = 0; k < sl.param.size(); k++) {
-        stack.assign(1, T.outputs[1 + (size_t)sl.param[k]]);
-        for (int steps = 0; !stack.empty() && steps < 65536; steps++) {
-          const uint32_t y = stack.back(); stack.pop_back();
+        int steps = 0;
+        std::function<void(uint32_t, bool)> walk = [&](uint32_t y, bool under_product) {
+          if (++steps > 65536) return;
           const Node &x = P.nodes[y];
-          if (x.dep != 0 && x.op == RH_RIR_ADD) { stack.push_back(x.a); stack.push_back(x.b); continue; }
-          if (x.op == RH_RIR_NOOP && P.nodes[x.a].op == RH_RIR_ADD) { stack.push_back(x.a); continue; }
-          if (x.op == RH_RIR_SEQ) { stack.push_back(x.b); continue; }
-          uint32_t lk = 0;
-          if (!peel(y, chain, lk)) continue;
-          const Node &cm = P.nodes[P.nodes[lk].a];
-          if (cm.a != sl.ix || P.nodes[cm.b].cval != (double)sl.low + (double)k) continue;
+          if (x.op == RH_RIR_SEQ) { walk(x.b, under_product); return; }
+          if (x.op == RH_RIR_NOOP) { walk(x.a, under_product); return; }
+          if (x.dep != 0 && x.op == RH_RIR_ADD) {
+            if (x.a == x.b) { chain.push_back({0xFFFFFFFFu, true}); walk(x.a, under_product); chain.pop_back(); }
+            else { if (!chain.empty()) sl.nested = true; walk(x.a, under_product); walk(x.b, under_product); }
+            return;
+          }
+          if (x.dep != 0 && x.op == RH_RIR_MUL) {
+            const bool da = P.nodes[x.a].dep != 0, db = P.nodes[x.b].dep != 0;
+            if (da == db) return;
+            chain.push_back({da ? x.b : x.a, da}); walk(da ? x.a : x.b, true); chain.pop_back();
+            return;
+          }
+          if (x.op != RH_RIR_LOOKUP || x.low != -1 || x.table.size() != 3) return;
+          const Node &z0 = P.nodes[x.table[0]], &z2 = P.nodes[x.table[2]];
+          if (!(z0.op == RH_RIR_CONST && z0.cval == 0.0 && z2.op == RH_RIR_CONST && z2.cval == 0.0)) return;
+          const Node &cm = P.nodes[x.a];
+          if (cm.op != RH_RIR_COMPARE || P.nodes[cm.b].op != RH_RIR_CONST) return;
+          if (cm.a != sl.ix || P.nodes[cm.b].cval != (double)sl.low + (double)k) return;
           sl.present[k] = 1;
-          const uint32_t val = P.nodes[lk].table[1];
+          const uint32_t val = x.table[1];
           if (!sl.have) { sl.have = true; sl.value = val; sl.chain = chain; }
           else {
             bool eq = F.same(sl.value, val) && sl.chain.size() == chain.size();
@@ -264,7 +279,9 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
               eq = chain[w].inner_left == sl.chain[w].inner_left && (chain[w].fac == 0xFFFFFFFFu || sl.chain[w].fac == 0xFFFFFFFFu ? chain[w].fac == sl.chain[w].fac : F.same(chain[w].fac, sl.chain[w].fac));
             if (!eq) sl.bad = true;
           }
-        }
+        };
+        chain.clear();
+        walk(T.outputs[1 + (size_t)sl.param[k]], false);
       }
     }
     uint32_t zero = 0xFFFFFFFFu;
@@ -300,7 +317,7 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
     // eq(index, k, w(T), 0) -- on the selected row the same operations on the same values, elsewhere 0 instead of 0 * factors (equal
     // unless a factor is not finite).  The entries of a slot share ONE w(T): the scatter value gather mode reads.
     for (Slot &sl : slots) {
-      if (!sl.have || sl.bad || sl.chain.empty()) continue;
+      if (!sl.have || sl.bad || sl.chain.empty() || sl.nested) continue;     // (nested: the strict roll carries the factors in, rollstrict.cpp)
       if (zero == 0xFFFFFFFFu) { Node z; z.op = RH_RIR_CONST; z.cval = 0.0; P.nodes.push_back(z); zero = (uint32_t)P.nodes.size() - 1; }
       uint32_t v = sl.value;
       for (size_t w = sl.chain.size(); w-- > 0;) {

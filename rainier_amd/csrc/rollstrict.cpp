@@ -96,7 +96,7 @@ struct Roller {
   uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
     auto it = cons.find(std::make_tuple(op, a, b));
     if (it != cons.end()) return it->second;
-    if (op == RH_RIR_MUL && commutative_mul) {      // a * b and b * a are the same double
+    if ((op == RH_RIR_MUL || op == RH_RIR_ADD) && commutative_mul) {      // a * b and b * a (a + b and b + a) are the same double
       it = cons.find(std::make_tuple(op, b, a));
       if (it != cons.end()) return it->second;
     }
@@ -144,6 +144,7 @@ struct Roller {
       else {
         h = mix(h, hmemo[n.a]);
         if (n.op == RH_RIR_LOOKUP) { h = mix(h, (uint64_t)(int64_t)n.low); for (uint32_t e : n.table) h = mix(h, hmemo[e]); }
+        else if ((n.op == RH_RIR_MUL || n.op == RH_RIR_ADD) && commutative_mul) h = mix(mix(0x51, n.op), hmemo[n.a] + hmemo[n.b]);   // blind to the operand order
         else if (binary_op(n.op)) h = mix(h, hmemo[n.b]);
       }
       hmemo[x] = h; hdone[x] = 1;
@@ -533,6 +534,30 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
       }
     }
     if (!ok) continue;
+    // (RH_INDEX_MASKS) a select with parameter-only factors around it, eq(index, k, T, 0) * f, carries them inside: eq(index, k, T * f, 0)
+    // -- the selected row computes the same product, the other rows 0 instead of 0 * f -- which is the one-scatter-value shape gather
+    // mode reads (emit.cpp detect_gather); hash-consing makes T * f one node for all the entries
+    auto sink = [&](uint32_t term) {
+      std::vector<std::pair<uint32_t, bool>> chain;     // (factor, select on the left), outermost first
+      uint32_t y = term;
+      while (P.nodes[y].op == RH_RIR_MUL && P.nodes[y].dep != 0) {
+        const Node &n = P.nodes[y];
+        const bool da = P.nodes[n.a].dep != 0, db = P.nodes[n.b].dep != 0;
+        if (da == db) return term;
+        chain.push_back({da ? n.b : n.a, da});
+        y = da ? n.a : n.b;
+      }
+      const Node lk = P.nodes[y];
+      if (chain.empty() || lk.op != RH_RIR_LOOKUP || lk.low != -1 || lk.table.size() != 3) return term;
+      const Node &z0 = P.nodes[lk.table[0]], &z2 = P.nodes[lk.table[2]];
+      if (!(z0.op == RH_RIR_CONST && z0.cval == 0.0 && !std::signbit(z0.cval) && z2.op == RH_RIR_CONST && z2.cval == 0.0 && !std::signbit(z2.cval))) return term;
+      if (P.nodes[lk.a].op != RH_RIR_COMPARE) return term;
+      uint32_t v = lk.table[1];
+      for (size_t w = chain.size(); w-- > 0;) v = chain[w].second ? R.op2(RH_RIR_MUL, v, chain[w].first) : R.op2(RH_RIR_MUL, chain[w].first, v);
+      Node q = lk; q.table[1] = v;
+      auto li = R.lookups.find(std::make_tuple(q.a, q.low, q.table));
+      return li != R.lookups.end() ? li->second : R.push(q);
+    };
     // rebuild: original order of the terms that stay (slot 0, loose), shared terms scaled by the exact 1 / S
     const uint32_t inv_s = R.constant(1.0 / (double)S);
     std::vector<uint32_t> outs(no);
@@ -542,7 +567,7 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
         const std::vector<uint32_t> c = R.cols(tm.node);
         uint32_t x;
         if (c.empty()) x = R.op2(RH_RIR_MUL, tm.node, inv_s);
-        else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = tm.node;
+        else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = index_masks_on() ? sink(tm.node) : tm.node;
         else continue;
         if (acc == 0xFFFFFFFFu) acc = tm.neg ? R.op2(RH_RIR_SUB, R.constant(0.0), x) : x;
         else acc = R.op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x);

@@ -60,7 +60,28 @@ def test_strict_cfg5_shape_beyond_the_generic_path_s_parameter_limit(monkeypatch
     m.close()
 
 
-def test_strict_location_scale_table_in_gather_mode_on_the_device(monkeypatch):
+def test_strict_glmm_poisson2_on_the_device(monkeypatch):
+    """bench/stan/GLMMPoisson2.scala, strict build: 452 -> 4 streamed columns (generic Lookup path: neither table is a trailing run)"""
+    import json, os
+    from rainier_amd import models
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glmm_poisson2.json")))
+    spec = models.glmm_poisson2_reference(100, 40, data)
+    qs = np.random.default_rng(23).normal(size=(3, 146)) * 0.3
+    d = O.OracleDensity(spec)
+    refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]
+    m = R.Model(spec, device=0, **STRICT)
+    assert "NCOLS = 4, COL0 = 0" in m.hip_source
+    for engine in (_capi.ENGINE_AUTO, _capi.ENGINE_TICK):
+        lp, g = m.density_batch(np.asarray(qs), engine=engine)
+        for c, (ref, ab) in enumerate(refs):
+            got = np.concatenate([[lp[c]], g[c]])
+            assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300), (engine, c)
+    m.close()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_strict_location_scale_table_in_gather_mode_on_the_device(split, monkeypatch):
     """alphas = Normal(mu, sd).latentVec(100): select sums folded, factors carried inside the selects (tests/test_emitter_host.py,
     test_strict_location_scale_table_in_gather_mode, is the host half)"""
     from rainier_amd import compute as CC
@@ -72,7 +93,7 @@ def test_strict_location_scale_table_in_gather_mode_on_the_device(monkeypatch):
     alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
     site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
     fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
-    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("centred_table_100", inline=False)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("centred_table_100", inline=False)
     d = O.OracleDensity(spec)
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
     refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]

@@ -451,12 +451,14 @@ def test_strict_builds_read_the_reference_s_mask_columns_as_a_scatter(family, n,
     assert max(ncols) <= 6 and sum(ncols) <= 13, ncols          # (x, site, y, constant terms) per row target + the lifted prior's index
 
 
-def test_strict_location_scale_table_in_gather_mode(monkeypatch):
+@pytest.mark.parametrize("split", [False, True])
+def test_strict_location_scale_table_in_gather_mode(split, monkeypatch):
     """alphas = Normal(mu, sd).latentVec(K), eta = alphas(site) + b x (the idiomatic form; entries z_k sd + mu, hoisted behind the
     lookup by the loader).  The reference writes d/d mu as sum_k (e_k + e_k) and d/d sd as sum_k e_k z_k ... with e_k = eq(site, k, g, 0)
     -- one select per entry and row -- and d/d z_k as e_k * sd.  With RH_INDEX_MASKS=1 strict builds fold the select sums (exactly one
     select is non-zero on a row: the sum IS g + g, resp. g * Lookup(site, z) ...) and carry the factor of d/d z_k inside the select,
-    so that the model runs in gather mode.  (Not yet through Model.observe's split: the slots are not rolled.)"""
+    so that the model runs in gather mode -- also through Model.observe's split (the strict roll carries the factor into the select
+    after the slots have been rolled)."""
     from rainier_amd import compute as CC
     monkeypatch.setenv("RH_INDEX_MASKS", "1")
     rng = np.random.default_rng(4)
@@ -465,16 +467,17 @@ def test_strict_location_scale_table_in_gather_mode(monkeypatch):
     alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
     site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
     fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
-    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("centred_table_100", inline=False)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("centred_table_100", inline=False)
     d = O.OracleDensity(spec)
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
     src = _check(spec, STRICT, qs, 1e-12)
     assert "#define RH_HAS_GATHER 1\n" in src and "#define RH_NSHARED 3\n" in src
 
 
-def test_strict_glmm_poisson2_streams_25_columns_instead_of_452(monkeypatch):
+def test_strict_glmm_poisson2_streams_4_columns_instead_of_452(monkeypatch):
     """bench/stan/GLMMPoisson2.scala in the reference's text, strict build: two Lookups over index columns, neither table a run of
-    trailing parameters (generic path).  With the masks recognised the row target reads 8 x (y, site, year) + 1 columns"""
+    trailing parameters (generic path).  With the masks recognised, the folded terms written back, the select sums folded and the 8
+    slots rolled the row target reads (count, site, year, the constant term) -- as the fast build does after deriving the gradient again"""
     import re
     data = json.load(open(os.path.join(G, "glmm_poisson2.json")))
     spec = models.glmm_poisson2_reference(100, 40, data)
@@ -484,7 +487,7 @@ def test_strict_glmm_poisson2_streams_25_columns_instead_of_452(monkeypatch):
     assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 452
     monkeypatch.setenv("RH_INDEX_MASKS", "1")
     src = _check(spec, STRICT, qs, 1e-12)
-    assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 25
+    assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 4
 
 
 @pytest.mark.parametrize("family", ["negbin-split", "negbin", "poisson-split"])
