@@ -349,19 +349,33 @@ struct TargetEmitter {
       std::vector<uint32_t> ops; operands(P.nodes[n], ops);
       for (uint32_t o : ops) if (is_param(o) && P.nodes[o].input >= ns) { err = "gather mode: a table parameter is used outside the gather"; return false; }
     }
+    bool have_sv = false;
     for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t oid = T.outputs[1 + ns + k];
+      uint32_t oid = T.outputs[1 + ns + k];
+      // (the front end's wrappers around a whole output: a NOOP marker, or the Translator's SEQ(definition, use) whose value is `use`
+      //  -- the definition is a sub-expression of the scatter value, evaluated with it)
+      while (index_masks_on() && (P.nodes[oid].op == RH_RIR_NOOP || P.nodes[oid].op == RH_RIR_SEQ)) oid = P.nodes[oid].op == RH_RIR_NOOP ? P.nodes[oid].a : P.nodes[oid].b;
       if (!gather.ok) { if (!is_const(oid, 0.0)) { err = "gather mode: table gradient without a gather"; return false; } continue; }
       const Node &on = P.nodes[oid];
+      if (index_masks_on() && is_const(oid, 0.0)) {
+        // an entry that no row of this target selects (Model.observe's initial chunk has at most 8 rows): the front end has folded its
+        // all-(-1) / all-(+1) mask and with it the gradient to 0, which is what the scatter adds to that entry -- accepted when the
+        // data says so (the index column's distinct values are known and low + k is not among them)
+        const size_t gc = (size_t)T.col0 + (size_t)gather.col;
+        bool absent = gc < P.col_domain.size() && !P.col_domain[gc].empty();
+        for (size_t i = 0; absent && i < P.col_domain[gc].size(); i++) absent = P.col_domain[gc][i] != (double)(gather.low + (int)k);
+        if (absent) continue;
+      }
       bool ok = on.op == RH_RIR_LOOKUP && on.low == -1 && on.table.size() == 3 && is_const(on.table[0], 0.0) && is_const(on.table[2], 0.0);
       if (ok) {
         const Node &cmp = P.nodes[on.a];
         ok = cmp.op == RH_RIR_COMPARE && cmp.a == P.nodes[gather.node].a && P.nodes[cmp.b].op == RH_RIR_CONST &&
              P.nodes[cmp.b].cval == (double)(gather.low + (int)k);
       }
-      if (ok) { if (k == 0) gather.sv = on.table[1]; else ok = on.table[1] == gather.sv; }
+      if (ok) { if (!have_sv) { gather.sv = on.table[1]; have_sv = true; } else ok = on.table[1] == gather.sv; }
       if (!ok) { err = "gather mode: gradient output of table parameter " + std::to_string(k) + " is not eq(index, k, g, 0)"; return false; }
     }
+    if (gather.ok && !have_sv) { err = "gather mode: no table gradient in a target that reads the table"; return false; }
     return true;
   }
 

@@ -71,6 +71,9 @@ int lift_single_entry_targets(Program &P, std::vector<std::vector<double>> &synt
 // true when the program was rewritten.
 bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,
                           std::string &err, bool allow_unroll = true);
+// RH_INDEX_MASKS=1/0: strict builds recognise the per-entry mask columns of a Lookup's index column (columns.cpp) and gather mode
+// reads a table gradient through the NOOP the front end may have wrapped it in (emit.cpp).  Off until it has run on the device.
+bool index_masks_on();
 
 // Fast-mode re-association of row targets after canonicalize_columns (refactor.cpp): products are merged into monomials
 // and the factor common to every term of an output is pulled out, so that x_k * w shapes reappear.

@@ -11,8 +11,24 @@
 // over S x the rows.  1 / S is exact for S = 8 and the shared terms are the only arithmetic that changes (by a power of two);
 // the order in which the rows are added up changes as it does in any parallel reduction.  Anything that does not match keeps the
 // 8-slot expression.
+//
+// With RH_INDEX_MASKS=1 (rir.hpp index_masks_on: the strict lowering of hierarchical models, off until it has run on the device) the
+// roll also reads through what keeps the reference's 8 slots from being ONE expression although they are one function:
+//   * SEQ(definition, use) -- the Translator's sequencing of a shared sub-expression, placed inside whichever slot used it first --
+//     is read as `use` (what the emitter evaluates anyway);
+//   * a term (sum over the slots) * (parameter-only factors) -- the chain rule through a transformed parameter -- has the factors
+//     distributed over the addends of different column groups: ONE extra rounding per addend;  (x + x) * f is written x f + x f
+//     (the same double: a doubling is exact);
+//   * if the slots still differ, once more with the addends of every data-dependent sum in ONE canonical order (SumNormaliser: the
+//     reference's Line is a map, its addends are folded in a different order in every slot): the ORDER of the additions inside a
+//     row's expression changes, nothing is merged or cancelled;  a * b and b * a are one node (the same double);
+//   * a loose column times parameter-only factors (a * (y_1 + ... + y_8) arrives as one pre-summed column) is kept on the first
+//     slot's rows and zero-padded for the others, like a bare loose column.
+// These are the only places where the per-row arithmetic of a rolled strict target is not the reference's operation for operation.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -56,7 +72,20 @@ struct Roller {
     else if (n.op == RH_RIR_LOOKUP) lookups.emplace(std::make_tuple(n.a, n.low, n.table), i);
     else cons.emplace(std::make_tuple(n.op, n.a, binary_op(n.op) ? n.b : 0xffffffffu), i);
   }
-  uint32_t push(const Node &n) { P.nodes.push_back(n); const uint32_t i = (uint32_t)P.nodes.size() - 1; index(i); return i; }
+  uint32_t push(const Node &n) {
+    P.nodes.push_back(n);
+    const uint32_t i = (uint32_t)P.nodes.size() - 1;
+    index(i);
+    if (!hasp.empty()) {      // (nodes made after the constructor: renamed trees, distributed products)
+      char h = 0;
+      if (n.op == RH_RIR_INPUT) h = n.input < P.n_params;
+      else if (n.op == RH_RIR_LOOKUP) { h = hasp[n.a]; for (uint32_t e : n.table) h = h || hasp[e]; }
+      else if (n.op != RH_RIR_CONST) h = hasp[n.a] || (binary_op(n.op) && hasp[n.b]);
+      hasp.resize(P.nodes.size(), 0);
+      hasp[i] = h;
+    }
+    return i;
+  }
   uint32_t constant(double v) {
     uint64_t b; std::memcpy(&b, &v, 8);
     auto it = consts.find(b);
@@ -67,9 +96,14 @@ struct Roller {
   uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
     auto it = cons.find(std::make_tuple(op, a, b));
     if (it != cons.end()) return it->second;
+    if ((op == RH_RIR_MUL || op == RH_RIR_ADD) && commutative_mul) {      // a * b and b * a (a + b and b + a) are the same double
+      it = cons.find(std::make_tuple(op, b, a));
+      if (it != cons.end()) return it->second;
+    }
     Node n; n.op = op; n.a = a; n.b = b; n.dep = P.nodes[a].dep ? P.nodes[a].dep : P.nodes[b].dep;
     return push(n);
   }
+  bool commutative_mul = index_masks_on();
   uint32_t op1(uint32_t op, uint32_t a) {
     auto it = cons.find(std::make_tuple(op, a, 0xffffffffu));
     if (it != cons.end()) return it->second;
@@ -110,6 +144,7 @@ struct Roller {
       else {
         h = mix(h, hmemo[n.a]);
         if (n.op == RH_RIR_LOOKUP) { h = mix(h, (uint64_t)(int64_t)n.low); for (uint32_t e : n.table) h = mix(h, hmemo[e]); }
+        else if ((n.op == RH_RIR_MUL || n.op == RH_RIR_ADD) && commutative_mul) h = mix(mix(0x51, n.op), hmemo[n.a] + hmemo[n.b]);   // blind to the operand order
         else if (binary_op(n.op)) h = mix(h, hmemo[n.b]);
       }
       hmemo[x] = h; hdone[x] = 1;
@@ -148,23 +183,168 @@ struct Roller {
 };
 
 struct Term { uint32_t node; bool neg; };
-void flatten(const Program &P, uint32_t id, bool neg, std::vector<Term> &out) {
+void flatten(const Program &P, uint32_t id, bool neg, std::vector<Term> &out, bool seq_through) {
   std::vector<std::pair<uint32_t, bool>> stack{{id, neg}};
   std::vector<Term> rev;
   while (!stack.empty()) {      // left operand first -> original left-to-right order
     auto [x, ng] = stack.back(); stack.pop_back();
     const Node &n = P.nodes[x];
     if (n.dep != 0 && (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB)) { stack.push_back({n.b, n.op == RH_RIR_SUB ? !ng : ng}); stack.push_back({n.a, ng}); }
+    else if (n.dep != 0 && n.op == RH_RIR_SEQ && seq_through) stack.push_back({n.b, ng});   // SEQ(definition, use): the value is `use`
     else rev.push_back({x, ng});
   }
   out.insert(out.end(), rev.begin(), rev.end());
 }
 
+// Every sum of data-dependent addends re-written with its addends in ONE canonical order (sorted by a column-blind, order-blind
+// structural hash; products likewise, which changes no bit).  The reference's Line is a map from terms to coefficients whose
+// iteration order -- hence the order in which the Translator folds the addends -- differs from slot to slot of Model.observe's
+// split; with the addends in one order the 8 slots are the same expression again.  The order of additions inside a row's
+// expression changes (rounding only); nothing is distributed, merged or cancelled.
+struct SumNormaliser {
+  const Program &P;
+  Program Q;
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cons;
+  std::map<std::tuple<uint32_t, int32_t, std::vector<uint32_t>>, uint32_t> lookups;
+  std::map<uint64_t, uint32_t> consts;
+  std::map<uint32_t, uint32_t> inputs;
+  std::vector<uint32_t> m;          // P node -> Q node
+  std::vector<char> done;
+  std::vector<uint64_t> qh;         // Q node -> hash
+  explicit SumNormaliser(const Program &p) : P(p) {
+    Q.n_params = P.n_params; Q.n_inputs = P.n_inputs; Q.n_cols_total = P.n_cols_total; Q.kind = P.kind; Q.targets = P.targets; Q.col_domain = P.col_domain;
+    m.assign(P.nodes.size(), 0); done.assign(P.nodes.size(), 0);
+  }
+  uint32_t push(const Node &n, uint64_t h) { Q.nodes.push_back(n); qh.push_back(h); return (uint32_t)Q.nodes.size() - 1; }
+  uint32_t constant(double v) {
+    uint64_t b; std::memcpy(&b, &v, 8);
+    auto it = consts.find(b);
+    if (it != consts.end()) return it->second;
+    Node n; n.op = RH_RIR_CONST; n.cval = v;
+    return consts[b] = push(n, mix(mix(0x51, RH_RIR_CONST), b));
+  }
+  uint32_t op2(uint32_t op, uint32_t a, uint32_t b) {
+    auto key = std::make_tuple(op, a, b);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.b = b; n.dep = Q.nodes[a].dep ? Q.nodes[a].dep : Q.nodes[b].dep;
+    uint64_t h;
+    if (op == RH_RIR_MUL) h = mix(mix(0x51, op), qh[a] + qh[b]);
+    else h = mix(mix(mix(0x51, op), qh[a]), qh[b]);       // (sums are hashed by their flattened addends in norm())
+    return cons[key] = push(n, h);
+  }
+  uint32_t op1(uint32_t op, uint32_t a) {
+    auto key = std::make_tuple(op, a, 0xffffffffu);
+    auto it = cons.find(key);
+    if (it != cons.end()) return it->second;
+    Node n; n.op = op; n.a = a; n.dep = Q.nodes[a].dep;
+    return cons[key] = push(n, mix(mix(0x51, op), qh[a]));
+  }
+  void addends(uint32_t id, bool neg, std::vector<std::pair<uint32_t, bool>> &out) {   // P ids, left to right
+    std::vector<std::pair<uint32_t, bool>> stack{{id, neg}};
+    while (!stack.empty()) {
+      auto [x, ng] = stack.back(); stack.pop_back();
+      const Node &n = P.nodes[x];
+      if (n.dep != 0 && (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB)) { stack.push_back({n.b, n.op == RH_RIR_SUB ? !ng : ng}); stack.push_back({n.a, ng}); }
+      else out.push_back({x, ng});
+    }
+  }
+  uint32_t norm(uint32_t root) {
+    std::vector<uint32_t> stack{root};
+    std::vector<uint32_t> ops;
+    while (!stack.empty()) {
+      const uint32_t x = stack.back();
+      if (done[x]) { stack.pop_back(); continue; }
+      const Node &n = P.nodes[x];
+      ops.clear();
+      std::vector<std::pair<uint32_t, bool>> ad;
+      const bool sum = n.dep != 0 && (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB);
+      if (sum) { addends(x, false, ad); for (auto &a : ad) ops.push_back(a.first); }
+      else if (n.op != RH_RIR_CONST && n.op != RH_RIR_INPUT) { ops.push_back(n.a); if (n.op == RH_RIR_LOOKUP) ops.insert(ops.end(), n.table.begin(), n.table.end()); else if (binary_op(n.op)) ops.push_back(n.b); }
+      bool ready = true;
+      for (uint32_t o : ops) if (!done[o]) { stack.push_back(o); ready = false; }
+      if (!ready) continue;
+      uint32_t r;
+      if (n.op == RH_RIR_CONST) r = constant(n.cval);
+      else if (n.op == RH_RIR_INPUT) {
+        auto it = inputs.find(n.input);
+        if (it != inputs.end()) r = it->second;
+        else { Node q = n; r = inputs[n.input] = push(q, n.input >= P.n_params ? mix(mix(0x51, RH_RIR_INPUT), 0xC01) : mix(mix(mix(0x51, RH_RIR_INPUT), 0x9A7), n.input)); }
+      } else if (sum) {
+        std::vector<std::tuple<int, uint64_t, size_t>> key;     // positive addends first, then by hash, then by original position
+        for (size_t i = 0; i < ad.size(); i++) key.push_back(std::make_tuple(ad[i].second ? 1 : 0, qh[m[ad[i].first]], i));
+        std::sort(key.begin(), key.end());
+        uint32_t acc = 0;
+        uint64_t hs = 0;
+        for (size_t i = 0; i < key.size(); i++) {
+          const auto &a = ad[std::get<2>(key[i])];
+          const uint32_t q = m[a.first];
+          hs += mix(qh[q], a.second ? 1 : 0);
+          if (i == 0) acc = a.second ? op2(RH_RIR_SUB, constant(0.0), q) : q;
+          else acc = op2(a.second ? RH_RIR_SUB : RH_RIR_ADD, acc, q);
+        }
+        r = acc;
+        qh[r] = mix(mix(0x51, RH_RIR_ADD), hs);               // order-blind: the same for every order the addends came in
+      } else if (n.op == RH_RIR_LOOKUP) {
+        Node q; q.op = RH_RIR_LOOKUP; q.a = m[n.a]; q.low = n.low; q.dep = Q.nodes[q.a].dep;
+        uint64_t h = mix(mix(mix(0x51, RH_RIR_LOOKUP), qh[q.a]), (uint64_t)(int64_t)n.low);
+        for (uint32_t e : n.table) { q.table.push_back(m[e]); if (Q.nodes[m[e]].dep) q.dep = Q.nodes[m[e]].dep; h = mix(h, qh[m[e]]); }
+        auto key = std::make_tuple(q.a, q.low, q.table);
+        auto it = lookups.find(key);
+        r = it != lookups.end() ? it->second : (lookups[key] = push(q, h));
+      } else if (n.op == RH_RIR_MUL) {
+        uint32_t a = m[n.a], b = m[n.b];
+        if (n.dep != 0 && std::make_pair(qh[b], b) < std::make_pair(qh[a], a)) std::swap(a, b);   // a * b == b * a, bit for bit
+        r = op2(RH_RIR_MUL, a, b);
+      } else if (binary_op(n.op)) r = op2(n.op, m[n.a], m[n.b]);
+      else r = op1(n.op, m[n.a]);
+      m[x] = r; done[x] = 1;
+      stack.pop_back();
+    }
+    return m[root];
+  }
+};
+
+bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int &not_rolled);
+
 }  // namespace
 
 bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
+  Program A = P;
+  std::vector<std::vector<uint32_t>> pa;
+  int left_a = 0;
+  const bool ok_a = roll_strict_impl(A, pa, left_a);
+  if (left_a > 0 && index_masks_on()) {   // a target kept its slots: once more with every sum's addends in one canonical order
+    SumNormaliser N(P);
+    for (Target &T : N.Q.targets) for (uint32_t &o : T.outputs) o = N.norm(o);
+    std::vector<std::vector<uint32_t>> pb;
+    int left_b = 0;
+    Program B = N.Q;
+    if (roll_strict_impl(B, pb, left_b) && left_b < left_a) { P = std::move(B); parts = std::move(pb); return true; }
+  }
+  if (ok_a) { P = std::move(A); parts = std::move(pa); }
+  else { parts.clear(); for (uint32_t c = 0; c < P.n_cols_total; c++) parts.push_back({c}); }
+  return ok_a;
+}
+
+namespace {
+bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int &not_rolled) {
+  not_rolled = 0;
   parts.clear();
   for (uint32_t c = 0; c < P.n_cols_total; c++) parts.push_back({c});
+  if (index_masks_on()) {
+    // SEQ(definition, use) -- the Translator's sequencing of a shared sub-expression's first use -- has the value of `use` and sits
+    // wherever that first use happened to be (inside ONE slot's term): read through it, so that the slots are the same expression
+    std::vector<uint32_t> fwd(P.nodes.size());
+    for (uint32_t i = 0; i < P.nodes.size(); i++) fwd[i] = P.nodes[i].op == RH_RIR_SEQ ? fwd[P.nodes[i].b] : i;
+    for (Node &n : P.nodes) {
+      if (n.op == RH_RIR_CONST || n.op == RH_RIR_INPUT) continue;
+      n.a = fwd[n.a];
+      if (n.op == RH_RIR_LOOKUP) { for (uint32_t &e : n.table) e = fwd[e]; }
+      else if (binary_op(n.op)) n.b = fwd[n.b];
+    }
+    for (Target &T : P.targets) for (uint32_t &o : T.outputs) o = fwd[o];
+  }
   Roller R(P);
   bool any = false;
   const size_t NT = P.targets.size();
@@ -175,10 +355,66 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
     if (!P.targets[t].n_cols) continue;
     const size_t no = P.targets[t].outputs.size();
     std::vector<std::vector<Term>> terms(no);
-    for (size_t o = 0; o < no; o++) flatten(P, P.targets[t].outputs[o], false, terms[o]);
+    for (size_t o = 0; o < no; o++) flatten(P, P.targets[t].outputs[o], false, terms[o], index_masks_on());
     // components of the columns: joined when one term reads both
     std::map<uint32_t, uint32_t> parent;
     std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { auto it = parent.find(x); if (it == parent.end()) { parent[x] = x; return x; } if (it->second == x) return x; const uint32_t r = find(it->second); parent[x] = r; return r; };
+    if (index_masks_on()) {
+      // A term  (sum over the slots) * (parameter-only factor)  -- the chain rule through a transformed parameter, e.g. d/d log(tau) of
+      // tau * z(site): (sum_s g_s * z(site_s)) * exp(.) -- ties all the slots together as it stands.  The factor is distributed over
+      // the addends that belong to different column groups (one extra rounding per addend: the only arithmetic of a rolled target
+      // that is not the reference's, next to the exact 1 / S of the shared terms); a product inside one group is left as it is.
+      // (sum) * f1 * f2 ...: the chain of parameter-only factors around a data-dependent sum, outermost first; side = the sum is
+      // the left operand of that product
+      struct Wrap { uint32_t fac; bool sum_left; };
+      auto split_of = [&](const Term &tm, uint32_t &sum, std::vector<Wrap> &chain) {
+        chain.clear();
+        uint32_t x = tm.node;
+        while (true) {
+          const Node &n = P.nodes[x];
+          if (n.dep == 0) return false;
+          if (n.op == RH_RIR_ADD || n.op == RH_RIR_SUB) { sum = x; return !chain.empty(); }
+          if (n.op != RH_RIR_MUL) return false;
+          const bool da = P.nodes[n.a].dep != 0, db = P.nodes[n.b].dep != 0;
+          if (da == db) return false;
+          chain.push_back({da ? n.b : n.a, da});
+          x = da ? n.a : n.b;
+        }
+      };
+      uint32_t sum = 0;
+      std::vector<Wrap> chain;
+      for (auto &to : terms) for (const Term &tm : to) {
+        if (split_of(tm, sum, chain)) continue;
+        const std::vector<uint32_t> c = R.cols(tm.node);
+        for (size_t i = 1; i < c.size(); i++) parent[find(c[i])] = find(c[0]);
+        if (!c.empty()) find(c[0]);
+      }
+      for (auto &to : terms) {
+        std::vector<Term> out;
+        std::vector<Term> work(to.rbegin(), to.rend());
+        while (!work.empty()) {
+          const Term tm = work.back(); work.pop_back();
+          bool spans = false;
+          if (split_of(tm, sum, chain)) {
+            const std::vector<uint32_t> c = R.cols(tm.node);
+            for (size_t i = 1; i < c.size() && !spans; i++) spans = find(c[i]) != find(c[0]);
+            // (x + x) * f, the Translator's 2 x f: written x f + x f for an entry whose rows straddle two slots -- the same double
+            // either way (a doubling is exact), so it is brought to the second form everywhere
+            if (!spans && P.nodes[sum].op == RH_RIR_ADD && P.nodes[sum].a == P.nodes[sum].b) spans = true;
+          }
+          if (!spans) { out.push_back(tm); continue; }
+          std::vector<Term> addends;
+          flatten(P, sum, tm.neg, addends, true);
+          const std::vector<Wrap> ch = chain;
+          for (size_t i = addends.size(); i-- > 0;) {
+            uint32_t prod = addends[i].node;
+            for (size_t w = ch.size(); w-- > 0;) prod = ch[w].sum_left ? R.op2(RH_RIR_MUL, prod, ch[w].fac) : R.op2(RH_RIR_MUL, ch[w].fac, prod);   // innermost factor first
+            work.push_back({prod, addends[i].neg});
+          }
+        }
+        to.swap(out);
+      }
+    }
     std::map<uint32_t, char> param_comp;
     for (auto &to : terms) for (const Term &tm : to) {
       const std::vector<uint32_t> c = R.cols(tm.node);
@@ -203,7 +439,10 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
       for (size_t c : idx) { cs.push_back(comps[c]); cp.push_back(comp_param[c]); }
       comps.swap(cs); comp_param.swap(cp);
     }
+    const bool loose_param = index_masks_on();
+    const bool say = std::getenv("RH_ROLL_WHY") != nullptr;   // RH_ROLL_WHY=1: why a target with several column groups keeps them
     if (comps.size() < 2) continue;
+    not_rolled++;                                   // (taken back at the end of the loop body when the target does roll)
     std::map<uint32_t, size_t> comp_of;
     for (size_t c = 0; c < comps.size(); c++) for (uint32_t col : comps[c]) comp_of[col] = c;
     std::vector<uint64_t> ch(comps.size(), 0x5107);
@@ -216,21 +455,50 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
         if (c.empty()) continue;
         hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg));
         const Node &n = P.nodes[tm.node];
-        const bool lin = is_col(tm.node) || (n.op == RH_RIR_MUL && ((is_col(n.a) && P.nodes[n.b].op == RH_RIR_CONST) || (is_col(n.b) && P.nodes[n.a].op == RH_RIR_CONST)));
+        bool lin = is_col(tm.node) || (n.op == RH_RIR_MUL && ((is_col(n.a) && P.nodes[n.b].op == RH_RIR_CONST) || (is_col(n.b) && P.nodes[n.a].op == RH_RIR_CONST)));
+        if (!lin && loose_param) {
+          // column * (parameter-only factors), in any nesting: a * (y_1 + ... + y_8) arrives as ONE column times the parameter (the
+          // Line algebra has added the 8 slots' columns up front); it vanishes on zero padding like a bare column does
+          uint32_t x = tm.node;
+          while (P.nodes[x].op == RH_RIR_MUL && P.nodes[x].dep != 0) {
+            const Node &m = P.nodes[x];
+            if (P.nodes[m.a].dep == 0) x = m.b; else if (P.nodes[m.b].dep == 0) x = m.a; else break;
+          }
+          lin = is_col(x);
+        }
         if (!lin) linear[comp_of[c[0]]] = 0;
       }
       for (size_t c = 0; c < comps.size(); c++) { std::sort(hs[c].begin(), hs[c].end()); uint64_t h = mix(ch[c], o); for (uint64_t x : hs[c]) h = mix(h, x); ch[c] = h; }
     }
     std::map<uint64_t, std::vector<size_t>> classes;
     for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
+    if (say && classes.size() > 2)     // which output tells the column groups apart: the first one on which two of them differ
+      for (size_t o = 0; o < no; o++) {
+        std::vector<std::vector<uint64_t>> hs(comps.size());
+        for (const Term &tm : terms[o]) { const std::vector<uint32_t> c = R.cols(tm.node); if (!c.empty()) hs[comp_of[c[0]]].push_back(mix(R.hash(tm.node), tm.neg)); }
+        size_t c0 = comps.size(), cd = comps.size();
+        for (size_t c = 0; c < comps.size() && cd == comps.size(); c++) {
+          if (!comp_param[c] || comps[c].size() < 2) continue;
+          std::sort(hs[c].begin(), hs[c].end());
+          if (c0 == comps.size()) c0 = c; else if (hs[c] != hs[c0]) cd = c;
+        }
+        if (cd != comps.size()) { std::fprintf(stderr, "rainier-hip: strict roll, target %zu: output %zu tells column group %zu (%zu terms) from group %zu (%zu terms)\n", t, o, c0, hs[c0].size(), cd, hs[cd].size()); break; }
+      }
     size_t S = 0; bool ok = true;
-    for (auto &kv : classes) { if (!comp_param[kv.second[0]]) continue; if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false; }
-    if (!ok || S < 2 || (S & (S - 1)) != 0) continue;            // 1 / S must be exact
+    for (auto &kv : classes) {
+      if (!comp_param[kv.second[0]]) continue;
+      if (loose_param && kv.second.size() == 1 && linear[kv.second[0]] && comps[kv.second[0]].size() == 1) continue;   // a loose column times a parameter
+      if (S == 0) S = kv.second.size(); else if (kv.second.size() != S) ok = false;
+    }
+    if (!ok || S < 2 || (S & (S - 1)) != 0) {                     // 1 / S must be exact
+      if (say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: %zu column groups in %zu structural classes, no common slot count (S = %zu)\n", t, comps.size(), classes.size(), S);
+      continue;
+    }
     for (auto &kv : classes) {
       if (kv.second.size() == S) continue;
-      for (size_t c : kv.second) { if (comp_param[c] || !linear[c]) ok = false; for (uint32_t col : comps[c]) loose[col] = 1; }
+      for (size_t c : kv.second) { if ((comp_param[c] && !loose_param) || !linear[c]) ok = false; for (uint32_t col : comps[c]) loose[col] = 1; }
     }
-    if (!ok) continue;
+    if (!ok) { if (say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: a column group outside the %zu slots is not a loose linear data term\n", t, S); continue; }
     std::vector<std::map<uint32_t, char>> slot_cols(S);
     for (auto &kv : classes) if (kv.second.size() == S) for (size_t s = 0; s < S; s++) for (uint32_t col : comps[kv.second[s]]) slot_cols[s][col] = 1;
     std::map<uint32_t, size_t> slot_of;
@@ -247,7 +515,7 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
     }
     const size_t mcols = order[0].size();
     for (size_t s = 0; s < S && ok; s++) ok = order[s].size() == mcols && mcols == slot_cols[s].size();
-    if (!ok) continue;
+    if (!ok) { if (say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: the slots read different numbers of columns\n", t); continue; }
     // verify: slot s's terms, renamed, are slot 0's terms (as multisets, with their signs)
     std::vector<std::vector<Term>> slot0(no);
     for (size_t o = 0; o < no && ok; o++) {
@@ -262,9 +530,34 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
         for (auto &x : st[s]) got.push_back({R.rename(x.first, cmap, memo), x.second});
         std::sort(got.begin(), got.end());
         ok = got == want;
+        if (!ok && say) std::fprintf(stderr, "rainier-hip: strict roll, target %zu: output %zu, slot %zu has %zu terms, slot 0 %zu, and they differ after renaming\n", t, o, s, got.size(), want.size());
       }
     }
     if (!ok) continue;
+    // (RH_INDEX_MASKS) a select with parameter-only factors around it, eq(index, k, T, 0) * f, carries them inside: eq(index, k, T * f, 0)
+    // -- the selected row computes the same product, the other rows 0 instead of 0 * f -- which is the one-scatter-value shape gather
+    // mode reads (emit.cpp detect_gather); hash-consing makes T * f one node for all the entries
+    auto sink = [&](uint32_t term) {
+      std::vector<std::pair<uint32_t, bool>> chain;     // (factor, select on the left), outermost first
+      uint32_t y = term;
+      while (P.nodes[y].op == RH_RIR_MUL && P.nodes[y].dep != 0) {
+        const Node &n = P.nodes[y];
+        const bool da = P.nodes[n.a].dep != 0, db = P.nodes[n.b].dep != 0;
+        if (da == db) return term;
+        chain.push_back({da ? n.b : n.a, da});
+        y = da ? n.a : n.b;
+      }
+      const Node lk = P.nodes[y];
+      if (chain.empty() || lk.op != RH_RIR_LOOKUP || lk.low != -1 || lk.table.size() != 3) return term;
+      const Node &z0 = P.nodes[lk.table[0]], &z2 = P.nodes[lk.table[2]];
+      if (!(z0.op == RH_RIR_CONST && z0.cval == 0.0 && !std::signbit(z0.cval) && z2.op == RH_RIR_CONST && z2.cval == 0.0 && !std::signbit(z2.cval))) return term;
+      if (P.nodes[lk.a].op != RH_RIR_COMPARE) return term;
+      uint32_t v = lk.table[1];
+      for (size_t w = chain.size(); w-- > 0;) v = chain[w].second ? R.op2(RH_RIR_MUL, v, chain[w].first) : R.op2(RH_RIR_MUL, chain[w].first, v);
+      Node q = lk; q.table[1] = v;
+      auto li = R.lookups.find(std::make_tuple(q.a, q.low, q.table));
+      return li != R.lookups.end() ? li->second : R.push(q);
+    };
     // rebuild: original order of the terms that stay (slot 0, loose), shared terms scaled by the exact 1 / S
     const uint32_t inv_s = R.constant(1.0 / (double)S);
     std::vector<uint32_t> outs(no);
@@ -274,7 +567,7 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
         const std::vector<uint32_t> c = R.cols(tm.node);
         uint32_t x;
         if (c.empty()) x = R.op2(RH_RIR_MUL, tm.node, inv_s);
-        else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = tm.node;
+        else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = index_masks_on() ? sink(tm.node) : tm.node;
         else continue;
         if (acc == 0xFFFFFFFFu) acc = tm.neg ? R.op2(RH_RIR_SUB, R.constant(0.0), x) : x;
         else acc = R.op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x);
@@ -293,6 +586,7 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
       src[t].push_back(cs);
     }
     any = true;
+    not_rolled--;
   }
   if (!any) return false;
   // renumber the columns that are left
@@ -321,5 +615,6 @@ bool roll_strict(Program &P, std::vector<std::vector<uint32_t>> &parts) {
     }
   return true;
 }
+}  // namespace
 
 }  // namespace rh

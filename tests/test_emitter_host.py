@@ -414,6 +414,82 @@ def test_gather_shaped_model_without_gather_preconditions_takes_the_generic_path
             assert ("#define RH_HAS_GATHER 1\n" in src) == (not centred or opts is FAST)
 
 
+def _raw_table_spec(family, K=100, n=1500, seed=4):
+    """the usual non-centred hierarchical model in the reference's text (cfg 5's shape): z = Normal(0,1).latentVec(K) created last,
+    eta = a + tau * z(site) + b x, NegBin-logit or Poisson-log likelihood, with or without Model.observe's 8-way split"""
+    from rainier_amd import compute as CC
+    rng = np.random.default_rng(seed)
+    a = M.Normal(0, 1).latent; b = M.Normal(0, 1).latent; tau = M.Exponential(1).latent
+    zs = M.Normal(0, 1).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n)
+    eta = lambda s, u: a + tau * CC.Lookup.apply(s, zs) + b * u
+    if family.startswith("negbin"):
+        ys = rng.poisson(3.0, n).astype(float); fn = lambda s, u: M.NegativeBinomial(eta(s, u).logistic, 5.0)
+    else:
+        ys = rng.poisson(2.0, n).astype(float); fn = lambda s, u: M.Poisson(eta(s, u).exp())
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=family.endswith("split")).compile("raw_table_" + family, inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
+    return spec, qs
+
+
+@pytest.mark.parametrize("family,n", [("negbin", 1500), ("negbin-split", 1500), ("poisson", 1500), ("poisson-split", 1500), ("negbin", 150), ("negbin-split", 333)])
+def test_strict_builds_read_the_reference_s_mask_columns_as_a_scatter(family, n, monkeypatch):
+    """RH_INDEX_MASKS=1 (off by default until it has run on the device).  The reference's gradient of Lookup(site, z) with respect to
+    entry k is eq(site, k, g, 0) with Compare(site, k) evaluated ahead of time: one data column of -1 / 0 / +1 per entry and slot
+    (compute/Gradient.scala:146-152).  Strict builds keep that expression (fast builds derive the gradient again), so the columns
+    themselves are recognised in the data (csrc/columns.cpp), terms the front end folded for entries no row selects are written back,
+    the 8 slots are rolled with their addends in one order (csrc/rollstrict.cpp) -- and the model runs in gather mode: 4 columns
+    streamed instead of 100 + per slot, O(rows) instead of O(rows x entries), the reference's arithmetic on every row."""
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    spec, qs = _raw_table_spec(family, n=n)
+    assert qs
+    src = _check(spec, STRICT, qs, 1e-12)
+    assert "#define RH_HAS_GATHER 1\n" in src
+    import re
+    ncols = [int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)]
+    assert max(ncols) <= 6 and sum(ncols) <= 13, ncols          # (x, site, y, constant terms) per row target + the lifted prior's index
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_strict_location_scale_table_in_gather_mode(split, monkeypatch):
+    """alphas = Normal(mu, sd).latentVec(K), eta = alphas(site) + b x (the idiomatic form; entries z_k sd + mu, hoisted behind the
+    lookup by the loader).  The reference writes d/d mu as sum_k (e_k + e_k) and d/d sd as sum_k e_k z_k ... with e_k = eq(site, k, g, 0)
+    -- one select per entry and row -- and d/d z_k as e_k * sd.  With RH_INDEX_MASKS=1 strict builds fold the select sums (exactly one
+    select is non-zero on a row: the sum IS g + g, resp. g * Lookup(site, z) ...) and carry the factor of d/d z_k inside the select,
+    so that the model runs in gather mode -- also through Model.observe's split (the strict roll carries the factor into the select
+    after the slots have been rolled)."""
+    from rainier_amd import compute as CC
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    rng = np.random.default_rng(4)
+    K, n = 100, 1500
+    b = M.Normal(0, 1).latent
+    alphas = M.Normal(M.Normal(0, 2).latent, M.Exponential(1).latent).latentVec(K)
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, alphas) + b * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=split).compile("centred_table_100", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
+    src = _check(spec, STRICT, qs, 1e-12)
+    assert "#define RH_HAS_GATHER 1\n" in src and "#define RH_NSHARED 3\n" in src
+
+
+def test_strict_glmm_poisson2_streams_4_columns_instead_of_452(monkeypatch):
+    """bench/stan/GLMMPoisson2.scala in the reference's text, strict build: two Lookups over index columns, neither table a run of
+    trailing parameters (generic path).  With the masks recognised, the folded terms written back, the select sums folded and the 8
+    slots rolled the row target reads (count, site, year, the constant term) -- as the fast build does after deriving the gradient again"""
+    import re
+    data = json.load(open(os.path.join(G, "glmm_poisson2.json")))
+    spec = models.glmm_poisson2_reference(100, 40, data)
+    qs = np.random.default_rng(23).normal(size=(2, 146)) * 0.3
+    monkeypatch.delenv("RH_INDEX_MASKS", raising=False)
+    src = _check(spec, STRICT, qs, 1e-12)
+    assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 452
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    src = _check(spec, STRICT, qs, 1e-12)
+    assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 4
+
+
 @pytest.mark.parametrize("family", ["negbin-split", "negbin", "poisson-split"])
 def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family):
     """the usual non-centred hierarchical model in the reference's text (cfg 5's shape): z = Normal(0,1).latentVec(K) created last,
