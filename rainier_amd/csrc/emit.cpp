@@ -389,7 +389,9 @@ struct TargetEmitter {
   void find_families() {
     in_family.assign(basis.size(), 0);
     families.clear();
-    if (!has_rows() || !factor || gmode) return;
+    // (strict builds accumulate every output itself; with RH_INDEX_MASKS their eq(column, k, g, 0) outputs -- the reference's masks,
+    //  recognised by the loader -- form families too: `acc[k] += g` on the selected row instead of `+= g or +0.0` on every accumulator)
+    if (!has_rows() || (!factor && !index_masks_on()) || gmode) return;
     std::map<std::pair<uint32_t, uint32_t>, std::map<int, int>> cand;   // (column node, g) -> k -> basis index
     for (size_t j = 0; j < basis.size(); j++) {
       const Node &nd = P.nodes[basis[j]];

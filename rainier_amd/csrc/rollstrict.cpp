@@ -563,14 +563,25 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
     std::vector<uint32_t> outs(no);
     for (size_t o = 0; o < no; o++) {
       uint32_t acc = 0xFFFFFFFFu;
+      uint32_t last_sel = 0xFFFFFFFFu;      // (RH_INDEX_MASKS) the select just added: a second copy of it is folded into the first
       for (const Term &tm : terms[o]) {
         const std::vector<uint32_t> c = R.cols(tm.node);
         uint32_t x;
         if (c.empty()) x = R.op2(RH_RIR_MUL, tm.node, inv_s);
         else if (loose.count(c[0]) || slot_of[c[0]] == 0) x = index_masks_on() ? sink(tm.node) : tm.node;
         else continue;
-        if (acc == 0xFFFFFFFFu) acc = tm.neg ? R.op2(RH_RIR_SUB, R.constant(0.0), x) : x;
-        else acc = R.op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x);
+        if (index_masks_on() && !tm.neg && acc == last_sel && x == last_sel && P.nodes[x].op == RH_RIR_LOOKUP && P.nodes[x].low == -1 && P.nodes[x].table.size() == 3) {
+          // eq(index, k, V, 0) + eq(index, k, V, 0) -- the Translator's 2 x -- is eq(index, k, V + V, 0): the same sum on the selected
+          // row, 0 + 0 elsewhere; ONE select per entry again (the shape scatter families and gather mode read)
+          Node q = P.nodes[x];
+          q.table[1] = R.op2(RH_RIR_ADD, q.table[1], q.table[1]);
+          auto li = R.lookups.find(std::make_tuple(q.a, q.low, q.table));
+          acc = li != R.lookups.end() ? li->second : R.push(q);
+          last_sel = 0xFFFFFFFFu;
+          continue;
+        }
+        if (acc == 0xFFFFFFFFu) { acc = tm.neg ? R.op2(RH_RIR_SUB, R.constant(0.0), x) : x; last_sel = tm.neg ? 0xFFFFFFFFu : x; }
+        else { acc = R.op2(tm.neg ? RH_RIR_SUB : RH_RIR_ADD, acc, x); last_sel = 0xFFFFFFFFu; }
       }
       outs[o] = acc == 0xFFFFFFFFu ? R.constant(0.0) : acc;
     }
