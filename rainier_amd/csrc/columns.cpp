@@ -554,6 +554,50 @@ void fold_select_sums(Program &P, const double *const *columns, const int64_t *n
   P.nodes.swap(Q);
 }
 
+// Do two programs over the same inputs compute the same outputs?  Sample rows of every row target x 3 parameter vectors, extended
+// precision (rederive.cpp's block interpreter); "same" = equal to 1e-13 relative, or the same NaN / infinity on both sides.
+bool same_outputs(const Program &A, const Program &Bq, const double *const *columns, const int64_t *nrows, const std::vector<uint32_t> &kept) {
+  if (A.targets.size() != Bq.targets.size() || A.n_inputs != Bq.n_inputs) return false;
+  constexpr int B = 32;
+  static const double kScale[3] = {1.2, 0.2, 3.6};
+  for (size_t t = 0; t < A.targets.size(); t++) {
+    const Target &TA = A.targets[t], &TB = Bq.targets[t];
+    if (!TA.n_cols || nrows[t] <= 0) continue;
+    if (TA.outputs == TB.outputs && A.nodes.size() == Bq.nodes.size()) continue;     // untouched
+    const BlockEvaluator EA(A, TA.outputs), EB(Bq, TB.outputs);
+    const int64_t nr = nrows[t];
+    const int S = (int)std::min<int64_t>(96, nr);
+    uint64_t lcg = 0x9E3779B97F4A7C15ull + (uint64_t)t;
+    auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) / 9007199254740992.0 - 0.5; };
+    std::vector<long double> in((size_t)A.n_inputs * B, 0.0L), va, vb;
+    std::vector<char> oka, okb;
+    for (int trial = 0; trial < 3; trial++) {
+      std::vector<double> th(A.n_params);
+      for (uint32_t p = 0; p < A.n_params; p++) th[p] = kScale[trial] * uni();
+      for (int s0 = 0; s0 < S; s0 += B) {
+        const int nb = std::min(B, S - s0);
+        for (int r = 0; r < B; r++) {
+          const int64_t row = (int64_t)std::min(s0 + r, S - 1) * nr / S;
+          for (uint32_t p = 0; p < A.n_params; p++) in[(size_t)p * B + r] = (long double)th[p];
+          for (uint32_t j = 0; j < TA.n_cols; j++) in[(size_t)(TA.input_start + j) * B + r] = (long double)columns[kept[TA.col0 + j]][row];
+        }
+        if (!EA.run(in, B, va, oka) || !EB.run(in, B, vb, okb)) return false;
+        for (size_t o = 0; o < TA.outputs.size(); o++) {
+          const long double *a = &va[(size_t)TA.outputs[o] * B], *b = &vb[(size_t)TB.outputs[o] * B];
+          for (int r = 0; r < nb; r++) {
+            if (oka[(size_t)r] != okb[(size_t)r]) return false;
+            if (!oka[(size_t)r]) continue;
+            const bool fa = std::isfinite(a[r]), fb = std::isfinite(b[r]);
+            if (!fa || !fb) { if (fa != fb || std::isnan(a[r]) != std::isnan(b[r]) || (std::isinf(a[r]) && a[r] != b[r])) return false; continue; }
+            if (std::fabs(a[r] - b[r]) > 1e-13L * std::max(std::fabs(a[r]), std::fabs(b[r]))) return false;
+          }
+        }
+      }
+    }
+  }
+  return true;
+}
+
 }  // namespace
 
 bool index_masks_on() {
@@ -953,7 +997,17 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     Q.targets[t].outputs = acc;
   }
   P = std::move(Q);
-  if (index_masks_on() && !fast) { complete_scatter_terms(P, columns, nrows, kept); fold_select_sums(P, columns, nrows, kept); }
+  if (index_masks_on() && !fast) {
+    // the two rewrites below are exact by construction; like every other rewrite of the loader they are also VERIFIED before they
+    // are kept: every output of every row target, before against after, on up to 96 rows x 3 parameter vectors in extended precision
+    const Program before = P;
+    complete_scatter_terms(P, columns, nrows, kept);
+    fold_select_sums(P, columns, nrows, kept);
+    if (!same_outputs(before, P, columns, nrows, kept)) {
+      if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: the select rewrites of a strict build did not reproduce the original outputs: dropped\n");
+      P = before;
+    }
+  }
   return true;
 }
 
