@@ -414,4 +414,6 @@ def test_model_create_host_time_budget():
     # the budget (2 s / 4 s) is for an otherwise idle host -- measured 0.43 s / 2.83 s at the end of round 3; the assertion leaves
     # 1.5 x for a busy one (the driver runs the suite serially beside other work), 3 x under xdist
     slack = 3.0 if os.environ.get("PYTEST_XDIST_WORKER") else 1.5
+    if os.environ.get("RH_SANITIZED") == "1":      # tools/run_sanitized.py: the instrumented library is several times slower
+        slack *= 8.0
     assert t4 <= 2.0 * slack and tt <= 4.0 * slack, (t4, tt)
