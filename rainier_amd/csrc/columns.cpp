@@ -192,7 +192,8 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
     if (!T.n_cols) continue;
     auto local_col = [&](uint32_t id) { const Node &x = P.nodes[id]; return (x.op == RH_RIR_INPUT && x.input >= P.n_params && x.dep == t + 1) ? (int)(x.input - T.input_start) : -1; };
     struct Wrap { uint32_t fac; bool inner_left; };
-    struct Slot { uint32_t ix; int col; int32_t low; std::vector<long> param; bool have = false, bad = false, nested = false; uint32_t value = 0; std::vector<Wrap> chain; std::vector<char> present; };
+    struct Slot { uint32_t ix; int col; int32_t low; std::vector<long> param; bool have = false, bad = false, nested = false; uint32_t value = 0; std::vector<Wrap> chain; std::vector<char> present;
+                  uint32_t table_node = 0; bool raw = false, own_param = false; size_t ref_k = 0; };
     std::vector<Slot> slots;
     const size_t n0 = P.nodes.size();
     for (size_t i = 0; i < n0; i++) {
@@ -214,6 +215,9 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
       if (!ok || sl.param.size() != nd.table.size()) continue;
       { std::vector<long> u = sl.param; std::sort(u.begin(), u.end()); if (std::adjacent_find(u.begin(), u.end()) != u.end()) continue; }
       sl.present.assign(nd.table.size(), 0);
+      sl.table_node = (uint32_t)i;
+      sl.raw = true;
+      for (size_t k = 0; k < nd.table.size(); k++) sl.raw = sl.raw && P.nodes[nd.table[k]].op == RH_RIR_INPUT && (long)P.nodes[nd.table[k]].input == sl.param[k];
       slots.push_back(sl);
     }
     if (slots.empty()) continue;
@@ -272,11 +276,21 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
           if (cm.a != sl.ix || P.nodes[cm.b].cval != (double)sl.low + (double)k) return;
           sl.present[k] = 1;
           const uint32_t val = x.table[1];
-          if (!sl.have) { sl.have = true; sl.value = val; sl.chain = chain; }
+          if (!sl.have) { sl.have = true; sl.value = val; sl.chain = chain; sl.ref_k = k; }
           else {
             bool eq = F.same(sl.value, val) && sl.chain.size() == chain.size();
-            for (size_t w = 0; eq && w < chain.size(); w++)
-              eq = chain[w].inner_left == sl.chain[w].inner_left && (chain[w].fac == 0xFFFFFFFFu || sl.chain[w].fac == 0xFFFFFFFFu ? chain[w].fac == sl.chain[w].fac : F.same(chain[w].fac, sl.chain[w].fac));
+            for (size_t w = 0; eq && w < chain.size(); w++) {
+              eq = chain[w].inner_left == sl.chain[w].inner_left;
+              if (!eq) break;
+              if (chain[w].fac == 0xFFFFFFFFu || sl.chain[w].fac == 0xFFFFFFFFu) { eq = chain[w].fac == sl.chain[w].fac; continue; }
+              if (F.same(chain[w].fac, sl.chain[w].fac)) continue;
+              // the factor holds the entry's own parameter (entries exp(z_k): d/d z_k = eq(site, k, g, 0) * exp(z_k)): the template's
+              // factor with the template entry's parameter replaced by this entry's
+              long pa = sl.param[sl.ref_k], pb = sl.param[k];
+              std::map<std::pair<uint32_t, uint32_t>, char> memo;
+              eq = pa != pb && F.same_but(sl.chain[w].fac, chain[w].fac, pa, pb, memo);
+              if (eq) sl.own_param = true;
+            }
             if (!eq) sl.bad = true;
           }
         };
@@ -286,6 +300,7 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
     }
     uint32_t zero = 0xFFFFFFFFu;
     for (Slot &sl : slots) {
+      if (sl.own_param && !sl.raw) sl.bad = true;      // (the entry's parameter is put in through the table: its entries must BE the parameters)
       if (!sl.have || sl.bad) continue;
       const size_t cnt = sl.param.size();
       std::vector<char> selected(cnt, 0);        // which entries do the rows of this index column select?
@@ -301,10 +316,13 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
         Node cm; cm.op = RH_RIR_COMPARE; cm.a = sl.ix; cm.b = (uint32_t)P.nodes.size() - 1; cm.dep = (uint32_t)t + 1; P.nodes.push_back(cm);
         Node lk; lk.op = RH_RIR_LOOKUP; lk.a = (uint32_t)P.nodes.size() - 1; lk.low = -1; lk.table = {zero, sl.value, zero}; lk.dep = (uint32_t)t + 1; P.nodes.push_back(lk);
         uint32_t term = (uint32_t)P.nodes.size() - 1;
+        std::map<uint32_t, uint32_t> smemo;
         for (size_t w = sl.chain.size(); w-- > 0;) {
           Node mu; mu.op = RH_RIR_MUL; mu.dep = (uint32_t)t + 1;
-          if (sl.chain[w].fac == 0xFFFFFFFFu) { mu.op = RH_RIR_ADD; mu.a = term; mu.b = term; }
-          else if (sl.chain[w].inner_left) { mu.a = term; mu.b = sl.chain[w].fac; } else { mu.a = sl.chain[w].fac; mu.b = term; }
+          uint32_t fac = sl.chain[w].fac;
+          if (fac != 0xFFFFFFFFu && sl.own_param) fac = F.substitute(fac, sl.param[sl.ref_k], P.nodes[sl.table_node].table[k], 0, smemo);   // (raw tables only, see below)
+          if (fac == 0xFFFFFFFFu) { mu.op = RH_RIR_ADD; mu.a = term; mu.b = term; }
+          else if (sl.chain[w].inner_left) { mu.a = term; mu.b = fac; } else { mu.a = fac; mu.b = term; }
           P.nodes.push_back(mu); term = (uint32_t)P.nodes.size() - 1;
         }
         uint32_t &out = T.outputs[1 + (size_t)sl.param[k]];
@@ -320,10 +338,14 @@ void complete_scatter_terms(Program &P, const double *const *columns, const int6
       if (!sl.have || sl.bad || sl.chain.empty() || sl.nested) continue;     // (nested: the strict roll carries the factors in, rollstrict.cpp)
       if (zero == 0xFFFFFFFFu) { Node z; z.op = RH_RIR_CONST; z.cval = 0.0; P.nodes.push_back(z); zero = (uint32_t)P.nodes.size() - 1; }
       uint32_t v = sl.value;
+      std::map<uint32_t, uint32_t> vmemo;
       for (size_t w = sl.chain.size(); w-- > 0;) {
         Node mu; mu.op = RH_RIR_MUL; mu.dep = (uint32_t)t + 1;
-        if (sl.chain[w].fac == 0xFFFFFFFFu) { mu.op = RH_RIR_ADD; mu.a = v; mu.b = v; }
-        else if (sl.chain[w].inner_left) { mu.a = v; mu.b = sl.chain[w].fac; } else { mu.a = sl.chain[w].fac; mu.b = v; }
+        uint32_t fac = sl.chain[w].fac;
+        // a factor that holds the entry's own parameter reads it through the table: on the selected row Lookup(index, z) IS z_k
+        if (fac != 0xFFFFFFFFu && sl.own_param) fac = F.substitute(fac, sl.param[sl.ref_k], sl.table_node, (uint32_t)t + 1, vmemo);
+        if (fac == 0xFFFFFFFFu) { mu.op = RH_RIR_ADD; mu.a = v; mu.b = v; }
+        else if (sl.chain[w].inner_left) { mu.a = v; mu.b = fac; } else { mu.a = fac; mu.b = v; }
         P.nodes.push_back(mu); v = (uint32_t)P.nodes.size() - 1;
       }
       for (size_t k = 0; k < sl.param.size(); k++) {

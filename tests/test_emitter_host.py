@@ -474,6 +474,24 @@ def test_strict_location_scale_table_in_gather_mode(split, monkeypatch):
     assert "#define RH_HAS_GATHER 1\n" in src and "#define RH_NSHARED 3\n" in src
 
 
+def test_strict_table_of_transformed_entries_in_gather_mode(monkeypatch):
+    """entries exp(z_k) (a positive random effect): the loader moves the exp behind the lookup, and the reference's gradient of z_k is
+    eq(site, k, g, 0) * exp(z_k) -- the entry's own parameter in the factor around its select.  With RH_INDEX_MASKS=1 the factor is
+    carried into the select reading the parameter through the table (on the selected row Lookup(site, z) IS z_k): one scatter value"""
+    from rainier_amd import compute as CC
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    rng = np.random.default_rng(5)
+    K, n = 80, 900
+    pre = M.Normal(0, 1).latent
+    tab = [z.exp() for z in M.Normal(0, 0.3).latentVec(K)]
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, tab) + pre * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("exp_table", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
+    assert "#define RH_HAS_GATHER 1\n" in _check(spec, STRICT, qs, 1e-12)
+
+
 def test_strict_glmm_poisson2_streams_4_columns_instead_of_452(monkeypatch):
     """bench/stan/GLMMPoisson2.scala in the reference's text, strict build: two Lookups over index columns, neither table a run of
     trailing parameters (generic path).  With the masks recognised, the folded terms written back, the select sums folded and the 8
