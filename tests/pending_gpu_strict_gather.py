@@ -104,3 +104,28 @@ def test_strict_location_scale_table_in_gather_mode_on_the_device(split, monkeyp
         got = np.concatenate([[lp[c]], g[c]])
         assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300)
     m.close()
+
+
+def test_strict_table_of_transformed_entries_on_the_device(monkeypatch):
+    """entries exp(z_k): the factor around an entry's select holds the entry's own parameter and is carried into the select reading it
+    through the table (tests/test_emitter_host.py::test_strict_table_of_transformed_entries_in_gather_mode is the host half)"""
+    from rainier_amd import compute as CC
+    from rainier_amd import modeling as M
+    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    rng = np.random.default_rng(5)
+    K, n = 80, 900
+    pre = M.Normal(0, 1).latent
+    tab = [z.exp() for z in M.Normal(0, 0.3).latentVec(K)]
+    site = rng.integers(0, K, n).astype(float); x = rng.normal(size=n); ys = rng.poisson(3.0, n).astype(float)
+    fn = lambda s, u: M.NegativeBinomial((CC.Lookup.apply(s, tab) + pre * u).logistic, 5.0)
+    spec = M.Model.observe_vec(ys, [site, x], fn, split=False).compile("exp_table", inline=False)
+    d = O.OracleDensity(spec)
+    qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:3]
+    refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]
+    m = R.Model(spec, device=0, **STRICT)
+    assert "#define RH_HAS_GATHER 1\n" in m.hip_source
+    lp, g = m.density_batch(np.asarray(qs), engine=_capi.ENGINE_TICK)
+    for c, (ref, ab) in enumerate(refs):
+        got = np.concatenate([[lp[c]], g[c]])
+        assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300)
+    m.close()
