@@ -624,7 +624,7 @@ bool same_outputs(const Program &A, const Program &Bq, const double *const *colu
 
 bool index_masks_on() {
   const char *e = std::getenv("RH_INDEX_MASKS");
-  return e ? std::atoi(e) != 0 : false;
+  return e ? std::atoi(e) != 0 : true;
 }
 
 bool canonicalize_columns(Program &P, const double *const *columns, const int64_t *nrows, bool fast, std::vector<uint32_t> &kept,

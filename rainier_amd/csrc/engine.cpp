@@ -8,6 +8,7 @@
 #include <hip/hiprtc.h>
 
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -256,7 +257,7 @@ void assemble_source(rh_model *m) {
   for (const auto &T : m->prog.targets) if (T.n_cols) m->n_row_targets_hint++;
   if (!m->shape_guessed) {
     // First guesses that spare a heavy model the attempts it is known to lose (each one a compilation of tens of seconds): a
-    // generated function of more than 1200 statements goes to the memory-resident lowering at once, and a generic model beyond 512
+    // generated function of more than 1000 statements goes to the memory-resident lowering at once, and a generic model beyond 512
     // parameters (theta and the outputs in memory, chain vectors in HBM) starts big mode's vector loops at 4 slots in flight --
     // where the 601- and 701-parameter state-space models of the tests end up after five attempts otherwise.
     m->shape_guessed = true;
@@ -268,7 +269,7 @@ void assemble_source(rh_model *m) {
       longest = std::max(longest, c);
     }
     bool again = false;
-    if (longest > 1200 && m->eopt.chunk == 0 && !std::getenv("RH_NO_CHUNKS")) {
+    if (longest > 1000 && m->eopt.chunk == 0 && !std::getenv("RH_NO_CHUNKS")) {
       m->eopt.chunk = 48; again = true;
       if (!std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = 1;   // (such a model's chain kernel has never fitted two wavefronts per SIMD)
     }
@@ -455,7 +456,17 @@ void build_code(rh_model *m) {
     m->compile_attempts++;
     std::string unfit;   // "\n"-separated names of the unfit kernels of an attempt that was abandoned before
     const bool marker = !keep && abandoned_attempt(m->arch, m->source, extra, unfit);
+    const auto t_attempt = std::chrono::steady_clock::now();
     if (!marker) m->code = build_source(m->arch, m->source, extra);
+    if (std::getenv("RH_BUILD_LOG")) {   // diagnostics: what every attempt cost and which shape it had
+      std::string unfit_now;
+      for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel", "rh_density_fin_kernel"})
+        if (marker ? unfit.find(std::string("\n") + k + "\n") != std::string::npos : kernel_health(m->code, k) == KH_BAD) unfit_now += std::string(" ") + k;
+      std::fprintf(stderr, "[rh build] attempt %d%s: %.1f s, %zu KB source, rows_unroll %d grad_unroll %d K %d waves %d pipeline %d chunk %d bigu %d; unfit:%s\n",
+                   m->compile_attempts, marker ? " (marker)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_attempt).count(),
+                   m->source.size() / 1024, m->eopt.rows_unroll, m->eopt.grad_unroll, m->info.grad_k, m->eopt.chain_waves, m->eopt.grad_pipeline,
+                   m->eopt.chunk, m->eopt.big_unroll, unfit_now.empty() ? " none" : unfit_now.c_str());
+    }
     if (keep) return;
     auto bad = [&](const char *k) {
       if (marker) return unfit.find(std::string("\n") + k + "\n") != std::string::npos;
@@ -1080,6 +1091,10 @@ extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **ou
     m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds;
     m->goff_host = src->goff_host; m->gather_count = src->gather_count; m->col_len = src->col_len; m->col_src = src->col_src;
     m->rows_total = src->rows_total; m->data = src->data; m->data.cols = nullptr;
+    // ... and the state of the lowering itself: build_code / build_variant_code decide from it which kernels the model needs and
+    // how the shape may still be lightened (a clone whose n_row_targets_hint stayed 0 accepted a variant with an unfit tick kernel)
+    m->n_row_targets_hint = src->n_row_targets_hint; m->rows_unroll_auto = src->rows_unroll_auto; m->unroll_auto = src->unroll_auto;
+    m->shape_guessed = src->shape_guessed; m->synth_cols = src->synth_cols; m->ncols_max = src->ncols_max; m->glm_ncols = src->glm_ncols;
     m->device = dev;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));

@@ -435,7 +435,7 @@ def _raw_table_spec(family, K=100, n=1500, seed=4):
 
 @pytest.mark.parametrize("family,n", [("negbin", 1500), ("negbin-split", 1500), ("poisson", 1500), ("poisson-split", 1500), ("negbin", 150), ("negbin-split", 333)])
 def test_strict_builds_read_the_reference_s_mask_columns_as_a_scatter(family, n, monkeypatch):
-    """RH_INDEX_MASKS=1 (off by default until it has run on the device).  The reference's gradient of Lookup(site, z) with respect to
+    """RH_INDEX_MASKS (on by default since round 5).  The reference's gradient of Lookup(site, z) with respect to
     entry k is eq(site, k, g, 0) with Compare(site, k) evaluated ahead of time: one data column of -1 / 0 / +1 per entry and slot
     (compute/Gradient.scala:146-152).  Strict builds keep that expression (fast builds derive the gradient again), so the columns
     themselves are recognised in the data (csrc/columns.cpp), terms the front end folded for entries no row selects are written back,
@@ -500,10 +500,10 @@ def test_strict_glmm_poisson2_streams_4_columns_instead_of_452(monkeypatch):
     data = json.load(open(os.path.join(G, "glmm_poisson2.json")))
     spec = models.glmm_poisson2_reference(100, 40, data)
     qs = np.random.default_rng(23).normal(size=(2, 146)) * 0.3
-    monkeypatch.delenv("RH_INDEX_MASKS", raising=False)
+    monkeypatch.setenv("RH_INDEX_MASKS", "0")          # the reference's text as it stands: one mask column per entry and slot
     src = _check(spec, STRICT, qs, 1e-12)
     assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 452
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+    monkeypatch.delenv("RH_INDEX_MASKS", raising=False)   # the default since round 5
     src = _check(spec, STRICT, qs, 1e-12)
     assert max(int(x) for x in re.findall(r"NCOLS = (\d+), COL0", src)) == 4
     # ... and the 100 site and 40 year gradients as two scatter families (acc[base + index] += g) instead of one select per entry
@@ -511,13 +511,14 @@ def test_strict_glmm_poisson2_streams_4_columns_instead_of_452(monkeypatch):
 
 
 @pytest.mark.parametrize("family", ["negbin-split", "negbin", "poisson-split"])
-def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family):
+def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family, monkeypatch):
     """the usual non-centred hierarchical model in the reference's text (cfg 5's shape): z = Normal(0,1).latentVec(K) created last,
     eta = a + tau * z(site) + b x.  The reference's front end puts the z prior into the data-free target; the loader lifts it into a
     row target over the group index (lift_table_priors), after which fast builds -- whose gradient is re-derived into
     eq(index, k, g, 0) form -- run in gather mode, also through Model.observe's 8-way split (rolled back first).  Strict builds keep
-    the reference's mask-column gradient and take the generic path; so does a Poisson likelihood through the split (its 8 slots
-    cannot be rolled: DESIGN 8)"""
+    the reference's mask-column gradient: its columns are recognised in the data and read as the selects they are (columns.cpp
+    index masks, the default since round 5), so they run in gather mode too -- also the Poisson likelihood through the split, whose
+    8 slots the fast build's re-association cannot roll.  RH_INDEX_MASKS=0: strict builds on the generic path, as before"""
     from rainier_amd import compute as CC
     rng = np.random.default_rng(4)
     K, n = 100, 1500
@@ -533,11 +534,13 @@ def test_reference_text_model_with_a_raw_table_of_trailing_parameters(family):
     d = O.OracleDensity(spec)
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
     gather = {opts is FAST: "#define RH_HAS_GATHER 1\n" in _check(spec, opts, qs, 1e-9) for opts in (STRICT, FAST)}
-    assert gather == {True: family.startswith("negbin"), False: False}
+    assert gather == {True: family.startswith("negbin"), False: True}
+    monkeypatch.setenv("RH_INDEX_MASKS", "0")
+    assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_the_canonical_hierarchical_construction_runs_in_gather_mode(split):
+def test_the_canonical_hierarchical_construction_runs_in_gather_mode(split, monkeypatch):
     """alphas = Normal(mu, sd).latentVec(K) -- entries z_k * sd + mu -- created last, eta = alphas(site) + b x: the loader moves the
     affine map behind the lookup (hoist_table_maps: Lookup(site, [f(z_k)]) = f(Lookup(site, [z_k])), the same arithmetic on the
     selected entry; the Translator's VarDef chain over the entries goes), lifts the z prior, and fast builds run in gather mode"""
@@ -552,7 +555,9 @@ def test_the_canonical_hierarchical_construction_runs_in_gather_mode(split):
     d = O.OracleDensity(spec)
     qs = [q for q in rng.normal(size=(6, spec.n_params)) * 0.3 if np.all(np.isfinite(d.update(q)))][:2]
     assert "#define RH_HAS_GATHER 1\n" in _check(spec, FAST, qs, 1e-9)
-    assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)     # the reference's mask-column gradient: generic path
+    assert "#define RH_HAS_GATHER 1\n" in _check(spec, STRICT, qs, 1e-9)         # the reference's mask columns read as selects (round 5)
+    monkeypatch.setenv("RH_INDEX_MASKS", "0")
+    assert "#define RH_HAS_GATHER 1\n" not in _check(spec, STRICT, qs, 1e-9)     # ... switched off: generic path
 
 
 @pytest.mark.parametrize("split,lik", [(False, "negbin"), (True, "negbin"), (False, "normal")])

@@ -165,3 +165,5 @@ def test_cfg5_centred_parameterisation_in_gather_mode():
               ["%.3f" % r for r in rhat], np.array2string(post, precision=3), tw, dt, dt / (lf * iters) * 1e3))
     # the data were generated with b = (0.3, -0.2), alpha_g ~ N(1, 0.5): mu -> 1, s -> log 0.5
     assert abs(post[0] - 0.3) < 0.05 and abs(post[1] + 0.2) < 0.05 and abs(post[2] - 1.0) < 0.1 and abs(post[3] - np.log(0.5)) < 0.1, post
+    # ... and the chains agree with each other: R-hat of the four shared parameters over 64 chains (measured 0.995 .. 1.017)
+    assert max(rhat) < 1.05, rhat

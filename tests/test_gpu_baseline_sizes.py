@@ -136,16 +136,25 @@ def test_cfg4_sampler_config_nuts_diag_mass_recovers_beta():
     assert abs(post_mean[0]) < 0.05 and np.max(np.abs(post_mean[1:] - beta_true)) < 0.2, np.max(np.abs(post_mean[1:] - beta_true))
 
 
-def test_cfg5_hier_negbin_10k_groups_gather_kernel_vs_oracle():
-    """cfg 5 at full size: 10 000 groups x 100 observations, nVars = 10 004, through rh_grad_gather_kernel (group-major
-    segmented reduction) + big-mode combine; 1024 chains.  One parameter vector against the oracle (its interpreter
-    evaluates the reference's O(rows x G) Lookup semantics: ~70 s), all chains against a numpy closed form."""
-    G, per, chains = 10_000, 100, 1024
+@pytest.fixture(scope="module")
+def cfg5_case():
+    """cfg 5 at full size + the oracle's (logp, gradient, sum|term|) at ONE parameter vector (its interpreter evaluates the reference's
+    O(rows x G) Lookup semantics: ~70 s), shared by the fast-build and the strict-build test"""
+    G, per = 10_000, 100
     spec = models.hier_negbin(G, per)
+    distinct = np.random.default_rng(55).normal(size=(4, spec.n_params)) * 0.3
+    ref, ab = O.OracleDensity(spec).update_both(distinct[0])
+    return spec, distinct, ref, ab
+
+
+def test_cfg5_hier_negbin_10k_groups_gather_kernel_vs_oracle(cfg5_case):
+    """cfg 5 at full size: 10 000 groups x 100 observations, nVars = 10 004, through rh_grad_gather_kernel (group-major
+    segmented reduction) + big-mode combine; 1024 chains.  One parameter vector against the oracle, all chains against a numpy
+    closed form."""
+    G, per, chains = 10_000, 100, 1024
+    spec, distinct, ref0, ab0 = cfg5_case
     m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True)
     assert "rh_grad_gather_kernel" in m.hip_source and "#define RH_BIGN 1" in m.hip_source
-    rng = np.random.default_rng(55)
-    distinct = rng.normal(size=(4, spec.n_params)) * 0.3
     q, idx = _tile(distinct, chains, 5)
     lp, g = m.density_batch(q)                       # gather-mode models always take the tick path
     got = np.concatenate([lp[:, None], g], axis=1)
@@ -169,7 +178,26 @@ def test_cfg5_hier_negbin_10k_groups_gather_kernel_vs_oracle():
         assert np.max(np.abs(row[5:] - gz)) <= 1e-11 * np.max(np.exp(s) * np.bincount(gi, weights=np.abs(w), minlength=G))
         assert abs(row[3] - (-b0 + np.sum(w * x0))) <= 1e-11 * np.sum(np.abs(w * x0))
     # the oracle, one vector
-    d = O.OracleDensity(spec)
-    ref, ab = d.update_both(distinct[0])
-    err = np.abs(got[idx == 0][0] - ref) / (TOL_BIG * ab + 1e-300)
+    err = np.abs(got[idx == 0][0] - ref0) / (TOL_BIG * ab0 + 1e-300)
     assert np.all(err <= 1.0), ("cfg5", float(err.max()), int(np.argmax(err)))
+    m.close()
+
+
+def test_cfg5_hier_negbin_10k_groups_strict_build_vs_oracle(cfg5_case):
+    """cfg 5 at full size in a STRICT (JVM-faithful: fdlibm exp / log, IEEE division, no FMA, un-factored outputs) build: the same
+    gather kernel + big-mode combine, 64 chains, one parameter vector against the oracle at the same bound -- and against the fast
+    build's closed-form link only through it."""
+    spec, distinct, ref0, ab0 = cfg5_case
+    m = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+    assert "#define RH_HAS_GATHER 1\n" in m.hip_source and "#define RH_BIGN 1" in m.hip_source and "#define RH_FP_CONTRACT 0" in m.hip_source
+    eng = m.engines()
+    assert eng["tick"], eng["why"]
+    q, idx = _tile(distinct[:2], 64, 6)
+    lp, g = m.density_batch(q)
+    got = np.concatenate([lp[:, None], g], axis=1)
+    for j in range(2):
+        rows = got[idx == j]
+        assert np.all(rows == rows[0])
+    err = np.abs(got[idx == 0][0] - ref0) / (TOL_BIG * ab0 + 1e-300)
+    assert np.all(err <= 1.0), ("cfg5-strict", float(err.max()), int(np.argmax(err)))
+    m.close()

@@ -43,6 +43,26 @@ def test_rh_sample_multi_is_independent_of_the_shard_count(builder, engine, stri
         assert [s.stepSize for s in tr.stats] == [s.stepSize for s in base.stats]
 
 
+def test_a_clone_takes_the_lowering_decisions_of_its_source():
+    """rh_model_clone carries the lowering state (row-target count, which unrolls were the engine's choice): a clone that builds a
+    sampler-kernel variant by itself -- NUTS asked of the CLONE first -- lightens the shape like its source would, keeps the same
+    engines usable and returns the same chains (a clone with n_row_targets_hint = 0 accepted an unfit tick kernel)."""
+    spec = models.hier_negbin(6, 7, seed=6)              # the round-3 reproducer: its first shapes do not fit
+    seeds = [7100 + c for c in range(5)]
+    for engine in (_capi.ENGINE_AUTO, _capi.ENGINE_TICK):
+        cfg = R.make_config(6, 12, R.NUTSSampler(5), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(4, 1.5, 2, 2), engine=engine)
+        m0 = R.Model(spec, device=0, math_mode=_capi.MATH_STRICT)
+        c = m0.clone(0)
+        first = c.sample(cfg, seeds=seeds)                # the clone builds / loads the NUTS variant on its own
+        base = m0.sample(cfg, seeds=seeds)
+        e0, e1 = m0.engines(), c.engines()
+        assert {k: e0[k] for k in ("chain", "tick", "density")} == {k: e1[k] for k in ("chain", "tick", "density")}, (e0, e1)
+        assert np.array_equal(first.chains, base.chains)
+        tr = R.sample_multi([c, m0], cfg, seeds)
+        assert np.array_equal(tr.chains, base.chains)
+        c.close(); m0.close()
+
+
 def test_rh_sample_multi_rejects_bad_arguments():
     m = R.Model(models.funnel(10), device=0)
     m2 = R.Model(models.eight_schools(), device=0)

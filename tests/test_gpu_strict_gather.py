@@ -1,13 +1,11 @@
-"""NOT COLLECTED (the file name has no test_ prefix): the device half of RH_INDEX_MASKS=1, written when the round's GPU budget was
-spent.  First GPU call of the next round: `RH_INDEX_MASKS=1 python -m pytest tests/pending_gpu_strict_gather.py -q -p no:cacheprovider`
-(pytest runs a file it is given whatever its name); green -> flip the default in csrc/columns.cpp index_masks_on(), rename this file
-to test_gpu_strict_gather.py, update the strict expectations of tests/test_emitter_host.py (the three `gather == {...}` asserts) and
-run the whole GPU tier.
+"""Strict (JVM-faithful) builds of hierarchical models on the device: the reference's per-entry mask columns read as the selects
+they are (csrc/columns.cpp index masks, csrc/rollstrict.cpp; RH_INDEX_MASKS, on by default since round 5 -- DESIGN 8.10).
 
 What it checks: the reference-text cfg-5 shapes (raw table of trailing parameters, NegBin-logit and Poisson-log, with and without
 Model.observe's 8-way split, with entries no row selects) in a STRICT build run through rh_grad_gather_kernel -- density and
-gradient against the oracle on the original program at 1e-12 * sum|term| on both seams, and a short static-HMC run chain for chain
-against the oracle's sampler."""
+gradient against the oracle on the ORIGINAL program (compute/Gradient.scala:146-152's eq(index, k, g, 0) gradient, one mask column
+per entry) at 1e-12 * sum|term| on both seams, and a short static-HMC run chain for chain against the oracle's sampler;
+bench/stan/GLMMPoisson2.scala in a strict build (4 streamed columns instead of 452) the same way."""
 import numpy as np
 import pytest
 
@@ -22,8 +20,7 @@ STRICT = dict(math_mode=_capi.MATH_STRICT)
 
 
 @pytest.mark.parametrize("family,n", [("negbin", 1500), ("negbin-split", 1500), ("poisson", 1500), ("poisson-split", 1500), ("negbin", 150), ("negbin-split", 333)])
-def test_strict_reference_text_hierarchical_models_in_gather_mode(family, n, monkeypatch):
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
+def test_strict_reference_text_hierarchical_models_in_gather_mode(family, n):
     spec, qs = _raw_table_spec(family, n=n)
     d = O.OracleDensity(spec)
     refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]      # oracle first
@@ -45,9 +42,8 @@ def test_strict_reference_text_hierarchical_models_in_gather_mode(family, n, mon
     m.close()
 
 
-def test_strict_cfg5_shape_beyond_the_generic_path_s_parameter_limit(monkeypatch):
+def test_strict_cfg5_shape_beyond_the_generic_path_s_parameter_limit():
     """600 groups = 603 parameters: outside gather mode a strict build of this model takes the memory-resident generic path"""
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
     spec, qs = _raw_table_spec("negbin", K=600, n=6000, seed=11)
     d = O.OracleDensity(spec)
     refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]
@@ -60,33 +56,44 @@ def test_strict_cfg5_shape_beyond_the_generic_path_s_parameter_limit(monkeypatch
     m.close()
 
 
-def test_strict_glmm_poisson2_on_the_device(monkeypatch):
+def test_strict_glmm_poisson2_on_the_device():
     """bench/stan/GLMMPoisson2.scala, strict build: 452 -> 4 streamed columns (generic Lookup path: neither table is a trailing run)"""
     import json, os
     from rainier_amd import models
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
     data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glmm_poisson2.json")))
     spec = models.glmm_poisson2_reference(100, 40, data)
     qs = np.random.default_rng(23).normal(size=(3, 146)) * 0.3
     d = O.OracleDensity(spec)
     refs = [d.update_both(np.asarray(q, dtype=np.float64)) for q in qs]
+    from tests.test_gpu_parity import _oracle_cfg
+    cfg = R.make_config(4, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner())
+    seeds = [5200, 5201]
+    want = [O.sample_model(spec, _oracle_cfg(cfg, O.JM_DET), sd)[0] for sd in seeds]      # oracle first
+    import time
+    t0 = time.perf_counter()
     m = R.Model(spec, device=0, **STRICT)
+    create_s = time.perf_counter() - t0
     assert "NCOLS = 4, COL0 = 0" in m.hip_source
+    eng = m.engines()
+    assert eng["tick"] and eng["density"], eng["why"]          # every kernel the model launches is fit to run
+    assert eng["compile_attempts"] <= 2, eng
+    print("strict GLMMPoisson2: rh_model_create %.1f s, %d attempt(s)" % (create_s, eng["compile_attempts"]))
     for engine in (_capi.ENGINE_AUTO, _capi.ENGINE_TICK):
         lp, g = m.density_batch(np.asarray(qs), engine=engine)
         for c, (ref, ab) in enumerate(refs):
             got = np.concatenate([[lp[c]], g[c]])
             assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300), (engine, c)
+    got = m.sample(cfg, seeds=seeds).chains                      # a 4-iteration static-HMC run, chain for chain
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10)
     m.close()
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_strict_location_scale_table_in_gather_mode_on_the_device(split, monkeypatch):
+def test_strict_location_scale_table_in_gather_mode_on_the_device(split):
     """alphas = Normal(mu, sd).latentVec(100): select sums folded, factors carried inside the selects (tests/test_emitter_host.py,
     test_strict_location_scale_table_in_gather_mode, is the host half)"""
     from rainier_amd import compute as CC
     from rainier_amd import modeling as M
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
     rng = np.random.default_rng(4)
     K, n = 100, 1500
     b = M.Normal(0, 1).latent
@@ -106,12 +113,11 @@ def test_strict_location_scale_table_in_gather_mode_on_the_device(split, monkeyp
     m.close()
 
 
-def test_strict_table_of_transformed_entries_on_the_device(monkeypatch):
+def test_strict_table_of_transformed_entries_on_the_device():
     """entries exp(z_k): the factor around an entry's select holds the entry's own parameter and is carried into the select reading it
     through the table (tests/test_emitter_host.py::test_strict_table_of_transformed_entries_in_gather_mode is the host half)"""
     from rainier_amd import compute as CC
     from rainier_amd import modeling as M
-    monkeypatch.setenv("RH_INDEX_MASKS", "1")
     rng = np.random.default_rng(5)
     K, n = 80, 900
     pre = M.Normal(0, 1).latent

@@ -18,6 +18,8 @@ import pytest
 
 from rainier_amd import _capi, models
 import rainier_amd as R
+from tests import oracle_lib as O
+from tests.test_gpu_parity import _oracle_cfg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = "Java_com_stripe_rainier_hip_Native_00024_"
@@ -222,6 +224,16 @@ def test_shim_sample_is_bit_identical_to_the_ctypes_path(jvm):
                     (R.HMC(30, 10, 7), dict(fp_contract=1, factor_outputs=1))]:                        # the fast build
         h = _create(fj, spec, **kw)
         d, m, s = _sample(fj, [h], cfg, seeds, spec.n_params)
+        # the ORACLE first (oracle/sampler.c: Driver.sample restated), so that a wrong-but-consistent engine cannot pass: strict
+        # builds bit for bit -- draws, mass matrix, step size, leapfrog count --; the fast build (FMA, fast log) on its first
+        # iterations, before rounding differences have been amplified by the trajectories
+        for c in (0, len(seeds) - 1):
+            want, wmass, wst = O.sample_model(spec, _oracle_cfg(cfg, O.JM_DET), seeds[c])
+            if kw.get("math_mode") == 1:
+                assert np.array_equal(d[c], want) and np.array_equal(m[c], wmass), ("shim vs oracle", kw, c)
+                assert s[c, 0] == wst.leapfrog_steps and s[c, 5] == wst.step_size
+            else:
+                np.testing.assert_allclose(d[c][:3], want[:3], rtol=1e-5, atol=1e-7, err_msg="shim (fast build) vs oracle")
         ref = R.Model(spec, device=0, math_mode=kw.get("math_mode", 0), fp_contract=bool(kw.get("fp_contract")),
                       factor_outputs=bool(kw.get("factor_outputs"))).sample(cfg, seeds=seeds)
         assert np.array_equal(d, ref.chains) and np.array_equal(m, ref.mass)
@@ -240,6 +252,8 @@ def test_shim_sample_is_bit_identical_to_the_ctypes_path(jvm):
     sm = np.linspace(0.5, 2.0, 10)
     cfg = R.make_config(10, 10, R.HMCSampler(3), R.StaticStepSize(0.05), R.StaticMassMatrix(R.DiagonalMassMatrix(sm)))
     d, m, _ = _sample(fj, [h], cfg, seeds, 10, static_mass=sm)
+    want, _, _ = O.sample_model(spec, _oracle_cfg(cfg, O.JM_DET), seeds[0])
+    assert np.array_equal(d[0], want), "shim (static mass / static step) vs oracle"
     ref = R.Model(spec, device=0, math_mode=1).sample(cfg, seeds=seeds)
     assert np.array_equal(d, ref.chains) and np.array_equal(m, np.tile(sm, (5, 1)))
     # a shared java.util.Random stream: seeds = state ^ multiplier, pending nextNextGaussian per chain
@@ -265,9 +279,14 @@ def test_shim_density_optimize_and_requirements(fj):
     h = _create(fj, spec, fp_contract=1, factor_outputs=1, grad_chains=8)
     m = R.Model(spec, device=0, fp_contract=True, factor_outputs=True, grad_chains=8)
     q = np.random.default_rng(1).normal(size=(9, 5)) * 0.4
+    od = O.OracleDensity(spec)
+    refs = [od.update_both(qq) for qq in q]                 # the oracle: (logp, gradient) and sum|term| per output
     for engine in (_capi.ENGINE_AUTO, _capi.ENGINE_CHAIN, _capi.ENGINE_TICK):
         jl, jg = JArr(fj, np.zeros(9)), JArr(fj, np.zeros(45))
         call(fj, "densityEval", h, JArr(fj, q.ravel()), 9, engine, 0, jl, jg)
+        for c, (ref, ab) in enumerate(refs):                # the shim against the ORACLE first
+            got = np.concatenate([[jl.get()[c]], jg.get().reshape(9, 5)[c]])
+            assert np.all(np.abs(got - ref) <= 1e-12 * ab + 1e-300), ("shim densityEval vs oracle", engine, c)
         lp, g = m.density_batch(q, engine=engine)
         assert np.array_equal(jl.get(), lp) and np.array_equal(jg.get().reshape(9, 5), g)
     with pytest.raises(RuntimeError, match="IllegalArgumentException"):
@@ -275,6 +294,9 @@ def test_shim_density_optimize_and_requirements(fj):
     x, ev, st = JArr(fj, np.zeros(10)), JArr(fj, np.zeros(2, dtype=np.int32)), JArr(fj, np.zeros(2, dtype=np.int32))
     x0 = np.concatenate([np.zeros(5), np.full(5, 0.1)])
     call(fj, "optimize", h, JArr(fj, x0), 2, 0, x, ev, st)
+    ox, oev = O.optimize_model(spec, x0[:5])                # the oracle's L-BFGS (optimizer/LBFGS.java restated) from the first start
+    assert oev > 0
+    np.testing.assert_allclose(x.get().reshape(2, 5)[0], ox, rtol=1e-6, atol=1e-8, err_msg="shim optimize vs the oracle's L-BFGS")
     xr, er, sr = m.optimize(x0.reshape(2, 5))
     assert np.array_equal(x.get().reshape(2, 5), xr) and np.array_equal(ev.get(), er) and np.array_equal(st.get(), sr)
     call(fj, "modelDestroy", h)
@@ -282,6 +304,8 @@ def test_shim_density_optimize_and_requirements(fj):
     dr = np.random.default_rng(2).normal(size=(33, 10))
     out = JArr(fj, np.zeros(33 * nreq))
     call(fj, "requirementsEval", JArr(fj, np.frombuffer(rir, dtype=np.int8)), JArr(fj, copts(math_mode=1)), JArr(fj, dr.ravel()), 33, out)
+    orq = O.OracleDensity(models.ModelSpec("req", rir, [], [0] * nreq, 10), O.JM_DET)
+    assert np.array_equal(out.get().reshape(33, nreq), np.array([orq.requirements(qq, nreq) for qq in dr])), "shim requirementsEval vs oracle"
     assert np.array_equal(out.get().reshape(33, nreq), R.predict(rir, dr, nreq, math_mode=_capi.MATH_STRICT))
     with pytest.raises(RuntimeError, match="RuntimeException|IllegalArgumentException"):
         call(fj, "requirementsEval", JArr(fj, np.frombuffer(models.funnel().rir, dtype=np.int8)), JArr(fj, copts()), JArr(fj, dr.ravel()), 33, out)
