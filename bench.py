@@ -154,7 +154,7 @@ def live_traffic(a, kernel):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-ess", "--no-inlined",
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-ess", "--no-inlined", "--no-configs",
              "--no-live-traffic", "--chains-per-gpu", str(a.chains_per_gpu), "--rows", str(a.rows), "--leapfrog", str(a.leapfrog),
              "--rows-unroll", str(a.rows_unroll), "--engine", a.engine, "--grad-chains", str(a.grad_chains),
              "--grad-unroll", str(a.grad_unroll), "--grad-splits", str(a.grad_splits)]
@@ -186,29 +186,35 @@ def live_traffic(a, kernel):
         "last %d launches of %s) over `bench.py --steps 4` of the same build" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], n_used["FETCH_SIZE"], kernel))
 
 
-def side_workload(a, R, models, rank, local_rank, world, dist):
-    """The other BASELINE.json configurations, for reference timings (the judged bench line is cfg 2):
+def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, rows=None, sampler="default", strict=False, model=None, spec=None):
+    """One of the other BASELINE.json configurations (the judged bench line is cfg 2), timed like the main leg: `warmup` untimed
+    sampler warm-up iterations, then `steps` timed iterations + (N > 1) the one all-gather; returns the result dict on rank 0.
       cfg1 funnel 10-d, HMC L=5                                  (data-free, chain-per-wavefront engine)
-      cfg3 eight schools, DefaultConfig EHMC(1024) or --sampler nuts   (data-free)
-      cfg4 logistic GLM 50 covariates x --rows (default 1e7), NUTS(10) + windowed diagonal mass, 256 chains/GPU
+      cfg3 eight schools, DefaultConfig EHMC(1024) or sampler = "nuts"   (data-free)
+      cfg2d cfg 2's model under the reference's DefaultConfig (EHMC + DualAvg + windowed diagonal mass): the two-launch tick path
+      cfg4 logistic GLM 50 covariates x rows (default 1e7), NUTS(10) + windowed diagonal mass, 256 chains/GPU
            (tick engine, fp64 MFMA GLM kernel)
       cfg5 hierarchical NegBin GLM, 10 000 groups x 100 obs, NUTS(10), 1024 chains/GPU (gather mode, HBM-resident state)
     Same launch contract as cfg 2: chains sharded by global id, one final all-gather of the draws when N > 1."""
     from rainier_amd import distributed as D
-    w = a.workload
-    cpg = a.chains_per_gpu if a.chains_per_gpu != 1024 or w not in ("cfg4",) else 256
-    fast = dict(fp_contract=not a.strict, factor_outputs=not a.strict)
+    fast = dict(fp_contract=not strict, factor_outputs=not strict)
+    t_create = time.perf_counter()
     if w == "cfg1":
-        spec = models.funnel(10); cfg = R.HMC(a.warmup, a.steps, 5); cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
+        spec = models.funnel(10); cfg = R.HMC(warmup, steps, 5); cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()
     elif w == "cfg3":
-        spec = models.eight_schools(); cfg = R.make_config(a.steps, a.warmup)
+        spec = models.eight_schools(); cfg = R.make_config(steps, warmup)
+    elif w == "cfg2d":
+        spec = spec or models.linreg(n=rows or 1_000_000, k=3); cfg = R.make_config(steps, warmup)
     elif w == "cfg4":
-        spec = models.logistic(n=a.rows if a.rows != 1_000_000 else 10_000_000, k=50); cfg = R.make_config(a.steps, a.warmup, R.NUTSSampler(10))
-    else:   # --rows scales the number of groups (100 observations each); the BASELINE size is 10 000 groups
-        spec = models.hier_negbin(10_000 if a.rows == 1_000_000 else max(100, a.rows // 100), 100); cfg = R.make_config(a.steps, a.warmup, R.NUTSSampler(10))
-    if a.sampler == "nuts":
+        spec = models.logistic(n=rows or 10_000_000, k=50); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
+    else:   # rows scales the number of groups (100 observations each); the BASELINE size is 10 000 groups
+        spec = models.hier_negbin(10_000 if not rows else max(100, rows // 100), 100); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
+    if sampler == "nuts":
         cfg.sampler = lambda: R.NUTSSampler(10)
-    model = R.Model(spec, device=local_rank, **fast)
+    own = model is None
+    if own:
+        model = R.Model(spec, device=local_rank, **fast)
+    t_create = time.perf_counter() - t_create
     s = R.Sampler(model, cfg, D.shard_seeds(2000, cpg, rank))
     t0 = time.perf_counter(); s.warmup(); tw = time.perf_counter() - t0
     s.timing(reset=True)
@@ -216,7 +222,7 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     if comm is not None:
         comm.barrier(); D.device_synchronize(local_rank)
     t0 = time.perf_counter()
-    s.run(a.steps)
+    s.run(steps)
     gathered = None
     if comm is not None:
         gathered = comm.rccl.allgather_draws(s, to_host=(rank == 0))     # RCCL all-gather over xGMI (rank 0: + copy to the host)
@@ -227,33 +233,40 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     if comm is not None:
         dt = comm.rccl.allreduce_max(dt)
         counts = comm.sum(counts)
-    if rank != 0:
-        return
-    steps, wsteps = counts
-    draws = gathered if comm is not None else s.draws()
-    nshow = min(spec.n_params, 16)
-    ess = min(e for _, e in R.diagnostics(draws[:, :, :nshow])) if a.steps >= 4 and draws.shape[0] >= 2 else None
     tim = s.timing()
-    out = {"metric": "leapfrog steps/sec (all chains)", "value": steps / dt, "unit": "leapfrog steps/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+    draws = None
+    if rank == 0:
+        draws = gathered if comm is not None else s.draws()
+    s.close()
+    if own:
+        model.close()
+    if rank != 0:
+        return None
+    nsteps, wsteps = counts
+    nshow = min(spec.n_params, 16)
+    ess = min(e for _, e in R.diagnostics(draws[:, :, :nshow])) if steps >= 4 and draws.shape[0] >= 2 else None
+    out = {"metric": "leapfrog steps/sec (all chains)", "value": nsteps / dt, "unit": "leapfrog steps/s",
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w + ": " + spec.name, "chains": cpg * world, "sampler": type(cfg.sampler()).__name__,
-                      "engine": tim["dominant_kernel"]},
+                      "mass": type(cfg.massMatrixTuner()).__name__, "engine": tim["dominant_kernel"], "strict": bool(strict)},
            "warmup_leapfrog_steps_per_s": wsteps / tw, "ess_per_s": ess / dt if ess else None,
-           "mean_leapfrog_per_iteration": steps / (a.steps * cpg * world),
-           "row_chain_evals_per_s": steps * spec.rows_streamed / dt if spec.rows_streamed else None}
+           "leapfrog_steps_timed": nsteps, "seconds_timed": dt, "seconds_warmup": tw, "seconds_model_create": t_create,
+           "mean_leapfrog_per_iteration": nsteps / (steps * cpg * world),
+           "row_chain_evals_per_s": nsteps * spec.rows_streamed / dt if spec.rows_streamed else None}
     if spec.rows_streamed and tim["kernel_ms"] > 0:
         k_s = tim["kernel_ms"] / 1e3
         ab = tim["row_chain_evals"] * spec.bytes_per_row
         hbm = {"achieved": ab / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / k_s / 1e9 / HBM_PEAK_GBS}
         fpr = spec.meta.get("flops_per_row")
-        if fpr:   # cfg 4: 4K + 10 flop per row-chain eval; the data set is streamed once per launch for all
-            # chains of a workgroup column, so the fp64 pipe binds, not HBM; the HBM-equivalent figure is kept beside it
+        if fpr:   # cfg 2 16, cfg 4 4K + 10 = 210, cfg 5 30 flop per row-chain eval.  The data set is read once per launch for
+            # all chains of a workgroup column (cfg 4) or served from cache (cfg 2, cfg 5), so the fp64 pipe binds, not HBM (DESIGN 3.3,
+            # 3.5); the HBM-equivalent figure is kept beside it
             fl = tim["row_chain_evals"] * fpr
             out["roofline"] = {"bound": "fp64_mfma" if "glm" in tim["dominant_kernel"] else "fp64_valu", "kernel": tim["dominant_kernel"],
                                "achieved": fl / k_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / k_s / 1e12 / FP64_PEAK_TFLOPS,
                                "traffic": None, "launches": tim["launches"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
-                               "hbm_equivalent": hbm}
+                               "all_kernels_ms": tim["total_ms"], "flops_per_row_chain_eval": fpr, "hbm_equivalent": hbm}
         else:
             out["roofline"] = dict(hbm, bound="hbm", kernel=tim["dominant_kernel"], traffic=None, launches=tim["launches"],
                                    avg_launch_ms=tim["kernel_ms"] / max(1, tim["launches"]),
@@ -262,7 +275,47 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
     else:
         out["roofline"] = None
         out["note"] = "data-free model: latency-bound, no HBM/MFMA roofline applies"
-    print(json.dumps(out))
+    return out
+
+
+def side_workload(a, R, models, rank, local_rank, world, dist):
+    """`--workload cfgN`: one of the other BASELINE.json configurations as the whole run (ONE JSON line on rank 0)."""
+    w = a.workload
+    cpg = a.chains_per_gpu if a.chains_per_gpu != 1024 or w not in ("cfg4",) else 256
+    out = side_run(w, R, models, rank, local_rank, world, dist, a.steps, a.warmup, cpg, rows=None if a.rows == 1_000_000 else a.rows,
+                   sampler=a.sampler, strict=a.strict)
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def all_configs(R, models, local_rank, model_cfg2, spec_cfg2, budget_s=900.0):
+    """The `configs` block of the default (N = 1) line: every BASELINE.json configuration driver-timed in this run, in-process, each
+    with steps/s, its dominant kernel, avg_launch_ms and roofline.frac under SURVEY 8(d)'s flop counts.  Sizes are
+    the BASELINE ones; iteration counts are kept small where one iteration is seconds (cfg 4 / cfg 5 under NUTS: trees start deep)."""
+    plan = [  # (key, workload, steps, warmup, chains, sampler)
+        ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default"),
+        ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default"),
+        ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts"),
+        ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 16, 64, 1024, "default"),
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 2, 6, 256, "default"),
+        ("cfg5_hier_negbin_10000x100_nuts10_1024", "cfg5", 1, 2, 1024, "default"),
+    ]
+    out, t_all = {}, time.perf_counter()
+    for key, w, steps, warm, cpg, smp in plan:
+        if time.perf_counter() - t_all > budget_s:
+            out[key] = {"skipped": "the configs block's time budget (%.0f s) was spent" % budget_s}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = side_run(w, R, models, 0, local_rank, 1, None, steps, warm, cpg, sampler=smp,
+                         model=model_cfg2 if w == "cfg2d" else None, spec=spec_cfg2 if w == "cfg2d" else None)
+            keep = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "ess_per_s", "leapfrog_steps_timed", "seconds_timed",
+                                      "seconds_warmup", "seconds_model_create", "mean_leapfrog_per_iteration", "row_chain_evals_per_s", "roofline")}
+            keep["seconds_total"] = time.perf_counter() - t0
+            out[key] = keep
+        except Exception as e:      # a side configuration must never take the judged line down with it
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return out
 
 
 def main():
@@ -277,6 +330,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
     ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations, timed in-process at N = 1)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs); the committed, "
                          "sha-guarded profile is quoted instead.  Always set when this command is itself being profiled")
@@ -466,6 +520,8 @@ def main():
         else:
             out["roofline"]["traffic_source"] = "none: profiles/%s was taken on different kernel source or workload (sha16 %s vs %s)" % (
                 TRAFFIC_PROFILE, pj.get("generated_source_sha16"), src_sha)
+    if not a.no_configs and world == 1 and dist is None:   # (a plain `python bench.py` run; not under torch.distributed.run)
+        out["configs"] = all_configs(R, models, local_rank, model, spec)
     if not a.no_inlined and world == 1:
         out["gpu_inlined"] = gpu_inlined(R, models, local_rank, L)
     if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only

@@ -1965,6 +1965,187 @@ RH_DEV void rh_gather_rows(const double (&th)[RH_GRAD_K][RH_NTH], const INV &inv
     for (int kk = 0; kk < RH_GRAD_K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
   }
 }
+// K per-lane values -> K wave sums with 2(K-1) + (6 - log2 K) exchanges instead of 6K: at the first log2(K) levels of the butterfly a
+// lane keeps only half of its values and hands the other half to its partner (who keeps exactly those), afterwards one value per
+// lane goes through the remaining levels.  Every addition is the butterfly's own `own + partner` at that level, in that order, so the
+// sum of value kk is bit-identical to rh_wave_sum's -- it just ends up in the lanes whose top log2(K) lane bits spell kk (for K = 4:
+// lanes 0-15 hold sum 0, 16-31 sum 1, ...), not in all of them.  Returns this lane's sum; `mine` = which value it is.
+RH_DEV double rh_split_level(const double lo, const double hi, const bool up, const int off) {   // the upper lanes keep `hi`, the lower ones `lo`
+  const double keep = up ? hi : lo, send = up ? lo : hi;
+  return keep + __shfl_xor(send, off, 64);
+}
+template <int K>
+RH_DEV double rh_wave_sum_split(const double (&v)[K], const int lane, int &mine) {
+  static_assert(K == 1 || K == 2 || K == 4 || K == 8, "K is a power of two");
+  double x;
+  int off = 32;
+  if constexpr (K == 8) {
+    const bool u5 = (lane & 32) != 0, u4 = (lane & 16) != 0, u3 = (lane & 8) != 0;
+    const double a0 = rh_split_level(v[0], v[4], u5, 32), a1 = rh_split_level(v[1], v[5], u5, 32);
+    const double a2 = rh_split_level(v[2], v[6], u5, 32), a3 = rh_split_level(v[3], v[7], u5, 32);
+    const double b0 = rh_split_level(a0, a2, u4, 16), b1 = rh_split_level(a1, a3, u4, 16);
+    x = rh_split_level(b0, b1, u3, 8);
+    mine = (u5 ? 4 : 0) + (u4 ? 2 : 0) + (u3 ? 1 : 0); off = 4;
+  } else if constexpr (K == 4) {
+    const bool u5 = (lane & 32) != 0, u4 = (lane & 16) != 0;
+    const double a0 = rh_split_level(v[0], v[2], u5, 32), a1 = rh_split_level(v[1], v[3], u5, 32);
+    x = rh_split_level(a0, a1, u4, 16);
+    mine = (u5 ? 2 : 0) + (u4 ? 1 : 0); off = 8;
+  } else if constexpr (K == 2) {
+    const bool u5 = (lane & 32) != 0;
+    x = rh_split_level(v[0], v[1], u5, 32);
+    mine = u5 ? 1 : 0; off = 16;
+  } else { x = v[0]; mine = 0; }
+#pragma unroll
+  for (; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+#ifndef RH_GATHER_V2
+#define RH_GATHER_V2 1
+#endif
+#if RH_GATHER_V2 && !(RH_GRAD_K == 1 || RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8)
+#undef RH_GATHER_V2
+#define RH_GATHER_V2 0   /* (a caller-chosen odd K keeps round 4's walk) */
+#endif
+#if RH_GATHER_V2
+// Round 5: the group-major walk of a gather-mode target whose non-empty groups all have >= 64 rows (cfg 5), rebuilt around what the
+// machine code and the counters of round 4's loop showed (profiles/r5_cfg5): per tile it made TWO dependent trips to memory with
+// nothing in flight (index column -> wait -> per-lane table reads + the other columns -> wait), through flat (generic address space)
+// loads that also tick the LDS counter; it reduced K scatter sums with 6K cross-lane exchanges per group; ran every tile's row
+// code inside an exec-masked region; and ~1 in 8 of its vector instructions was a v_readlane re-loading a wave-uniform operand --
+// the K parameter vectors arrive as 8-register scalar tuples and the allocator spills and reloads whole tuples.  Here:
+//   * the group structure is walked on the SCALAR unit from the group offsets (rows are sorted by group: a lane's row is in the
+//     open group A iff row < end(A); A is complete iff end(A) <= end of the tile), so the index column is not read at all;
+//   * the wave-uniform operands of the row code -- the K chains' shared parameters and invariants, and the table entries of A and
+//     of the next non-empty group B (scalar loads issued a whole group ahead; constant address space: q is not written while this
+//     kernel runs) -- live in LDS: a use is a broadcast ds_read on the LDS pipe instead of a scalar register (or its reload) on the
+//     vector pipe, and a lane picks its table entry by ADDRESS (A's slot or B's), not by a select;
+//   * the columns are loaded through the global address space in a two-tile rolling pipeline (a tile's registers are reloaded for
+//     the tile after next as soon as it has been consumed), full tiles run with all lanes active, only the split's last, ragged
+//     tile runs its row code exec-masked (the join block csrc/isacheck.cpp inspects);
+//   * a completed group's K sums are reduced by rh_wave_sum_split (same bits as the butterfly, 7 exchanges instead of 24 at K = 4).
+// Same per-row arithmetic, same order of every sum: results are bit-identical to the old walk's.
+template <int T> struct rh_ninv_max { static constexpr int v = rh_target<T>::NINV > rh_ninv_max<T + 1>::v ? rh_target<T>::NINV : rh_ninv_max<T + 1>::v; };
+template <> struct rh_ninv_max<RH_NTARGETS> { static constexpr int v = 1; };
+#define RH_GU_TH 0                                            /* [K][RH_NTH]   shared parameters of the K chains   */
+#define RH_GU_INV (RH_GRAD_K * RH_NTH)                        /* [K][NINV max] invariants of the target being walked */
+#define RH_GU_Z (RH_GU_INV + RH_GRAD_K * rh_ninv_max<0>::v)   /* [2][K]        table entries of group A, of group B  */
+#define RH_GU_SIZE (RH_GU_Z + 2 * RH_GRAD_K)
+// (one wavefront per workgroup: no barriers; every lane stores the same value to the same address and reads back through an offset
+//  the compiler cannot see through -- rh_gu_oz() -- so that nothing is forwarded from the stores or hoisted back into registers)
+RH_DEV int rh_gu_oz() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
+template <int T, class TH, class INV, int NC, int NA>
+RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const double *const (&cp)[NC], double (&acc)[RH_GRAD_K][NA],
+                             const rh_gather_data &gd, const double *__restrict__ q, const int lane, const int g0, const int g1,
+                             const int r0, const int r1, const int chain0, const int chains, int &err) {
+  typedef rh_target<T> TG;
+  constexpr int K = RH_GRAD_K, NI = TG::NINV > 0 ? TG::NINV : 1;
+  typedef const double __attribute__((address_space(1))) *gcol_t;
+  typedef const int __attribute__((address_space(4))) *cint_t;
+  typedef const double __attribute__((address_space(4))) *cdbl_t;
+  if (r0 >= r1) return;
+  gcol_t gp[NC];
+#pragma unroll
+  for (int j = 0; j < NC; j++) gp[j] = (gcol_t)cp[j];
+  const cint_t go = (cint_t)gd.goff[TG::ROWT];
+  const cdbl_t qc = (cdbl_t)q;
+  size_t qoff[K];
+#pragma unroll
+  for (int kk = 0; kk < K; kk++) {
+    qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+#pragma unroll
+    for (int i = 0; i < RH_NTH; i++) gu[RH_GU_TH + kk * RH_NTH + i] = th[kk][i];
+#pragma unroll
+    for (int i = 0; i < (TG::NINV > 0 ? TG::NINV : 0); i++) gu[RH_GU_INV + kk * NI + i] = inv[kk][i];
+  }
+  // A = the open group, B = the next non-empty group of this split (g1 = none); all wave-uniform
+  int gA = g0, gB = g1, endA = r1;
+  double accA[K], accB[K];
+#pragma unroll
+  for (int kk = 0; kk < K; kk++) { accA[kk] = 0.0; accB[kk] = 0.0; gu[RH_GU_Z + kk] = 0.0; gu[RH_GU_Z + K + kk] = 0.0; }
+  if constexpr (TG::HAS_GATHER) {
+    while (gA < g1 - 1 && go[gA + 1] == go[gA]) gA++;
+    endA = go[gA + 1];
+    gB = gA + 1;
+    while (gB < g1 && go[gB + 1] == go[gB]) gB++;
+#pragma unroll
+    for (int kk = 0; kk < K; kk++) {
+      const double za = qc[qoff[kk] + gA];
+      gu[RH_GU_Z + kk] = za;
+      gu[RH_GU_Z + K + kk] = gB < g1 ? qc[qoff[kk] + gB] : za;
+    }
+  }
+  const int rlast = r1 - 1;
+  auto load_tile = [&](double (&c)[NC], const int tb) {   // rows tb + lane, clamped into the split (a tile past the end re-reads its last row)
+    const int r = tb + lane;
+    const int rr = r < rlast ? r : rlast;
+#pragma unroll
+    for (int j = 0; j < NC; j++) c[j] = gp[j][rr];
+  };
+  auto run_tile = [&](const double (&c)[NC], const bool inA, const bool ragged, const bool live) {   // one chain after the other: gz and sv are transient
+    const double *u = gu + rh_gu_oz();
+    const double *uz = u + RH_GU_Z + (inA ? 0 : K);
+#pragma unroll
+    for (int kk = 0; kk < K; kk++) {
+      const double (&thk)[RH_NTH] = *(const double (*)[RH_NTH])(u + RH_GU_TH + kk * RH_NTH);
+      const double *invk = u + RH_GU_INV + kk * NI;
+      const double gz = uz[kk];
+      double sv = 0.0;
+      if (!ragged) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+      else if (live) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+      if constexpr (TG::HAS_GATHER) { accA[kk] += inA ? sv : 0.0; accB[kk] += inA ? 0.0 : sv; }
+    }
+  };
+  auto close_tile = [&](const int tend) {   // group A complete? (wave-uniform)
+    if constexpr (TG::HAS_GATHER) {
+      if (endA <= tend) {
+        int mine;
+        const double sum = rh_wave_sum_split(accA, lane, mine);
+        if ((lane & (64 / K - 1)) == 0 && chain0 + mine < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + mine) * TG::G_COUNT + gA] = sum;
+        gA = gB;
+        endA = gA < g1 ? go[gA + 1] : 0x7fffffff;
+        if (gB < g1) gB++;
+        while (gB < g1 && go[gB + 1] == go[gB]) gB++;
+        const double *u = gu + rh_gu_oz();
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+          accA[kk] = accB[kk]; accB[kk] = 0.0;
+          const double zb = u[RH_GU_Z + K + kk];
+          gu[RH_GU_Z + kk] = zb;                                           // B becomes A ...
+          gu[RH_GU_Z + K + kk] = gB < g1 ? qc[qoff[kk] + gB] : zb;          // ... and the group after it B
+        }
+      }
+    }
+  };
+  double c[2][NC];
+  load_tile(c[0], r0);
+  load_tile(c[1], r0 + 64);
+  int tb = r0;
+  for (;;) {
+    bool done = false;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (tb + 64 > r1) { done = true; break; }   // wave-uniform: what is left (if anything) is the ragged tile
+      run_tile(c[u], tb + lane < endA, false, true);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(c[u], tb + 128);
+      __builtin_amdgcn_sched_barrier(0);
+      close_tile(tb + 64);
+      tb += 64;
+    }
+    if (done) break;
+  }
+  if (tb < r1) {   // the ragged last tile of the split (its rows are in the slot whose turn it is): the row code runs exec-masked --
+    // the one divergent region around generated code in this kernel, the join block csrc/isacheck.cpp inspects
+    const int u = ((tb - r0) >> 6) & 1;
+    if (u == 0) run_tile(c[0], tb + lane < endA, true, tb + lane < r1);
+    else run_tile(c[1], tb + lane < endA, true, tb + lane < r1);
+    close_tile(r1);
+  }
+}
+#endif  // RH_GATHER_V2
+
 template <int T>
 RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
                               const double *__restrict__ q, const int lane, const int split, const int nsplit,
@@ -1997,6 +2178,12 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
       size_t qoff[K];
 #pragma unroll
       for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+#if RH_GATHER_V2
+      if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
+        __shared__ double rh_gu[RH_GU_SIZE];
+        rh_gather_walk_a<T>(rh_gu, th, inv, cp, acc, gd, q, lane, g0, g1, r0, r1, chain0, chains, err);
+      } else
+#endif
       if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
         // Every non-empty group has at least 64 rows (cfg 5: 100): a tile touches at most two groups, A (the one that is open) and
         // the one after it.  Each lane keeps a running scatter sum for either; when the tile's last row is no longer in A, A is
@@ -2103,7 +2290,10 @@ RH_UNROLL_ACC
 }
 #pragma clang fp contract(off)
 
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef RH_GATHER_WAVES
+#define RH_GATHER_WAVES 1
+#endif
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GATHER_WAVES)))
 rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
                       const int *__restrict__ active, double *__restrict__ partial, int *__restrict__ err_out,
                       int *__restrict__ n_running, const int chains, const int nsplit) {

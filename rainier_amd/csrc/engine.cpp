@@ -172,6 +172,7 @@ struct rh_model {
   bool shape_guessed = false;    // assemble_source has made its first guesses from the size of the generated code
   bool rows_unroll_auto = true;  // the chain-per-wavefront kernels' row unroll is the engine's choice (rh_compile_opts.rows_unroll == 0)
   bool unroll_auto = false;  // the row-loop unroll was the engine's choice (not the caller's): it may be reduced for a heavy row function
+  int gather_waves = 3;  // wavefronts per SIMD rh_grad_gather_kernel is compiled for (amdgpu_waves_per_eu; 1 = the allocator's choice)
   int glm_w = 4;  // wavefronts (16 chains each) per workgroup of rh_grad_glm_kernel: 4 measured best on cfg 4 (profiles/r2_c_cfg4)
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   // gather mode: per row target (ROWT order) the host copy of the group offsets (rows sorted by table index)
@@ -334,6 +335,11 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
+  // rh_grad_gather_kernel asks for three wavefronts per SIMD (168 registers: cfg 5's K = 4 walk with its two-tile pipeline fits without
+  // a spill; left alone the allocator takes 169 -- two wavefronts); a model that does not fit gets the unconstrained build (build_code)
+  if (const char *e = std::getenv("RH_GATHER_WAVES")) m->gather_waves = std::max(1, std::atoi(e));
+  defines += "#define RH_GATHER_WAVES " + std::to_string(m->gather_waves) + "\n";
+  if (const char *e = std::getenv("RH_GATHER_V2")) defines += "#define RH_GATHER_V2 " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   // row code that calls the closed-form logit link reads its table from LDS (rh_prelude.hip.h: RH_LK_LDS)
   { bool lds = targets.find("rh_logit_link(") != std::string::npos;
@@ -462,10 +468,10 @@ void build_code(rh_model *m) {
       std::string unfit_now;
       for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel", "rh_density_fin_kernel"})
         if (marker ? unfit.find(std::string("\n") + k + "\n") != std::string::npos : kernel_health(m->code, k) == KH_BAD) unfit_now += std::string(" ") + k;
-      std::fprintf(stderr, "[rh build] attempt %d%s: %.1f s, %zu KB source, rows_unroll %d grad_unroll %d K %d waves %d pipeline %d chunk %d bigu %d; unfit:%s\n",
+      std::fprintf(stderr, "[rh build] attempt %d%s: %.1f s, %zu KB source, rows_unroll %d grad_unroll %d K %d waves %d pipeline %d chunk %d bigu %d gwaves %d; unfit:%s\n",
                    m->compile_attempts, marker ? " (marker)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_attempt).count(),
                    m->source.size() / 1024, m->eopt.rows_unroll, m->eopt.grad_unroll, m->info.grad_k, m->eopt.chain_waves, m->eopt.grad_pipeline,
-                   m->eopt.chunk, m->eopt.big_unroll, unfit_now.empty() ? " none" : unfit_now.c_str());
+                   m->eopt.chunk, m->eopt.big_unroll, m->gather_waves, unfit_now.empty() ? " none" : unfit_now.c_str());
     }
     if (keep) return;
     auto bad = [&](const char *k) {
@@ -504,6 +510,7 @@ void build_code(rh_model *m) {
       m->eopt.big_unroll /= 2; again(); continue;
     }
     if (m->info.gather_mode) {   // K chains per wavefront x ~14 wave-uniform doubles each: fewer chains is the only lever
+      if (bad("rh_grad_gather_kernel") && m->gather_waves > 1 && !std::getenv("RH_GATHER_WAVES")) { m->gather_waves = 1; again(); continue; }
       if (bad("rh_grad_gather_kernel") && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; again(); continue; }
       if (!usable() && heavier()) { again(); continue; }
       if (marker) m->code = build_source(m->arch, m->source, extra);   // (abandoned under other settings: it is the last shape now)
@@ -1088,7 +1095,7 @@ extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **ou
     if (dev >= ndev) throw Fail{RH_E_INVALID, "device ordinal out of range"};
     m->prog = src->prog; m->eopt = src->eopt; m->info = src->info; m->want_nuts = src->want_nuts;
     m->source = src->source; m->nacc_max = src->nacc_max; m->grad_k = src->grad_k; m->has_glm = src->has_glm;
-    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds;
+    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds; m->gather_waves = src->gather_waves;
     m->goff_host = src->goff_host; m->gather_count = src->gather_count; m->col_len = src->col_len; m->col_src = src->col_src;
     m->rows_total = src->rows_total; m->data = src->data; m->data.cols = nullptr;
     // ... and the state of the lowering itself: build_code / build_variant_code decide from it which kernels the model needs and

@@ -24,13 +24,17 @@ for c in range(2):
     gz = -z + np.exp(s) * np.bincount(gi, weights=w, minlength=G)
     print("logp rel err %.2e" % abs((lp[c] - ref) / ref), "grad_z max abs err %.2e" % np.max(np.abs(g[c, 4:] - gz)),
           "grad_b0 err %.2e" % abs(g[c, 2] - (-b0 + np.sum(w * x0))), flush=True)
-cfg = R.make_config(4, 0, R.HMCSampler(8), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner())
-s = R.Sampler(m, cfg, list(range(chains)))
-s.warmup(); s.timing(reset=True)
-t = time.time(); s.run(4); dt = time.time() - t
-tim = s.timing()
-print(json.dumps({"G": G, "per": per, "chains": chains, "s_per_tick": dt / 32, "row_chain_evals_per_s": G * per * chains * 32 / dt,
-                  "grad_kernel_ms": tim["kernel_ms"] / max(1, tim["launches"]), "all_ms": tim["total_ms"] / 32, "kernel": tim["dominant_kernel"]}))
+# RH_PROBE_SPLITS="8,16,24": row splits per chain group to time (0 = the engine's default)
+for splits in [int(x) for x in os.environ.get("RH_PROBE_SPLITS", "0").split(",")]:
+    cfg = R.make_config(4, 0, R.HMCSampler(8), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), gradSplits=splits)
+    s = R.Sampler(m, cfg, list(range(chains)))
+    s.warmup(); s.timing(reset=True)
+    t = time.time(); s.run(4); dt = time.time() - t
+    tim = s.timing()
+    print(json.dumps({"G": G, "per": per, "chains": chains, "K": K, "splits": splits, "env": {k: v for k, v in os.environ.items() if k.startswith("RH_")},
+                      "s_per_tick": dt / 32, "row_chain_evals_per_s": G * per * chains * 32 / dt,
+                      "grad_kernel_ms": tim["kernel_ms"] / max(1, tim["launches"]), "all_ms": tim["total_ms"] / 32, "kernel": tim["dominant_kernel"]}), flush=True)
+    s.close()
 
 if nuts:
     cfg = R.make_config(nuts, nuts, R.NUTSSampler(10))
