@@ -912,13 +912,15 @@ RH_UNROLL_SLOTS
 #endif
       } else {
         for (int k = idx_max; k >= idx_min && !sub_turning; k--) {
-          RH_TMP(rk); RH_TMP(rsk);
 #if RH_BIGN
-          wv_zero(rk); wv_zero(rsk);
-#pragma unroll
-          for (int j = 0; j < RH_NUTS_MAXD; j++)
-            if (j == k) { rk = c.ckr[j]; rsk = c.ckrs[j]; }
+          // checkpoint k is read IN PLACE (round 5): rk / rsk are views on the chain's state block -- checkpoint j sits 2 j vectors
+          // behind checkpoint 0 (rh_chain_load) -- where round 4 zeroed two pool vectors and copied the checkpoint into them: four
+          // 80 KB writes and two reads per U-turn check at cfg 5's size for values that are only read
+          wvec rk, rsk;
+          rk.s.p = c.ckr[0].s.p + (size_t)k * 2 * RH_SLOTS * 64;
+          rsk.s.p = c.ckrs[0].s.p + (size_t)k * 2 * RH_SLOTS * 64;
 #else
+          RH_TMP(rk); RH_TMP(rsk);
 RH_UNROLL_SLOTS
           for (int s2 = 0; s2 < RH_SLOTS; s2++) {
             rk.s[s2] = __longlong_as_double((rh_i64)c.ck[(size_t)((k * RH_SLOTS + s2) * 2) * 64 + lane]);
@@ -2008,6 +2010,9 @@ RH_DEV double rh_wave_sum_split(const double (&v)[K], const int lane, int &mine)
 #undef RH_GATHER_V2
 #define RH_GATHER_V2 0   /* (a caller-chosen odd K keeps round 4's walk) */
 #endif
+#ifndef RH_GATHER_TAIL_SELECT
+#define RH_GATHER_TAIL_SELECT 1
+#endif
 #if RH_GATHER_V2
 // Round 5: the group-major walk of a gather-mode target whose non-empty groups all have >= 64 rows (cfg 5), rebuilt around what the
 // machine code and the counters of round 4's loop showed (profiles/r5_cfg5): per tile it made TWO dependent trips to memory with
@@ -2022,8 +2027,8 @@ RH_DEV double rh_wave_sum_split(const double (&v)[K], const int lane, int &mine)
 //     kernel runs) -- live in LDS: a use is a broadcast ds_read on the LDS pipe instead of a scalar register (or its reload) on the
 //     vector pipe, and a lane picks its table entry by ADDRESS (A's slot or B's), not by a select;
 //   * the columns are loaded through the global address space in a two-tile rolling pipeline (a tile's registers are reloaded for
-//     the tile after next as soon as it has been consumed), full tiles run with all lanes active, only the split's last, ragged
-//     tile runs its row code exec-masked (the join block csrc/isacheck.cpp inspects);
+//     the tile after next as soon as it has been consumed), full tiles run with all lanes active, and the split's last, ragged
+//     tile runs its row code on all lanes too, behind a select (no divergent region is left around generated code in this walk);
 //   * a completed group's K sums are reduced by rh_wave_sum_split (same bits as the butterfly, 7 exchanges instead of 24 at K = 4).
 // Same per-row arithmetic, same order of every sum: results are bit-identical to the old walk's.
 template <int T> struct rh_ninv_max { static constexpr int v = rh_target<T>::NINV > rh_ninv_max<T + 1>::v ? rh_target<T>::NINV : rh_ninv_max<T + 1>::v; };
@@ -2093,7 +2098,23 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
       const double gz = uz[kk];
       double sv = 0.0;
       if (!ragged) TG::row(thk, invk, c, gz, acc[kk], sv, err);
-      else if (live) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+      else {
+#if RH_GATHER_TAIL_SELECT
+        // the ragged tile without a divergent region (as rh_rows_ragged): every lane runs the row code -- a lane past the end on the
+        // split's last row, which load_tile gave it -- into temporaries that start at -0.0 (x + -0.0 is x in every bit), and a
+        // select keeps the live lanes' `acc + t`: the very addition the full tiles perform
+        double t[NA];
+#pragma unroll
+        for (int o = 0; o < NA; o++) t[o] = -0.0;
+        double svt = -0.0;
+        TG::row(thk, invk, c, gz, t, svt, err);
+#pragma unroll
+        for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
+        sv = live ? 0.0 + svt : 0.0;
+#else
+        if (live) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+#endif
+      }
       if constexpr (TG::HAS_GATHER) { accA[kk] += inA ? sv : 0.0; accB[kk] += inA ? 0.0 : sv; }
     }
   };
@@ -2136,8 +2157,7 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
     }
     if (done) break;
   }
-  if (tb < r1) {   // the ragged last tile of the split (its rows are in the slot whose turn it is): the row code runs exec-masked --
-    // the one divergent region around generated code in this kernel, the join block csrc/isacheck.cpp inspects
+  if (tb < r1) {   // the ragged last tile of the split (its rows are in the slot whose turn it is)
     const int u = ((tb - r0) >> 6) & 1;
     if (u == 0) run_tile(c[0], tb + lane < endA, true, tb + lane < r1);
     else run_tile(c[1], tb + lane < endA, true, tb + lane < r1);
@@ -2732,6 +2752,81 @@ RH_UNROLL_SLOTS
         rh_chain_stats_dev *out = stats + chain;
         out->leapfrog_steps = c.n_leapfrog; out->warmup_leapfrog_steps = c.n_warm_leapfrog; out->gradient_evaluations = c.n_grad + 1;
         out->error = c.err; out->status = RH_ADV_NEED_GRAD;
+        active[chain] = 1;
+        atomicAdd(n_running, 1);
+      }
+      return;
+    }
+  }
+#endif
+#if RH_TICK_FAST && RH_BIGN && RH_HAS_GATHER && !RH_WITH_DENSE && RH_PACK_L == 64 && RH_NTH == RH_NSHARED && RH_NTH <= 64
+  // The same fast path for gather-mode models in big mode (cfg 5: 10 004 parameters, the chain's vectors in HBM), round 5.  The
+  // general path walks the 80 KB vectors once per helper -- scatter sums -> pend_g, Bg = pend_g, p += eps g, v = velocity(p),
+  // q += eps v, q -> qbuf: six loops, ~16 vector passes of memory traffic and ~75 000 vector instructions per chain and step
+  // (profiles/r5_cfg5: 0.56 ms per launch at 1024 chains, one wavefront per chain).  Here ONE loop does the element's whole update
+  // from five loads (the two scatter sums, p, q, the mass element), eight slots' loads in flight, and stores what the general path
+  // leaves behind (pend_g, Bg, p, q, qbuf): the same per-element arithmetic spelled the same way (multiply, round, add, round;
+  // contraction is off here), so the chains are bit-identical to the general path's.
+  if (!fresh) {
+    rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
+    const int pc = rh_uniform_i((int)(rh_i64)sc[RH_SI_pc]), need = rh_uniform_i((int)(rh_i64)sc[RH_SI_need_eval]);
+    const int ts_i = rh_uniform_i((int)(rh_i64)sc[RH_SI_ts_i]), ts_l = rh_uniform_i((int)(rh_i64)sc[RH_SI_ts_l]);
+    if (pc == RH_S_TS_MID && need != 0 && ts_i < ts_l) {
+      const bool ident = rh_uniform_i((int)(rh_i64)sc[RH_SI_mass_identity]) != 0;
+      const int sampling_started = rh_uniform_i((int)(rh_i64)sc[RH_SI_sampling_started]);
+      int cerr = rh_uniform_i((int)(rh_i64)sc[RH_SI_err]);
+      const double eps = __longlong_as_double((rh_i64)sc[RH_SI_eps]);
+      const rh_i64 n_grad = (rh_i64)sc[RH_SI_n_grad];
+      rh_i64 n_leapfrog = (rh_i64)sc[RH_SI_n_leapfrog], n_warm_leapfrog = (rh_i64)sc[RH_SI_n_warm_leapfrog];
+      double *const vBp = (double *)(st + (size_t)RH_VI_Bp * RH_SLOTS * 64), *const vBq = (double *)(st + (size_t)RH_VI_Bq * RH_SLOTS * 64);
+      double *const vBg = (double *)(st + (size_t)RH_VI_Bg * RH_SLOTS * 64), *const vPend = (double *)(st + (size_t)RH_VI_pend_g * RH_SLOTS * 64);
+      const double *const vM = (const double *)(st + (size_t)RH_VI_M * RH_SLOTS * 64);
+      // shared outputs exactly as rh_combine_chain computes them (theta = the first RH_NTH elements of q, before the update)
+      double th[RH_NTH];
+#pragma unroll
+      for (int i = 0; i < RH_NTH; i++) th[i] = vBq[i];
+      double tot[RH_NOUT];
+#pragma unroll
+      for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
+      int err = grad_err[0];
+      rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+      cerr |= err;
+      const double pend_logp = tot[0];
+      double gsh = 0.0;   // this lane's shared-parameter gradient (element `lane` of slot 0, lane < RH_NTH)
+#pragma unroll
+      for (int i = 0; i < RH_NTH && i < 64; i++) gsh = (i == lane) ? tot[1 + i] : gsh;
+      constexpr int U = 8;
+      _Pragma("unroll 1") for (int k0 = 0; k0 < RH_SLOTS; k0 += U) {
+        double g[U], pv[U], qv[U], mv[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          const int kc = k0 + j < RH_SLOTS ? k0 + j : RH_SLOTS - 1;
+          const int i = kc * 64 + lane;
+          g[j] = 0.0;
+          if (i >= RH_NSHARED && i < RH_NVARS) rh_scatter_sum<0>(gd, chain, i - RH_NSHARED, g[j]);
+          pv[j] = vBp[i]; qv[j] = vBq[i]; mv[j] = ident ? 1.0 : vM[i];
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          const int i = (k0 + j) * 64 + lane;
+          if (k0 + j < RH_SLOTS && i < RH_NVARS) {   // (the lanes past RH_NVARS of the last slot hold zeros and keep them)
+            const double gi = i < RH_NTH ? gsh : g[j];
+            const double pn = pv[j] + eps * gi;                   // wv_axpy(Bp, eps, Bg)
+            const double vel = ident ? pn : pn * mv[j];           // rh_velocity
+            const double qn = qv[j] + eps * vel;                  // wv_axpy(Bq, eps, v)
+            vPend[i] = gi; vBg[i] = gi; vBp[i] = pn; vBq[i] = qn;
+            qbuf[(size_t)chain * RH_NVARS + i] = qn;
+          }
+        }
+      }
+      if (sampling_started) n_leapfrog += 1; else n_warm_leapfrog += 1;
+      if (lane == 0) {
+        sc[RH_SI_BU] = (rh_u64)__double_as_longlong(pend_logp * -1); sc[RH_SI_pend_logp] = (rh_u64)__double_as_longlong(pend_logp);
+        sc[RH_SI_ts_i] = (rh_u64)(rh_i64)(ts_i + 1); sc[RH_SI_err] = (rh_u64)(rh_i64)cerr;
+        sc[RH_SI_n_grad] = (rh_u64)(n_grad + 1); sc[RH_SI_n_leapfrog] = (rh_u64)n_leapfrog; sc[RH_SI_n_warm_leapfrog] = (rh_u64)n_warm_leapfrog;
+        rh_chain_stats_dev *out = stats + chain;
+        out->leapfrog_steps = n_leapfrog; out->warmup_leapfrog_steps = n_warm_leapfrog; out->gradient_evaluations = n_grad + 1;
+        out->error = cerr; out->status = RH_ADV_NEED_GRAD;
         active[chain] = 1;
         atomicAdd(n_running, 1);
       }

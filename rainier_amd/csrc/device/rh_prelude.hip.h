@@ -268,12 +268,18 @@ RH_DEV void rh_lk_init() {   // at the top of a kernel, before any thread return
 #define RH_LK_TAB rh_lk_tab
 RH_DEV void rh_lk_init() {}
 #endif
+// low word of a double (the integer a 2^52-scale shift leaves in the mantissa)
+RH_DEV int rh_lo32(const double v) { long long b; __builtin_memcpy(&b, &v, 8); return (int)b; }
 RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
   const double at = __builtin_fabs(t);
   // e^{-|t|}: k = round(x / ln 2), r = x - k ln 2 in [-0.347, 0.347], degree-13 Taylor polynomial, scale by 2^k.
-  // x = max(-|t|, -800): e^{-800} is exactly 0 in fp64 (v_ldexp_f64 underflows gradually and correctly down to it)
+  // x = max(-|t|, -800): e^{-800} is exactly 0 in fp64 (v_ldexp_f64 underflows gradually and correctly down to it).
+  // Both roundings to an integer go through a shift (round 5: 3 vector instructions fewer per evaluation than rint + convert):
+  // x log2(e) + 1.5 * 2^52 has unit spacing, so the fused sum IS the nearest integer -- as a double after subtracting the shift,
+  // as a two's-complement int in its low word; u + 2^44 has spacing 2^-8, so its low word is round(256 u).
   const double x = __builtin_fmax(-at, -800.0);
-  const double kf = __builtin_rint(x * 0x1.71547652b82fep+0);
+  const double ks = __builtin_fma(x, 0x1.71547652b82fep+0, 0x1.8p+52);
+  const double kf = ks - 0x1.8p+52;
   double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, x);
   r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);
   double p = 0x1.6124613a86d09p-33;                       // 1/13!
@@ -290,8 +296,8 @@ RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
   p = __builtin_fma(p, r, 0x1p-1);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  const double u = __builtin_ldexp(p, (int)kf);            // v_ldexp_f64: correct gradual underflow
-  const int j = (int)__builtin_rint(u * 256.0);            // 0 .. 256
+  const double u = __builtin_ldexp(p, rh_lo32(ks));        // v_ldexp_f64: correct gradual underflow
+  const int j = rh_lo32(u + 0x1p+44);                      // round(256 u): 0 .. 256
   const double rc = RH_LK_TAB[2 * j], L = RH_LK_TAB[2 * j + 1];   // one 16-byte load
   const double r2 = __builtin_fma(u, rc, rc - 1.0);
   double q = __builtin_fma(r2, 0x1.5555555555555p-3, -0x1.999999999999ap-3);   // 1/6, -1/5

@@ -41,6 +41,9 @@ static const char *kPreludeSrc =
 static const char *kEngineSrc =
 #include "gen/rh_engine.inc"
     ;
+static const char *kGlm4rSrc =   // appended for models with a dense GLM target only (rh_grad_glm4r_kernel)
+#include "gen/rh_glm4r.inc"
+    ;
 
 namespace {
 thread_local std::string g_err;
@@ -164,6 +167,8 @@ struct rh_model {
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
   bool glm4 = false;       // k_grad_glm is rh_grad_glm4_kernel (v_mfma_f64_4x4x4_4b_f64, row-major LDS tile)
+  bool glm4r = false;      // k_grad_glm is rh_grad_glm4r_kernel (the four-block shape with blocks = row groups; device/rh_glm4r.hip.h)
+  int glm4r_lds = 0, glm4r_w = 4;   // its dynamic LDS and wavefronts per workgroup, read back from the module
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
@@ -339,6 +344,7 @@ void assemble_source(rh_model *m) {
   // a spill; left alone the allocator takes 169 -- two wavefronts); a model that does not fit gets the unconstrained build (build_code)
   if (const char *e = std::getenv("RH_GATHER_WAVES")) m->gather_waves = std::max(1, std::atoi(e));
   defines += "#define RH_GATHER_WAVES " + std::to_string(m->gather_waves) + "\n";
+  if (const char *e = std::getenv("RH_GATHER_TAIL_SELECT")) defines += "#define RH_GATHER_TAIL_SELECT " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GATHER_V2")) defines += "#define RH_GATHER_V2 " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   // row code that calls the closed-form logit link reads its table from LDS (rh_prelude.hip.h: RH_LK_LDS)
@@ -349,6 +355,7 @@ void assemble_source(rh_model *m) {
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
+  if (m->has_glm && !m->glm_small) m->source += std::string("\n") + kGlm4rSrc;
 }
 
 // Which compiler hiprtc dispatches to is a property of the PROCESS, not of the hiprtc version number: a process that imported
@@ -605,6 +612,23 @@ void load_module(rh_model *m) {
     if (const char *e = std::getenv("RH_GLM4")) want = std::atoi(e) != 0;
     hipFunction_t f4 = want ? fit_kernel(m->code, m->module, "rh_grad_glm4_kernel") : nullptr;
     if (f4) { m->k_grad_glm = f4; m->glm4 = true; }
+  }
+  // Round 5: the four-block shape with its blocks as ROW groups (rh_grad_glm4r_kernel): one LDS operand read feeds four MFMAs, as with
+  // the big shape, at the four-block shape's issue rate; one wavefront per SIMD (208 registers of operands and accumulators at 51
+  // predictors).  Opt-in (RH_GLM4R=1) until measured.
+  m->glm4r = false;
+  if (m->k_grad_glm && !m->glm_small && !m->glm4) {
+    bool want = false;
+    if (const char *e = std::getenv("RH_GLM4R")) want = std::atoi(e) != 0;
+    hipFunction_t fr = want ? fit_kernel(m->code, m->module, "rh_grad_glm4r_kernel") : nullptr;
+    if (fr) {
+      hipDeviceptr_t p; size_t sz;
+      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_lds_bytes"));
+      HIPCHK(hipMemcpy(&m->glm4r_lds, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_waves"));
+      HIPCHK(hipMemcpy(&m->glm4r_w, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+      if ((size_t)m->glm4r_lds + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u) { m->k_grad_glm = fr; m->glm4r = true; }
+    }
   }
   // (Round 3 also measured the contractions OFF the matrix pipe -- one chain per lane, row values scalar-loaded as SGPR operands,
   //  162 VALU instructions per 64 evaluations: 33.9 vs 17.5 ms, bound by scalar-load latency; git 28d5e00, profiles/r3_cfg4.)
@@ -935,23 +959,44 @@ bool outputs_agree(const double *lp, const double *g, const double *lp_ref, cons
   return true;
 }
 // rh_density_kernel against the tick engine's gradient path (gradient kernel + rh_density_fin_kernel) at three points, when a
-// model has both and its data are small enough for one wavefront per chain.  They are different kernels around the same row code;
-// a disagreement beyond summation-order noise means one of them is wrong on this device, and nothing says which: creation fails.
+// model has both.  They are different kernels around the same row code; a disagreement beyond summation-order noise means one of
+// them is wrong on this device, and nothing says which: creation fails.  Round 5: the comparison is repeated on PREFIXES of the data
+// -- 63, 6 and 1 rows per row target: the ragged-tile shapes, where row code runs under a partial mask or behind a select (the shape
+// of round 3's fault) -- and a data set too large for one wavefront per chain (cfg 4: 1e7 rows) is checked on a prefix of 2^20 + 37
+// rows instead of being skipped.  A prefix is taken by handing the kernels a smaller row count; the columns are not touched.
 void selfcheck_density(rh_model *m) {
-  if (!selfcheck_enabled() || !m->density_ok || !m->tick_ok || m->info.gather_mode || m->rows_total > ((int64_t)1 << 22)) return;
+  if (!selfcheck_enabled() || !m->density_ok || !m->tick_ok || m->info.gather_mode) return;
   const int nc = 3, n = (int)m->prog.n_params;
   std::vector<double> q((size_t)nc * n), la(nc), lb(nc), ga((size_t)nc * n), gb((size_t)nc * n);
   uint64_t x = 0x9E3779B97F4A7C15ULL;
   for (double &v : q) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; v = ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 1.2; }
-  int rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_CHAIN, 0, la.data(), ga.data());
-  if (rc == RH_E_LOOKUP) return;   // the data hold an index outside a Lookup table: every later call reports it
-  if (rc == RH_OK) rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_TICK, 0, lb.data(), gb.data());
-  if (rc != RH_OK) throw Fail{rc, "create-time self-check: " + m->err};
-  for (int c = 0; c < nc; c++) {
-    std::string what;
-    if (!outputs_agree(&la[c], &ga[(size_t)c * n], &lb[c], &gb[(size_t)c * n], n, what))
-      throw Fail{RH_E_DEVICE, "create-time self-check: rh_density_kernel and the tick engine's gradient path disagree at a test point (" + what +
-                               "): one of the two is wrong on this device"};
+  const rh_model_data full = m->data;
+  const int64_t rows_full = m->rows_total;
+  struct Restore { rh_model *m; rh_model_data d; int64_t r; ~Restore() { m->data = d; m->rows_total = r; } } restore{m, full, rows_full};
+  int64_t longest = 0;
+  for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) longest = std::max<int64_t>(longest, full.nrows[t]);
+  const int64_t big = ((int64_t)1 << 20) + 37;
+  for (const int64_t clip : {(int64_t)0, (int64_t)63, (int64_t)6, (int64_t)1}) {
+    const int64_t lim = clip == 0 ? (m->rows_total > ((int64_t)1 << 22) ? big : longest) : clip;
+    if (clip != 0 && lim >= longest) continue;   // (the whole data set is that small already: checked by the first pass)
+    m->data = full;
+    m->rows_total = 0;
+    for (size_t t = 0; t < m->prog.targets.size(); t++) {
+      if (!m->prog.targets[t].n_cols) continue;
+      m->data.nrows[t] = std::min<long long>(full.nrows[t], lim);
+      m->rows_total += m->data.nrows[t];
+    }
+    int rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_CHAIN, 0, la.data(), ga.data());
+    if (rc == RH_E_LOOKUP) return;   // the data hold an index outside a Lookup table: every later call reports it
+    if (rc == RH_OK) rc = rh_density_eval_ex(m, q.data(), nc, RH_ENGINE_TICK, 0, lb.data(), gb.data());
+    if (rc != RH_OK) throw Fail{rc, "create-time self-check: " + m->err};
+    for (int c = 0; c < nc; c++) {
+      std::string what;
+      if (!outputs_agree(&la[c], &ga[(size_t)c * n], &lb[c], &gb[(size_t)c * n], n, what))
+        throw Fail{RH_E_DEVICE, "create-time self-check (" + (clip ? "first " + std::to_string(lim) + " rows" : std::string("all rows")) +
+                                 "): rh_density_kernel and the tick engine's gradient path disagree at a test point (" + what +
+                                 "): one of the two is wrong on this device"};
+    }
   }
 }
 
@@ -1208,7 +1253,9 @@ std::string code_report(const std::vector<char> &code, const std::string &tag) {
     rh::kernel_meta(code, k, km);
     std::string why;
     const int h = kernel_health(code, k, &why);
-    r += tag + " kernel=" + k + " vgprs=" + std::to_string(km.vgprs) + " sgprs=" + std::to_string(km.sgprs) + " vgpr_spills=" + std::to_string(km.vgpr_spills) +
+    int unproven = 0;
+    { std::vector<std::string> f; (void)rh::check_code_object(code, k, f, &unproven); }
+    r += tag + " kernel=" + k + " unproven=" + std::to_string(unproven) + " vgprs=" + std::to_string(km.vgprs) + " sgprs=" + std::to_string(km.sgprs) + " vgpr_spills=" + std::to_string(km.vgpr_spills) +
          " sgpr_spills=" + std::to_string(km.sgpr_spills) + " scratch=" + std::to_string(km.scratch_bytes) + " fit=" + (h == KH_OK ? "1" : "0") +
          (h == KH_OK ? std::string() : " why=" + why) + "\n";
   }
@@ -1398,6 +1445,10 @@ int default_nsplit(const rh_model *m, int chains) {
   // the generic kernel with the rolling row loop hides its loads inside the wavefront: 2 wavefronts per SIMD in ONE round
   // (2048) beat 4096 in 1.33 rounds of three (profiles/r3_a_cfg2/sweep.txt)
   int nsplit = (int)std::max<int64_t>(1, ((m->eopt.grad_pipeline == 2 ? 2048 : 4096) + ngroups - 1) / ngroups);
+  // the gather kernel (three wavefronts per SIMD, its own two-tile pipeline): two rounds of 3072 wavefronts measured best on cfg 5 --
+  // 8 / 16 / 24 splits of 256 chain groups: 3.41 / 3.11 / 2.92 ms per launch (profiles/r5_cfg5)
+  if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (6144 + ngroups - 1) / ngroups);
+  if (const char *e = std::getenv("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
   if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
@@ -1420,6 +1471,10 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
   if (m->k_grad_glm && m->glm_small) {
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
     launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
+  } else if (m->k_grad_glm && m->glm4r) {
+    const int ctiles = (chains + 15) / 16;
+    const unsigned blocks = (unsigned)(((ctiles + m->glm4r_w - 1) / m->glm4r_w) * nsplit);
+    HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm4r_w, 1, 1, (unsigned)m->glm4r_lds, m->stream, args, nullptr));
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
@@ -1981,7 +2036,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4r ? "rh_grad_glm4r_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
   });
 }

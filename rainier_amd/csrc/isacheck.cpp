@@ -326,7 +326,8 @@ int kernel_touches_scratch(const std::vector<char> &code, const std::string &nam
 }
 
 // -> findings, one line each: "<kernel>+0x<offset>: ..."; returns false when the code object cannot be walked at all
-bool check_code_object(const std::vector<char> &code, const std::string &only_kernel, std::vector<std::string> &findings) {
+bool check_code_object(const std::vector<char> &code, const std::string &only_kernel, std::vector<std::string> &findings, int *unproven) {
+  if (unproven) *unproven = 0;
   std::vector<Sec> secs; std::vector<std::string> sn;
   if (!sections(code, secs, sn)) { findings.push_back("not an ELF64 code object"); return false; }
   std::vector<Func> funcs;
@@ -418,7 +419,9 @@ bool check_code_object(const std::vector<char> &code, const std::string &only_ke
         const Ins &lm = ins[j - 2];   // s_andn2_b64 exec, exec, s[a:b]
         join = lm.writes_exec && lm.reads_exec && lm.src_pair == ins[i].pair;
       }
-      if (!join) continue;
+      // (not proven: counted and reported per kernel -- rh_code_object_report's `unproven` -- so that what the rule cannot classify is
+      //  visible; such blocks are common and mostly legitimate: a then / else arm that ends in the restore, profiles/r5_parity)
+      if (!join) { if (unproven) ++*unproven; continue; }
       std::snprintf(buf, sizeof buf, "%s+0x%x: exec restore (s[%d:%d]) behind vector instructions of its own block (first at +0x%x): "
                     "they ran under the mask of the region that ended", f.name.c_str(), ins[i].off, ins[i].pair, ins[i].pair + 1, first_vec);
       findings.push_back(buf);

@@ -164,6 +164,8 @@ int kernel_touches_scratch(const std::vector<char> &code, const std::string &nam
 bool kernel_instruction_offsets(const std::vector<char> &code, const std::string &name, std::vector<uint32_t> &offs);
 // static check for vector instructions ahead of a join block's exec restore (this toolchain's register-allocator fault, see
 // isacheck.cpp); only_kernel empty = every kernel.  Returns false when the code could not be walked; findings are text lines.
-bool check_code_object(const std::vector<char> &code, const std::string &only_kernel, std::vector<std::string> &findings);
+// *unproven (optional): exec restores behind vector instructions of their own block whose block could NOT be proven to be a join
+// block (no s_cbranch_execz / execnz witness) -- not findings, but what the rule cannot see
+bool check_code_object(const std::vector<char> &code, const std::string &only_kernel, std::vector<std::string> &findings, int *unproven = nullptr);
 
 }  // namespace rh
