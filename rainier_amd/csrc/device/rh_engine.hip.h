@@ -2764,9 +2764,12 @@ RH_UNROLL_SLOTS
   // general path walks the 80 KB vectors once per helper -- scatter sums -> pend_g, Bg = pend_g, p += eps g, v = velocity(p),
   // q += eps v, q -> qbuf: six loops, ~16 vector passes of memory traffic and ~75 000 vector instructions per chain and step
   // (profiles/r5_cfg5: 0.56 ms per launch at 1024 chains, one wavefront per chain).  Here ONE loop does the element's whole update
-  // from five loads (the two scatter sums, p, q, the mass element), eight slots' loads in flight, and stores what the general path
-  // leaves behind (pend_g, Bg, p, q, qbuf): the same per-element arithmetic spelled the same way (multiply, round, add, round;
-  // contraction is off here), so the chains are bit-identical to the general path's.
+  // from five loads (the two scatter sums, p, q, the mass element), eight slots' loads in flight, and stores p, q and qbuf: the same
+  // per-element arithmetic spelled the same way (multiply, round, add, round; contraction is off here), so the chains are
+  // bit-identical to the general path's.  pend_g and Bg are NOT written: whatever tick follows -- this path again or the general
+  // one -- begins by overwriting both (rh_combine_chain -> pend_g, RH_S_TS_MID: Bg = pend_g) before anything reads them.
+  // Measured at 1024 chains (profiles/r5_cfg5): the launch is bound by its 0.6-0.8 GB of HBM traffic moved by one wavefront per
+  // chain in lock-step bursts, not by instructions -- 0.73 -> 0.65 ms per step with the five-store form.
   if (!fresh) {
     rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
     const int pc = rh_uniform_i((int)(rh_i64)sc[RH_SI_pc]), need = rh_uniform_i((int)(rh_i64)sc[RH_SI_need_eval]);
@@ -2779,7 +2782,6 @@ RH_UNROLL_SLOTS
       const rh_i64 n_grad = (rh_i64)sc[RH_SI_n_grad];
       rh_i64 n_leapfrog = (rh_i64)sc[RH_SI_n_leapfrog], n_warm_leapfrog = (rh_i64)sc[RH_SI_n_warm_leapfrog];
       double *const vBp = (double *)(st + (size_t)RH_VI_Bp * RH_SLOTS * 64), *const vBq = (double *)(st + (size_t)RH_VI_Bq * RH_SLOTS * 64);
-      double *const vBg = (double *)(st + (size_t)RH_VI_Bg * RH_SLOTS * 64), *const vPend = (double *)(st + (size_t)RH_VI_pend_g * RH_SLOTS * 64);
       const double *const vM = (const double *)(st + (size_t)RH_VI_M * RH_SLOTS * 64);
       // shared outputs exactly as rh_combine_chain computes them (theta = the first RH_NTH elements of q, before the update)
       double th[RH_NTH];
@@ -2814,7 +2816,7 @@ RH_UNROLL_SLOTS
             const double pn = pv[j] + eps * gi;                   // wv_axpy(Bp, eps, Bg)
             const double vel = ident ? pn : pn * mv[j];           // rh_velocity
             const double qn = qv[j] + eps * vel;                  // wv_axpy(Bq, eps, v)
-            vPend[i] = gi; vBg[i] = gi; vBp[i] = pn; vBq[i] = qn;
+            vBp[i] = pn; vBq[i] = qn;
             qbuf[(size_t)chain * RH_NVARS + i] = qn;
           }
         }

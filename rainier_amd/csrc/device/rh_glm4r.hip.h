@@ -34,6 +34,14 @@
 #ifndef RH_GLM4R_W
 #define RH_GLM4R_W 4
 #endif
+// chain groups (of four chains) per wavefront: 4 = sixteen chains, one wavefront per SIMD (the operands and accumulators of four
+// groups are 208 registers at 51 predictors); 2 = eight chains, half the registers, two wavefronts per SIMD -- an operand read then
+// feeds two MFMAs instead of four.  Measured on cfg 4 (profiles/r5_cfg4): with ONE wavefront per SIMD the pipe idles half the time
+// (LDS, MFMA -> VALU and barrier latencies have nothing to hide behind): 4.62 ms per launch against rh_grad_glm_kernel's 3.55.
+#ifndef RH_GLM4R_JG
+#define RH_GLM4R_JG 2
+#endif
+#define RH_GLM4R_WPS (RH_GLM4R_JG >= 4 ? 1 : 2)   /* wavefronts per SIMD the kernel is compiled for */
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
@@ -85,8 +93,9 @@ typedef rh_glm4r_map<rh_glm<RH_GLM_TARGET>> rh_g4r;
 extern "C" __device__ const int rh_glm4r_lds_bytes =
     ((2 * 64 * rh_g4r::ST * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1) * 64 * rh_g4r::ST * 8;
 extern "C" __device__ const int rh_glm4r_waves = RH_GLM4R_W;
+extern "C" __device__ const int rh_glm4r_chains_per_wave = 4 * RH_GLM4R_JG;
 
-extern "C" __global__ void __launch_bounds__(64 * RH_GLM4R_W, 1)
+extern "C" __global__ void __launch_bounds__(64 * RH_GLM4R_W, RH_GLM4R_WPS)
 rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
                      double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                      const int chains, const int nsplit, const int xcd_aware) {
@@ -94,7 +103,7 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
   typedef rh_glm<RH_GLM_TARGET> GL;
   typedef rh_target<RH_GLM_TARGET> TG;
   typedef rh_g4r MP;
-  constexpr int P = GL::P, W = RH_GLM4R_W, NP = MP::NP, NPP = MP::NPP, S4 = MP::S4, ST = MP::ST;
+  constexpr int P = GL::P, W = RH_GLM4R_W, NP = MP::NP, NPP = MP::NPP, S4 = MP::S4, ST = MP::ST, JG = RH_GLM4R_JG;
   constexpr int MYP = (NP + W - 1) / W;   // LDS positions a wavefront stages per tile
   constexpr int NBUF = (2 * 64 * ST * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1;
   constexpr int NO = GL::NOTHER > 0 ? GL::NOTHER : 1, NU = GL::NTHU > 0 ? GL::NTHU : 1;
@@ -109,12 +118,12 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
     split = xcd + 8 * (idx % spx);
     bgroup = idx / spx;
   } else { split = b % nsplit; bgroup = b / nsplit; }
-  const int chain0 = (bgroup * W + wave) * 16;
-  // this lane's four chains: chain0 + 4 jg + le
-  int cl[4];
-  bool cv[4], mine = false;
+  const int chain0 = (bgroup * W + wave) * (4 * JG);
+  // this lane's JG chains: chain0 + 4 jg + le
+  int cl[JG];
+  bool cv[JG], mine = false;
 #pragma unroll
-  for (int jg = 0; jg < 4; jg++) {
+  for (int jg = 0; jg < JG; jg++) {
     const int c = chain0 + 4 * jg + le;
     cv[jg] = c < chains;
     cl[jg] = cv[jg] ? c : chains - 1;
@@ -123,26 +132,26 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
   const bool compute = __any(mine);
   if (!__syncthreads_or(compute ? 1 : 0)) return;   // no chain of this workgroup is waiting for a gradient
   // forward B operands: lane (k = lk, *, j = le) holds scale * theta[chain 4 jg + le][pred(lk, s)]
-  double Bf[S4][4];
+  double Bf[S4][JG];
 #pragma unroll
   for (int s = 0; s < S4; s++) {
     const int pf = S4 * lk + s;
 #pragma unroll
-    for (int jg = 0; jg < 4; jg++)
+    for (int jg = 0; jg < JG; jg++)
       Bf[s][jg] = (pf < P) ? GL::pred_scale[pf < P ? pf : 0] * q[(size_t)cl[jg] * RH_NVARS + GL::pred_param[pf < P ? pf : 0]] : 0.0;
   }
-  double thu[4][NU];
+  double thu[JG][NU];
 #pragma unroll
-  for (int jg = 0; jg < 4; jg++)
+  for (int jg = 0; jg < JG; jg++)
 #pragma unroll
     for (int k = 0; k < GL::NTHU; k++) thu[jg][k] = q[(size_t)cl[jg] * RH_NVARS + GL::thu_param[k]];
-  double G[S4][4], oth[4][NO];
+  double G[S4][JG], oth[JG][NO];
 #pragma unroll
   for (int s = 0; s < S4; s++)
 #pragma unroll
-    for (int jg = 0; jg < 4; jg++) G[s][jg] = 0.0;
+    for (int jg = 0; jg < JG; jg++) G[s][jg] = 0.0;
 #pragma unroll
-  for (int jg = 0; jg < 4; jg++)
+  for (int jg = 0; jg < JG; jg++)
 #pragma unroll
     for (int k = 0; k < NO; k++) oth[jg][k] = 0.0;
   int err = 0;
@@ -190,23 +199,25 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
     if (t + 1 < ntiles) fetch(t + 1);
     if (compute) {
       const double *tile = rh_lds + (size_t)buf * 64 * ST;
-      const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 16 <= chains);
+      const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 4 * JG <= chains);
 #pragma unroll 1
       for (int sub = 0; sub < 4; sub++) {
         const double *ts = tile + (size_t)sub * 16 * ST;
-        double Dv[4] = {0.0, 0.0, 0.0, 0.0};
+        double Dv[JG];
+#pragma unroll
+        for (int jg = 0; jg < JG; jg++) Dv[jg] = 0.0;
         // forward: one operand read per step feeds the four chain groups (four independent accumulators)
 #pragma unroll
         for (int s = 0; s < S4; s++) {
           const double a = ts[fbase + s];
 #pragma unroll
-          for (int jg = 0; jg < 4; jg++) Dv[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Bf[s][jg], Dv[jg], 0, 0, 0);
+          for (int jg = 0; jg < JG; jg++) Dv[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Bf[s][jg], Dv[jg], 0, 0, 0);
         }
         // the scalar part: this lane's row, its four chains
         const int rrow = sub * 16 + myrow;
         const bool row_ok = full || (r0 + t * 64 + rrow < r1);
 #pragma unroll
-        for (int jg = 0; jg < 4; jg++) {
+        for (int jg = 0; jg < JG; jg++) {
           double w = 0.0, o[NO];
           GL::elem(thu[jg], Dv[jg], [&](int j) { return tile[(size_t)rrow * ST + rh_glm4r_tabs<GL>::POS.v[j]]; }, w, o, err);
           const bool valid = full || (row_ok && cv[jg]);
@@ -219,7 +230,7 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
         for (int s = 0; s < S4; s++) {
           const double a = ts[bbase + s];
 #pragma unroll
-          for (int jg = 0; jg < 4; jg++) G[s][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Dv[jg], G[s][jg], 0, 0, 0);
+          for (int jg = 0; jg < JG; jg++) G[s][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Dv[jg], G[s][jg], 0, 0, 0);
         }
       }
     }
@@ -232,7 +243,7 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
 #pragma unroll
     for (int s = 0; s < S4; s++)
 #pragma unroll
-      for (int jg = 0; jg < 4; jg++) {
+      for (int jg = 0; jg < JG; jg++) {
         double v = G[s][jg];
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 8, 64);
@@ -243,7 +254,7 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
         }
       }
 #pragma unroll
-    for (int jg = 0; jg < 4; jg++)
+    for (int jg = 0; jg < JG; jg++)
 #pragma unroll
       for (int k = 0; k < GL::NOTHER; k++) {   // a chain's evaluations sit in the 16 lanes that share le: fold lb and lk
         double v = oth[jg][k];

@@ -168,7 +168,7 @@ struct rh_model {
   hipFunction_t k_grad_glm = nullptr;
   bool glm4 = false;       // k_grad_glm is rh_grad_glm4_kernel (v_mfma_f64_4x4x4_4b_f64, row-major LDS tile)
   bool glm4r = false;      // k_grad_glm is rh_grad_glm4r_kernel (the four-block shape with blocks = row groups; device/rh_glm4r.hip.h)
-  int glm4r_lds = 0, glm4r_w = 4;   // its dynamic LDS and wavefronts per workgroup, read back from the module
+  int glm4r_lds = 0, glm4r_w = 4, glm4r_cw = 16;   // its dynamic LDS, wavefronts per workgroup and chains per wavefront, read back from the module
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
@@ -196,6 +196,8 @@ struct rh_model {
   int64_t rows_total = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  std::recursive_mutex engine_mu;   // rh_sampler_create: engine choice + the create-time engine self-check, which updates the variant's
+                                    // shared kernel set (recursive: the self-check creates a sampler of its own on this thread)
   // what the code object's kernels are fit for (kernel_health): an engine whose kernels are not is never chosen, and an explicit
   // request for it fails with RH_E_UNSUPPORTED and the reason
   bool chain_ok = false, density_ok = false, tick_ok = false;
@@ -337,6 +339,8 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = std::max(1, std::atoi(e));
   defines += "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
+  if (const char *e = std::getenv("RH_GLM4R_JG")) defines += "#define RH_GLM4R_JG " + std::to_string(std::atoi(e) >= 4 ? 4 : (std::atoi(e) >= 2 ? 2 : 1)) + "\n";
+  if (const char *e = std::getenv("RH_GLM4R_W")) defines += "#define RH_GLM4R_W " + std::to_string(std::max(1, std::min(16, std::atoi(e)))) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
@@ -410,17 +414,26 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 }
 // An attempt the engine abandons (build_code lowers the model again with a lighter shape) is not kept as a code object: a small
 // marker with the kernels that were unfit takes its place, so that the next process takes the same decision without compiling.
+// (a marker records a verdict of kernel_health: it carries the version of those rules and whether they were switched off, and a marker
+//  written under other rules is ignored -- the attempt is compiled and judged again)
+const int kHealthRulesVersion = 2;   // 2: round 5 (rh_grad_gather_kernel's wavefront request; the gather walk without a divergent region)
+std::string marker_header() {
+  return "rules=" + std::to_string(kHealthRulesVersion) + " allow_unhealthy=" + (std::getenv("RH_ALLOW_UNHEALTHY") ? "1" : "0") + "\n";
+}
 void abandon_attempt(const std::string &arch, const std::string &source, const std::string &extra, const std::string &unfit) {
   if (std::getenv("RH_NO_KERNEL_CACHE")) return;
   const std::string base = cache_path(arch, source, extra);
   std::remove((base + ".hsaco").c_str());
-  write_file(base + ".unfit", std::vector<char>(unfit.begin(), unfit.end()));
+  const std::string text = marker_header() + unfit;
+  write_file(base + ".unfit", std::vector<char>(text.begin(), text.end()));
 }
 bool abandoned_attempt(const std::string &arch, const std::string &source, const std::string &extra, std::string &unfit) {
   if (std::getenv("RH_NO_KERNEL_CACHE")) return false;
   std::vector<char> b;
   if (!read_file(cache_path(arch, source, extra) + ".unfit", b)) return false;
-  unfit.assign(b.begin(), b.end());
+  const std::string text(b.begin(), b.end()), head = marker_header();
+  if (text.compare(0, head.size(), head) != 0) return false;
+  unfit = text.substr(head.size());
   return true;
 }
 const char *kNutsDefine = "#define RH_WITH_NUTS 1\n";
@@ -627,6 +640,8 @@ void load_module(rh_model *m) {
       HIPCHK(hipMemcpy(&m->glm4r_lds, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
       HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_waves"));
       HIPCHK(hipMemcpy(&m->glm4r_w, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
+      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_chains_per_wave"));
+      HIPCHK(hipMemcpy(&m->glm4r_cw, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
       if ((size_t)m->glm4r_lds + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u) { m->k_grad_glm = fr; m->glm4r = true; }
     }
   }
@@ -1445,12 +1460,18 @@ int default_nsplit(const rh_model *m, int chains) {
   // the generic kernel with the rolling row loop hides its loads inside the wavefront: 2 wavefronts per SIMD in ONE round
   // (2048) beat 4096 in 1.33 rounds of three (profiles/r3_a_cfg2/sweep.txt)
   int nsplit = (int)std::max<int64_t>(1, ((m->eopt.grad_pipeline == 2 ? 2048 : 4096) + ngroups - 1) / ngroups);
-  // the gather kernel (three wavefronts per SIMD, its own two-tile pipeline): two rounds of 3072 wavefronts measured best on cfg 5 --
+  // the gather kernel (three wavefronts per SIMD, its own two-tile pipeline): many short workgroups measured best on cfg 5 --
   // 8 / 16 / 24 splits of 256 chain groups: 3.41 / 3.11 / 2.92 ms per launch (profiles/r5_cfg5)
-  if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (6144 + ngroups - 1) / ngroups);
+  // (call B, another box: 16 / 24 / 32 / 48 splits 3.00 / 2.78 / 2.71 / 2.67 ms -- four rounds of 3072 wavefronts)
+  if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (12288 + ngroups - 1) / ngroups);
   if (const char *e = std::getenv("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
+  if (m->k_grad_glm && m->glm4r) {   // one round of workgroups at the kernel's wavefronts per SIMD (2 below sixteen chains per wavefront, else 1)
+    const int cols = ((chains + m->glm4r_cw - 1) / m->glm4r_cw + m->glm4r_w - 1) / m->glm4r_w;
+    const int wgs = 1024 * (m->glm4r_cw >= 16 ? 1 : 2) / m->glm4r_w;
+    nsplit = (int)std::max<int64_t>(1, (wgs + cols - 1) / cols);
+  }
   if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
   nsplit = ((nsplit + 7) / 8) * 8;
   const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);
@@ -1472,7 +1493,7 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
     launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
   } else if (m->k_grad_glm && m->glm4r) {
-    const int ctiles = (chains + 15) / 16;
+    const int ctiles = (chains + m->glm4r_cw - 1) / m->glm4r_cw;
     const unsigned blocks = (unsigned)(((ctiles + m->glm4r_w - 1) / m->glm4r_w) * nsplit);
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm4r_w, 1, 1, (unsigned)m->glm4r_lds, m->stream, args, nullptr));
   } else if (m->k_grad_glm) {
@@ -1700,6 +1721,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       // Engine choice.  AUTO: the tick engine for gather mode and from 65 536 rows on, the chain engine below -- and whichever of
       // the two has kernels that are fit to run (kernel_health) and agree with the density kernel on this device (self-check)
       // when the preferred one does not.  An explicit request is never rerouted: it fails with the reason.
+      std::lock_guard<std::recursive_mutex> elk(m->engine_mu);   // (two samplers may be created concurrently on one model)
       for (int round = 0; ; round++) {
         const bool want_tick = m->info.gather_mode || cfg->engine == RH_ENGINE_TICK ||
                                (cfg->engine == RH_ENGINE_AUTO && m->n_row_targets > 0 && (m->rows_total >= 65536 || !ks.k_chain));

@@ -103,7 +103,9 @@ def test_no_cached_code_object_is_an_abandoned_attempt():
     stems = {os.path.basename(f)[:-6] for f in files}
     assert not stems & {os.path.basename(m)[:-6] for m in markers}
     for m in markers:
-        names = open(m).read().split()
+        head, _, rest = open(m).read().partition("\n")
+        assert head.startswith("rules=") and "allow_unhealthy=0" in head, (m, head)   # the verdict's rules version (csrc/engine.cpp marker_header)
+        names = rest.split()
         assert names and all(n.startswith("rh_") for n in names), m
 
 
