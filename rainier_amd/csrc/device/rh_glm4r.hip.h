@@ -194,43 +194,63 @@ rh_grad_glm4r_kernel(const rh_model_data d, const double *__restrict__ q, const 
   const int myrow = 4 * lb + lk;   // the row of this lane's four evaluations
   if (ntiles > 0) { fetch(0); park(0); }
   __syncthreads();
+  // The operand reads are phased by hand (the compiler hoists all of a sub-tile's 2 S4 LDS reads to its top and waits for the lot): the
+  // forward operands of the NEXT 16 rows are requested before the backward MFMAs of the current ones, the backward operands before
+  // the scalar part -- every read has a phase of arithmetic to land behind, and the two sets share their registers' lifetime.
+  double fa[S4];
   for (long long t = 0; t < ntiles; t++) {
     const int buf = NBUF == 2 ? (int)(t & 1) : 0;
     if (t + 1 < ntiles) fetch(t + 1);
     if (compute) {
       const double *tile = rh_lds + (size_t)buf * 64 * ST;
       const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 4 * JG <= chains);
+#pragma unroll
+      for (int s = 0; s < S4; s++) fa[s] = tile[fbase + s];
 #pragma unroll 1
       for (int sub = 0; sub < 4; sub++) {
         const double *ts = tile + (size_t)sub * 16 * ST;
-        double Dv[JG];
+        // forward: one operand per step feeds the JG chain groups; even and odd steps go to separate accumulators, so that 2 JG
+        // independent MFMA chains are in flight (a dependent MFMA waits for the previous one to drain)
+        double D0[JG], D1[JG];
 #pragma unroll
-        for (int jg = 0; jg < JG; jg++) Dv[jg] = 0.0;
-        // forward: one operand read per step feeds the four chain groups (four independent accumulators)
+        for (int jg = 0; jg < JG; jg++) { D0[jg] = 0.0; D1[jg] = 0.0; }
 #pragma unroll
         for (int s = 0; s < S4; s++) {
-          const double a = ts[fbase + s];
 #pragma unroll
-          for (int jg = 0; jg < JG; jg++) Dv[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Bf[s][jg], Dv[jg], 0, 0, 0);
+          for (int jg = 0; jg < JG; jg++) {
+            if (s & 1) D1[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s], Bf[s][jg], D1[jg], 0, 0, 0);
+            else D0[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[s], Bf[s][jg], D0[jg], 0, 0, 0);
+          }
         }
-        // the scalar part: this lane's row, its four chains
+        __builtin_amdgcn_sched_barrier(0);
+        double ba[S4];
+#pragma unroll
+        for (int s = 0; s < S4; s++) ba[s] = ts[bbase + s];
+        __builtin_amdgcn_sched_barrier(0);
+        // the scalar part: this lane's row, its JG chains
         const int rrow = sub * 16 + myrow;
         const bool row_ok = full || (r0 + t * 64 + rrow < r1);
+        double Dv[JG];
 #pragma unroll
         for (int jg = 0; jg < JG; jg++) {
           double w = 0.0, o[NO];
-          GL::elem(thu[jg], Dv[jg], [&](int j) { return tile[(size_t)rrow * ST + rh_glm4r_tabs<GL>::POS.v[j]]; }, w, o, err);
+          GL::elem(thu[jg], D0[jg] + D1[jg], [&](int j) { return tile[(size_t)rrow * ST + rh_glm4r_tabs<GL>::POS.v[j]]; }, w, o, err);
           const bool valid = full || (row_ok && cv[jg]);
           Dv[jg] = valid ? w : 0.0;
 #pragma unroll
           for (int k = 0; k < GL::NOTHER; k++) oth[jg][k] += valid ? o[k] : 0.0;
         }
-        // backward: again one operand read per step for the four chain groups; S4 x 4 independent accumulators
+        __builtin_amdgcn_sched_barrier(0);
+        if (sub < 3) {
+#pragma unroll
+          for (int s = 0; s < S4; s++) fa[s] = ts[16 * ST + fbase + s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // backward: S4 x JG independent accumulators
 #pragma unroll
         for (int s = 0; s < S4; s++) {
-          const double a = ts[bbase + s];
 #pragma unroll
-          for (int jg = 0; jg < JG; jg++) G[s][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Dv[jg], G[s][jg], 0, 0, 0);
+          for (int jg = 0; jg < JG; jg++) G[s][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ba[s], Dv[jg], G[s][jg], 0, 0, 0);
         }
       }
     }

@@ -233,7 +233,7 @@ def hier_negbin(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fai
     dv, dc, dg, dx0, dx1 = hier_negbin_data(G, per_group, seed, n_fail)
     cols = [np.arange(G, dtype=np.float64), dv, dc, dg, dx0, dx1]
     return ModelSpec("hier_negbin_%dx%d" % (G, per_group), rir, cols, [0, G, G * per_group], n_params,
-                     {"kind": "hier_negbin", "groups": G})
+                     {"kind": "hier_negbin", "groups": G, "flops_per_row": 30})   # ~30 flop per row-chain eval (+ 1 exp, ~4 log)
 
 
 def hier_negbin_centred(groups: int = 10_000, per_group: int = 100, seed: int = 5, n_fail: float = 10.0) -> ModelSpec:
