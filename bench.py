@@ -300,12 +300,13 @@ def all_configs(R, models, local_rank, model_cfg2, spec_cfg2, budget_s=900.0):
         ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default"),
         ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts"),
         ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 16, 64, 1024, "default"),
-        # cfg 4 / cfg 5: the BASELINE sampler (NUTS: chains finish their trees at different launches, so late launches of an iteration
-        # serve few chains) and, for the kernel's own roofline fraction, static HMC (every launch serves every chain)
+        # cfg 4 / cfg 5: the BASELINE sampler (NUTS: chains run free across iterations, but the launches behind the last chain to finish
+        # the leg serve fewer and fewer of them -- its roofline fraction is the leg's, tail included) and, for the kernel's own
+        # fraction, static HMC (every launch serves every chain)
         ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8"),
-        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 2, 8, 256, "default"),
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 12, 8, 256, "default"),
         ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8"),
-        ("cfg5_hier_negbin_10000x100_nuts10_1024", "cfg5", 1, 6, 1024, "default"),
+        ("cfg5_hier_negbin_10000x100_nuts10_1024", "cfg5", 4, 6, 1024, "default"),
     ]
     shared = {}   # cfg 4 / cfg 5 models are created once and serve both of their legs (4 GB of columns, a 1.2 MB program)
     out, t_all = {}, time.perf_counter()

@@ -60,7 +60,13 @@ struct Lin {  // alpha * term + beta
 // but this toolchain mis-selects the flat accesses volatile private memory is left with: "Illegal instruction detected".)  The arithmetic and its order are untouched (the results are the same bits); the
 // live state of the function is one chunk's temporaries, whatever the size of the model.  Slots are reused when a value's last
 // reader has passed.
-static std::string chunk_body(const std::string &body, int chunk, const std::string &indent = "    ") {
+// `parts` (the data-free target's row(), round 5): beyond kPartChunks chunks the chunks are also grouped into PARTS, each a noinline
+// function of its own (a static member of a local struct; theta, the accumulators and the scratch array reach it by pointer).  hiprtc's
+// time grows faster than linearly in the size of a function -- a 701-parameter state-space prior is ONE function of 16 000 statements:
+// 52 s -- and the chunks already pass every value that crosses them through memory, so cutting along chunk borders changes nothing
+// but the unit the compiler's passes run on (the reference: ir/Packer.scala:10-71 splits methods at 200 nodes for the same reason).
+static const size_t kPartChunks = 10;
+static std::string chunk_body(const std::string &body, int chunk, const std::string &indent = "    ", bool parts = false) {
   std::vector<std::string> lines;
   { std::istringstream is(body); std::string ln; while (std::getline(is, ln)) lines.push_back(ln); }
   struct Group { std::vector<std::string> text; std::vector<long> defs, uses; };
@@ -112,7 +118,14 @@ static std::string chunk_body(const std::string &body, int chunk, const std::str
   std::vector<std::vector<long>> dies(nch);
   for (auto &kv : last_use) if (def_chunk.count(kv.first) && kv.second > def_chunk[kv.first]) dies[kv.second].push_back(kv.first);
   std::ostringstream os, out;
+  const bool split = parts && nch > kPartChunks;
+  size_t npart = 0;
   for (size_t c = 0; c < nch; c++) {
+    if (split && c % kPartChunks == 0) {
+      if (c == 0) os << "#ifndef RH_DEV_NOINLINE\n#define RH_DEV_NOINLINE __device__ __attribute__((noinline))\n#endif\n";
+      os << indent << "struct rh_part" << npart << " { static RH_DEV_NOINLINE void run(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, "
+            "rh_acc_t *acc, int &err, double *rh_sp) {\n" << indent << "(void)th; (void)inv; (void)c; (void)acc; (void)err; (void)rh_sp;\n";
+    }
     os << indent << "{\n";
     std::vector<long> loads, stores;
     std::map<long, char> seen;
@@ -132,6 +145,10 @@ static std::string chunk_body(const std::string &body, int chunk, const std::str
         }
     }
     os << indent << "}\n";
+    if (split && (c % kPartChunks == kPartChunks - 1 || c + 1 == nch)) {
+      os << indent << "} };\n" << indent << "rh_part" << npart << "::run(th, inv, c, acc, err, rh_sp);\n";
+      npart++;
+    }
     for (long v : dies[c]) free_slots.push_back(slot.at(v));
   }
   out << head << indent << "double rh_sp[" << std::max(1, nslots) << "];\n" << os.str();
@@ -1286,7 +1303,7 @@ struct TargetEmitter {
             if (on.op == RH_RIR_CONST && on.cval == 0.0 && !std::signbit(on.cval)) continue;  // += +0.0 is the identity
             b << "    acc[" << o << oz() << "] += " << ref(P.targets[tt].outputs[o], 1) << ";\n";
           }
-        os << (chunk > 0 ? chunk_body(b.str(), chunk) : b.str());
+        os << (chunk > 0 ? chunk_body(b.str(), chunk, "    ", true) : b.str());
       }
       os << "  }\n";
     }

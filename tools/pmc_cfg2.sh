@@ -9,7 +9,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; HEAD=${1:-unknown}; NAME=${2:-r4_cfg2}
 O=$R/gpurun_out/$NAME; mkdir -p $O
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ess --no-inlined --no-live-traffic"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ess --no-inlined --no-configs --no-live-traffic"
 $BENCH > $O/bench_noprof.json 2> $O/bench_noprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $BENCH > $O/bench_stats_run.json 2> $O/stats.err
 f=$(find $O/stats -name "bench_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
