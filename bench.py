@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # MI355X public FP64 vector peak (not in the local guide)
-TRAFFIC_PROFILE = "r3_b_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
+TRAFFIC_PROFILE = "r5_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
 
 
 def cpu_baseline(spec, L, seconds_budget=20.0):
