@@ -41,7 +41,7 @@
 #ifndef RH_GLM4R_JG
 #define RH_GLM4R_JG 2
 #endif
-#define RH_GLM4R_WPS (RH_GLM4R_JG >= 4 ? 1 : (RH_GLM4R_JG >= 2 ? 2 : 3))   /* wavefronts per SIMD the kernel is compiled for */
+#define RH_GLM4R_WPS (RH_GLM4R_JG >= 4 ? 1 : 2)   /* wavefronts per SIMD the kernel is compiled for */
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
