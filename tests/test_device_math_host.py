@@ -62,3 +62,52 @@ def test_logit_link_text_on_the_host_is_within_three_ulp(tmp_path):
     # the table in the header is the generator's output
     tab = subprocess.check_output(["python", os.path.join(ROOT, "tools", "gen_lk_table.py")]).decode()
     assert tab in pre
+
+
+def test_split_wave_reduction_has_the_butterfly_s_bits():
+    """rh_wave_sum_split (csrc/device/rh_engine.hip.h, the gather walk's per-group reduction of K scatter sums): at the first log2(K)
+    levels of the xor butterfly a lane keeps half of its values and hands the other half to its partner.  Lane-for-lane emulation in
+    numpy (fp64 adds are the hardware's; `a + b` commutes): the sum of value kk it leaves in the lanes whose top bits spell kk is the
+    very double rh_wave_sum's butterfly (masks 32, 16, ..., 1; own + partner) leaves in every lane."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    lanes = np.arange(64)
+
+    def butterfly(v):                       # v[64] -> every lane's result
+        v = v.copy()
+        off = 32
+        while off >= 1:
+            v = v + v[lanes ^ off]
+            off >>= 1
+        return v
+
+    def split_level(lo, hi, up, off):       # rh_split_level: the upper lanes keep `hi`, the lower ones `lo`
+        keep = np.where(up, hi, lo)
+        send = np.where(up, lo, hi)
+        return keep + send[lanes ^ off]
+
+    for K in (1, 2, 4, 8):
+        for trial in range(50):
+            scale = 10.0 ** rng.integers(-8, 8, size=(K, 64))
+            v = rng.standard_normal((K, 64)) * scale
+            want = np.array([butterfly(v[kk]) for kk in range(K)])
+            assert all(np.all(want[kk] == want[kk][0]) for kk in range(K))          # the butterfly leaves the same bits in every lane
+            u5, u4, u3 = (lanes & 32) != 0, (lanes & 16) != 0, (lanes & 8) != 0
+            if K == 8:
+                a = [split_level(v[i], v[i + 4], u5, 32) for i in range(4)]
+                b = [split_level(a[0], a[2], u4, 16), split_level(a[1], a[3], u4, 16)]
+                x, mine, off = split_level(b[0], b[1], u3, 8), 4 * u5 + 2 * u4 + 1 * u3, 4
+            elif K == 4:
+                a = [split_level(v[0], v[2], u5, 32), split_level(v[1], v[3], u5, 32)]
+                x, mine, off = split_level(a[0], a[1], u4, 16), 2 * u5 + 1 * u4, 8
+            elif K == 2:
+                x, mine, off = split_level(v[0], v[1], u5, 32), 1 * u5, 16
+            else:
+                x, mine, off = v[0].copy(), np.zeros(64, dtype=int), 32
+            while off >= 1:
+                x = x + x[lanes ^ off]
+                off >>= 1
+            for lane in range(64):
+                assert x[lane] == want[int(mine[lane])][0], (K, trial, lane)
+            # the lanes the kernel stores from: (lane & (64 / K - 1)) == 0, chain slot = mine
+            assert sorted(int(mine[l]) for l in range(64) if (l & (64 // K - 1)) == 0) == list(range(K))
