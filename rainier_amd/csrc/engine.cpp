@@ -16,6 +16,7 @@
 #include <atomic>
 #include <fstream>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -494,16 +495,24 @@ void build_code(rh_model *m) {
                    m->eopt.chunk, m->eopt.big_unroll, m->gather_waves, unfit_now.empty() ? " none" : unfit_now.c_str());
     }
     if (keep) return;
+    // (one verdict per kernel and attempt: kernel_health parses the ELF and walks the machine code of the kernel and of every device
+    //  function each time it is asked, and the ladder below asks a dozen times)
+    std::map<std::string, int> verdicts;
+    auto health = [&](const char *k) {
+      auto it = verdicts.find(k);
+      if (it == verdicts.end()) it = verdicts.emplace(k, kernel_health(m->code, k)).first;
+      return it->second;
+    };
     auto bad = [&](const char *k) {
       if (marker) return unfit.find(std::string("\n") + k + "\n") != std::string::npos;
-      return kernel_health(m->code, k) == KH_BAD;
+      return health(k) == KH_BAD;
     };
     auto again = [&] {   // this attempt is abandoned: leave the marker, lower again
       if (!marker) {
         std::string names = "\n";
         for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel",
                               "rh_density_fin_kernel"})
-          if (kernel_health(m->code, k) == KH_BAD) names += std::string(k) + "\n";
+          if (health(k) == KH_BAD) names += std::string(k) + "\n";
         abandon_attempt(m->arch, m->source, extra, names);
       }
       assemble_source(m);
@@ -515,7 +524,7 @@ void build_code(rh_model *m) {
     auto usable = [&] {
       if (m->info.gather_mode) return !bad("rh_grad_gather_kernel") && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
       // (a dense linear predictor's gradients come from the MFMA kernel: load_module prefers it, so it can stand in for rh_grad_kernel)
-      const bool glm = m->has_glm && m->n_row_targets_hint == 1 && !m->glm_small && !marker && kernel_health(m->code, "rh_grad_glm_kernel") == KH_OK;
+      const bool glm = m->has_glm && m->n_row_targets_hint == 1 && !m->glm_small && !marker && health("rh_grad_glm_kernel") == KH_OK;
       const bool tick = m->n_row_targets_hint > 0 && (!bad("rh_grad_kernel") || glm) && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
       return tick || (!bad("rh_chain_kernel") && !bad("rh_density_kernel"));
     };
