@@ -1472,7 +1472,8 @@ int default_nsplit(const rh_model *m, int chains) {
   // the gather kernel (three wavefronts per SIMD, its own two-tile pipeline): many short workgroups measured best on cfg 5 --
   // 8 / 16 / 24 splits of 256 chain groups: 3.41 / 3.11 / 2.92 ms per launch (profiles/r5_cfg5)
   // (call B, another box: 16 / 24 / 32 / 48 splits 3.00 / 2.78 / 2.71 / 2.67 ms -- four rounds of 3072 wavefronts)
-  if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (12288 + ngroups - 1) / ngroups);
+  // (call C: 32 / 48 / 64 / 96 splits 2.68 / 2.67 / 2.61 / 2.60 ms; 64 is also the most partial sums the tick's combine reads in one pass)
+  if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (16384 + ngroups - 1) / ngroups);
   if (const char *e = std::getenv("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
