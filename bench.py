@@ -72,7 +72,13 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
         return time.perf_counter() - t, float(sum(steps))
 
     t1, _ = run_all(1)                                   # calibration, all threads busy
-    iters = max(1, min(200, int(0.6 * seconds_budget / max(t1, 1e-3))))
+    # When ONE iteration of every chain over the FULL data set fits the budget (cost is linear in the rows: t1 x N / n_s), the figure
+    # is measured at full size -- no extrapolation (round 5; on the 256-core GPU box: ~6 s); otherwise on the sample, as before.
+    if n_s < N and t1 * (N / n_s) <= 1.2 * seconds_budget:
+        n_s, spec_s = N, spec
+        iters = max(1, min(4, int(0.6 * seconds_budget / max(t1 * (N / 100_000), 1e-3))))
+    else:
+        iters = max(1, min(200, int(0.6 * seconds_budget / max(t1, 1e-3))))
     dt, total = run_all(iters)
     total_full = total * n_s / N                         # leapfrog steps over the FULL data set this corresponds to
     # second figure ("speed build"): the same streamed gradient written out by hand and compiled -O3 with
@@ -110,9 +116,11 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
                "sample": "%d threads x %d leapfrog steps on the inlined density, hand-written C -O3, %.1f s" % (cores, nsteps, dt3)}
     return {"value": total_full / dt, "compiled_closed_form": closed, "inlined_sufficient_statistics": inlined,
             "unit": "leapfrog steps/s", "cores": cores, "nproc": nproc, "kind": "port",
-            "sample": "%d chains (one per core) x %d HMC iterations (L=%d) over the first %d of the %d rows, RIR interpreter, "
-                      "reference's 2L+1 gradient evaluations per trajectory, %.1f s; value = measured steps/s x %d/%d "
-                      "(full-size equivalent)" % (cores, iters, L, n_s, N, dt, n_s, N),
+            "sample": ("%d chains (one per core) x %d HMC iteration(s) (L=%d) over ALL %d rows, RIR interpreter, reference's 2L+1 gradient "
+                       "evaluations per trajectory, %.1f s; value = measured steps/s (no extrapolation)" % (cores, iters, L, N, dt)) if n_s == N else
+                      ("%d chains (one per core) x %d HMC iterations (L=%d) over the first %d of the %d rows, RIR interpreter, "
+                       "reference's 2L+1 gradient evaluations per trajectory, %.1f s; value = measured steps/s x %d/%d "
+                       "(full-size equivalent)" % (cores, iters, L, n_s, N, dt, n_s, N)),
             "measured_on_sample": {"leapfrog_steps_per_s": total / dt, "rows": n_s},
             "row_chain_evals_per_s": total * n_s / dt}
 
