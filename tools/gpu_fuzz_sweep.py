@@ -32,7 +32,7 @@ def prebuild(lo, hi, worker, nworkers):
 def run(lo, hi):
     import rainier_amd as R
     from tests import oracle_lib as O
-    bad = done = 0
+    bad = done = chains_done = 0
     for kind, seed, kw in cases(lo, hi):
         spec, qs, mode = gpu_fuzz_case(kind, seed, kw)
         if not qs:
@@ -60,12 +60,26 @@ def run(lo, hi):
                             print("FAIL", kind, seed, kw, name, "engine", engine, "splits", splits, "point", c, "worst", float(np.nanmax(ratio)),
                                   re.findall(r"#define RH_GRAD_[UK] \d+", m.hip_source), flush=True)
                             break
+                # SWEEP_CHAINS=1: also through the SAMPLER kernels (they carry their own inlined copy of the density): 4 iterations of
+                # tame static HMC from every engine in use against the oracle's chains, strict builds (as tests/test_gpu_fuzz.py)
+                if os.environ.get("SWEEP_CHAINS") and name == "strict" and np.all(np.isfinite(O.OracleDensity(spec).update(np.asarray(qs[0], dtype=np.float64)))):
+                    from tests.test_gpu_parity import _oracle_cfg
+                    cfg = lambda e: R.make_config(4, 0, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner(), engine=e)
+                    seeds = [4000 + seed, 4100 + seed]
+                    want = np.array([O.sample_model(spec, _oracle_cfg(cfg(0), O.JM_DET), sd)[0] for sd in seeds])
+                    eng = m.engines()
+                    for e in ([_capi.ENGINE_TICK] if eng["tick"] else []) + ([_capi.ENGINE_CHAIN] if eng["chain"] else []):
+                        got = m.sample(cfg(e), seeds=seeds).chains
+                        chains_done += 1
+                        if np.all(np.isfinite(want)) and not np.allclose(got, want, rtol=1e-8, atol=1e-10):
+                            bad += 1
+                            print("FAIL-CHAIN", kind, seed, kw, "engine", e, "max abs diff", float(np.nanmax(np.abs(got - want))), flush=True)
                 m.close()
                 done += 1
             except Exception as e:
                 bad += 1
                 print("ERROR", kind, seed, kw, name, repr(e)[:200], flush=True)
-    print("sweep", lo, hi, "model builds", done, "failures", bad, flush=True)
+    print("sweep", lo, hi, "model builds", done, "sampler runs vs the oracle's chains", chains_done, "failures", bad, flush=True)
 
 
 if __name__ == "__main__":
