@@ -282,9 +282,6 @@ void assemble_source(rh_model *m) {
       m->eopt.chunk = 48; again = true;
       if (!std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = 1;   // (such a model's chain kernel has never fitted two wavefronts per SIMD)
     }
-    // (round 5) ... and from 200 statements on rh_chain_kernel has never fitted two wavefronts per SIMD (eight schools: 228; every build
-    // job and test model of that size ended at one): ask for one at once instead of compiling the translation unit twice
-    if (longest >= 200 && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES") && !m->info.gather_mode) { m->eopt.chain_waves = 1; again = true; }
     if (m->info.bign && !m->info.gather_mode && m->prog.n_params > 512 && m->eopt.big_unroll > 4) { m->eopt.big_unroll = 4; again = true; }
     if (again) { assemble_source(m); return; }
   }
