@@ -101,6 +101,10 @@ extern "C" int rh_comm_unique_id(unsigned char id[RH_COMM_ID_BYTES]) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!id) return fail(RH_E_INVALID, "rh_comm_unique_id: NULL");
   if (!g_rccl.load()) return fail(RH_E_UNSUPPORTED, g_rccl.err);
+  // (no device: say so before RCCL is touched -- its bootstrap would fail the same way, and leave a "[FATAL ERROR]" line on stderr
+  //  when the process exits)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RH_E_DEVICE, "rh_comm_unique_id: no HIP device");
   nccl_uid u;
   const int rc = g_rccl.GetUniqueId(&u);
   if (rc) return nccl_fail("ncclGetUniqueId", rc);
