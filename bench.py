@@ -35,7 +35,7 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X public FP64 vector peak (n
 TRAFFIC_PROFILE = "r5_cfg2/pmc_grad_kernel.json"   # PMC summary of the dominant kernel (see the roofline.traffic comment)
 
 
-def cpu_baseline(spec, L, seconds_budget=20.0):
+def cpu_baseline(spec, L, seconds_budget=30.0):
     """The oracle (oracle/: C restatement of the reference JVM path, kind = "port") timed on ALL of this box's host
     cores on a bounded sample of the same workload: one chain per thread, each running whole HMC iterations
     (L=32) over the full data set with the reference's own 2L+1 gradient evaluations per trajectory.
@@ -57,8 +57,8 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
     n_s = min(N, 100_000)
     spec_s = _m.linreg(n=n_s, k=len(spec.columns) - 1, columns=[np.ascontiguousarray(c[:n_s]) for c in spec.columns])
 
-    def run_all(iters):
-        cfg = O.make_config(sampler=O.HMC, n_steps=L, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
+    def run_all(iters, Lc=L):     # (reads spec_s when called: the sample in rows, or the full data set)
+        cfg = O.make_config(sampler=O.HMC, n_steps=Lc, iterations=iters, warmup=0, step_tuner=O.STEP_STATIC,
                             static_step=1e-3, math_mode=O.JM_LIBM)
         steps = [0] * cores
 
@@ -71,15 +71,24 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
         [x.start() for x in th]; [x.join() for x in th]
         return time.perf_counter() - t, float(sum(steps))
 
-    t1, _ = run_all(1)                                   # calibration, all threads busy
-    # When ONE iteration of every chain over the FULL data set fits the budget (cost is linear in the rows: t1 x N / n_s), the figure
-    # is measured at full size -- no extrapolation (round 5; on the 256-core GPU box: ~6 s); otherwise on the sample, as before.
-    if n_s < N and t1 * (N / n_s) <= 1.2 * seconds_budget:
-        n_s, spec_s = N, spec
-        iters = max(1, min(4, int(0.6 * seconds_budget / max(t1 * (N / 100_000), 1e-3))))
+    t1, _ = run_all(1)                                   # calibration, all threads busy: one L-step iteration on the first n_s rows
+    # The figure is measured over the FULL data set whenever one iteration of every chain over it fits the budget (cost is linear
+    # in the rows: t1 x N / n_s) -- if need be with a shorter static trajectory: a leapfrog step costs (2 L + 1) / L gradient
+    # evaluations in the reference (LeapFrog.scala:158-188), 2.03 at L = 32 and 2.125 at L = 8, so steps/s at L = 8 understates the
+    # L = 32 figure by 4 %, stated in `sample`.  Only when even that does not fit is the sample cut in rows, as before.
+    L_cpu = L
+    full = None
+    for Lc in [L] + [x for x in (16, 8, 4) if x < L]:
+        if n_s < N and t1 * (N / n_s) * ((2 * Lc + 1) / (2.0 * L + 1)) <= seconds_budget:
+            full = Lc
+            break
+    if n_s == N:
+        iters = max(1, min(200, int(0.6 * seconds_budget / max(t1, 1e-3))))
+    elif full is not None:
+        n_s, spec_s, L_cpu, iters = N, spec, full, 1
     else:
         iters = max(1, min(200, int(0.6 * seconds_budget / max(t1, 1e-3))))
-    dt, total = run_all(iters)
+    dt, total = run_all(iters, L_cpu)
     total_full = total * n_s / N                         # leapfrog steps over the FULL data set this corresponds to
     # second figure ("speed build"): the same streamed gradient written out by hand and compiled -O3 with
     # AVX2/FMA (oracle/closed_form.c) -- an upper bound for any JVM on these cores; one chain per thread, ~3 s
@@ -116,8 +125,11 @@ def cpu_baseline(spec, L, seconds_budget=20.0):
                "sample": "%d threads x %d leapfrog steps on the inlined density, hand-written C -O3, %.1f s" % (cores, nsteps, dt3)}
     return {"value": total_full / dt, "compiled_closed_form": closed, "inlined_sufficient_statistics": inlined,
             "unit": "leapfrog steps/s", "cores": cores, "nproc": nproc, "kind": "port",
-            "sample": ("%d chains (one per core) x %d HMC iteration(s) (L=%d) over ALL %d rows, RIR interpreter, reference's 2L+1 gradient "
-                       "evaluations per trajectory, %.1f s; value = measured steps/s (no extrapolation)" % (cores, iters, L, N, dt)) if n_s == N else
+            "sample": ("%d chains (one per core) x %d HMC iteration(s) (L=%d%s) over ALL %d rows, RIR interpreter, reference's 2L+1 gradient "
+                       "evaluations per trajectory, %.1f s; value = measured steps/s (no extrapolation)" % (
+                           cores, iters, L_cpu, "" if L_cpu == L else ": a shorter trajectory than the bench's %d so that the full data set fits the "
+                           "budget -- %.3f instead of %.3f gradient evaluations per step, i.e. the figure understates L=%d by %.0f %%" % (
+                               L, (2 * L_cpu + 1) / L_cpu, (2 * L + 1) / L, L, 100 * (1 - ((2 * L + 1) / L) / ((2 * L_cpu + 1) / L_cpu))), N, dt)) if n_s == N else
                       ("%d chains (one per core) x %d HMC iterations (L=%d) over the first %d of the %d rows, RIR interpreter, "
                        "reference's 2L+1 gradient evaluations per trajectory, %.1f s; value = measured steps/s x %d/%d "
                        "(full-size equivalent)" % (cores, iters, L, n_s, N, dt, n_s, N)),
@@ -215,8 +227,16 @@ def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, ro
         spec = spec or models.linreg(n=rows or 1_000_000, k=3); cfg = R.make_config(steps, warmup)
     elif w == "cfg4":
         spec = spec or models.logistic(n=rows or 10_000_000, k=50); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
-    else:   # rows scales the number of groups (100 observations each); the BASELINE size is 10 000 groups
-        spec = spec or models.hier_negbin(10_000 if not rows else max(100, rows // 100), 100); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
+    else:   # rows scales the number of groups (100 observations each); the BASELINE size is 10 000 groups.  cfg5c: the CENTRED
+        # parameterisation (alpha_g ~ Normal(mu, sigma) sampled directly) -- the form on which NUTS converges at this size
+        # (tests/test_gpu_baseline_samplers.py: R-hat < 1.05; the non-centred one above keeps R-hat at 3-6 for any affordable length)
+        mk = models.hier_negbin_centred if w == "cfg5c" else models.hier_negbin
+        spec = spec or mk(10_000 if not rows else max(100, rows // 100), 100); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
+    if w in ("cfg4", "cfg5", "cfg5c") and warmup < 150:
+        # DefaultConfig's mass windows (50, x1.5, skip 50 / 50: sampler/Sampler.scala:24-25) never open in a warm-up this short:
+        # the same tuner scaled to the leg's warm-up, so that "NUTS + diag mass-matrix adapt" (BASELINE cfg 4) really adapts
+        k = max(1, warmup // 6)
+        cfg.massMatrixTuner = lambda: R.DiagonalMassMatrixTuner(k, 1.5, k, k)
     if sampler == "nuts":
         cfg.sampler = lambda: R.NUTSSampler(10)
     elif sampler.startswith("hmc"):      # static HMC, L = the number behind "hmc": every chain asks for a gradient at every launch, so the
@@ -245,23 +265,34 @@ def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, ro
         dt = comm.rccl.allreduce_max(dt)
         counts = comm.sum(counts)
     tim = s.timing()
+    nshow = min(spec.n_params, 16)
     draws = None
     if rank == 0:
-        draws = gathered if comm is not None else s.draws()
+        if comm is not None:
+            draws = gathered[:, :, :nshow]
+        else:   # the first `nshow` parameters of every draw, fetched a few iterations at a time (cfg 5: 10 004 parameters per draw)
+            step_it = max(1, int(2.5e8 // max(1, cpg * spec.n_params)))
+            draws = np.concatenate([s.draws(f, min(step_it, steps - f))[:, :, :nshow] for f in range(0, steps, step_it)], axis=1)
     s.close()
     if own:
         model.close()
     if rank != 0:
         return None
     nsteps, wsteps = counts
-    nshow = min(spec.n_params, 16)
-    ess = min(e for _, e in R.diagnostics(draws[:, :, :nshow])) if steps >= 4 and draws.shape[0] >= 2 else None
+    diag = R.diagnostics(draws) if steps >= 4 and draws.shape[0] >= 2 else None
+    ess = min(e for _, e in diag) if diag else None
+    rhat_max = max(r for r, _ in diag) if diag else None
+    converged = bool(rhat_max is not None and rhat_max < 1.05)
     out = {"metric": "leapfrog steps/sec (all chains)", "value": nsteps / dt, "unit": "leapfrog steps/s",
            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w + ": " + spec.name, "chains": cpg * world, "sampler": type(cfg.sampler()).__name__,
                       "mass": type(cfg.massMatrixTuner()).__name__, "engine": tim["dominant_kernel"], "strict": bool(strict)},
-           "warmup_leapfrog_steps_per_s": wsteps / tw, "ess_per_s": ess / dt if ess else None,
+           "warmup_leapfrog_steps_per_s": wsteps / tw,
+           # ESS/s (min over the first 16 parameters, Trace.diagnostics' formula) is quoted only for draws that have converged;
+           # otherwise the figure is kept under another name with the R-hat that disqualifies it
+           "ess_per_s": ess / dt if ess and converged else None, "rhat_max": rhat_max, "converged_rhat_below_1_05": converged,
+           "ess_per_s_unconverged": ess / dt if ess and not converged else None,
            "leapfrog_steps_timed": nsteps, "seconds_timed": dt, "seconds_warmup": tw, "seconds_model_create": t_create,
            "mean_leapfrog_per_iteration": nsteps / (steps * cpg * world),
            "row_chain_evals_per_s": nsteps * spec.rows_streamed / dt if spec.rows_streamed else None}
@@ -277,7 +308,14 @@ def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, ro
             out["roofline"] = {"bound": "fp64_mfma" if "glm" in tim["dominant_kernel"] else "fp64_valu", "kernel": tim["dominant_kernel"],
                                "achieved": fl / k_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / k_s / 1e12 / FP64_PEAK_TFLOPS,
                                "traffic": None, "launches": tim["launches"], "avg_launch_ms": tim["kernel_ms"] / max(1, tim["launches"]),
-                               "all_kernels_ms": tim["total_ms"], "flops_per_row_chain_eval": fpr, "hbm_equivalent": hbm}
+                               "all_kernels_ms": tim["total_ms"], "flops_per_row_chain_eval": fpr, "hbm_equivalent": hbm,
+                               # the launches serve the chains that wait for a gradient (live-chain lists): slots served vs needed,
+                               # and the same fraction over the launches that served >= 90 % of the chains (the run's tail excluded)
+                               "chain_slots_served": tim["chain_slots"], "chain_slots_needed": tim["density_evals"],
+                               "slot_efficiency": tim["density_evals"] / max(1, tim["chain_slots"]),
+                               "steady_state": ({"launches": tim["steady_launches"], "avg_launch_ms": tim["steady_kernel_ms"] / tim["steady_launches"],
+                                                 "frac": tim["steady_density_evals"] * spec.rows_streamed * fpr / (tim["steady_kernel_ms"] / 1e3) / 1e12 / FP64_PEAK_TFLOPS,
+                                                 "what": "launches that served >= 90 % of the chains"} if tim["steady_launches"] else None)}
         else:
             out["roofline"] = dict(hbm, bound="hbm", kernel=tim["dominant_kernel"], traffic=None, launches=tim["launches"],
                                    avg_launch_ms=tim["kernel_ms"] / max(1, tim["launches"]),
@@ -299,47 +337,49 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
         print(json.dumps(out))
 
 
-def all_configs(R, models, local_rank, model_cfg2, spec_cfg2, budget_s=900.0):
-    """The `configs` block of the default (N = 1) line: every BASELINE.json configuration driver-timed in this run, in-process, each
-    with steps/s, its dominant kernel, avg_launch_ms and roofline.frac under SURVEY 8(d)'s flop counts.  Sizes are
-    the BASELINE ones; iteration counts are kept small where one iteration is seconds (cfg 4 / cfg 5 under NUTS: trees start deep)."""
-    plan = [  # (key, workload, steps, warmup, chains, sampler)
-        ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default"),
-        ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default"),
-        ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts"),
-        ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 16, 64, 1024, "default"),
-        # cfg 4 / cfg 5: the BASELINE sampler (NUTS: chains run free across iterations, but the launches behind the last chain to finish
-        # the leg serve fewer and fewer of them -- its roofline fraction is the leg's, tail included) and, for the kernel's own
-        # fraction, static HMC (every launch serves every chain)
-        ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8"),
-        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 12, 8, 256, "default"),
-        ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8"),
-        ("cfg5_hier_negbin_10000x100_nuts10_1024", "cfg5", 4, 6, 1024, "default"),
+def all_configs(budget_s=1000.0):
+    """The `configs` block of the default (N = 1) line: every BASELINE.json configuration driver-timed in this run, each leg a CHILD
+    process (`bench.py --workload ...`, the same code path as `--workload` from the command line) under a watchdog, so that a leg
+    that hangs or dies cannot take the judged cfg-2 line with it.  Sizes are the BASELINE ones.  The legs under the
+    samplers BASELINE names (NUTS) and the reference defaults to (EHMC + windowed diagonal mass: sampler/Sampler.scala:17-27) are
+    sized to tens of seconds each -- enough iterations for R-hat < 1.05, beside which alone an ESS/s is printed -- and carry the
+    live-chain accounting of their gradient launches (roofline.slot_efficiency, roofline.steady_state); the static-HMC legs are the
+    dominant kernel's own figure (every launch serves every chain)."""
+    plan = [  # (key, workload, steps, warmup, chains, sampler, watchdog seconds)
+        ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default", 120),
+        ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default", 120),
+        ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts", 120),
+        ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 64, 200, 1024, "default", 240),
+        ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8", 240),
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 100, 60, 256, "default", 420),
+        ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8", 240),
+        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 60, 36, 1024, "default", 420),
     ]
-    shared = {}   # cfg 4 / cfg 5 models are created once and serve both of their legs (4 GB of columns, a 1.2 MB program)
     out, t_all = {}, time.perf_counter()
-    for key, w, steps, warm, cpg, smp in plan:
-        if time.perf_counter() - t_all > budget_s:
+    for key, w, steps, warm, cpg, smp, limit in plan:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 30:
             out[key] = {"skipped": "the configs block's time budget (%.0f s) was spent" % budget_s}
             continue
         t0 = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", w, "--sampler", smp, "--steps", str(steps),
+               "--warmup", str(warm), "--chains-per-gpu", str(cpg)]
         try:
-            if w in ("cfg4", "cfg5") and w not in shared:
-                t1 = time.perf_counter()
-                sp = models.logistic(n=10_000_000, k=50) if w == "cfg4" else models.hier_negbin(10_000, 100)
-                shared[w] = (R.Model(sp, device=local_rank, fp_contract=True, factor_outputs=True), sp, time.perf_counter() - t1)
-            mdl, sp = (model_cfg2, spec_cfg2) if w == "cfg2d" else (shared[w][0], shared[w][1]) if w in shared else (None, None)
-            r = side_run(w, R, models, 0, local_rank, 1, None, steps, warm, cpg, sampler=smp, model=mdl, spec=sp)
-            if w in shared:
-                r["seconds_model_create"] = shared[w][2]
-            keep = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "ess_per_s", "leapfrog_steps_timed", "seconds_timed",
-                                      "seconds_warmup", "seconds_model_create", "mean_leapfrog_per_iteration", "row_chain_evals_per_s", "roofline")}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(limit, left))   # (N = 1, not under torch.distributed.run: the same device 0)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[key] = {"error": "exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            keep = {k: d.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "ess_per_s", "rhat_max", "converged_rhat_below_1_05",
+                                          "ess_per_s_unconverged", "leapfrog_steps_timed", "seconds_timed", "seconds_warmup", "seconds_model_create",
+                                          "mean_leapfrog_per_iteration", "row_chain_evals_per_s", "roofline")}
             keep["seconds_total"] = time.perf_counter() - t0
             out[key] = keep
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": "watchdog: the leg did not finish within %.0f s" % min(limit, left)}
         except Exception as e:      # a side configuration must never take the judged line down with it
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    for mdl, _, _ in shared.values():
-        mdl.close()
     return out
 
 
@@ -368,9 +408,9 @@ def main():
                          "5120 / 8192 draws -- the apparent tau keeps growing -- so it is reported, flagged, and not waited for)")
     ap.add_argument("--ess-multi", action="store_true", help="run the ESS legs on every rank at N > 1 too")
     ap.add_argument("--ess-warmup", type=int, default=384)
-    ap.add_argument("--sampler", choices=["default", "nuts"], default="default",
-                    help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC")
-    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3", "cfg4", "cfg5"], default="cfg2",
+    ap.add_argument("--sampler", default="default",
+                    help="side workloads only: 'nuts' = NUTSSampler(10) (extension) instead of the reference's EHMC; 'hmcN' = static HMC with N steps")
+    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3", "cfg2d", "cfg4", "cfg5", "cfg5c"], default="cfg2",
                     help="cfg2 is the BASELINE metric's configuration (default); the others are the remaining BASELINE.json "
                          "configurations, timed for reference (see side_workload)")
     ap.add_argument("--strict", action="store_true",
@@ -546,7 +586,7 @@ def main():
             out["roofline"]["traffic_source"] = "none: profiles/%s was taken on different kernel source or workload (sha16 %s vs %s)" % (
                 TRAFFIC_PROFILE, pj.get("generated_source_sha16"), src_sha)
     if not a.no_configs and world == 1 and dist is None:   # (a plain `python bench.py` run; not under torch.distributed.run)
-        out["configs"] = all_configs(R, models, local_rank, model, spec)
+        out["configs"] = all_configs()
     if not a.no_inlined and world == 1:
         out["gpu_inlined"] = gpu_inlined(R, models, local_rank, L)
     if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only

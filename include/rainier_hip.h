@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 5  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
+#define RH_ABI_VERSION 6  /* 2: rh_chain_stats.bfmi, rh_config.rng_next_gaussian, rh_optimize, rh_sampler_progress / mass_dense;
                              3: rh_density_eval_ex, rh_sample_multi, rh_comm_* (RCCL all-gather of the draws);
                              4: rh_model_clone;
-                             5: rh_model_engines, rh_compile_count */
+                             5: rh_model_engines, rh_compile_count;
+                             6: rh_timing.chain_slots / steady_* (the tick engine's gradient launches serve the live chains only) */
 
 enum rh_status {
   RH_OK = 0,
@@ -248,6 +249,15 @@ typedef struct rh_timing {
   int64_t density_evals;     /* chain-level density evaluations in those launches */
   int64_t row_chain_evals;   /* rows streamed x chains: the unit of SURVEY.md 8(d) */
   char dominant_kernel[64];  /* name of the kernel that accounts for kernel_ms */
+  /* The tick engine's gradient launches serve the chains that wait for a gradient (under EHMCSampler -- DefaultConfig's,
+   * sampler/Sampler.scala:17-27 -- and NUTS the chains' trajectories end at different launches).  chain_slots: the chains listed for
+   * those launches, summed (= density_evals when no launch served a chain that did not need it; launches x chains without
+   * compaction).  steady_*: the same three figures restricted to the launches that served >= 90 % of the sampler's chains -- the
+   * dominant kernel at full occupancy, the tail of a run (few chains left) excluded.  Chain engine: chain_slots = density_evals, steady_* = 0. */
+  int64_t chain_slots;
+  double steady_kernel_ms;
+  int64_t steady_launches;
+  int64_t steady_density_evals;
 } rh_timing;
 int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset);
 /* Progress polling instead of a callback into the caller (Driver.sample's `progress: Progress` argument,

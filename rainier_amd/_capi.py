@@ -59,7 +59,8 @@ class ChainStats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("launches", C.c_int64), ("density_evals", C.c_int64),
-                ("row_chain_evals", C.c_int64), ("dominant_kernel", C.c_char * 64)]
+                ("row_chain_evals", C.c_int64), ("dominant_kernel", C.c_char * 64), ("chain_slots", C.c_int64),
+                ("steady_kernel_ms", C.c_double), ("steady_launches", C.c_int64), ("steady_density_evals", C.c_int64)]
 
 
 class RainierHipError(RuntimeError):

@@ -1020,6 +1020,52 @@ rh_chain_kernel(const rh_model_data d, const rh_cfg_dev cfg, rh_u64 *__restrict_
 #endif  // !RH_HAS_GATHER
 
 #if RH_NROWTARGETS > 0
+// ---- live chains (round 6) ------------------------------------------------------------------------------------------------------
+// Under the reference's dynamic samplers (EHMCSampler is DefaultConfig's, sampler/Sampler.scala:17-27; NUTS is BASELINE's) the chains
+// of a run finish their iterations at different launches: round 5's driver-timed legs served 46 % (cfg 2, EHMC), 32 % (cfg 4, NUTS)
+// and 7 % (cfg 5, NUTS) of the chain slots they computed, because a chain group was fixed by chain id and a launch cost the same
+// whatever the number of chains still waiting for a gradient.  Now rh_compact_kernel, after every tick, lists the chains that wait
+// for a gradient in ascending chain id (`list`, `*nlive`); the gradient kernels take their chains from that list -- slot s of the
+// launch is chain list[s], so chain groups / MFMA tiles are full -- and the tick runs one wavefront per listed chain.
+//   Row splits.  The partial sums are indexed by CHAIN id: what a chain's sums are depends on the row split count only -- not on
+// the other chains of its group, on the live count or on the slot it was served in; the combine adds the same `nsplit` values in
+// the same order.  For the dynamic samplers the host chooses MORE, shorter splits than a lock-step launch needs (rh_sampler_create):
+// a launch with few live chains then still spreads over the machine, and the workgroups of the slots past the live count -- the
+// last ones of the grid -- return at once.  (A per-launch choice of splits per workgroup, with a loop over "fine" splits inside
+// the kernels, was tried first: what the loop keeps alive across its iterations cost rh_grad_gather_kernel its third wavefront
+// per SIMD, 166 -> 192..220 registers, for the same number of pipeline fills and wave reductions.)
+RH_DEV int rh_live_count(const int *__restrict__ nlive, const int chains) {
+  return nlive ? __builtin_amdgcn_readfirstlane(*nlive) : chains;
+}
+// the chain in slot `slot` of the launch (a slot past the live count reads the last live chain; its results are dropped)
+RH_DEV int rh_live_chain(const int *__restrict__ list, const int slot, const int nl) {
+  return list[slot < nl ? slot : nl - 1];   // (the host always passes a list to the gradient kernels: the identity when every chain is served)
+}
+// active[chain] != 0 (the chain's last tick asked for a gradient) -> list of those chains, ascending, and their number.  One
+// workgroup: 1024 flags per pass, wave ballots + a 16-entry carry through LDS; a launch of a few microseconds behind every tick.
+extern "C" __global__ void __launch_bounds__(1024)
+rh_compact_kernel(const int *__restrict__ active, int *__restrict__ list, int *__restrict__ nlive, int *__restrict__ log, const int chains) {
+  __shared__ int wcount[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < chains; c0 += 1024) {
+    const int c = c0 + tid;
+    const bool a = c < chains && active[c] != 0;
+    const unsigned long long bal = __ballot(a);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += wcount[w];
+    if (a) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; w++) t += wcount[w]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) { *nlive = base; *log = base; }   // log: the host's per-launch record of the live counts (rh_timing.chain_slots / steady_*)
+}
+
 #if !RH_HAS_GATHER
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
@@ -1036,7 +1082,7 @@ typedef double rh_thk_t[RH_GRAD_K][RH_NTH];
 // from another XCD within the same launch
 template <int T, bool COHERENT>
 RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
-                            const int split, const int nsplit, const int chain0, const int chains,
+                            const int split, const int nsplit, const int *__restrict__ lp, const int nvalid, const int chains,
                             double *__restrict__ partial, int &err) {
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
@@ -1159,8 +1205,10 @@ RH_UNROLL_ACC
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
         rh_wave_sum_all(acc[kk]);   // a chain's NA sums level by level: their exchanges overlap
-        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
-        if (lane == 0 && chain0 + kk < chains) {
+        // (the chain id of slot kk is looked up again here, a scalar load, rather than held in a scalar register through the row
+        //  walk: the K parameter vectors already take 2 K nVars of them.  lp = the group's part of the list, nvalid of its K slots hold a chain)
+        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + lp[kk < nvalid ? kk : 0]) * RH_NACC_MAX;
+        if (lane == 0 && kk < nvalid) {
 RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) {
             if constexpr (COHERENT) __hip_atomic_store(out + o, acc[kk][o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1169,7 +1217,7 @@ RH_UNROLL_ACC
         }
       }
     }
-    rh_grad_targets<T + 1, COHERENT>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+    rh_grad_targets<T + 1, COHERENT>(th, d, lane, split, nsplit, lp, nvalid, chains, partial, err);
   }
 }
 #pragma clang fp contract(off)
@@ -1186,24 +1234,22 @@ RH_DEV void rh_grad_map(const int b, const int nsplit, const int xcd_aware, int 
     group = idx / spx;
   } else { split = b % nsplit; group = b / nsplit; }
 }
-// returns the first chain of the workgroup's chain group, or -1 when there is nothing to do for it (no chain waits for a gradient)
+// one workgroup of the plain gradient kernel: its chain group's parameters, then its row split
 template <bool COHERENT>
-RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ active, double *partial,
-                        int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit,
-                        const int xcd_aware, int &group) {
+RH_DEV void rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ list, const int *__restrict__ nlive,
+                         double *partial, int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit,
+                         const int xcd_aware) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0; // re-armed for the tick kernel that follows in stream order
-  int split;
+  const int nl = rh_live_count(nlive, chains);
+  int split, group;
   rh_grad_map(b, nsplit, xcd_aware, split, group);
-  const int chain0 = group * RH_GRAD_K;
-  if (chain0 >= chains) return -1;
-  bool any = false;
+  if (group * RH_GRAD_K >= nl) return;   // (no live chain for this workgroup)
   rh_thk_t th;
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
-    const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
-    any = any || (active[c] != 0);
+    const int c = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
 #if RH_BIGTH
     th[kk] = q + (size_t)c * RH_NVARS;
 #else
@@ -1211,19 +1257,16 @@ RH_DEV int rh_grad_body(const rh_model_data &d, const double *q, const int *__re
     for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i]; // wave-uniform address -> s_load
 #endif
   }
-  if (!any) return -1;
   int err = 0;
-  rh_grad_targets<0, COHERENT>(th, d, lane, split, nsplit, chain0, chains, partial, err);
+  rh_grad_targets<0, COHERENT>(th, d, lane, split, nsplit, list + group * RH_GRAD_K, nl - group * RH_GRAD_K, chains, partial, err);
   if (err && lane == 0) atomicOr(err_out, 1);
-  return chain0;
 }
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
-rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
                double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
-  int group;
-  (void)rh_grad_body<false>(d, q, active, partial, err_out, n_running, chains, nsplit, xcd_aware, group);
+  rh_grad_body<false>(d, q, list, nlive, partial, err_out, n_running, chains, nsplit, xcd_aware);
 }
 
 // ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
@@ -1243,8 +1286,8 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 #endif
 template <int T>
 RH_DEV void rh_grad_lds_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
-                                const int wave, const int split, const int nsplit, const int chain0, const int chains,
-                                const bool compute, double *__restrict__ partial, double *lds, int &err) {
+                                const int wave, const int split, const int nsplit, const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K],
+                                const int chains, const bool compute, double *__restrict__ partial, double *lds, int &err) {
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (TG::HAS_ROWS) {
@@ -1301,22 +1344,22 @@ RH_DEV void rh_grad_lds_targets(const rh_thk_t &th, const rh_model_data &d, cons
 #pragma unroll
         for (int kk = 0; kk < K; kk++) {
           rh_wave_sum_all(acc[kk]);
-          double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
-          if (lane == 0 && chain0 + kk < chains) {
+          double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cid[kk]) * RH_NACC_MAX;
+          if (lane == 0 && cok[kk]) {
 #pragma unroll
             for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
           }
         }
       }
     }
-    rh_grad_lds_targets<T + 1>(th, d, lane, wave, split, nsplit, chain0, chains, compute, partial, lds, err);
+    rh_grad_lds_targets<T + 1>(th, d, lane, wave, split, nsplit, cid, cok, chains, compute, partial, lds, err);
   }
 }
 #pragma clang fp contract(off)
 
 // grid: ceil(ngroups / W) * nsplit workgroups of W wavefronts; dynamic LDS = 2 * max(NCOLS) * 64 doubles
 extern "C" __global__ void __launch_bounds__(64 * RH_GRAD_W)
-rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
@@ -1324,31 +1367,28 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0) *n_running = 0;
+  const int nl = rh_live_count(nlive, chains);
   int bgroup, split;
-  if (xcd_aware && (nsplit % 8) == 0) {
-    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
-    split = xcd + 8 * (idx % spx);
-    bgroup = idx / spx;
-  } else { split = b % nsplit; bgroup = b / nsplit; }
+  rh_grad_map(b, nsplit, xcd_aware, split, bgroup);
+  if (bgroup * RH_GRAD_W * RH_GRAD_K >= nl) return;   // (uniform over the workgroup)
   const int group = __builtin_amdgcn_readfirstlane(bgroup * RH_GRAD_W + wave);
-  const int chain0 = group * RH_GRAD_K;
-  bool any = false;
+  const bool any = group * RH_GRAD_K < nl;   // (a wavefront without a live chain still stages its columns of the tile)
+  int cid[RH_GRAD_K];
+  bool cok[RH_GRAD_K];
   rh_thk_t th;
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
-    int c = chain0 + kk;
-    if (c >= chains) c = chains - 1;
-    any = any || (chain0 + kk < chains && active[c] != 0);
+    cok[kk] = group * RH_GRAD_K + kk < nl;
+    cid[kk] = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
 #if RH_BIGTH
-    th[kk] = q + (size_t)c * RH_NVARS;
+    th[kk] = q + (size_t)cid[kk] * RH_NVARS;
 #else
 #pragma unroll
-    for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
+    for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)cid[kk] * RH_NVARS + i];
 #endif
   }
-  if (!__syncthreads_or(any ? 1 : 0)) return;
   int err = 0;
-  rh_grad_lds_targets<0>(th, d, lane, wave, split, nsplit, chain0, chains, any, partial, rh_lds, err);
+  rh_grad_lds_targets<0>(th, d, lane, wave, split, nsplit, cid, cok, chains, any, partial, rh_lds, err);
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 
@@ -1376,7 +1416,7 @@ typedef double rh_v4d __attribute__((ext_vector_type(4)));
 #define RH_GLM_WAVES_PER_SIMD 2
 #endif
 extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIMD)
-rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
@@ -1399,17 +1439,15 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0) *n_running = 0;
+  // live chains: slot s of the launch is chain list[s]; a workgroup column serves 16 W consecutive slots
+  const int nl = rh_live_count(nlive, chains);
   int bgroup, split;
-  if (xcd_aware && (nsplit % 8) == 0) {
-    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
-    split = xcd + 8 * (idx % spx);
-    bgroup = idx / spx;
-  } else { split = b % nsplit; bgroup = b / nsplit; }
-  const int chain0 = (bgroup * W + wave) * 16;
-  const int mychain = chain0 + li;
-  const int cl = mychain < chains ? mychain : chains - 1;
-  const bool compute = __any((mychain < chains) && (active[cl] != 0));
-  if (!__syncthreads_or(compute ? 1 : 0)) return; // no chain of this workgroup is waiting for a gradient
+  rh_grad_map(b, nsplit, xcd_aware, split, bgroup);
+  if (bgroup * W * 16 >= nl) return;               // (uniform over the workgroup: none of its slots holds a live chain)
+  const int slot0 = (bgroup * W + wave) * 16;
+  const bool mine = slot0 + li < nl;                // this lane's slot holds a live chain
+  const int cl = rh_live_chain(list, slot0 + li, nl);
+  const bool compute = slot0 < nl;                  // (a wavefront without one still stages its columns of the tile)
   // forward B operands: lane (li, lg) holds theta[chain li][pred 4 ks + lg]
   double Bf[PT];
   int acol[PT];
@@ -1433,15 +1471,14 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
   for (int k = 0; k < GL::NTHU; k++) thu[k] = q[(size_t)cl * RH_NVARS + GL::thu_param[k]];
   rh_v4d G[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ct++) G[ct] = (rh_v4d){0.0, 0.0, 0.0, 0.0};
   double oth[GL::NOTHER > 0 ? GL::NOTHER : 1];
-#pragma unroll
-  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
   int err = 0;
-
   const long long n = d.nrows[RH_GLM_TARGET];
   const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
+#pragma unroll
+  for (int ct = 0; ct < CT; ct++) G[ct] = (rh_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
   long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
   if (r0 > n) r0 = n;
   if (r1 > n) r1 = n;
@@ -1495,7 +1532,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #define RH_GLM_ELEM_UNROLL 4
 #endif
         // full tiles of a wavefront whose 16 chains all exist need no validity masks (the common case by far)
-        const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 16 <= chains);
+        const bool full = (r0 + t * 64 + 64 <= r1) && (slot0 + 16 <= nl);
         if (full) {
 #pragma unroll RH_GLM_ELEM_UNROLL
           for (int r = 0; r < 4; r++) {
@@ -1510,7 +1547,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll RH_GLM_ELEM_UNROLL
           for (int r = 0; r < 4; r++) {
             const int rrow = row0s + lg + 4 * r;
-            const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
+            const bool valid = (r0 + t * 64 + rrow < r1) && mine;
             double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
             GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
             Wv[r] = valid ? w : 0.0;
@@ -1546,224 +1583,26 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int pred = 16 * ct + lg + 4 * r;
-        if (pred < PM && mychain < chains) out[GL::pred_acc[pred < PM ? pred : 0]] = G[ct][r];
+        if (pred < PM && mine) out[GL::pred_acc[pred < PM ? pred : 0]] = G[ct][r];
       }
 #pragma unroll
     for (int k = 0; k < RV; k++) {  // fold the 4 lane groups (rows lg + 4 r) of the VALU remainder
       double v = Gv[k];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (lg == 0 && mychain < chains) out[GL::pred_acc[PM + k]] = v;
+      if (lg == 0 && mine) out[GL::pred_acc[PM + k]] = v;
     }
 #pragma unroll
     for (int k = 0; k < GL::NOTHER; k++) {
       double v = oth[k];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (lg == 0 && mychain < chains) out[GL::other_acc[k]] = v;
+      if (lg == 0 && mine) out[GL::other_acc[k]] = v;
     }
   }
   if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
 }
 #pragma clang fp contract(off)
-
-// ---- the same contractions on v_mfma_f64_4x4x4_4b_f64 ---------------------------------------------------------------------------
-// Measured on MI355X (tools/ubench/fma64_cycles mfma, profiles/r3_d_fp64_mfma): v_mfma_f64_16x16x4_f64 issues once per 105 cycles
-// and SIMD (19.4 flop/cycle/SIMD; SQ_VALU_MFMA_BUSY_CYCLES counts 64 of them busy), the four-block shape v_mfma_f64_4x4x4_4b_f64
-// once per 16.7 cycles = 30.7 flop/cycle/SIMD -- 0.96 of the vector FMA rate, 1.58x the big shape per flop.  Its lane layout
-// (tools/ubench/mfma4_layout.hip; the guide documents the 16x16x4 form only): with k = lane >> 4, block = (lane >> 2) & 3 and
-// e = lane & 3,   A[block][i = e][k],   B[block][k][j = e],   and D[block][i][j] in lane 16 i + 4 block + j.
-// Mapping used here -- block = chain block, so that a lane's chain is lane & 15 exactly as in rh_grad_glm_kernel:
-//   forward   eta[row r0 + 4 rb + i][chain]  += X[r0 + 4 rb + i][pred(k, s)] . theta[pred(k, s)][chain]      A: lane (k, *, i), one LDS read
-//             per (rb, s) that the four chain blocks share (the same address in 4 lanes: a broadcast); D[rb] lane 16 i + chain
-//   backward  G[pred(i, s)][chain]          += X[r0 + 4 rb + k][pred(i, s)] . w[r0 + 4 rb + k][chain]         B: lane 16 k + chain IS the
-//             forward D[rb] register after the scalar part -- w never moves between lanes here either
-// with pred(g, s) = S4 g + s (S4 = ceil(PM / 4) steps; predictor groups of S4, so that both contractions walk the same grouping).
-// The row tile sits in LDS ROW-major ([row][column], odd stride) because a lane now reads 4 rows x 4 predictors per step.
-// 96 instead of 24 MFMA instructions per 16 rows x 16 chains, each a quarter of the flops; 96 broadcast LDS reads instead of 24.
-#ifndef RH_GLM4
-#define RH_GLM4 1
-#endif
-#if RH_GLM4
-#if RH_FP_CONTRACT
-#pragma clang fp contract(fast)
-#endif
-extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIMD)
-rh_grad_glm4_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
-                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
-                    const int chains, const int nsplit, const int xcd_aware) {
-  rh_lk_init();
-  typedef rh_glm<RH_GLM_TARGET> GL;
-  typedef rh_target<RH_GLM_TARGET> TG;
-  constexpr int P = GL::P, NC = GL::NCOLS, W = RH_GLM_W;
-  constexpr int RV = (P % 16 != 0 && P % 16 <= 4 && P > 16) ? P % 16 : 0;   // a few left-over predictors on the VALU, as in rh_grad_glm_kernel
-  constexpr int PM = P - RV;
-  constexpr int S4 = (PM + 3) / 4;     // steps; predictor of (group g, step s) = S4 g + s
-  constexpr int ST = NC | 1;           // row stride in doubles (odd: the 64 rows of a staging store hit 64 different bank pairs)
-  constexpr int MYC = (NC + W - 1) / W;
-  constexpr int NBUF = (2 * 64 * ST * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) double rh_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lk = lane >> 4, le = lane & 3;
-  const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0) *n_running = 0;
-  int bgroup, split;
-  if (xcd_aware && (nsplit % 8) == 0) {
-    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
-    split = xcd + 8 * (idx % spx);
-    bgroup = idx / spx;
-  } else { split = b % nsplit; bgroup = b / nsplit; }
-  const int chain0 = (bgroup * W + wave) * 16;
-  const int mychain = chain0 + li;
-  const int cl = mychain < chains ? mychain : chains - 1;
-  const bool compute = __any((mychain < chains) && (active[cl] != 0));
-  if (!__syncthreads_or(compute ? 1 : 0)) return;
-  // forward B operands: lane (k = lk, chain li) holds scale * theta[chain][pred(lk, s)]; fcol / bcol: the LDS column a lane reads
-  // in step s of the forward (predictor group lk) and of the backward (predictor group le) product (-1: the constant 1, -2: none)
-  double Bf[S4];
-  int fcol[S4], bcol[S4];
-#pragma unroll
-  for (int sidx = 0; sidx < S4; sidx++) {
-    const int pf = S4 * lk + sidx, pb = S4 * le + sidx;
-    Bf[sidx] = (pf < PM) ? GL::pred_scale[pf < PM ? pf : 0] * q[(size_t)cl * RH_NVARS + GL::pred_param[pf < PM ? pf : 0]] : 0.0;
-    fcol[sidx] = (pf < PM) ? GL::pred_col[pf < PM ? pf : 0] : -2;
-    bcol[sidx] = (pb < PM) ? GL::pred_col[pb < PM ? pb : 0] : -2;
-  }
-  double thv[RV > 0 ? RV : 1], Gv[RV > 0 ? RV : 1];
-  int vcol[RV > 0 ? RV : 1];
-#pragma unroll
-  for (int k = 0; k < RV; k++) { thv[k] = GL::pred_scale[PM + k] * q[(size_t)cl * RH_NVARS + GL::pred_param[PM + k]]; vcol[k] = GL::pred_col[PM + k]; Gv[k] = 0.0; }
-  double thu[GL::NTHU > 0 ? GL::NTHU : 1];
-#pragma unroll
-  for (int k = 0; k < GL::NTHU; k++) thu[k] = q[(size_t)cl * RH_NVARS + GL::thu_param[k]];
-  double G[S4];
-#pragma unroll
-  for (int sidx = 0; sidx < S4; sidx++) G[sidx] = 0.0;
-  double oth[GL::NOTHER > 0 ? GL::NOTHER : 1];
-#pragma unroll
-  for (int k = 0; k < GL::NOTHER; k++) oth[k] = 0.0;
-  int err = 0;
-
-  const long long n = d.nrows[RH_GLM_TARGET];
-  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
-  long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
-  if (r0 > n) r0 = n;
-  if (r1 > n) r1 = n;
-  const long long ntiles = (r1 - r0 + 63) / 64;
-  double stage[MYC];
-  auto fetch = [&](long long tile) {       // wave w fetches columns w, w + W, ...; lane = row: coalesced 512 B per column
-    long long row = r0 + tile * 64 + lane;
-    if (row >= n) row = n - 1;
-#pragma unroll
-    for (int m = 0; m < MYC; m++) {
-      const int j = wave + m * W;
-      stage[m] = (j < NC && n > 0) ? d.cols[TG::COL0 + j][row] : 0.0;
-    }
-  };
-  auto park = [&](int buf) {               // ... and parks them row-major
-#pragma unroll
-    for (int m = 0; m < MYC; m++) {
-      const int j = wave + m * W;
-      if (j < NC) rh_lds[(size_t)buf * 64 * ST + (size_t)lane * ST + j] = stage[m];
-    }
-  };
-  if (ntiles > 0) { fetch(0); park(0); }
-  __syncthreads();
-  for (long long t = 0; t < ntiles; t++) {
-    const int buf = NBUF == 2 ? (int)(t & 1) : 0;
-    if (t + 1 < ntiles) fetch(t + 1);
-    if (compute) {
-      const double *tile = rh_lds + (size_t)buf * 64 * ST;
-#pragma unroll 1
-      for (int sub = 0; sub < 4; sub++) {
-        const int row0s = sub * 16;
-        double D[4] = {0.0, 0.0, 0.0, 0.0};
-        // forward: step outermost, the four row blocks are four independent accumulators
-#pragma unroll
-        for (int sidx = 0; sidx < S4; sidx++)
-#pragma unroll
-          for (int rb = 0; rb < 4; rb++) {
-            const double a = fcol[sidx] >= 0 ? tile[(row0s + 4 * rb + le) * ST + fcol[sidx]] : (fcol[sidx] == -1 ? 1.0 : 0.0);
-            D[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Bf[sidx], D[rb], 0, 0, 0);
-          }
-        // this lane's rows: row0s + 4 rb + lk
-        double xv[RV > 0 ? RV : 1][4];
-#pragma unroll
-        for (int k = 0; k < RV; k++)
-#pragma unroll
-          for (int rb = 0; rb < 4; rb++) {
-            xv[k][rb] = vcol[k] >= 0 ? tile[(row0s + 4 * rb + lk) * ST + vcol[k]] : 1.0;
-            D[rb] += thv[k] * xv[k][rb];
-          }
-        double Wv[4];
-        const bool full = (r0 + t * 64 + 64 <= r1) && (chain0 + 16 <= chains);
-        if (full) {
-#pragma unroll RH_GLM_ELEM_UNROLL
-          for (int rb = 0; rb < 4; rb++) {
-            const int rrow = row0s + 4 * rb + lk;
-            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-            GL::elem(thu, D[rb], [&](int j) { return tile[rrow * ST + j]; }, w, o, err);
-            Wv[rb] = w;
-#pragma unroll
-            for (int k = 0; k < GL::NOTHER; k++) oth[k] += o[k];
-          }
-        } else {
-#pragma unroll RH_GLM_ELEM_UNROLL
-          for (int rb = 0; rb < 4; rb++) {
-            const int rrow = row0s + 4 * rb + lk;
-            const bool valid = (r0 + t * 64 + rrow < r1) && (mychain < chains);
-            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-            GL::elem(thu, D[rb], [&](int j) { return tile[rrow * ST + j]; }, w, o, err);
-            Wv[rb] = valid ? w : 0.0;
-#pragma unroll
-            for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < RV; k++)
-#pragma unroll
-          for (int rb = 0; rb < 4; rb++) Gv[k] += xv[k][rb] * Wv[rb];
-        // backward: row block outermost, so that consecutive MFMAs write different accumulators
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-          for (int sidx = 0; sidx < S4; sidx++) {
-            const double a = bcol[sidx] >= 0 ? tile[(row0s + 4 * rb + lk) * ST + bcol[sidx]] : (bcol[sidx] == -1 ? 1.0 : 0.0);
-            G[sidx] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, Wv[rb], G[sidx], 0, 0, 0);
-          }
-      }
-    }
-    if (NBUF == 1) __syncthreads();
-    if (t + 1 < ntiles) park(NBUF == 2 ? (buf ^ 1) : 0);
-    __syncthreads();
-  }
-  if (compute) {
-    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cl) * RH_NACC_MAX;
-    // G[s] at lane 16 i + chain = sum over the rows of x[pred(i, s)] * w for that chain
-#pragma unroll
-    for (int sidx = 0; sidx < S4; sidx++) {
-      const int pred = S4 * lk + sidx;
-      if (pred < PM && mychain < chains) out[GL::pred_acc[pred < PM ? pred : 0]] = G[sidx];
-    }
-#pragma unroll
-    for (int k = 0; k < RV; k++) {  // the VALU remainder and the other sums: fold the 4 lane groups (rows lk + 4 rb)
-      double v = Gv[k];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lk == 0 && mychain < chains) out[GL::pred_acc[PM + k]] = v;
-    }
-#pragma unroll
-    for (int k = 0; k < GL::NOTHER; k++) {
-      double v = oth[k];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lk == 0 && mychain < chains) out[GL::other_acc[k]] = v;
-    }
-  }
-  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
-}
-#pragma clang fp contract(off)
-#endif  // RH_GLM4
 
 // ---- narrow GLMs (P <= 8 predictors): forward on the matrix cores, backward on the VALU ---------------------------
 // With few predictors the backward contraction would fill only P of the 16 MFMA output rows, so only
@@ -1829,7 +1668,7 @@ RH_DEV void rh_glms_tile(const double *tile, const long long rows_left, const in
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active,
+rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
                     double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                     const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
@@ -1840,15 +1679,12 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0;
+  const int nl = rh_live_count(nlive, chains);
   int group, split;
-  if (xcd_aware && (nsplit % 8) == 0) {
-    const int xcd = b & 7, idx = b >> 3, spx = nsplit >> 3;
-    split = xcd + 8 * (idx % spx);
-    group = idx / spx;
-  } else { split = b % nsplit; group = b / nsplit; }
-  const int chain0 = group * 16 * CTN;
-  if (chain0 >= chains) return;
-  bool cvalid[CTN], any = false;
+  rh_grad_map(b, nsplit, xcd_aware, split, group);
+  const int slot0 = group * 16 * CTN;
+  if (slot0 >= nl) return;
+  bool cvalid[CTN];
   int cl[CTN];
   double Bf[CTN][PT], thu[CTN][GL::NTHU > 0 ? GL::NTHU : 1];
   int acol[PT];
@@ -1856,10 +1692,8 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
   for (int ks = 0; ks < PT; ks++) { const int pred = 4 * ks + lg; acol[ks] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2; }
 #pragma unroll
   for (int t = 0; t < CTN; t++) {
-    const int c = chain0 + 16 * t + li;
-    cvalid[t] = c < chains;
-    cl[t] = cvalid[t] ? c : chains - 1;
-    any = any || (cvalid[t] && active[cl[t]] != 0);
+    cvalid[t] = slot0 + 16 * t + li < nl;
+    cl[t] = rh_live_chain(list, slot0 + 16 * t + li, nl);
 #pragma unroll
     for (int ks = 0; ks < PT; ks++) {
       const int pred = 4 * ks + lg;
@@ -1868,8 +1702,10 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
 #pragma unroll
     for (int k = 0; k < GL::NTHU; k++) thu[t][k] = q[(size_t)cl[t] * RH_NVARS + GL::thu_param[k]];
   }
-  if (!__any(any)) return;
   double accp[CTN][P], acco[CTN][GL::NOTHER > 0 ? GL::NOTHER : 1];
+  int err = 0;
+  const long long n = d.nrows[RH_GLM_TARGET];
+  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
 #pragma unroll
   for (int t = 0; t < CTN; t++) {
 #pragma unroll
@@ -1877,9 +1713,6 @@ rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const i
 #pragma unroll
     for (int k = 0; k < GL::NOTHER; k++) acco[t][k] = 0.0;
   }
-  int err = 0;
-  const long long n = d.nrows[RH_GLM_TARGET];
-  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
   long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
   if (r0 > n) r0 = n;
   if (r1 > n) r1 = n;
@@ -2043,7 +1876,7 @@ RH_DEV int rh_gu_oz() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return
 template <int T, class TH, class INV, int NC, int NA>
 RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const double *const (&cp)[NC], double (&acc)[RH_GRAD_K][NA],
                              const rh_gather_data &gd, const double *__restrict__ q, const int lane, const int g0, const int g1,
-                             const int r0, const int r1, const int chain0, const int chains, int &err) {
+                             const int r0, const int r1, const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K], int &err) {
   typedef rh_target<T> TG;
   constexpr int K = RH_GRAD_K, NI = TG::NINV > 0 ? TG::NINV : 1;
   typedef const double __attribute__((address_space(1))) *gcol_t;
@@ -2058,12 +1891,17 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
   size_t qoff[K];
 #pragma unroll
   for (int kk = 0; kk < K; kk++) {
-    qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+    qoff[kk] = (size_t)cid[kk] * RH_NVARS + TG::G_FIRST;
 #pragma unroll
     for (int i = 0; i < RH_NTH; i++) gu[RH_GU_TH + kk * RH_NTH + i] = th[kk][i];
 #pragma unroll
     for (int i = 0; i < (TG::NINV > 0 ? TG::NINV : 0); i++) gu[RH_GU_INV + kk * NI + i] = inv[kk][i];
   }
+  // the chain whose group sums end up in this lane (rh_wave_sum_split: the lanes whose top log2 K lane bits spell kk hold sum kk)
+  int cmine = cid[0];
+  bool okmine = cok[0];
+#pragma unroll
+  for (int kk = 1; kk < K; kk++) { const bool me = lane / (64 / K) == kk; cmine = me ? cid[kk] : cmine; okmine = me ? cok[kk] : okmine; }
   // A = the open group, B = the next non-empty group of this split (g1 = none); all wave-uniform
   int gA = g0, gB = g1, endA = r1;
   double accA[K], accB[K];
@@ -2123,7 +1961,8 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
       if (endA <= tend) {
         int mine;
         const double sum = rh_wave_sum_split(accA, lane, mine);
-        if ((lane & (64 / K - 1)) == 0 && chain0 + mine < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + mine) * TG::G_COUNT + gA] = sum;
+        (void)mine;
+        if ((lane & (64 / K - 1)) == 0 && okmine) gd.sbuf[TG::ROWT][(size_t)cmine * TG::G_COUNT + gA] = sum;
         gA = gB;
         endA = gA < g1 ? go[gA + 1] : 0x7fffffff;
         if (gB < g1) gB++;
@@ -2169,7 +2008,8 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
 template <int T>
 RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
                               const double *__restrict__ q, const int lane, const int split, const int nsplit,
-                              const int chain0, const int chains, double *__restrict__ partial, int &err) {
+                              const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K], const int chains, double *gu_lds,
+                              double *__restrict__ partial, int &err) {
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (TG::HAS_ROWS) {
@@ -2197,11 +2037,10 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
       const int r0 = goff[g0], r1 = goff[g1];
       size_t qoff[K];
 #pragma unroll
-      for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)((chain0 + kk < chains) ? chain0 + kk : chains - 1) * RH_NVARS + TG::G_FIRST;
+      for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)cid[kk] * RH_NVARS + TG::G_FIRST;
 #if RH_GATHER_V2
       if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
-        __shared__ double rh_gu[RH_GU_SIZE];
-        rh_gather_walk_a<T>(rh_gu, th, inv, cp, acc, gd, q, lane, g0, g1, r0, r1, chain0, chains, err);
+        rh_gather_walk_a<T>(gu_lds, th, inv, cp, acc, gd, q, lane, g0, g1, r0, r1, cid, cok, err);
       } else
 #endif
       if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
@@ -2217,7 +2056,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
           rh_wave_sum_all(accA);
 #pragma unroll
           for (int kk = 0; kk < K; kk++)
-            if (lane == 0 && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + gdone] = accA[kk];
+            if (lane == 0 && cok[kk]) gd.sbuf[TG::ROWT][(size_t)cid[kk] * TG::G_COUNT + gdone] = accA[kk];
         };
         // (A software-pipelined walk -- index column two tiles ahead, the other columns and the table entries one ahead -- was
         //  measured in round 3: 162 VGPRs = three wavefronts per SIMD instead of four, 3.37 ms against 3.16-3.21 ms for cfg 5.  The
@@ -2289,7 +2128,7 @@ RH_UNROLL_ACC
           for (int kk = 0; kk < K; kk++) {
             double v = rh_segmented_scan(sv[kk], start, lane);
             v += (start < 0) ? carry[kk] : 0.0;               // the group that was open at the end of the previous tile
-            if (tail && chain0 + kk < chains) gd.sbuf[TG::ROWT][(size_t)(chain0 + kk) * TG::G_COUNT + g] = v;
+            if (tail && cok[kk]) gd.sbuf[TG::ROWT][(size_t)cid[kk] * TG::G_COUNT + g] = v;
             carry[kk] = last_open ? rh_readlane(v, last) : 0.0;
           }
         }
@@ -2298,14 +2137,14 @@ RH_UNROLL_ACC
 #pragma unroll
       for (int kk = 0; kk < K; kk++) {
         rh_wave_sum_all(acc[kk]);
-        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + (chain0 + kk)) * RH_NACC_MAX;
-        if (lane == 0 && chain0 + kk < chains) {
+        double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cid[kk]) * RH_NACC_MAX;
+        if (lane == 0 && cok[kk]) {
 #pragma unroll
           for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
         }
       }
     }
-    rh_gather_targets<T + 1>(th, d, gd, q, lane, split, nsplit, chain0, chains, partial, err);
+    rh_gather_targets<T + 1>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu_lds, partial, err);
   }
 }
 #pragma clang fp contract(off)
@@ -2315,27 +2154,34 @@ RH_UNROLL_ACC
 #endif
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GATHER_WAVES)))
 rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
-                      const int *__restrict__ active, double *__restrict__ partial, int *__restrict__ err_out,
+                      const int *__restrict__ list, const int *__restrict__ nlive, double *__restrict__ partial, int *__restrict__ err_out,
                       int *__restrict__ n_running, const int chains, const int nsplit) {
   rh_lk_init();
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0;
+  const int nl = rh_live_count(nlive, chains);
   const int split = b % nsplit, group = b / nsplit;
-  const int chain0 = group * RH_GRAD_K;
-  if (chain0 >= chains) return;
-  bool any = false;
+  if (group * RH_GRAD_K >= nl) return;
+  int cid[RH_GRAD_K];
+  bool cok[RH_GRAD_K];
   double th[RH_GRAD_K][RH_NTH];
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
-    const int c = (chain0 + kk < chains) ? chain0 + kk : chains - 1;
-    any = any || (active[c] != 0);
+    cok[kk] = group * RH_GRAD_K + kk < nl;
+    cid[kk] = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
 #pragma unroll
-    for (int i = 0; i < RH_NTH; i++) th[kk][i] = q[(size_t)c * RH_NVARS + i];
+    for (int i = 0; i < RH_NTH; i++) th[kk][i] = q[(size_t)cid[kk] * RH_NVARS + i];
   }
-  if (!any) return;
+  // the walk's wave-uniform operands (ONE buffer for every target's walk: they run one after the other)
+#if RH_GATHER_V2
+  __shared__ double rh_gu[RH_GU_SIZE];
+  double *const gu = rh_gu;
+#else
+  double *const gu = nullptr;
+#endif
   int err = 0;
-  rh_gather_targets<0>(th, d, gd, q, lane, split, nsplit, chain0, chains, partial, err);
+  rh_gather_targets<0>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu, partial, err);
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 #endif  // RH_HAS_GATHER
@@ -2553,11 +2399,12 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
 // launch was a plain one and the state image is current), partial_in = its partial sums.
 RH_DEV void rh_fused_prologue(double (&thk)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const double *__restrict__ q,
                               const rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec_in, rh_u64 *__restrict__ rec_out, const double *__restrict__ partial_in,
-                              const int chains, const int nsplit, const int chain0, const int lane, const bool writer) {
+                              const int chains, const int nsplit, const int *__restrict__ list, const int slot0, const int nl,
+                              const int lane, const bool writer) {
   constexpr int LPC = 64 / RH_GRAD_K;
   const int kk = lane / LPC, j = lane & (LPC - 1), base = lane & ~(LPC - 1);
-  const bool exists = chain0 + kk < chains;
-  const int chain = exists ? chain0 + kk : chains - 1;
+  const bool exists = slot0 + kk < nl;
+  const int chain = rh_live_chain(list, slot0 + kk, nl);
   const rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
   const rh_u64 *sc = st + (size_t)(RH_STATE_DENSE_OFF + RH_STATE_NDENSE) * 64;
   const bool live = j < RH_NVARS;
@@ -2638,28 +2485,23 @@ RH_DEV void rh_fused_prologue(double (&thk)[RH_GRAD_K][RH_NTH], const rh_model_d
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
-rh_grad_fused_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ active, const double *__restrict__ partial_in,
-                     double *__restrict__ partial_out, int *__restrict__ err_out, int *__restrict__ n_running,
+rh_grad_fused_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
+                     const double *__restrict__ partial_in, double *__restrict__ partial_out, int *__restrict__ err_out, int *__restrict__ n_running,
                      const rh_u64 *__restrict__ state, const rh_u64 *__restrict__ rec_in, rh_u64 *__restrict__ rec_out,
                      const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
   const int lane = threadIdx.x, b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0;
+  // (every listed chain waits for a gradient, and the list does not change between the launches of a trajectory: each launch writes
+  //  the record of every chain the next one reads)
+  const int nl = rh_live_count(nlive, chains);
   int split, group;
   rh_grad_map(b, nsplit, xcd_aware, split, group);
-  const int chain0 = group * RH_GRAD_K;
-  if (chain0 >= chains) return;
-  bool any = false;
-#pragma unroll
-  for (int kk = 0; kk < RH_GRAD_K; kk++) any = any || (active[(chain0 + kk < chains) ? chain0 + kk : chains - 1] != 0);
-  if (!any) {   // nothing of this group is advanced by this launch: its records must not look as if something had been
-    if (split == 0 && lane < RH_GRAD_K && chain0 + lane < chains) rec_out[(size_t)(chain0 + lane) * RH_REC_U64 + RH_REC_VALID] = 0;
-    return;
-  }
+  if (group * RH_GRAD_K >= nl) return;
   double th[RH_GRAD_K][RH_NTH];
-  rh_fused_prologue(th, d, q, state, rec_in, rec_out, partial_in, chains, nsplit, chain0, lane, split == 0);
+  rh_fused_prologue(th, d, q, state, rec_in, rec_out, partial_in, chains, nsplit, list, group * RH_GRAD_K, nl, lane, split == 0);
   int err = 0;
-  rh_grad_targets<0, false>(th, d, lane, split, nsplit, chain0, chains, partial_out, err);
+  rh_grad_targets<0, false>(th, d, lane, split, nsplit, list + group * RH_GRAD_K, nl - group * RH_GRAD_K, chains, partial_out, err);
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 
@@ -2703,10 +2545,17 @@ rh_tick_kernel(const rh_model_data d,
                const double *__restrict__ static_mass, double *__restrict__ draws,
                rh_chain_stats_dev *__restrict__ stats, int *__restrict__ n_running, double *__restrict__ qbuf,
                int *__restrict__ active, const double *__restrict__ partial, const int *__restrict__ grad_err,
+               const int *__restrict__ list, const int *__restrict__ nlive,
                const int chains, const int nsplit, const int it_stop, const int fresh) {
-  const int chain = blockIdx.x;
+  // one wavefront per chain of the gradient launch this tick follows (list: rh_compact_kernel's, see "live chains" above); the
+  // first tick of a call (list == nullptr) visits every chain -- a paused one resumes there, and nothing else ever re-lists it
+  int chain = blockIdx.x;
   const int lane = threadIdx.x;
   if (chain >= chains) return;
+  if (list) {
+    if (chain >= __builtin_amdgcn_readfirstlane(*nlive)) return;
+    chain = __builtin_amdgcn_readfirstlane(list[chain]);
+  }
   rh_u64 *st = state + (size_t)chain * RH_STATE_U64;
 #if RH_TICK_FAST && !RH_BIGN && !RH_WITH_DENSE && !RH_HAS_GATHER && RH_PACK_L == 64
   // Fast path for the tick that follows a mid-trajectory gradient (all but one of the L ticks of an HMC / EHMC trajectory):

@@ -42,10 +42,6 @@ static const char *kPreludeSrc =
 static const char *kEngineSrc =
 #include "gen/rh_engine.inc"
     ;
-static const char *kGlm4rSrc =   // appended for models with a dense GLM target only (rh_grad_glm4r_kernel)
-#include "gen/rh_glm4r.inc"
-    ;
-
 namespace {
 thread_local std::string g_err;
 std::atomic<long> g_compiles{0};   // hiprtc compilations of this process (cache misses): rh_compile_count
@@ -164,12 +160,10 @@ struct rh_model {
   hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
   hipFunction_t k_grad_fused = nullptr;  // rh_grad_kernel + the mid-trajectory leapfrog update as its prologue (static HMC); absent when the model does not qualify
   hipFunction_t k_absorb = nullptr;      // the fused launches' per-chain records -> state image, before the tick that ends a trajectory
+  hipFunction_t k_compact = nullptr;     // active flags -> ascending list of the chains that wait for a gradient (rh_compact_kernel)
   int grad_w = 8, ncols_max = 0, glm_ncols = 0;
   bool use_lds_grad = false;
   hipFunction_t k_grad_glm = nullptr;
-  bool glm4 = false;       // k_grad_glm is rh_grad_glm4_kernel (v_mfma_f64_4x4x4_4b_f64, row-major LDS tile)
-  bool glm4r = false;      // k_grad_glm is rh_grad_glm4r_kernel (the four-block shape with blocks = row groups; device/rh_glm4r.hip.h)
-  int glm4r_lds = 0, glm4r_w = 4, glm4r_cw = 16;   // its dynamic LDS, wavefronts per workgroup and chains per wavefront, read back from the module
   bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
   int glms_ct = 4;
@@ -220,10 +214,17 @@ struct rh_sampler {
   bool started = false, warmed = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   double kernel_ms = 0, total_ms = 0;
+  // live-chain accounting of the tick engine's gradient launches (rh_timing.chain_slots / steady_*)
+  int64_t chain_slots = 0, steady_launches = 0, steady_evals = 0;
+  double steady_ms = 0;
+  int cur_live = 0;                // chains in the list the next gradient launch serves
+  void *d_livelog = nullptr;       // [257] live counts logged by rh_compact_kernel, one per tick of a batch (+ the call's first tick)
   int64_t launches = 0;
   // tick engine
   bool tick_engine = false;
   int nsplit = 0, xcd_aware = 1;
+  bool compact = true;             // gradient launches and ticks serve the listed (live) chains only
+  void *d_list = nullptr, *d_nlive = nullptr;
   void *d_qbuf = nullptr, *d_active = nullptr, *d_partial = nullptr, *d_graderr = nullptr;
   void *d_partial2 = nullptr, *d_rec[2] = {nullptr, nullptr};  // fused launches: the second partial-sum buffer and the two record buffers (alternating)
   int pp = 0;                                                   // which of the two the next launch writes
@@ -340,8 +341,6 @@ void assemble_source(rh_model *m) {
   if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = std::max(1, std::atoi(e));
   defines += "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
-  if (const char *e = std::getenv("RH_GLM4R_JG")) defines += "#define RH_GLM4R_JG " + std::to_string(std::atoi(e) >= 4 ? 4 : (std::atoi(e) >= 2 ? 2 : 1)) + "\n";
-  if (const char *e = std::getenv("RH_GLM4R_W")) defines += "#define RH_GLM4R_W " + std::to_string(std::max(1, std::min(16, std::atoi(e)))) + "\n";
   if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
   if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
@@ -360,7 +359,6 @@ void assemble_source(rh_model *m) {
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
               "\n" + kPreludeSrc + "\n// ---- generated from RIR -------------------------------------------\n" + targets + "\n" +
               kEngineSrc;
-  if (m->has_glm && !m->glm_small) m->source += std::string("\n") + kGlm4rSrc;
 }
 
 // Which compiler hiprtc dispatches to is a property of the PROCESS, not of the hiprtc version number: a process that imported
@@ -612,6 +610,7 @@ void load_module(rh_model *m) {
     m->k_absorb = fit_kernel(m->code, m->module, "rh_absorb_kernel");
     if (!m->k_absorb) m->k_grad_fused = nullptr;
   }
+  if (m->n_row_targets > 0) m->k_compact = fit_kernel(m->code, m->module, "rh_compact_kernel");   // (unfit: every launch serves every chain)
   m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
   for (auto &T : m->prog.targets) m->ncols_max = std::max<int>(m->ncols_max, (int)T.n_cols);
@@ -624,41 +623,11 @@ void load_module(rh_model *m) {
   if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
     m->k_grad_glm = fit_kernel(m->code, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel");   // (unfit: the plain VALU kernel)
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
-  // The four-block MFMA shape issues at 0.96 of the vector FMA rate, the 16x16x4 shape at 0.61 (profiles/r3_d_fp64_mfma), but it
-  // carries a quarter of the flops per operand: the kernel written for it (rh_grad_glm4_kernel) needs 96 LDS operand reads per
-  // 16 rows x 16 chains instead of 24 and is LDS-latency-bound with the two wavefronts per SIMD its registers allow -- measured
-  // 24.9 vs 17.6 ms per cfg-4 gradient (profiles/r3_cfg4).  It is correct (the parity tests ran on it) and stays opt-in: RH_GLM4=1.
-  m->glm4 = false;
-  if (m->k_grad_glm && !m->glm_small) {
-    bool want = false;
-    if (const char *e = std::getenv("RH_GLM4")) want = std::atoi(e) != 0;
-    hipFunction_t f4 = want ? fit_kernel(m->code, m->module, "rh_grad_glm4_kernel") : nullptr;
-    if (f4) { m->k_grad_glm = f4; m->glm4 = true; }
-  }
-  // Round 5: the four-block shape with its blocks as ROW groups (rh_grad_glm4r_kernel): one LDS operand read feeds four MFMAs, as with
-  // the big shape, at the four-block shape's issue rate; one wavefront per SIMD (208 registers of operands and accumulators at 51
-  // predictors).  Opt-in (RH_GLM4R=1) until measured.
-  m->glm4r = false;
-  if (m->k_grad_glm && !m->glm_small && !m->glm4) {
-    bool want = false;
-    if (const char *e = std::getenv("RH_GLM4R")) want = std::atoi(e) != 0;
-    hipFunction_t fr = want ? fit_kernel(m->code, m->module, "rh_grad_glm4r_kernel") : nullptr;
-    if (fr) {
-      hipDeviceptr_t p; size_t sz;
-      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_lds_bytes"));
-      HIPCHK(hipMemcpy(&m->glm4r_lds, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
-      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_waves"));
-      HIPCHK(hipMemcpy(&m->glm4r_w, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
-      HIPCHK(hipModuleGetGlobal(&p, &sz, m->module, "rh_glm4r_chains_per_wave"));
-      HIPCHK(hipMemcpy(&m->glm4r_cw, (void *)p, sizeof(int), hipMemcpyDeviceToHost));
-      if ((size_t)m->glm4r_lds + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u) { m->k_grad_glm = fr; m->glm4r = true; }
-    }
-  }
   // (Round 3 also measured the contractions OFF the matrix pipe -- one chain per lane, row values scalar-loaded as SGPR operands,
   //  162 VALU instructions per 64 evaluations: 33.9 vs 17.5 ms, bound by scalar-load latency; git 28d5e00, profiles/r3_cfg4.)
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
-  {  // one 64-row tile of all columns must fit the CU's LDS (column-major stride 66 | row-major odd stride)
-    const size_t tile = m->glm4 ? (size_t)64 * ((size_t)m->glm_ncols | 1u) * sizeof(double) : (size_t)m->glm_ncols * 66u * sizeof(double);
+  {  // (column-major, stride 66)
+    const size_t tile = (size_t)m->glm_ncols * 66u * sizeof(double);
     if (!m->glm_small && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   }
   if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
@@ -1477,11 +1446,6 @@ int default_nsplit(const rh_model *m, int chains) {
   if (const char *e = std::getenv("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
   if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
-  if (m->k_grad_glm && m->glm4r) {   // one round of workgroups at the kernel's wavefronts per SIMD (2 below sixteen chains per wavefront, else 1)
-    const int cols = ((chains + m->glm4r_cw - 1) / m->glm4r_cw + m->glm4r_w - 1) / m->glm4r_w;
-    const int wgs = 1024 * (m->glm4r_cw >= 16 ? 1 : 2) / m->glm4r_w;
-    nsplit = (int)std::max<int64_t>(1, (wgs + cols - 1) / cols);
-  }
   if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
   nsplit = ((nsplit + 7) / 8) * 8;
   const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);
@@ -1489,28 +1453,25 @@ int default_nsplit(const rh_model *m, int chains) {
 }
 
 // one batched gradient launch of the tick engine: whichever row-streaming kernel the model was lowered to
-// (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial
-void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_active, void *d_partial, void *d_graderr, void *d_running,
+// (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial.
+// The grid covers every chain; with a list (d_list / d_nlive; nullptr = all `chains`) slot s of the launch is chain list[s] and the
+// workgroups of the slots past the live count -- the last of the grid -- return at once.
+void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_list, void *d_nlive, void *d_partial, void *d_graderr, void *d_running,
                  int chains, int nsplit, int xcd) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   if (m->info.gather_mode) {
-    void *ga[] = {&m->data, &gb->gd, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
+    void *ga[] = {&m->data, &gb->gd, &d_q, &d_list, &d_nlive, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
     launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
     return;
   }
-  void *args[] = {&m->data, &d_q, &d_active, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
+  void *args[] = {&m->data, &d_q, &d_list, &d_nlive, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
   if (m->k_grad_glm && m->glm_small) {
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
     launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
-  } else if (m->k_grad_glm && m->glm4r) {
-    const int ctiles = (chains + m->glm4r_cw - 1) / m->glm4r_cw;
-    const unsigned blocks = (unsigned)(((ctiles + m->glm4r_w - 1) / m->glm4r_w) * nsplit);
-    HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm4r_w, 1, 1, (unsigned)m->glm4r_lds, m->stream, args, nullptr));
   } else if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
-    const unsigned tile = m->glm4 ? 64u * ((unsigned)m->glm_ncols | 1u) * (unsigned)sizeof(double)
-                                  : (unsigned)m->glm_ncols * 66u * (unsigned)sizeof(double);  // the kernels' NBUF rule: two tiles while they fit
+    const unsigned tile = (unsigned)m->glm_ncols * 66u * (unsigned)sizeof(double);  // the kernel's NBUF rule: two tiles while they fit
     const unsigned lds = (2u * tile + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else if (m->use_lds_grad) {
@@ -1559,13 +1520,15 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       GatherBufs gb;
       if (m->info.gather_mode) gb.build(m, chains, nsplit);
       const size_t pbytes = sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max;
-      DevBuf bact(sizeof(int) * chains), bpart(pbytes), brun(sizeof(int));
-      std::vector<int> ones((size_t)chains, 1);
-      HIPCHK(hipMemcpyAsync(bact.p, ones.data(), sizeof(int) * chains, hipMemcpyHostToDevice, m->stream));
+      DevBuf bpart(pbytes), brun(sizeof(int)), blist(sizeof(int) * chains);
+      { std::vector<int> ident((size_t)chains);   // every chain is served: the identity list
+        for (int c = 0; c < chains; c++) ident[(size_t)c] = c;
+        HIPCHK(hipMemcpyAsync(blist.p, ident.data(), sizeof(int) * chains, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream)); }
       HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
       int xcd = 1;
       if (const char *e = std::getenv("RH_XCD_AWARE")) xcd = std::atoi(e);
-      launch_grad(m, &gb, dq, bact.p, bpart.p, de, brun.p, chains, nsplit, xcd);
+      launch_grad(m, &gb, dq, blist.p, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
         void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit, &dtot};
@@ -1783,8 +1746,30 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
     if (s->tick_engine) {
       int nsplit = cfg->grad_splits;
       if (nsplit <= 0) nsplit = default_nsplit(m, chains);
+      // The dynamic samplers' trajectories end at different launches (EHMC: DefaultConfig's, sampler/Sampler.scala:17-27; NUTS:
+      // BASELINE's): their launches serve the LISTED chains only (rh_compact_kernel), and the rows are cut into 8 x as many, shorter
+      // splits as a lock-step launch needs, so that a launch with few live chains still spreads over the machine (as long as a
+      // split keeps >= 1024 rows).  Static HMC runs in lock step -- every launch serves every chain -- and keeps the count it had.
+      // A function of the sampler and the model only: a chain's sums do not depend on how many chains there are, are live, or
+      // share the device (rh_sample_multi fixes grad_splits from the total chain count).
+      int subf = cfg->sampler == RH_SAMPLER_HMC ? 1 : 8;
+      if (const char *e = std::getenv("RH_SUBF")) { subf = 1; while (subf * 2 <= std::atoi(e) && subf < 64) subf *= 2; }
+      if (const char *e = std::getenv("RH_COMPACT")) s->compact = std::atoi(e) != 0;
+      { int64_t max_rows = 1;
+        for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
+        while (subf > 1 && max_rows / ((int64_t)nsplit * subf) < 1024) subf >>= 1; }
+      if (!m->k_compact) s->compact = false;
+      nsplit *= subf;
       if (nsplit > 65536) throw Fail{RH_E_INVALID, "grad_splits too large"};
       s->nsplit = nsplit;
+      HIPCHK(hipMalloc(&s->d_list, sizeof(int) * chains));
+      HIPCHK(hipMalloc(&s->d_nlive, sizeof(int)));
+      HIPCHK(hipMalloc(&s->d_livelog, sizeof(int) * 257));
+      HIPCHK(hipMemset(s->d_livelog, 0, sizeof(int) * 257));
+      { std::vector<int> ident((size_t)chains);   // (the list of a sampler that does not compact: every chain, every launch)
+        for (int c = 0; c < chains; c++) ident[(size_t)c] = c;
+        HIPCHK(hipMemcpy(s->d_list, ident.data(), sizeof(int) * chains, hipMemcpyHostToDevice)); }
+      HIPCHK(hipMemset(s->d_nlive, 0, sizeof(int)));
       if (const char *e = std::getenv("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
       HIPCHK(hipMalloc(&s->d_qbuf, sizeof(double) * n * chains));
       HIPCHK(hipMalloc(&s->d_active, sizeof(int) * chains));
@@ -1824,7 +1809,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
 extern "C" void rh_sampler_destroy(rh_sampler *s) {
   if (!s) return;
   if (s->m) hipSetDevice(s->m->device);
-  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_partial2, s->d_rec[0], s->d_rec[1]})
+  for (void *p : {s->d_state, s->d_seeds, s->d_mass, s->d_draws, s->d_stats, s->d_running, s->d_qbuf, s->d_active, s->d_partial, s->d_graderr, s->d_partial2, s->d_rec[0], s->d_rec[1],
+                  s->d_list, s->d_nlive, s->d_livelog})
     if (p) hipFree(p);
   for (hipEvent_t e : s->ev) hipEventDestroy(e);
   delete s->gb;
@@ -1834,28 +1820,37 @@ extern "C" void rh_sampler_destroy(rh_sampler *s) {
 }
 
 namespace {
-// tick engine: [tick] then repeat { [grad] [tick] } until no chain asks for a gradient any more.
+// tick engine: [tick, all chains] [compact] then repeat { [grad] [tick] [compact] } until no chain asks for a gradient any more.
+// rh_compact_kernel lists the chains whose tick asked for a gradient; the gradient launch and the tick behind it serve exactly those.
 void advance_to_ticks(rh_sampler *s, int it_stop) {
   rh_model *m = s->m;
   HIPCHK(hipSetDevice(m->device));
   int chains = s->chains, nsplit = s->nsplit, stop = it_stop, xcd = s->xcd_aware;
   void *pbuf[2] = {s->d_partial, s->d_partial2};
-  auto tick = [&](int fresh, bool reset_counter, void *partial) {
+  void *no_list = nullptr;
+  void *live_list = s->d_list, *live_n = s->compact ? s->d_nlive : nullptr;   // (without compaction d_list stays the identity)
+  auto tick = [&](int fresh, bool reset_counter, void *partial, bool listed, int log_slot) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
+    void *lst = listed && s->compact ? live_list : no_list, *nl = listed && s->compact ? live_n : no_list;
     if (m->info.gather_mode) {
       void *args[] = {&m->data, &s->gb->gd, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
-                      &s->d_active, &partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
+                      &s->d_active, &partial, &s->d_graderr, &lst, &nl, &chains, &nsplit, &stop, &fresh};
       launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
-      return;
+    } else {
+      void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
+                      &s->d_active, &partial, &s->d_graderr, &lst, &nl, &chains, &nsplit, &stop, &fresh};
+      launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
     }
-    void *args[] = {&m->data, &s->cfg, &s->d_state, &s->d_seeds, &s->d_mass, &s->d_draws, &s->d_stats, &s->d_running, &s->d_qbuf,
-                    &s->d_active, &partial, &s->d_graderr, &chains, &nsplit, &stop, &fresh};
-    launch(s->k_tick, (unsigned)chains, 64, m->stream, args);
+    if (s->compact) {
+      void *lg = (int *)s->d_livelog + log_slot;
+      void *ca[] = {&s->d_active, &s->d_list, &s->d_nlive, &lg, &chains};
+      launch(m->k_compact, 1u, 1024, m->stream, ca);
+    }
   };
-  auto grad = [&](void *partial) { launch_grad(m, s->gb, s->d_qbuf, s->d_active, partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
+  auto grad = [&](void *partial) { launch_grad(m, s->gb, s->d_qbuf, live_list, live_n, partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
   // gradient at the point the PREVIOUS launch's gradient moves every chain to (rh_fused_prologue); no tick between the two
   auto grad_fused = [&](void *partial_in, void *partial_out, void *rec_in, void *rec_out) {
-    void *args[] = {&m->data, &s->d_qbuf, &s->d_active, &partial_in, &partial_out, &s->d_graderr, &s->d_running, &s->d_state, &rec_in, &rec_out,
+    void *args[] = {&m->data, &s->d_qbuf, &live_list, &live_n, &partial_in, &partial_out, &s->d_graderr, &s->d_running, &s->d_state, &rec_in, &rec_out,
                     &chains, &nsplit, &xcd};
     launch(m->k_grad_fused, (unsigned)(((chains + m->grad_k - 1) / m->grad_k) * nsplit), 64, m->stream, args);
   };
@@ -1876,13 +1871,17 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
     remaining_hint = std::max(1, iters * std::max(1, s->cfg.hmc_steps));
   }
   HIPCHK(hipEventRecord(s->e0, m->stream));
-  tick(s->started ? 0 : 1, true, s->d_partial);
+  tick(s->started ? 0 : 1, true, s->d_partial, false, 256);
   s->started = true;
   HIPCHK(hipEventRecord(s->e1, m->stream));
-  for (;;) {
+  std::vector<int> livelog(257, 0);
+  std::vector<char> was_ticked(256, 0);
+  for (bool first = true;; first = false) {
     int running = 0;
     HIPCHK(hipMemcpyAsync(&running, s->d_running, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (first && s->compact) HIPCHK(hipMemcpyAsync(&s->cur_live, (int *)s->d_livelog + 256, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (!s->compact) s->cur_live = chains;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s->e0, s->e1));
     s->total_ms += ms;
@@ -1902,18 +1901,25 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
       prev_rec = pending;
       if (ticked) {
         if (prev_rec) absorb(s->d_rec[cur]);
-        tick(0, false, pbuf[cur]);
+        tick(0, false, pbuf[cur], true, i);
       }
       pending = !ticked;
+      was_ticked[(size_t)i] = ticked ? 1 : 0;
       if (fuse_now) s->pp ^= 1;
       pos++;
     }
     HIPCHK(hipEventRecord(s->e1, m->stream));
+    if (s->compact) HIPCHK(hipMemcpyAsync(livelog.data(), s->d_livelog, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     for (int i = 0; i < B; i++) {
       float g = 0;
       HIPCHK(hipEventElapsedTime(&g, s->ev[2 * i], s->ev[2 * i + 1]));
       s->kernel_ms += g;
+      // launch i served the chains listed by the last compaction before it
+      const int served = s->cur_live;
+      s->chain_slots += served;
+      if ((int64_t)served * 10 >= (int64_t)chains * 9) { s->steady_ms += g; s->steady_launches += 1; s->steady_evals += served; }
+      if (s->compact && was_ticked[(size_t)i]) s->cur_live = livelog[(size_t)i];
     }
     s->launches += B;
     remaining_hint = std::max(32, remaining_hint - B);
@@ -2068,8 +2074,10 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : s->m->glm4r ? "rh_grad_glm4r_kernel" : s->m->glm4 ? "rh_grad_glm4_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
-    if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; }
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    out->chain_slots = s->tick_engine ? s->chain_slots : out->density_evals;
+    out->steady_kernel_ms = s->steady_ms; out->steady_launches = s->steady_launches; out->steady_density_evals = s->steady_evals;
+    if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; s->chain_slots = 0; s->steady_ms = 0; s->steady_launches = 0; s->steady_evals = 0; }
   });
 }
 

@@ -287,7 +287,8 @@ class Sampler:
         t = _capi.Timing()
         _capi.check(_capi.lib().rh_sampler_timing(self._h, C.byref(t), int(reset)), self.model._h)
         return {"kernel_ms": t.kernel_ms, "total_ms": t.total_ms, "launches": t.launches, "density_evals": t.density_evals,
-                "row_chain_evals": t.row_chain_evals, "dominant_kernel": t.dominant_kernel.decode()}
+                "row_chain_evals": t.row_chain_evals, "dominant_kernel": t.dominant_kernel.decode(), "chain_slots": t.chain_slots,
+                "steady_kernel_ms": t.steady_kernel_ms, "steady_launches": t.steady_launches, "steady_density_evals": t.steady_density_evals}
 
     def close(self):
         if self._h:

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rh_abi_version() == 5
+    assert lib.rh_abi_version() == 6
 
 
 def test_struct_layouts_match_header(lib):
