@@ -232,11 +232,13 @@ def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, ro
         # (tests/test_gpu_baseline_samplers.py: R-hat < 1.05; the non-centred one above keeps R-hat at 3-6 for any affordable length)
         mk = models.hier_negbin_centred if w == "cfg5c" else models.hier_negbin
         spec = spec or mk(10_000 if not rows else max(100, rows // 100), 100); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
-    if w in ("cfg4", "cfg5", "cfg5c") and warmup < 150:
+    if w in ("cfg4", "cfg5", "cfg5c") and 24 <= warmup < 150:
         # DefaultConfig's mass windows (50, x1.5, skip 50 / 50: sampler/Sampler.scala:24-25) never open in a warm-up this short:
         # the same tuner scaled to the leg's warm-up, so that "NUTS + diag mass-matrix adapt" (BASELINE cfg 4) really adapts
-        k = max(1, warmup // 6)
+        k = warmup // 6
         cfg.massMatrixTuner = lambda: R.DiagonalMassMatrixTuner(k, 1.5, k, k)
+    elif w in ("cfg4", "cfg5", "cfg5c") and warmup < 24:
+        cfg.massMatrixTuner = lambda: R.IdentityMassMatrixTuner()   # (a kernel-speed leg of a few iterations: nothing to adapt from)
     if sampler == "nuts":
         cfg.sampler = lambda: R.NUTSSampler(10)
     elif sampler.startswith("hmc"):      # static HMC, L = the number behind "hmc": every chain asks for a gradient at every launch, so the

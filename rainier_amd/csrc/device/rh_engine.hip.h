@@ -1041,6 +1041,12 @@ RH_DEV int rh_live_count(const int *__restrict__ nlive, const int chains) {
 RH_DEV int rh_live_chain(const int *__restrict__ list, const int slot, const int nl) {
   return list[slot < nl ? slot : nl - 1];   // (the host always passes a list to the gradient kernels: the identity when every chain is served)
 }
+// Gradient-only requests.  active[chain] is 1 when the chain's tick asked for (logp, gradient) and 2 when only the gradient will be
+// read: a mid-trajectory step of takeSteps, whose potential the next step overwrites (sampler/LeapFrog.scala:175-184; rh_advance,
+// RH_S_TS_MID with ts_i < ts_l).  A wavefront whose chains all sent 2 walks its rows through the generated row_g() / elem_g() --
+// row() / elem() without what only the log-density needs (csrc/emit.cpp: value_only) -- and leaves zeros in those sums.
+template <int T> struct rh_any_value_only { static constexpr bool v = rh_target<T>::HAS_VALUE_ONLY || rh_any_value_only<T + 1>::v; };
+template <> struct rh_any_value_only<RH_NTARGETS> { static constexpr bool v = false; };
 // active[chain] != 0 (the chain's last tick asked for a gradient) -> list of those chains, ascending, and their number.  One
 // workgroup: 1024 flags per pass, wave ballots + a 16-entry carry through LDS; a launch of a few microseconds behind every tick.
 extern "C" __global__ void __launch_bounds__(1024)
@@ -1080,7 +1086,13 @@ typedef double rh_thk_t[RH_GRAD_K][RH_NTH];
 #endif
 // COHERENT: the partial sums are stored with agent-scope (write-through) stores -- rh_grad_fused_kernel, whose epilogue reads them
 // from another XCD within the same launch
-template <int T, bool COHERENT>
+// row() or, for a gradient-only request of a target that has a value-only part, row_g()
+template <class TG, bool NV, class TH, class INV, class CP, class ACC>
+RH_DEV void rh_row(const TH &th, const INV &inv, const CP &c, ACC &acc, int &err) {
+  if constexpr (NV || !TG::HAS_VALUE_ONLY) TG::row(th, inv, c, acc, err);
+  else TG::row_g(th, inv, c, acc, err);
+}
+template <int T, bool COHERENT, bool NV = true>   // NV: the log-density is needed (row()); otherwise row_g()
 RH_DEV void rh_grad_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
                             const int split, const int nsplit, const int *__restrict__ lp, const int nvalid, const int chains,
                             double *__restrict__ partial, int &err) {
@@ -1129,7 +1141,7 @@ RH_UNROLL_ACC
 #pragma unroll
             for (int u = 0; u < U; u++) {
 #pragma unroll
-              for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
+              for (int kk = 0; kk < K; kk++) rh_row<TG, NV>(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int j = 0; j < NC; j++) c[u][j] = gp[j][kl + 64LL * u];
@@ -1165,7 +1177,7 @@ RH_UNROLL_ACC
 #pragma unroll
           for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
+            for (int kk = 0; kk < K; kk++) rh_row<TG, NV>(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
           kb = kn;
           if (!more) break;
         }
@@ -1180,7 +1192,7 @@ RH_UNROLL_ACC
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
+          for (int kk = 0; kk < K; kk++) rh_row<TG, NV>(RH_THK(th, kk), inv[kk], c[u], acc[kk], err);
       }
 #endif
       // the ragged end of the last split: still a scalar loop; a lane past the end re-reads the last row and a select drops its
@@ -1197,7 +1209,7 @@ RH_UNROLL_ACC
           double t[NA];
 RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) t[o] = -0.0;
-          TG::row(RH_THK(th, kk), inv[kk], c, t, err);
+          rh_row<TG, NV>(RH_THK(th, kk), inv[kk], c, t, err);
 RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
         }
@@ -1217,7 +1229,7 @@ RH_UNROLL_ACC
         }
       }
     }
-    rh_grad_targets<T + 1, COHERENT>(th, d, lane, split, nsplit, lp, nvalid, chains, partial, err);
+    rh_grad_targets<T + 1, COHERENT, NV>(th, d, lane, split, nsplit, lp, nvalid, chains, partial, err);
   }
 }
 #pragma clang fp contract(off)
@@ -1237,8 +1249,8 @@ RH_DEV void rh_grad_map(const int b, const int nsplit, const int xcd_aware, int 
 // one workgroup of the plain gradient kernel: its chain group's parameters, then its row split
 template <bool COHERENT>
 RH_DEV void rh_grad_body(const rh_model_data &d, const double *q, const int *__restrict__ list, const int *__restrict__ nlive,
-                         double *partial, int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit,
-                         const int xcd_aware) {
+                         const int *__restrict__ vflag, double *partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                         const int chains, const int nsplit, const int xcd_aware) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0; // re-armed for the tick kernel that follows in stream order
@@ -1247,9 +1259,11 @@ RH_DEV void rh_grad_body(const rh_model_data &d, const double *q, const int *__r
   rh_grad_map(b, nsplit, xcd_aware, split, group);
   if (group * RH_GRAD_K >= nl) return;   // (no live chain for this workgroup)
   rh_thk_t th;
+  bool vfree = rh_any_value_only<0>::v && vflag != nullptr;   // every chain of the group asked for the gradient only
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     const int c = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
+    if constexpr (rh_any_value_only<0>::v) vfree = vfree && vflag[c] == 2;
 #if RH_BIGTH
     th[kk] = q + (size_t)c * RH_NVARS;
 #else
@@ -1258,15 +1272,19 @@ RH_DEV void rh_grad_body(const rh_model_data &d, const double *q, const int *__r
 #endif
   }
   int err = 0;
+  if constexpr (rh_any_value_only<0>::v) {
+    if (vfree) rh_grad_targets<0, COHERENT, false>(th, d, lane, split, nsplit, list + group * RH_GRAD_K, nl - group * RH_GRAD_K, chains, partial, err);
+    else rh_grad_targets<0, COHERENT, true>(th, d, lane, split, nsplit, list + group * RH_GRAD_K, nl - group * RH_GRAD_K, chains, partial, err);
+  } else
   rh_grad_targets<0, COHERENT>(th, d, lane, split, nsplit, list + group * RH_GRAD_K, nl - group * RH_GRAD_K, chains, partial, err);
   if (err && lane == 0) atomicOr(err_out, 1);
 }
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GRAD_WAVES)))
 rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-               double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+               const int *__restrict__ vflag, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
-  rh_grad_body<false>(d, q, list, nlive, partial, err_out, n_running, chains, nsplit, xcd_aware);
+  rh_grad_body<false>(d, q, list, nlive, vflag, partial, err_out, n_running, chains, nsplit, xcd_aware);
 }
 
 // ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
@@ -1360,7 +1378,7 @@ RH_DEV void rh_grad_lds_targets(const rh_thk_t &th, const rh_model_data &d, cons
 // grid: ceil(ngroups / W) * nsplit workgroups of W wavefronts; dynamic LDS = 2 * max(NCOLS) * 64 doubles
 extern "C" __global__ void __launch_bounds__(64 * RH_GRAD_W)
 rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-                   double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                   const int *__restrict__ /* vflag: this kernel always computes the value */, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
@@ -1417,7 +1435,7 @@ typedef double rh_v4d __attribute__((ext_vector_type(4)));
 #endif
 extern "C" __global__ void __launch_bounds__(64 * RH_GLM_W, RH_GLM_WAVES_PER_SIMD)
 rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-                   double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                   const int *__restrict__ vflag, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                    const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
   typedef rh_glm<RH_GLM_TARGET> GL;
@@ -1448,6 +1466,8 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   const bool mine = slot0 + li < nl;                // this lane's slot holds a live chain
   const int cl = rh_live_chain(list, slot0 + li, nl);
   const bool compute = slot0 < nl;                  // (a wavefront without one still stages its columns of the tile)
+  // gradient-only: every live chain of this wavefront's tile sent active == 2 (see rh_any_value_only)
+  const bool vfree = TG::HAS_VALUE_ONLY && vflag != nullptr && !__any(mine && vflag[cl] != 2);
   // forward B operands: lane (li, lg) holds theta[chain li][pred 4 ks + lg]
   double Bf[PT];
   int acol[PT];
@@ -1538,7 +1558,8 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
           for (int r = 0; r < 4; r++) {
             const int rrow = row0s + lg + 4 * r;
             double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-            GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            if (vfree) GL::elem_g(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            else GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
             Wv[r] = w;
 #pragma unroll
             for (int k = 0; k < GL::NOTHER; k++) oth[k] += o[k];
@@ -1549,7 +1570,8 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
             const int rrow = row0s + lg + 4 * r;
             const bool valid = (r0 + t * 64 + rrow < r1) && mine;
             double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-            GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            if (vfree) GL::elem_g(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            else GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
             Wv[r] = valid ? w : 0.0;
 #pragma unroll
             for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
@@ -1669,7 +1691,7 @@ RH_DEV void rh_glms_tile(const double *tile, const long long rows_left, const in
 
 extern "C" __global__ void __launch_bounds__(64)
 rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-                    double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
+                    const int *__restrict__ /* vflag: this kernel always computes the value */, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
                     const int chains, const int nsplit, const int xcd_aware) {
   rh_lk_init();
   typedef rh_glm<RH_GLM_TARGET> GL;
@@ -1786,18 +1808,38 @@ RH_DEV double rh_segmented_scan(double v, const int start, const int lane) {
   }
   return v;
 }
-// One 64-row tile of a gather-mode target for the K chains of the wavefront.  The ragged last tile of a split is the one place where a
-// row function still runs inside a divergent region (`if (live)`): the select-masked form of rh_rows_ragged keeps K x (NACC + 1)
-// temporaries alive next to the accumulators -- 163-175 VGPRs instead of 123 for cfg 5, i.e. two wavefronts per SIMD instead of four
-// and 3.8 ms per launch instead of 3.2 (measured, profiles/r4_cfg5) -- for a tile that occurs once per split.  The join block behind
-// this region is what csrc/isacheck.cpp looks at before the kernel may be launched.
-template <int T, class INV, int NC, int NA>
+template <class TG, bool NV, class TH, class INV, class CP, class ACC>
+RH_DEV void rh_row_gz(const TH &th, const INV &inv, const CP &c, const double gz, ACC &acc, double &sv, int &err) {   // (rh_row in gather mode)
+  if constexpr (NV || !TG::HAS_VALUE_ONLY) TG::row(th, inv, c, gz, acc, sv, err);
+  else TG::row_g(th, inv, c, gz, acc, sv, err);
+}
+// One 64-row tile of a gather-mode target for the K chains of the wavefront (the walks that rh_gather_walk_a does not serve: groups
+// of fewer than 64 rows -- a lifted prior has ONE row per group -- and RH_GATHER_V2=0).  Full tiles run the row code with every
+// lane active.  The ragged last tile of a split runs it on every lane too -- a lane past the end on the split's last row -- into
+// temporaries that start at -0.0 (x + -0.0 is x in every bit), one chain after the other, and a select keeps the live lanes'
+// `acc + t`: the very addition the full tiles perform.  Until round 6 the ragged tile ran inside `if (live)`: generated code in a
+// divergent region, the one construct whose join block this toolchain has been seen to get wrong -- and cfg 5's
+// centred form (second row target: the lifted prior, one row per group, every split ragged) gave chains that depended on which
+// other chains shared the wavefront (profiles/r6_live: compacted vs uncompacted launches, 21 of 1.14e6 leapfrog steps apart).
+template <int T, bool NV, class INV, int NC, int NA>
 RH_DEV void rh_gather_rows(const double (&th)[RH_GRAD_K][RH_NTH], const INV &inv, const double (&cc)[NC], const double (&gz)[RH_GRAD_K],
-                           double (&acc)[RH_GRAD_K][NA], double (&sv)[RH_GRAD_K], int &err, const bool live) {
+                           double (&acc)[RH_GRAD_K][NA], double (&sv)[RH_GRAD_K], int &err, const bool full, const bool live) {
   typedef rh_target<T> TG;
-  if (live) {
+  if (full) {   // wave-uniform
 #pragma unroll
-    for (int kk = 0; kk < RH_GRAD_K; kk++) TG::row(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
+    for (int kk = 0; kk < RH_GRAD_K; kk++) rh_row_gz<TG, NV>(th[kk], inv[kk], cc, gz[kk], acc[kk], sv[kk], err);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < RH_GRAD_K; kk++) {
+      double t[NA];
+#pragma unroll
+      for (int o = 0; o < NA; o++) t[o] = -0.0;
+      double svt = -0.0;
+      rh_row_gz<TG, NV>(th[kk], inv[kk], cc, gz[kk], t, svt, err);
+#pragma unroll
+      for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
+      sv[kk] = live ? sv[kk] + svt : sv[kk];
+    }
   }
 }
 // K per-lane values -> K wave sums with 2(K-1) + (6 - log2 K) exchanges instead of 6K: at the first log2(K) levels of the butterfly a
@@ -1873,7 +1915,7 @@ template <> struct rh_ninv_max<RH_NTARGETS> { static constexpr int v = 1; };
 // (one wavefront per workgroup: no barriers; every lane stores the same value to the same address and reads back through an offset
 //  the compiler cannot see through -- rh_gu_oz() -- so that nothing is forwarded from the stores or hoisted back into registers)
 RH_DEV int rh_gu_oz() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
-template <int T, class TH, class INV, int NC, int NA>
+template <int T, bool NV, class TH, class INV, int NC, int NA>
 RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const double *const (&cp)[NC], double (&acc)[RH_GRAD_K][NA],
                              const rh_gather_data &gd, const double *__restrict__ q, const int lane, const int g0, const int g1,
                              const int r0, const int r1, const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K], int &err) {
@@ -1935,7 +1977,7 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
       const double *invk = u + RH_GU_INV + kk * NI;
       const double gz = uz[kk];
       double sv = 0.0;
-      if (!ragged) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+      if (!ragged) rh_row_gz<TG, NV>(thk, invk, c, gz, acc[kk], sv, err);
       else {
 #if RH_GATHER_TAIL_SELECT
         // the ragged tile without a divergent region (as rh_rows_ragged): every lane runs the row code -- a lane past the end on the
@@ -1945,12 +1987,12 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
 #pragma unroll
         for (int o = 0; o < NA; o++) t[o] = -0.0;
         double svt = -0.0;
-        TG::row(thk, invk, c, gz, t, svt, err);
+        rh_row_gz<TG, NV>(thk, invk, c, gz, t, svt, err);
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
         sv = live ? 0.0 + svt : 0.0;
 #else
-        if (live) TG::row(thk, invk, c, gz, acc[kk], sv, err);
+        if (live) rh_row_gz<TG, NV>(thk, invk, c, gz, acc[kk], sv, err);
 #endif
       }
       if constexpr (TG::HAS_GATHER) { accA[kk] += inA ? sv : 0.0; accB[kk] += inA ? 0.0 : sv; }
@@ -2005,7 +2047,13 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
 }
 #endif  // RH_GATHER_V2
 
-template <int T>
+// SCAN: which row targets this instantiation walks.  false (rh_grad_gather_kernel): the targets without a gather and those whose non-empty
+// groups all have >= 64 rows -- the group-major walk; true (rh_grad_gather_scan_kernel): the targets with smaller groups (a lifted prior
+// has ONE row per group) -- the segmented scan over every tile.  Which of the two a target is, is a property of the DATA (gd.gmin),
+// so the test is made at run time, wave-uniformly; splitting the two kinds of walk into two kernels keeps the generated source
+// independent of the data AND keeps the scan walk's registers out of the kernel that cfg 5's 1e6 likelihood rows run through
+// (together: 205 vector registers, two wavefronts per SIMD; the group-major walk alone: 166, three).
+template <int T, bool NV, bool SCAN>
 RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_model_data &d, const rh_gather_data &gd,
                               const double *__restrict__ q, const int lane, const int split, const int nsplit,
                               const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K], const int chains, double *gu_lds,
@@ -2013,6 +2061,7 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (TG::HAS_ROWS) {
+     if ((!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) != SCAN) {   // this kernel's kind of target
       constexpr int NC = TG::NCOLS, K = RH_GRAD_K;
       double inv[K][TG::NINV > 0 ? TG::NINV : 1];
 #pragma unroll
@@ -2038,12 +2087,10 @@ RH_DEV void rh_gather_targets(const double (&th)[RH_GRAD_K][RH_NTH], const rh_mo
       size_t qoff[K];
 #pragma unroll
       for (int kk = 0; kk < K; kk++) qoff[kk] = (size_t)cid[kk] * RH_NVARS + TG::G_FIRST;
+      if constexpr (!SCAN) {
 #if RH_GATHER_V2
-      if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
-        rh_gather_walk_a<T>(gu_lds, th, inv, cp, acc, gd, q, lane, g0, g1, r0, r1, cid, cok, err);
-      } else
-#endif
-      if (!TG::HAS_GATHER || gd.gmin[TG::ROWT] >= 64) {
+        rh_gather_walk_a<T, NV>(gu_lds, th, inv, cp, acc, gd, q, lane, g0, g1, r0, r1, cid, cok, err);
+#else
         // Every non-empty group has at least 64 rows (cfg 5: 100): a tile touches at most two groups, A (the one that is open) and
         // the one after it.  Each lane keeps a running scatter sum for either; when the tile's last row is no longer in A, A is
         // complete: one wave reduction per GROUP (not per tile), as in the group-major walk, but with every lane busy.
@@ -2076,7 +2123,7 @@ RH_UNROLL_ACC
             gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
             sv[kk] = 0.0;
           }
-          rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, live);
+          rh_gather_rows<T, NV>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
           if constexpr (TG::HAS_GATHER) {
             if (g == gA) {
 #pragma unroll
@@ -2096,6 +2143,7 @@ RH_UNROLL_ACC
           }
         }
         if constexpr (TG::HAS_GATHER) { if (r0 < r1) flush(gA); }
+#endif
       } else {
       double carry[K];
 #pragma unroll
@@ -2118,7 +2166,7 @@ RH_UNROLL_ACC
           gz[kk] = TG::HAS_GATHER ? q[qoff[kk] + g] : 0.0;
           sv[kk] = 0.0;
         }
-        rh_gather_rows<T>(th, inv, cc, gz, acc, sv, err, live);
+        rh_gather_rows<T, NV>(th, inv, cc, gz, acc, sv, err, base + 64 <= r1, live);
         if constexpr (TG::HAS_GATHER) {
           const int start = gbeg - base;                      // first lane of this lane's group (<= 0: it began earlier)
           const bool tail = live && (r == gend - 1);          // last row of its group
@@ -2143,8 +2191,9 @@ RH_UNROLL_ACC
           for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
         }
       }
+     }
     }
-    rh_gather_targets<T + 1>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu_lds, partial, err);
+    rh_gather_targets<T + 1, NV, SCAN>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu_lds, partial, err);
   }
 }
 #pragma clang fp contract(off)
@@ -2152,11 +2201,10 @@ RH_UNROLL_ACC
 #ifndef RH_GATHER_WAVES
 #define RH_GATHER_WAVES 1
 #endif
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GATHER_WAVES)))
-rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
-                      const int *__restrict__ list, const int *__restrict__ nlive, double *__restrict__ partial, int *__restrict__ err_out,
-                      int *__restrict__ n_running, const int chains, const int nsplit) {
-  rh_lk_init();
+template <bool SCAN>
+RH_DEV void rh_gather_body(const rh_model_data &d, const rh_gather_data &gd, const double *__restrict__ q,
+                           const int *__restrict__ list, const int *__restrict__ nlive, const int *__restrict__ vflag, double *__restrict__ partial,
+                           int *__restrict__ err_out, int *__restrict__ n_running, const int chains, const int nsplit, double *gu) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b == 0 && lane == 0) *n_running = 0;
@@ -2166,13 +2214,28 @@ rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const doub
   int cid[RH_GRAD_K];
   bool cok[RH_GRAD_K];
   double th[RH_GRAD_K][RH_NTH];
+  bool vfree = rh_any_value_only<0>::v && vflag != nullptr;   // every chain of the group asked for the gradient only
 #pragma unroll
   for (int kk = 0; kk < RH_GRAD_K; kk++) {
     cok[kk] = group * RH_GRAD_K + kk < nl;
     cid[kk] = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
+    if constexpr (rh_any_value_only<0>::v) vfree = vfree && vflag[cid[kk]] == 2;
 #pragma unroll
     for (int i = 0; i < RH_NTH; i++) th[kk][i] = q[(size_t)cid[kk] * RH_NVARS + i];
   }
+  int err = 0;
+  if constexpr (rh_any_value_only<0>::v) {
+    if (vfree) rh_gather_targets<0, false, SCAN>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu, partial, err);
+    else rh_gather_targets<0, true, SCAN>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu, partial, err);
+  } else
+  rh_gather_targets<0, true, SCAN>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu, partial, err);
+  if (err && lane == 0) atomicOr(err_out, 1);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RH_GATHER_WAVES)))
+rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
+                      const int *__restrict__ list, const int *__restrict__ nlive, const int *__restrict__ vflag, double *__restrict__ partial, int *__restrict__ err_out,
+                      int *__restrict__ n_running, const int chains, const int nsplit) {
+  rh_lk_init();
   // the walk's wave-uniform operands (ONE buffer for every target's walk: they run one after the other)
 #if RH_GATHER_V2
   __shared__ double rh_gu[RH_GU_SIZE];
@@ -2180,9 +2243,15 @@ rh_grad_gather_kernel(const rh_model_data d, const rh_gather_data gd, const doub
 #else
   double *const gu = nullptr;
 #endif
-  int err = 0;
-  rh_gather_targets<0>(th, d, gd, q, lane, split, nsplit, cid, cok, chains, gu, partial, err);
-  if (err && lane == 0) atomicOr(err_out, 1);
+  rh_gather_body<false>(d, gd, q, list, nlive, vflag, partial, err_out, n_running, chains, nsplit, gu);
+}
+// the row targets whose groups are small (launched behind rh_grad_gather_kernel when the data have such a target)
+extern "C" __global__ void __launch_bounds__(64)
+rh_grad_gather_scan_kernel(const rh_model_data d, const rh_gather_data gd, const double *__restrict__ q,
+                           const int *__restrict__ list, const int *__restrict__ nlive, const int *__restrict__ vflag, double *__restrict__ partial, int *__restrict__ err_out,
+                           int *__restrict__ n_running, const int chains, const int nsplit) {
+  rh_lk_init();
+  rh_gather_body<true>(d, gd, q, list, nlive, vflag, partial, err_out, n_running, chains, nsplit, nullptr);
 }
 #endif  // RH_HAS_GATHER
 
@@ -2601,7 +2670,7 @@ RH_UNROLL_SLOTS
         rh_chain_stats_dev *out = stats + chain;
         out->leapfrog_steps = c.n_leapfrog; out->warmup_leapfrog_steps = c.n_warm_leapfrog; out->gradient_evaluations = c.n_grad + 1;
         out->error = c.err; out->status = RH_ADV_NEED_GRAD;
-        active[chain] = 1;
+        active[chain] = (ts_i + 1 < ts_l) ? 2 : 1;   // 2: the request just made is a mid-trajectory one too -- gradient only
         atomicAdd(n_running, 1);
       }
       return;
@@ -2678,7 +2747,7 @@ RH_UNROLL_SLOTS
         rh_chain_stats_dev *out = stats + chain;
         out->leapfrog_steps = n_leapfrog; out->warmup_leapfrog_steps = n_warm_leapfrog; out->gradient_evaluations = n_grad + 1;
         out->error = cerr; out->status = RH_ADV_NEED_GRAD;
-        active[chain] = 1;
+        active[chain] = (ts_i + 1 < ts_l) ? 2 : 1;
         atomicAdd(n_running, 1);
       }
       return;
@@ -2716,7 +2785,9 @@ RH_UNROLL_SLOTS
       if (k * 64 + lane < RH_NVARS) qbuf[(size_t)chain * RH_NVARS + k * 64 + lane] = c.Bq.s[k];
 #endif
   }
-  if (lane == 0) active[chain] = (status == RH_ADV_NEED_GRAD) ? 1 : 0;
+  // 1: (logp, gradient) wanted; 2: the gradient only -- the request will be consumed by RH_S_TS_MID as a mid-trajectory step, which
+  // overwrites the potential it stores before anything reads it (LeapFrog.scala:175-184)
+  if (lane == 0) active[chain] = (status == RH_ADV_NEED_GRAD) ? ((c.pc == RH_S_TS_MID && c.ts_i < c.ts_l) ? 2 : 1) : 0;
   rh_chain_store(c, st, lane);
   rh_stats_write(c, stats + chain, status, lane);
   if (status == RH_ADV_NEED_GRAD && lane == 0) atomicAdd(n_running, 1);

@@ -403,6 +403,53 @@ struct TargetEmitter {
     for (const Family &f : families) { r.push_back(f.g); r.push_back(f.col); }
     return r;
   }
+  // ---- gradient-only row code (round 6) -------------------------------------------------------------------------------------
+  // LeapFrog.twoFullSteps (sampler/LeapFrog.scala:175-184) overwrites pqBuf(potentialIndex) at every step of a trajectory and
+  // only the last step's value is read (finishIteration's energy, :61-82; EHMC's snapshot at step minSteps, EHMC.scala:38-41, is
+  // taken through takeSteps(1), whose only step is its last).  For a mid-trajectory gradient request the tick engine therefore
+  // runs row_g(): row() without the basis terms that only output 0 -- the log-density -- needs, and without what only they
+  // reach.  Their accumulators stay 0; every other sum is computed by the same statements in the same order (same bits).
+  std::vector<char> value_only() const {   // per basis index
+    std::vector<char> v(basis.size(), 1);
+    for (size_t o = 1; o < outs.size(); o++) {
+      if (outs[o].term != NONE && outs[o].alpha != ZERO) v[outs[o].term] = 0;
+      for (auto &tm : outs_multi[o]) if (tm.second != ZERO) v[tm.first] = 0;
+    }
+    for (size_t j = 0; j < basis.size(); j++) if ((j < in_family.size() && in_family[j]) || basis[j] == NONE) v[j] = 0;
+    return v;
+  }
+  // liveness of the row code from `roots` (+ the scatter value in gather mode), with the closed-form link's value and cores as leaves
+  std::vector<char> reach_from(const std::vector<uint32_t> &roots) const {
+    std::vector<char> r(P.nodes.size(), 0);
+    for (uint32_t b : roots) r[b] = 1;
+    if (gather.ok) r[gather.sv] = 1;
+    if (!link.ok) { sweep(r); return r; }
+    std::vector<uint32_t> ops;
+    bool any_link = false;
+    for (size_t n = P.nodes.size(); n-- > 0;) {
+      if (!r[n]) continue;
+      if (n == link.V) { for (auto &c : link.cterms) r[c.first] = 1; any_link = true; continue; }
+      if (link.cores.count((uint32_t)n)) { any_link = true; continue; }
+      operands(P.nodes[n], ops);
+      for (uint32_t o : ops) r[o] = 1;
+    }
+    if (any_link) {   // the prelude: t from L, the alpha / beta sums
+      std::vector<char> pre(P.nodes.size(), 0);
+      pre[link.L] = 1;
+      for (auto &c : link.alpha) if (c.first < NONE) pre[c.first] = 1;
+      for (auto &c : link.beta) if (c.first < NONE) pre[c.first] = 1;
+      sweep(pre);
+      for (size_t n = 0; n < P.nodes.size(); n++) if (pre[n]) r[n] = 1;
+    }
+    return r;
+  }
+  std::vector<uint32_t> row_roots_g() const {   // row_roots() without the value-only basis terms
+    const std::vector<char> vo = value_only();
+    std::vector<uint32_t> r;
+    for (size_t j = 0; j < basis.size(); j++) if (basis[j] != NONE && !(j < in_family.size() && in_family[j]) && !vo[j]) r.push_back(basis[j]);
+    for (const Family &f : families) { r.push_back(f.g); r.push_back(f.col); }
+    return r;
+  }
   void find_families() {
     in_family.assign(basis.size(), 0);
     families.clear();
@@ -1167,21 +1214,37 @@ struct TargetEmitter {
     for (auto &o : glm.others) oacc.push_back(o.second);
     for (uint32_t x : glm.thu) thu.push_back((int)x);
     arr("other_acc", oacc); arr("thu_param", thu);
-    // the scalar part; RH_GLM_COL(j) reads column j of the current row from the LDS tile
-    os << "  template <class ColFn>\n  static RH_DEV void elem(const double *thu, const double eta, ColFn RH_GLM_COL, double &w, double *other, int &err) {\n"
-          "    (void)thu; (void)eta; (void)other; (void)err;\n";
-    if (logit.ok) {  // verified closed form of the Bernoulli-logit scalar part (detect_logit)
-      os << "    const double s = (RH_GLM_COL(" << logit.ycol << ") == " << lit(logit.c) << ") ? " << lit(logit.s_hit) << " : " << lit(logit.s_miss) << ";\n"
-         << "    double sp, sg;\n    rh_logit_link(s * eta, sp, sg);\n"
-         << (logit.kappa == 1.0 ? std::string("    w = -(s * sg);\n") : "    w = " + lit(-logit.kappa) + " * (s * sg);\n") << "    other[0] = -sp;\n  }\n};\n";
-      return true;
+    // the scalar part; RH_GLM_COL(j) reads column j of the current row from the LDS tile.  elem_g(): the same without the terms only
+    // the log-density needs (their `other` sums stay 0), for the mid-trajectory gradient requests -- see value_only()
+    const std::vector<char> vo = value_only();
+    for (int pass = 0; pass < 2; pass++) {
+      const bool g_only = pass == 1;
+      os << "  template <class ColFn>\n  static RH_DEV void " << (g_only ? "elem_g" : "elem") << "(const double *thu, const double eta, ColFn RH_GLM_COL, double &w, double *other, int &err) {\n"
+            "    (void)thu; (void)eta; (void)other; (void)err;\n";
+      if (logit.ok) {  // verified closed form of the Bernoulli-logit scalar part (detect_logit)
+        const bool drop = g_only && !glm.others.empty() && vo[(size_t)glm.others[0].second];
+        os << "    const double s = (RH_GLM_COL(" << logit.ycol << ") == " << lit(logit.c) << ") ? " << lit(logit.s_hit) << " : " << lit(logit.s_miss) << ";\n"
+           << "    double sp, sg;\n    rh_logit_link(s * eta, sp, sg);\n"
+           << (logit.kappa == 1.0 ? std::string("    w = -(s * sg);\n") : "    w = " + lit(-logit.kappa) + " * (s * sg);\n")
+           << (drop ? "    other[0] = 0x0p+0; (void)sp;\n  }\n" : "    other[0] = -sp;\n  }\n");   // (dropped: the softplus half of the link is dead code)
+        continue;
+      }
+      // emit_node spells operands through ref(); the GLM scalar part needs its own spelling
+      std::vector<char> need(P.nodes.size(), 1);
+      if (g_only) {
+        need.assign(P.nodes.size(), 0);
+        need[glm.w] = 1;
+        for (auto &o : glm.others) if (!vo[(size_t)o.second]) need[o.first] = 1;
+        sweep(need);
+      }
+      for (uint32_t n : glm.inv_nodes) if (need[n] && !emit_glm_node(os, n, err)) return false;
+      for (uint32_t n : glm.elem_nodes) if (need[n] && !emit_glm_node(os, n, err)) return false;
+      os << "    w = " << glm_ref(glm.w) << ";\n";
+      for (size_t k = 0; k < glm.others.size(); k++)
+        os << "    other[" << k << "] = " << (g_only && vo[(size_t)glm.others[k].second] ? std::string("0x0p+0") : glm_ref(glm.others[k].first)) << ";\n";
+      os << "  }\n";
     }
-    // emit_node spells operands through ref(); the GLM scalar part needs its own spelling
-    for (uint32_t n : glm.inv_nodes) if (!emit_glm_node(os, n, err)) return false;
-    for (uint32_t n : glm.elem_nodes) if (!emit_glm_node(os, n, err)) return false;
-    os << "    w = " << glm_ref(glm.w) << ";\n";
-    for (size_t k = 0; k < glm.others.size(); k++) os << "    other[" << k << "] = " << glm_ref(glm.others[k].first) << ";\n";
-    os << "  }\n};\n";
+    os << "};\n";
     return true;
   }
   bool emit_glm_node(std::ostringstream &os, uint32_t id, std::string &err) const {
@@ -1223,6 +1286,9 @@ struct TargetEmitter {
     os << "  static constexpr int NCOLS = " << T.n_cols << ", COL0 = " << T.col0 << ", NINV = " << inv_slot.size()
        << ", NACC = " << nacc() << ", ROWT = " << rowt << ";\n";
     os << "  static constexpr bool HAS_ROWS = " << (rows ? "true" : "false") << ";\n";
+    { bool any_vo = false;
+      if (rows) for (char c : value_only()) any_vo = any_vo || c;
+      os << "  static constexpr bool HAS_VALUE_ONLY = " << (any_vo ? "true" : "false") << ";   // row_g() differs from row()\n"; }
     os << "  static constexpr bool HAS_GATHER = " << (gather.ok ? "true" : "false") << ";\n  static constexpr int G_COL = " << gather.col
        << ", G_FIRST = " << gather.first << ", G_COUNT = " << gather.count << ", G_LOW = " << gather.low << ";\n";
     // ---- invariants
@@ -1244,28 +1310,44 @@ struct TargetEmitter {
       else
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, rh_acc_t *acc, int &err) {\n"
               "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
-      bool link_open = false;
-      std::ostringstream b;
-      for (size_t n = 0; n < P.nodes.size(); n++) {
-        if (!reach_row[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
-        if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
-        if (link.ok && (n == link.V || link.cores.count((uint32_t)n))) {   // verified closed forms (detect_link)
-          if (!link_open) { emit_link_prelude(b); link_open = true; }
-          if (n == link.V) b << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
-          else b << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
-          continue;
+      // row() and, for the tick engine's mid-trajectory gradient requests, row_g(): the same statements without the value-only part
+      const std::vector<char> vo = value_only();
+      bool any_vo = false;
+      for (char c : vo) any_vo = any_vo || c;
+      for (int pass = 0; pass < (any_vo ? 2 : 1); pass++) {   // (no value-only part: row() serves both kinds of request)
+        const bool g_only = pass == 1;
+        const std::vector<char> reach = g_only ? reach_from(row_roots_g()) : reach_row;
+        if (g_only) {
+          if (gmode)
+            os << "  static RH_DEV void row_g(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, const double gz, rh_acc_t *acc, double &sv, int &err) {\n"
+                  "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+          else
+            os << "  static RH_DEV void row_g(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, rh_acc_t *acc, int &err) {\n"
+                  "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
         }
-        if (!emit_node(b, (uint32_t)n, 1, err)) return false;
+        bool link_open = false;
+        std::ostringstream b;
+        for (size_t n = 0; n < P.nodes.size(); n++) {
+          if (!reach[n] || trivial((uint32_t)n) || P.nodes[n].dep == 0) continue;
+          if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
+          if (link.ok && (n == link.V || link.cores.count((uint32_t)n))) {   // verified closed forms (detect_link)
+            if (!link_open) { emit_link_prelude(b); link_open = true; }      // (row_g: the softplus half of rh_logit_link is dead code there)
+            if (n == link.V) b << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
+            else b << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
+            continue;
+          }
+          if (!emit_node(b, (uint32_t)n, 1, err)) return false;
+        }
+        for (size_t j = 0; j < basis.size(); j++)
+          if (basis[j] != NONE && !in_family[j] && !(g_only && vo[j])) b << accumulate("acc[" + std::to_string(j) + oz() + "]", basis[j], 1);
+        for (const Family &f : families) {   // eq(column, k, g, 0) for every k of the block: the column's value picks the one accumulator
+          b << "    { const double ix = " << ref(f.col, 1) << "; const int kk = (int)ix - (" << f.kmin << ");\n"
+            << "      if (ix == (double)(int)ix && (unsigned)kk < " << f.size << "u) acc[" << f.base << " + kk] += " << ref(f.g, 1) << "; }\n";
+        }
+        if (gather.ok) b << accumulate("sv", gather.sv, 1);
+        os << (chunk > 0 && !link_open ? chunk_body(b.str(), chunk) : b.str());   // (the closed-form link is a light row by construction)
+        os << "  }\n";
       }
-      for (size_t j = 0; j < basis.size(); j++)
-        if (basis[j] != NONE && !in_family[j]) b << accumulate("acc[" + std::to_string(j) + oz() + "]", basis[j], 1);
-      for (const Family &f : families) {   // eq(column, k, g, 0) for every k of the block: the column's value picks the one accumulator
-        b << "    { const double ix = " << ref(f.col, 1) << "; const int kk = (int)ix - (" << f.kmin << ");\n"
-          << "      if (ix == (double)(int)ix && (unsigned)kk < " << f.size << "u) acc[" << f.base << " + kk] += " << ref(f.g, 1) << "; }\n";
-      }
-      if (gather.ok) b << accumulate("sv", gather.sv, 1);
-      os << (chunk > 0 && !link_open ? chunk_body(b.str(), chunk) : b.str());   // (the closed-form link is a light row by construction)
-      os << "  }\n";
       // ---- finish: tot[o] += alpha * S[j] + nrows * beta
       os << "  static RH_DEV void finish(const double (&th)[RH_NTH], const rh_acc_t *inv, const rh_acc_t *S, const double nrows, double (&tot_)[RH_NOUT]) {\n"
             "    (void)th; (void)inv; (void)S; (void)nrows; rh_acc_t *const tot = tot_; (void)tot;\n";

@@ -177,6 +177,7 @@ struct rh_model {
   int n_row_targets = 0, grad_k = 4, nacc_max = 1;
   // gather mode: per row target (ROWT order) the host copy of the group offsets (rows sorted by table index)
   hipFunction_t k_grad_gather = nullptr, k_density_fin = nullptr;
+  hipFunction_t k_grad_gather_scan = nullptr;   // the same launch for the row targets whose groups have fewer than 64 rows (rh_grad_gather_scan_kernel)
   std::vector<std::vector<int>> goff_host;   // [rowt][ngroups + 1]
   std::vector<void *> goff_dev;              // device copies
   std::vector<int> gather_count;             // per rowt: table size (0 = no gather)
@@ -293,7 +294,7 @@ void assemble_source(rh_model *m) {
     for (size_t hr = targets.find("HAS_ROWS = true;"); hr != std::string::npos; hr = targets.find("HAS_ROWS = true;", hr + 1)) {
       const size_t at = targets.find("void row(", hr);
       if (at == std::string::npos) break;
-      const size_t end = targets.find("void finish(", at);
+      const size_t end = std::min(targets.find("void row_g(", at), targets.find("void finish(", at));   // (row() only: row_g() repeats a part of it)
       size_t c = 0;
       for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
       row_ops = std::max(row_ops, c);
@@ -313,7 +314,7 @@ void assemble_source(rh_model *m) {
     for (size_t hr = targets.find("HAS_ROWS = true;"); hr != std::string::npos; hr = targets.find("HAS_ROWS = true;", hr + 1)) {
       const size_t at = targets.find("void row(", hr);
       if (at == std::string::npos) break;
-      const size_t end = targets.find("void finish(", at);
+      const size_t end = std::min(targets.find("void row_g(", at), targets.find("void finish(", at));   // (row() only: row_g() repeats a part of it)
       size_t c = 0;
       for (size_t i = targets.find("\n    const double n", at); i != std::string::npos && i < end; i = targets.find("\n    const double n", i + 1)) c++;
       row_ops = std::max(row_ops, c);
@@ -415,7 +416,7 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 // marker with the kernels that were unfit takes its place, so that the next process takes the same decision without compiling.
 // (a marker records a verdict of kernel_health: it carries the version of those rules and whether they were switched off, and a marker
 //  written under other rules is ignored -- the attempt is compiled and judged again)
-const int kHealthRulesVersion = 2;   // 2: round 5 (rh_grad_gather_kernel's wavefront request; the gather walk without a divergent region)
+const int kHealthRulesVersion = 3;   // 3: round 6 (rh_grad_gather_scan_kernel joins the gather-mode ladder); 2: round 5 (rh_grad_gather_kernel's wavefront request; the gather walk without a divergent region)
 std::string marker_header() {
   return "rules=" + std::to_string(kHealthRulesVersion) + " allow_unhealthy=" + (std::getenv("RH_ALLOW_UNHEALTHY") ? "1" : "0") + "\n";
 }
@@ -485,7 +486,7 @@ void build_code(rh_model *m) {
     if (!marker) m->code = build_source(m->arch, m->source, extra);
     if (std::getenv("RH_BUILD_LOG")) {   // diagnostics: what every attempt cost and which shape it had
       std::string unfit_now;
-      for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel", "rh_density_fin_kernel"})
+      for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_grad_gather_scan_kernel", "rh_tick_kernel", "rh_density_fin_kernel"})
         if (marker ? unfit.find(std::string("\n") + k + "\n") != std::string::npos : kernel_health(m->code, k) == KH_BAD) unfit_now += std::string(" ") + k;
       std::fprintf(stderr, "[rh build] attempt %d%s: %.1f s, %zu KB source, rows_unroll %d grad_unroll %d K %d waves %d pipeline %d chunk %d bigu %d gwaves %d; unfit:%s\n",
                    m->compile_attempts, marker ? " (marker)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_attempt).count(),
@@ -508,8 +509,8 @@ void build_code(rh_model *m) {
     auto again = [&] {   // this attempt is abandoned: leave the marker, lower again
       if (!marker) {
         std::string names = "\n";
-        for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_tick_kernel",
-                              "rh_density_fin_kernel"})
+        for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_grad_gather_scan_kernel",
+                              "rh_tick_kernel", "rh_density_fin_kernel"})
           if (health(k) == KH_BAD) names += std::string(k) + "\n";
         abandon_attempt(m->arch, m->source, extra, names);
       }
@@ -520,7 +521,7 @@ void build_code(rh_model *m) {
     // through a per-lane scratch array -- the analogue of the reference's method splitting, ir/Packer.scala:10-71), with smaller
     // chunks while that does not fit either.  Slower, same bits, any size.
     auto usable = [&] {
-      if (m->info.gather_mode) return !bad("rh_grad_gather_kernel") && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
+      if (m->info.gather_mode) return !bad("rh_grad_gather_kernel") && !bad("rh_grad_gather_scan_kernel") && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
       // (a dense linear predictor's gradients come from the MFMA kernel: load_module prefers it, so it can stand in for rh_grad_kernel)
       const bool glm = m->has_glm && m->n_row_targets_hint == 1 && !m->glm_small && !marker && health("rh_grad_glm_kernel") == KH_OK;
       const bool tick = m->n_row_targets_hint > 0 && (!bad("rh_grad_kernel") || glm) && !bad("rh_tick_kernel") && !bad("rh_density_fin_kernel");
@@ -538,7 +539,7 @@ void build_code(rh_model *m) {
     }
     if (m->info.gather_mode) {   // K chains per wavefront x ~14 wave-uniform doubles each: fewer chains is the only lever
       if (bad("rh_grad_gather_kernel") && m->gather_waves > 1 && !std::getenv("RH_GATHER_WAVES")) { m->gather_waves = 1; again(); continue; }
-      if (bad("rh_grad_gather_kernel") && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; again(); continue; }
+      if ((bad("rh_grad_gather_kernel") || bad("rh_grad_gather_scan_kernel")) && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; again(); continue; }
       if (!usable() && heavier()) { again(); continue; }
       if (marker) m->code = build_source(m->arch, m->source, extra);   // (abandoned under other settings: it is the last shape now)
       return;
@@ -589,6 +590,9 @@ void load_module(rh_model *m) {
   std::string wg, wf, wt;
   if (m->info.gather_mode) {  // parameter table indexed by a data column: tick engine with the group-major gather kernel only
     m->k_grad_gather = fit_kernel(m->code, m->module, "rh_grad_gather_kernel", &wg);
+    { std::string ws;   // (needed only when the data have a gather target with small groups; both must be fit for the tick engine to be)
+      m->k_grad_gather_scan = fit_kernel(m->code, m->module, "rh_grad_gather_scan_kernel", &ws);
+      if (m->k_grad_gather && !m->k_grad_gather_scan) { m->k_grad_gather = nullptr; wg = ws; } }
     m->k_density_fin = fit_kernel(m->code, m->module, "rh_density_fin_kernel", &wf);
     m->k_tick = fit_kernel(m->code, m->module, "rh_tick_kernel", &wt);
     m->tick_ok = m->k_grad_gather && m->k_density_fin && m->k_tick;
@@ -1390,6 +1394,7 @@ namespace {
 struct GatherBufs {
   rh_gather_data gd{};
   std::vector<void *> owned;
+  bool any_big = false, any_small = false;   // row targets for rh_grad_gather_kernel (no gather, or groups of >= 64 rows) / for rh_grad_gather_scan_kernel
   void build(rh_model *m, int chains, int nsplit) {
     for (size_t rt = 0; rt < m->goff_host.size(); rt++) {
       const std::vector<int> &off = m->goff_host[rt];
@@ -1413,6 +1418,7 @@ struct GatherBufs {
       for (int gi = 0; gi < ng; gi++) { const int sz = off[(size_t)gi + 1] - off[(size_t)gi]; if (sz > 0) gmin = std::min(gmin, sz); }
       gd.gmin[rt] = gmin;
       if (const char *e = std::getenv("RH_GATHER_SCAN")) if (std::atoi(e)) gd.gmin[rt] = 0;   // tests: the general (segmented scan) walk
+      if (m->gather_count[rt] == 0 || gd.gmin[rt] >= 64) any_big = true; else any_small = true;   // (the kernels' own test)
       if (m->gather_count[rt] > 0) {
         void *sb = nullptr;
         const size_t bytes = sizeof(double) * (size_t)chains * m->gather_count[rt];
@@ -1456,15 +1462,17 @@ int default_nsplit(const rh_model *m, int chains) {
 // (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial.
 // The grid covers every chain; with a list (d_list / d_nlive; nullptr = all `chains`) slot s of the launch is chain list[s] and the
 // workgroups of the slots past the live count -- the last of the grid -- return at once.
-void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_list, void *d_nlive, void *d_partial, void *d_graderr, void *d_running,
+// d_vflag: the chains' request flags (rh_tick_kernel: 2 = gradient only, the log-density of that evaluation is never read) or nullptr.
+void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_list, void *d_nlive, void *d_vflag, void *d_partial, void *d_graderr, void *d_running,
                  int chains, int nsplit, int xcd) {
   const int ngroups = (chains + m->grad_k - 1) / m->grad_k;
   if (m->info.gather_mode) {
-    void *ga[] = {&m->data, &gb->gd, &d_q, &d_list, &d_nlive, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
-    launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
+    void *ga[] = {&m->data, &gb->gd, &d_q, &d_list, &d_nlive, &d_vflag, &d_partial, &d_graderr, &d_running, &chains, &nsplit};
+    if (gb->any_big) launch(m->k_grad_gather, (unsigned)(ngroups * nsplit), 64, m->stream, ga);
+    if (gb->any_small) launch(m->k_grad_gather_scan, (unsigned)(ngroups * nsplit), 64, m->stream, ga);   // (its own row targets: other partial-sum slots)
     return;
   }
-  void *args[] = {&m->data, &d_q, &d_list, &d_nlive, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
+  void *args[] = {&m->data, &d_q, &d_list, &d_nlive, &d_vflag, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
   if (m->k_grad_glm && m->glm_small) {
     const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
     launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
@@ -1528,7 +1536,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
       int xcd = 1;
       if (const char *e = std::getenv("RH_XCD_AWARE")) xcd = std::atoi(e);
-      launch_grad(m, &gb, dq, blist.p, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
+      launch_grad(m, &gb, dq, blist.p, nullptr, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
         void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit, &dtot};
@@ -1829,6 +1837,8 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   void *pbuf[2] = {s->d_partial, s->d_partial2};
   void *no_list = nullptr;
   void *live_list = s->d_list, *live_n = s->compact ? s->d_nlive : nullptr;   // (without compaction d_list stays the identity)
+  void *vflag = s->d_active;   // gradient-only requests (RH_VALUE_FREE=0: every launch computes the log-density too)
+  if (const char *e = std::getenv("RH_VALUE_FREE")) if (std::atoi(e) == 0) vflag = nullptr;
   auto tick = [&](int fresh, bool reset_counter, void *partial, bool listed, int log_slot) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     void *lst = listed && s->compact ? live_list : no_list, *nl = listed && s->compact ? live_n : no_list;
@@ -1847,7 +1857,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
       launch(m->k_compact, 1u, 1024, m->stream, ca);
     }
   };
-  auto grad = [&](void *partial) { launch_grad(m, s->gb, s->d_qbuf, live_list, live_n, partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
+  auto grad = [&](void *partial) { launch_grad(m, s->gb, s->d_qbuf, live_list, live_n, vflag, partial, s->d_graderr, s->d_running, chains, nsplit, xcd); };
   // gradient at the point the PREVIOUS launch's gradient moves every chain to (rh_fused_prologue); no tick between the two
   auto grad_fused = [&](void *partial_in, void *partial_out, void *rec_in, void *rec_out) {
     void *args[] = {&m->data, &s->d_qbuf, &live_list, &live_n, &partial_in, &partial_out, &s->d_graderr, &s->d_running, &s->d_state, &rec_in, &rec_out,

@@ -265,7 +265,7 @@ def hier_negbin_centred(groups: int = 10_000, per_group: int = 100, seed: int = 
     rir = g.compile([prior, row])
     dv, dc, dg, dx0, dx1 = hier_negbin_data(G, per_group, seed, n_fail)
     return ModelSpec("hier_negbin_centred_%dx%d" % (G, per_group), rir, [dv, dc, dg, dx0, dx1], [0, G * per_group], n_params,
-                     {"kind": "hier_negbin_centred", "groups": G})
+                     {"kind": "hier_negbin_centred", "groups": G, "flops_per_row": 30})   # the same likelihood row as hier_negbin
 
 
 def random_walk(T: int = 2000, seed: int = 11, obs_sd: float = 0.5) -> ModelSpec:

@@ -123,7 +123,7 @@ def test_headers_are_c_and_library_links_from_c(tmp_path):
                            os.path.join(root, "tests", "stubs", "abi_check.c"), "-o", exe, "-L", os.path.join(root, "rainier_amd"),
                            "-lrainier_hip", "-Wl,-rpath," + os.path.join(root, "rainier_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([exe]).decode()
-    assert "abi 5 header 5" in out
+    assert "abi 6 header 6" in out
     assert "sizeof rh_config %d rh_chain_stats %d" % (C.sizeof(_capi.Config), C.sizeof(_capi.ChainStats)) in out
     assert "default 1000 1000 sampler 1 ehmc 1024 mass 1 50 1.5" in out          # DefaultConfig, sampler/Sampler.scala:17-27
     # (no `import torch` in this process: torch brings its own bundled comgr / LLVM under the system library's soname, and every model

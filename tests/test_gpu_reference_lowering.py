@@ -96,7 +96,7 @@ def test_linear_regression_reference_lowering_38_columns():
     _check(spec, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
     # the residual is computed once per row again: the row code is as short as the natural form's (5 basis sums + k + 1 FMAs)
     nat = R.Model(models.linreg(n=n, k=k, columns=cols), device=0, fp_contract=True, factor_outputs=True)
-    row = lambda src: src.split("static RH_DEV void row(")[2].split("static RH_DEV void finish(")[0].count("const double n")
+    row = lambda src: src.split("static RH_DEV void row(")[2].split("static RH_DEV void finish(")[0].split("static RH_DEV void row_g(")[0].count("const double n")
     assert row(mf.hip_source) <= row(nat.hip_source) + 4, (row(mf.hip_source), row(nat.hip_source))
 
 
