@@ -623,7 +623,7 @@ bool same_outputs(const Program &A, const Program &Bq, const double *const *colu
 }  // namespace
 
 bool index_masks_on() {
-  const char *e = std::getenv("RH_INDEX_MASKS");
+  const char *e = rh::knob("RH_INDEX_MASKS");
   return e ? std::atoi(e) != 0 : true;
 }
 
@@ -1026,7 +1026,7 @@ bool canonicalize_columns(Program &P, const double *const *columns, const int64_
     complete_scatter_terms(P, columns, nrows, kept);
     fold_select_sums(P, columns, nrows, kept);
     if (!same_outputs(before, P, columns, nrows, kept)) {
-      if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: the select rewrites of a strict build did not reproduce the original outputs: dropped\n");
+      if (rh::knob("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: the select rewrites of a strict build did not reproduce the original outputs: dropped\n");
       P = before;
     }
   }

@@ -815,6 +815,10 @@ RH_UNROLL_SLOTS
       return RH_ADV_NEED_GRAD;
     }
     case RH_S_TS_MID: {
+      // INVARIANT (two of rh_tick_kernel's shortcuts rest on it): this state begins by overwriting BU and Bg from the pending
+      // evaluation, and nothing reads either between two consecutive visits with ts_i < ts_l.  So (1) the big-mode gather fast path
+      // need not store pend_g / Bg for a mid-trajectory step (tests/test_gpu_live_chains.py compares it with this general path), and
+      // (2) the log-density of a mid-trajectory evaluation is never read: such requests are marked gradient-only (active == 2).
       c.BU = c.pend_logp * -1; c.Bg = c.pend_g;
       if (c.ts_i < c.ts_l) { // twoFullSteps (LeapFrog.scala:175-184): ONE p += eps * grad, then q
         wv_axpy(c.Bp, c.eps, c.Bg);
@@ -1287,129 +1291,6 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
   rh_grad_body<false>(d, q, list, nlive, vflag, partial, err_out, n_running, chains, nsplit, xcd_aware);
 }
 
-// ---- wide models: row tiles staged through LDS and shared by the RH_GRAD_W wavefronts of a workgroup ---------
-// With many columns (cfg 4: 51) the K x NACC accumulators leave room for only one or two chains per wavefront, so
-// every chain would re-read every row from L2.  Here a workgroup of W wavefronts (= W different chain groups) walks
-// the same row split: each 64-row tile is loaded from global memory ONCE per workgroup (wave w fetches columns
-// w, w+W, ...; coalesced 512 B per column), parked in LDS [column][row] and consumed by all W waves with
-// conflict-free ds_read_b64 (lane = row).  Global loads for tile t+1 are issued before tile t is consumed
-// (issue-early / write-late), one barrier per tile, two LDS buffers.
-#ifndef RH_GRAD_W
-#define RH_GRAD_W 8
-#endif
-#define RH_LDS_TRP 64 /* rows per tile; lane = row */
-
-#if RH_FP_CONTRACT
-#pragma clang fp contract(fast)
-#endif
-template <int T>
-RH_DEV void rh_grad_lds_targets(const rh_thk_t &th, const rh_model_data &d, const int lane,
-                                const int wave, const int split, const int nsplit, const int (&cid)[RH_GRAD_K], const bool (&cok)[RH_GRAD_K],
-                                const int chains, const bool compute, double *__restrict__ partial, double *lds, int &err) {
-  if constexpr (T < RH_NTARGETS) {
-    typedef rh_target<T> TG;
-    if constexpr (TG::HAS_ROWS) {
-      constexpr int NC = TG::NCOLS, K = RH_GRAD_K, W = RH_GRAD_W;
-      constexpr int MYC = (NC + W - 1) / W; // columns this wave stages
-      double inv[K][TG::NINV > 0 ? TG::NINV : 1];
-#pragma unroll
-      for (int kk = 0; kk < K; kk++) TG::invariants(RH_THK(th, kk), inv[kk], err);
-      const long long n = d.nrows[T];
-      const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit; // tiles per split
-      long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
-      if (r0 > n) r0 = n;
-      if (r1 > n) r1 = n;
-      const long long ntiles = (r1 - r0 + 63) / 64;
-      constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
-      double acc[K][NA];
-#pragma unroll
-      for (int kk = 0; kk < K; kk++)
-#pragma unroll
-        for (int o = 0; o < NA; o++) acc[kk][o] = 0.0;
-      double stage[MYC];
-      auto fetch = [&](long long tile) { // global -> registers (rows past the end are clamped, masked at use)
-        long long row = r0 + tile * 64 + lane;
-        if (row >= n) row = n - 1;
-#pragma unroll
-        for (int m = 0; m < MYC; m++) {
-          const int j = wave + m * W;
-          stage[m] = (j < NC && n > 0) ? d.cols[TG::COL0 + j][row] : 0.0;
-        }
-      };
-      auto park = [&](int buf) { // registers -> LDS
-#pragma unroll
-        for (int m = 0; m < MYC; m++) {
-          const int j = wave + m * W;
-          if (j < NC) lds[(buf * NC + j) * RH_LDS_TRP + lane] = stage[m];
-        }
-      };
-      if (ntiles > 0) { fetch(0); park(0); }
-      __syncthreads();
-      for (long long t = 0; t < ntiles; t++) {
-        const int buf = (int)(t & 1);
-        if (t + 1 < ntiles) fetch(t + 1);
-        if (compute && r0 + t * 64 + lane < r1) {
-          double c[NC];
-#pragma unroll
-          for (int j = 0; j < NC; j++) c[j] = lds[(buf * NC + j) * RH_LDS_TRP + lane];
-#pragma unroll
-          for (int kk = 0; kk < K; kk++) TG::row(RH_THK(th, kk), inv[kk], c, acc[kk], err);
-        }
-        if (t + 1 < ntiles) park(buf ^ 1);
-        __syncthreads();
-      }
-      if (compute) {
-#pragma unroll
-        for (int kk = 0; kk < K; kk++) {
-          rh_wave_sum_all(acc[kk]);
-          double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cid[kk]) * RH_NACC_MAX;
-          if (lane == 0 && cok[kk]) {
-#pragma unroll
-            for (int o = 0; o < NA; o++) out[o] = acc[kk][o];
-          }
-        }
-      }
-    }
-    rh_grad_lds_targets<T + 1>(th, d, lane, wave, split, nsplit, cid, cok, chains, compute, partial, lds, err);
-  }
-}
-#pragma clang fp contract(off)
-
-// grid: ceil(ngroups / W) * nsplit workgroups of W wavefronts; dynamic LDS = 2 * max(NCOLS) * 64 doubles
-extern "C" __global__ void __launch_bounds__(64 * RH_GRAD_W)
-rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-                   const int *__restrict__ /* vflag: this kernel always computes the value */, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
-                   const int chains, const int nsplit, const int xcd_aware) {
-  rh_lk_init();
-  extern __shared__ __attribute__((aligned(16))) double rh_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0) *n_running = 0;
-  const int nl = rh_live_count(nlive, chains);
-  int bgroup, split;
-  rh_grad_map(b, nsplit, xcd_aware, split, bgroup);
-  if (bgroup * RH_GRAD_W * RH_GRAD_K >= nl) return;   // (uniform over the workgroup)
-  const int group = __builtin_amdgcn_readfirstlane(bgroup * RH_GRAD_W + wave);
-  const bool any = group * RH_GRAD_K < nl;   // (a wavefront without a live chain still stages its columns of the tile)
-  int cid[RH_GRAD_K];
-  bool cok[RH_GRAD_K];
-  rh_thk_t th;
-#pragma unroll
-  for (int kk = 0; kk < RH_GRAD_K; kk++) {
-    cok[kk] = group * RH_GRAD_K + kk < nl;
-    cid[kk] = rh_live_chain(list, group * RH_GRAD_K + kk, nl);
-#if RH_BIGTH
-    th[kk] = q + (size_t)cid[kk] * RH_NVARS;
-#else
-#pragma unroll
-    for (int i = 0; i < RH_NVARS; i++) th[kk][i] = q[(size_t)cid[kk] * RH_NVARS + i];
-#endif
-  }
-  int err = 0;
-  rh_grad_lds_targets<0>(th, d, lane, wave, split, nsplit, cid, cok, chains, any, partial, rh_lds, err);
-  if (err && lane == 0) atomicOr(err_out, 1);
-}
-
 // ---- dense GLM targets on the fp64 matrix cores ---------------------------------------------------------------
 // rh_glm<T> (generated) describes a target whose row term is f(eta, other columns) with eta = X.theta a dense linear
 // predictor over P >= 8 columns.  Both contractions run on v_mfma_f64_16x16x4_f64 with 16 chains per wavefront:
@@ -1420,7 +1301,7 @@ rh_grad_lds_kernel(const rh_model_data d, const double *__restrict__ q, const in
 // runs on the VALU.  Row tiles (64 rows x all columns) are staged through LDS once per workgroup of RH_GLM_W waves
 // (= 16 * RH_GLM_W chains) with a padded column stride of 66 doubles (backward reads conflict-free, forward 2-way).
 // The G accumulators cost 4 VGPR pairs per 16 predictors for 16 chains -- the VALU path needs P+1 pairs per chain.
-#ifdef RH_GLM_TARGET
+#if defined(RH_GLM_TARGET) && !RH_GLM_SMALL   // (<= 8 predictors: the plain VALU kernel wins -- profiles/r1_c -- and nothing else is built)
 #ifndef RH_GLM_W
 #define RH_GLM_W 4
 #endif
@@ -1626,164 +1507,6 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 }
 #pragma clang fp contract(off)
 
-// ---- narrow GLMs (P <= 8 predictors): forward on the matrix cores, backward on the VALU ---------------------------
-// With few predictors the backward contraction would fill only P of the 16 MFMA output rows, so only
-// eta = X.theta goes to v_mfma_f64_16x16x4_f64 (ONE instruction per 16 rows x 16 chains when P <= 4) and the sums
-// w*x_k stay on the VALU -- the two pipes then run concurrently: per row-chain eval the VALU issues 1 (w) + others +
-// P accumulations instead of 2P+.. (cfg 2: 6 instead of 9 fp64 ops).  One wavefront walks a row split for
-// RH_GLMS_CT chain tiles (16 chains each): a lane's 4 rows of every 16-row sub-tile are read from the LDS tile once and
-// reused for all chain tiles; per-lane accumulators belong to chain (lane & 15) and are folded over the 4 lane groups
-// at the end.  Single-wave workgroups: no cross-wave barrier.
-#if RH_GLM_SMALL
-#ifndef RH_GLMS_CT
-#define RH_GLMS_CT 4
-#endif
-#if RH_FP_CONTRACT
-#pragma clang fp contract(fast)
-#endif
-template <bool TAIL>
-RH_DEV void rh_glms_tile(const double *tile, const long long rows_left, const int li, const int lg, const bool (&cvalid)[RH_GLMS_CT],
-                         const double (&Bf)[RH_GLMS_CT][(rh_glm<RH_GLM_TARGET>::P + 3) / 4],
-                         const int (&acol)[(rh_glm<RH_GLM_TARGET>::P + 3) / 4],
-                         const double (&thu)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::NTHU > 0 ? rh_glm<RH_GLM_TARGET>::NTHU : 1],
-                         double (&accp)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::P],
-                         double (&acco)[RH_GLMS_CT][rh_glm<RH_GLM_TARGET>::NOTHER > 0 ? rh_glm<RH_GLM_TARGET>::NOTHER : 1], int &err) {
-  typedef rh_glm<RH_GLM_TARGET> GL;
-  constexpr int P = GL::P, NC = GL::NCOLS, PT = (P + 3) / 4, CTN = RH_GLMS_CT;
-#pragma unroll 1
-  for (int sub = 0; sub < 4; sub++) {
-    const int row0s = sub * 16;
-    if (TAIL && row0s >= rows_left) break;
-    double xr[4][NC]; // this lane's 4 rows (lg + 4 r) of the sub-tile, all columns
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int j = 0; j < NC; j++) xr[r][j] = tile[j * RH_GLM_TRP + row0s + lg + 4 * r];
-    double a[PT];
-#pragma unroll
-    for (int ks = 0; ks < PT; ks++) a[ks] = acol[ks] >= 0 ? tile[acol[ks] * RH_GLM_TRP + row0s + li] : (acol[ks] == -1 ? 1.0 : 0.0);
-#pragma unroll
-    for (int t = 0; t < CTN; t++) {
-      rh_v4d D = (rh_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < PT; ks++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], Bf[t][ks], D, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
-        GL::elem(thu[t], D[r], [&](int j) { return xr[r][j]; }, w, o, err);
-        if (TAIL) {
-          const bool valid = (row0s + lg + 4 * r) < rows_left;
-          w = valid ? w : 0.0;
-#pragma unroll
-          for (int k = 0; k < GL::NOTHER; k++) o[k] = valid ? o[k] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-          if (GL::pred_col[j] >= 0) accp[t][j] += w * xr[r][GL::pred_col[j] >= 0 ? GL::pred_col[j] : 0];
-          else accp[t][j] += w;
-        }
-#pragma unroll
-        for (int k = 0; k < GL::NOTHER; k++) acco[t][k] += o[k];
-      }
-    }
-  }
-}
-
-extern "C" __global__ void __launch_bounds__(64)
-rh_grad_glms_kernel(const rh_model_data d, const double *__restrict__ q, const int *__restrict__ list, const int *__restrict__ nlive,
-                    const int *__restrict__ /* vflag: this kernel always computes the value */, double *__restrict__ partial, int *__restrict__ err_out, int *__restrict__ n_running,
-                    const int chains, const int nsplit, const int xcd_aware) {
-  rh_lk_init();
-  typedef rh_glm<RH_GLM_TARGET> GL;
-  typedef rh_target<RH_GLM_TARGET> TG;
-  constexpr int P = GL::P, NC = GL::NCOLS, PT = (P + 3) / 4, CTN = RH_GLMS_CT;
-  __shared__ __attribute__((aligned(16))) double lds[2 * NC * RH_GLM_TRP];
-  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x;
-  if (b == 0 && lane == 0) *n_running = 0;
-  const int nl = rh_live_count(nlive, chains);
-  int group, split;
-  rh_grad_map(b, nsplit, xcd_aware, split, group);
-  const int slot0 = group * 16 * CTN;
-  if (slot0 >= nl) return;
-  bool cvalid[CTN];
-  int cl[CTN];
-  double Bf[CTN][PT], thu[CTN][GL::NTHU > 0 ? GL::NTHU : 1];
-  int acol[PT];
-#pragma unroll
-  for (int ks = 0; ks < PT; ks++) { const int pred = 4 * ks + lg; acol[ks] = (pred < P) ? GL::pred_col[pred < P ? pred : 0] : -2; }
-#pragma unroll
-  for (int t = 0; t < CTN; t++) {
-    cvalid[t] = slot0 + 16 * t + li < nl;
-    cl[t] = rh_live_chain(list, slot0 + 16 * t + li, nl);
-#pragma unroll
-    for (int ks = 0; ks < PT; ks++) {
-      const int pred = 4 * ks + lg;
-      Bf[t][ks] = (pred < P) ? GL::pred_scale[pred < P ? pred : 0] * q[(size_t)cl[t] * RH_NVARS + GL::pred_param[pred < P ? pred : 0]] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < GL::NTHU; k++) thu[t][k] = q[(size_t)cl[t] * RH_NVARS + GL::thu_param[k]];
-  }
-  double accp[CTN][P], acco[CTN][GL::NOTHER > 0 ? GL::NOTHER : 1];
-  int err = 0;
-  const long long n = d.nrows[RH_GLM_TARGET];
-  const long long per = (((n + 63) / 64) + nsplit - 1) / nsplit;
-#pragma unroll
-  for (int t = 0; t < CTN; t++) {
-#pragma unroll
-    for (int j = 0; j < P; j++) accp[t][j] = 0.0;
-#pragma unroll
-    for (int k = 0; k < GL::NOTHER; k++) acco[t][k] = 0.0;
-  }
-  long long r0 = (long long)split * per * 64, r1 = r0 + per * 64;
-  if (r0 > n) r0 = n;
-  if (r1 > n) r1 = n;
-  const long long ntiles = (r1 - r0 + 63) / 64;
-  double stage[NC];
-  auto fetch = [&](long long tile) {
-    long long row = r0 + tile * 64 + lane;
-    if (row >= n) row = n - 1;
-#pragma unroll
-    for (int j = 0; j < NC; j++) stage[j] = n > 0 ? d.cols[TG::COL0 + j][row] : 0.0;
-  };
-  auto park = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NC; j++) lds[(buf * NC + j) * RH_GLM_TRP + lane] = stage[j];
-  };
-  if (ntiles > 0) { fetch(0); park(0); }
-  __syncthreads();
-  for (long long t = 0; t < ntiles; t++) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < ntiles) fetch(t + 1);
-    const double *tile = lds + (size_t)buf * NC * RH_GLM_TRP;
-    const long long rows_left = r1 - (r0 + t * 64);
-    if (rows_left >= 64) rh_glms_tile<false>(tile, 64, li, lg, cvalid, Bf, acol, thu, accp, acco, err);
-    else rh_glms_tile<true>(tile, rows_left, li, lg, cvalid, Bf, acol, thu, accp, acco, err);
-    if (t + 1 < ntiles) park(buf ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int t = 0; t < CTN; t++) {
-    double *out = partial + (((size_t)TG::ROWT * nsplit + split) * chains + cl[t]) * RH_NACC_MAX;
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-      double v = accp[t][j];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lg == 0 && cvalid[t]) out[GL::pred_acc[j]] = v;
-    }
-#pragma unroll
-    for (int k = 0; k < GL::NOTHER; k++) {
-      double v = acco[t][k];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lg == 0 && cvalid[t]) out[GL::other_acc[k]] = v;
-    }
-  }
-  if (__any(err != 0) && lane == 0) atomicOr(err_out, 1);
-}
-#pragma clang fp contract(off)
-#endif  // RH_GLM_SMALL
 #endif  // RH_GLM_TARGET
 
 #else  // RH_HAS_GATHER
@@ -1885,9 +1608,6 @@ RH_DEV double rh_wave_sum_split(const double (&v)[K], const int lane, int &mine)
 #undef RH_GATHER_V2
 #define RH_GATHER_V2 0   /* (a caller-chosen odd K keeps round 4's walk) */
 #endif
-#ifndef RH_GATHER_TAIL_SELECT
-#define RH_GATHER_TAIL_SELECT 1
-#endif
 #if RH_GATHER_V2
 // Round 5: the group-major walk of a gather-mode target whose non-empty groups all have >= 64 rows (cfg 5), rebuilt around what the
 // machine code and the counters of round 4's loop showed (profiles/r5_cfg5): per tile it made TWO dependent trips to memory with
@@ -1979,7 +1699,6 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
       double sv = 0.0;
       if (!ragged) rh_row_gz<TG, NV>(thk, invk, c, gz, acc[kk], sv, err);
       else {
-#if RH_GATHER_TAIL_SELECT
         // the ragged tile without a divergent region (as rh_rows_ragged): every lane runs the row code -- a lane past the end on the
         // split's last row, which load_tile gave it -- into temporaries that start at -0.0 (x + -0.0 is x in every bit), and a
         // select keeps the live lanes' `acc + t`: the very addition the full tiles perform
@@ -1991,9 +1710,6 @@ RH_DEV void rh_gather_walk_a(double *gu, const TH &th, const INV &inv, const dou
 #pragma unroll
         for (int o = 0; o < NA; o++) acc[kk][o] = live ? acc[kk][o] + t[o] : acc[kk][o];
         sv = live ? 0.0 + svt : 0.0;
-#else
-        if (live) rh_row_gz<TG, NV>(thk, invk, c, gz, acc[kk], sv, err);
-#endif
       }
       if constexpr (TG::HAS_GATHER) { accA[kk] += inA ? sv : 0.0; accB[kk] += inA ? 0.0 : sv; }
     }

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cctype>
 #include <map>
 #include <sstream>
@@ -118,7 +119,24 @@ static std::string chunk_body(const std::string &body, int chunk, const std::str
   std::vector<std::vector<long>> dies(nch);
   for (auto &kv : last_use) if (def_chunk.count(kv.first) && kv.second > def_chunk[kv.first]) dies[kv.second].push_back(kv.first);
   std::ostringstream os, out;
-  const bool split = parts && nch > kPartChunks;
+  bool split = parts && nch > kPartChunks;
+  if (split) {
+    // a part is a static member of a LOCAL struct: it sees its arguments (th, inv, c, acc, err, rh_sp) and nothing of the enclosing
+    // function's scope.  The data-free row() this was written for references nothing else; a body that does -- rh1 of the fma
+    // spelling, gz / sv of gather mode, the closed-form link's lk_* -- keeps its chunks in one function
+    auto has_token = [](const std::string &ln, const char *tok) {
+      const size_t L = std::strlen(tok);
+      for (size_t i = ln.find(tok); i != std::string::npos; i = ln.find(tok, i + 1)) {
+        const bool left = i == 0 || !(std::isalnum((unsigned char)ln[i - 1]) || ln[i - 1] == '_');
+        const bool right = i + L >= ln.size() || !(std::isalnum((unsigned char)ln[i + L]) || ln[i + L] == '_');
+        if (left && right) return true;
+      }
+      return false;
+    };
+    for (const Group &g : groups)
+      for (const std::string &t : g.text)
+        if (has_token(t, "rh1") || has_token(t, "gz") || has_token(t, "sv") || t.find("lk_") != std::string::npos) split = false;
+  }
   size_t npart = 0;
   for (size_t c = 0; c < nch; c++) {
     if (split && c % kPartChunks == 0) {
@@ -1461,7 +1479,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
   I.gather_mode = gmode; I.n_shared = (int)n_shared; I.grad_k = grad_k; I.nacc_max = nacc_max; I.glm_target = glm_target; I.glm_small = glm_small;
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << grad_k << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
-    << "\n#define RH_GRAD_PIPELINE " << o.grad_pipeline << "\n#define RH_GRAD_W " << (o.grad_waves > 0 ? o.grad_waves : 8) << "\n";
+    << "\n#define RH_GRAD_PIPELINE " << o.grad_pipeline << "\n";
   if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) " << (o.fast_log ? "rh_fast_log(x)" : "log(x)") << "\n";
@@ -1476,7 +1494,7 @@ bool emit_hip(const Program &P, const EmitOptions &o, std::string &defines, std:
   // preconditions -- e.g. the table's prior sits in a data-free target -- is lowered on the generic path (the table as a
   // per-evaluation array: correct, slow) as long as it has few enough parameters for it
   if (err.rfind("gather mode:", 0) != 0) return false;
-  if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: generic path instead of gather mode: %s\n", err.c_str());
+  if (rh::knob("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: generic path instead of gather mode: %s\n", err.c_str());
   EmitOptions o2 = o;
   o2.gather_min = 0x7fffffff;
   std::string err2;

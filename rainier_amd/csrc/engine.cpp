@@ -157,16 +157,14 @@ struct rh_model {
   int device = 0;
   bool loaded = false;
   hipModule_t module = nullptr;
-  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr, k_grad_lds = nullptr;
+  hipFunction_t k_chain = nullptr, k_density = nullptr, k_selftest = nullptr, k_grad = nullptr, k_tick = nullptr;
   hipFunction_t k_grad_fused = nullptr;  // rh_grad_kernel + the mid-trajectory leapfrog update as its prologue (static HMC); absent when the model does not qualify
   hipFunction_t k_absorb = nullptr;      // the fused launches' per-chain records -> state image, before the tick that ends a trajectory
   hipFunction_t k_compact = nullptr;     // active flags -> ascending list of the chains that wait for a gradient (rh_compact_kernel)
-  int grad_w = 8, ncols_max = 0, glm_ncols = 0;
-  bool use_lds_grad = false;
+  int ncols_max = 0, glm_ncols = 0;
   hipFunction_t k_grad_glm = nullptr;
-  bool glm_small = false;  // <= 8 predictors: rh_grad_glms_kernel (MFMA forward, VALU backward)
+  bool glm_small = false;  // <= 8 predictors: the plain VALU kernel (the fp64 matrix pipe pays from ~9 predictors on, profiles/r1_c)
   bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
-  int glms_ct = 4;
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int n_row_targets_hint = 0; // row targets of the lowered program (known before the module is loaded)
   bool shape_guessed = false;    // assemble_source has made its first guesses from the size of the generated code
@@ -207,6 +205,7 @@ namespace { struct GatherBufs; }
 struct rh_sampler {
   hipFunction_t k_chain = nullptr, k_tick = nullptr;
   int state_words = 0, dense_off = 0, pack_l = 64;  // pack_l: lanes per chain of the chosen chain kernel
+  int off_Pq = -1, off_Pg = -1, off_PU = -1;        // u64 word offsets of (q, gradient at q, -logp at q) of the current point in a chain's image
   rh_model *m = nullptr;
   rh_cfg_dev cfg{};
   int chains = 0;
@@ -240,19 +239,19 @@ namespace {
 
 void assemble_source(rh_model *m) {
   std::string defines, targets, err;
-  if (const char *e = std::getenv("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e);
-  if (const char *e = std::getenv("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_LOGIT_LINK")) m->eopt.logit_link = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RH_CHUNK")) if (m->eopt.chunk == 0) m->eopt.chunk = std::max(0, std::atoi(e));   // tests: the memory-resident lowering for any model
+  if (const char *e = rh::knob("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e);
+  if (const char *e = rh::knob("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_LOGIT_LINK")) m->eopt.logit_link = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_CHUNK")) if (m->eopt.chunk == 0) m->eopt.chunk = std::max(0, std::atoi(e));   // tests: the memory-resident lowering for any model
   if (m->eopt.chunk > 0) {   // the memory-resident lowering comes with the lightest kernel shapes and without the special-cased rows
     m->eopt.rows_unroll = 1; m->eopt.grad_unroll = 1; m->eopt.grad_pipeline = 0; m->unroll_auto = false;
     m->eopt.grad_chains = 1;
   }
-  if (const char *e = std::getenv("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
+  if (const char *e = rh::knob("RH_GATHER_MIN")) m->eopt.gather_min = std::max(1, std::atoi(e));  // tests: gather mode for small tables
   {  // tick-engine defaults from the register budget: K*NACC fp64 accumulators + U*NCOLS row values per lane
     int ncols_max = 1;
     for (auto &T : m->prog.targets) ncols_max = std::max<int>(ncols_max, (int)T.n_cols);
@@ -280,9 +279,9 @@ void assemble_source(rh_model *m) {
       longest = std::max(longest, c);
     }
     bool again = false;
-    if (longest > 1000 && m->eopt.chunk == 0 && !std::getenv("RH_NO_CHUNKS")) {
+    if (longest > 1000 && m->eopt.chunk == 0 && !rh::knob("RH_NO_CHUNKS")) {
       m->eopt.chunk = 48; again = true;
-      if (!std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = 1;   // (such a model's chain kernel has never fitted two wavefronts per SIMD)
+      if (!rh::knob("RH_CHAIN_WAVES")) m->eopt.chain_waves = 1;   // (such a model's chain kernel has never fitted two wavefronts per SIMD)
     }
     if (m->info.bign && !m->info.gather_mode && m->prog.n_params > 512 && m->eopt.big_unroll > 4) { m->eopt.big_unroll = 4; again = true; }
     if (again) { assemble_source(m); return; }
@@ -334,27 +333,24 @@ void assemble_source(rh_model *m) {
   m->grad_k = m->info.grad_k;
   m->has_glm = m->info.glm_target >= 0;
   m->glm_small = m->info.glm_small;
-  if (const char *e = std::getenv("RH_GLMS_CT")) { m->glms_ct = std::max(1, std::min(8, std::atoi(e))); }
-  defines += "#define RH_GLMS_CT " + std::to_string(m->glms_ct) + "\n";
   // experiment knobs of the MFMA GLM kernel (workgroup waves, forced waves per SIMD, scalar-part unroll)
-  if (const char *e = std::getenv("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
+  if (const char *e = rh::knob("RH_GLM_W")) { m->glm_w = std::max(1, std::min(16, std::atoi(e))); }
   defines += "#define RH_GLM_W " + std::to_string(m->glm_w) + "\n";
-  if (const char *e = std::getenv("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_CHAIN_WAVES")) m->eopt.chain_waves = std::max(1, std::atoi(e));
+  if (const char *e = rh::knob("RH_GRAD_WAVES")) defines += "#define RH_GRAD_WAVES " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_CHAIN_WAVES")) m->eopt.chain_waves = std::max(1, std::atoi(e));
   defines += "#define RH_CHAIN_WAVES " + std::to_string(m->eopt.chain_waves) + "\n";
-  if (const char *e = std::getenv("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_GLM_WPS")) defines += "#define RH_GLM_WAVES_PER_SIMD " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_FUSE_SYNC")) defines += "#define RH_FUSE_SYNC " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_TICK_FAST")) defines += "#define RH_TICK_FAST " + std::to_string(std::atoi(e)) + "\n";
   // rh_grad_gather_kernel asks for three wavefronts per SIMD (168 registers: cfg 5's K = 4 walk with its two-tile pipeline fits without
   // a spill; left alone the allocator takes 169 -- two wavefronts); a model that does not fit gets the unconstrained build (build_code)
-  if (const char *e = std::getenv("RH_GATHER_WAVES")) m->gather_waves = std::max(1, std::atoi(e));
+  if (const char *e = rh::knob("RH_GATHER_WAVES")) m->gather_waves = std::max(1, std::atoi(e));
   defines += "#define RH_GATHER_WAVES " + std::to_string(m->gather_waves) + "\n";
-  if (const char *e = std::getenv("RH_GATHER_TAIL_SELECT")) defines += "#define RH_GATHER_TAIL_SELECT " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_GATHER_V2")) defines += "#define RH_GATHER_V2 " + std::to_string(std::atoi(e)) + "\n";
-  if (const char *e = std::getenv("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_GATHER_V2")) defines += "#define RH_GATHER_V2 " + std::to_string(std::atoi(e)) + "\n";
+  if (const char *e = rh::knob("RH_GLM_EU")) defines += "#define RH_GLM_ELEM_UNROLL " + std::to_string(std::atoi(e)) + "\n";
   // row code that calls the closed-form logit link reads its table from LDS (rh_prelude.hip.h: RH_LK_LDS)
   { bool lds = targets.find("rh_logit_link(") != std::string::npos;
-    if (const char *e = std::getenv("RH_LK_LDS")) lds = lds && std::atoi(e) != 0;
+    if (const char *e = rh::knob("RH_LK_LDS")) lds = lds && std::atoi(e) != 0;
     m->lk_lds = lds;
     if (lds) defines += "#define RH_LK_LDS 1\n"; }
   m->source = "// generated by rainier-hip: RIR -> HIP (gfx950), one translation unit per model\n" + defines + kSharedSrc +
@@ -418,7 +414,7 @@ std::vector<char> build_source(const std::string &arch, const std::string &sourc
 //  written under other rules is ignored -- the attempt is compiled and judged again)
 const int kHealthRulesVersion = 3;   // 3: round 6 (rh_grad_gather_scan_kernel joins the gather-mode ladder); 2: round 5 (rh_grad_gather_kernel's wavefront request; the gather walk without a divergent region)
 std::string marker_header() {
-  return "rules=" + std::to_string(kHealthRulesVersion) + " allow_unhealthy=" + (std::getenv("RH_ALLOW_UNHEALTHY") ? "1" : "0") + "\n";
+  return "rules=" + std::to_string(kHealthRulesVersion) + " allow_unhealthy=" + (rh::unsafe_knob("RH_ALLOW_UNHEALTHY") ? "1" : "0") + "\n";
 }
 void abandon_attempt(const std::string &arch, const std::string &source, const std::string &extra, const std::string &unfit) {
   if (std::getenv("RH_NO_KERNEL_CACHE")) return;
@@ -452,7 +448,7 @@ int kernel_health(const std::vector<char> &code, const std::string &name, std::s
   std::vector<std::string> names;
   if (!rh::list_kernels(code, names)) { if (why) *why = name + ": the code object cannot be read"; return KH_BAD; }
   if (std::find(names.begin(), names.end(), name) == names.end()) return KH_ABSENT;
-  if (std::getenv("RH_ALLOW_UNHEALTHY")) return KH_OK;
+  if (rh::unsafe_knob("RH_ALLOW_UNHEALTHY")) return KH_OK;
   if (!rh::kernel_meta(code, name, km)) { if (why) *why = name + ": no metadata entry (spill count unknown)"; return KH_BAD; }
   // The count includes the allocator's VGPR -> AGPR copies: without a single scratch instruction in the kernel nothing went to
   // memory.  That reading is granted to the SAMPLER kernels only (rh_chain_kernel / rh_tick_kernel: their NUTS variants carry 64
@@ -475,16 +471,16 @@ int kernel_health(const std::vector<char> &code, const std::string &name, std::s
 // not fit to run (every attempt is cached under its own key, so this costs a parse after the first time; the attempts are counted
 // in m->compile_attempts).  What is still unfit afterwards is recorded by load_module (m->chain_ok, m->tick_ok, ...).
 void build_code(rh_model *m) {
-  const char *e = std::getenv("RH_HIPRTC_EXTRA");
+  const char *e = rh::knob("RH_HIPRTC_EXTRA");
   const std::string extra = e ? e : "";
-  const bool keep = std::getenv("RH_KEEP_UNROLL") != nullptr;
+  const bool keep = rh::knob("RH_KEEP_UNROLL") != nullptr;
   for (;;) {
     m->compile_attempts++;
     std::string unfit;   // "\n"-separated names of the unfit kernels of an attempt that was abandoned before
     const bool marker = !keep && abandoned_attempt(m->arch, m->source, extra, unfit);
     const auto t_attempt = std::chrono::steady_clock::now();
     if (!marker) m->code = build_source(m->arch, m->source, extra);
-    if (std::getenv("RH_BUILD_LOG")) {   // diagnostics: what every attempt cost and which shape it had
+    if (rh::knob("RH_BUILD_LOG")) {   // diagnostics: what every attempt cost and which shape it had
       std::string unfit_now;
       for (const char *k : {"rh_chain_kernel", "rh_density_kernel", "rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_gather_kernel", "rh_grad_gather_scan_kernel", "rh_tick_kernel", "rh_density_fin_kernel"})
         if (marker ? unfit.find(std::string("\n") + k + "\n") != std::string::npos : kernel_health(m->code, k) == KH_BAD) unfit_now += std::string(" ") + k;
@@ -528,7 +524,7 @@ void build_code(rh_model *m) {
       return tick || (!bad("rh_chain_kernel") && !bad("rh_density_kernel"));
     };
     auto heavier = [&] {
-      if (std::getenv("RH_NO_CHUNKS")) return false;
+      if (rh::knob("RH_NO_CHUNKS")) return false;
       if (m->eopt.chunk == 0) { m->eopt.chunk = 48; return true; }   // (assemble_source sets what goes with it)
       if (m->eopt.chunk > 12) { m->eopt.chunk /= 2; return true; }
       return false;
@@ -538,7 +534,7 @@ void build_code(rh_model *m) {
       m->eopt.big_unroll /= 2; again(); continue;
     }
     if (m->info.gather_mode) {   // K chains per wavefront x ~14 wave-uniform doubles each: fewer chains is the only lever
-      if (bad("rh_grad_gather_kernel") && m->gather_waves > 1 && !std::getenv("RH_GATHER_WAVES")) { m->gather_waves = 1; again(); continue; }
+      if (bad("rh_grad_gather_kernel") && m->gather_waves > 1 && !rh::knob("RH_GATHER_WAVES")) { m->gather_waves = 1; again(); continue; }
       if ((bad("rh_grad_gather_kernel") || bad("rh_grad_gather_scan_kernel")) && m->info.grad_k > 1) { m->eopt.grad_chains = m->info.grad_k / 2; again(); continue; }
       if (!usable() && heavier()) { again(); continue; }
       if (marker) m->code = build_source(m->arch, m->source, extra);   // (abandoned under other settings: it is the last shape now)
@@ -552,7 +548,7 @@ void build_code(rh_model *m) {
       continue;
     }
     // rh_chain_kernel asks for two wavefronts per SIMD (256 registers: +47 % on cfg 3); a model that does not fit gets one (512)
-    if (bad("rh_chain_kernel") && m->eopt.chain_waves != 1 && !std::getenv("RH_CHAIN_WAVES")) { m->eopt.chain_waves = 1; again(); continue; }
+    if (bad("rh_chain_kernel") && m->eopt.chain_waves != 1 && !rh::knob("RH_CHAIN_WAVES")) { m->eopt.chain_waves = 1; again(); continue; }
     if (bad("rh_grad_kernel") || bad("rh_grad_fused_kernel")) {
       // first fewer tiles per chunk, then fewer chains per wavefront; a row function that does not fit even alone keeps the plain row loop
       bool lighter = true;
@@ -607,7 +603,6 @@ void load_module(rh_model *m) {
   if (m->n_row_targets > 0 && !m->info.gather_mode) {  // the tick engine only exists for models that stream rows
     m->k_grad = fit_kernel(m->code, m->module, "rh_grad_kernel", &wg);
     m->k_tick = fit_kernel(m->code, m->module, "rh_tick_kernel", &wt);
-    m->k_grad_lds = fit_kernel(m->code, m->module, "rh_grad_lds_kernel");
     m->k_density_fin = fit_kernel(m->code, m->module, "rh_density_fin_kernel", &wf);
     // compiled only for models whose chain group fits one wavefront's lanes (RH_HAVE_FUSED in rh_engine.hip.h)
     m->k_grad_fused = fit_kernel(m->code, m->module, "rh_grad_fused_kernel");
@@ -615,27 +610,24 @@ void load_module(rh_model *m) {
     if (!m->k_absorb) m->k_grad_fused = nullptr;
   }
   if (m->n_row_targets > 0) m->k_compact = fit_kernel(m->code, m->module, "rh_compact_kernel");   // (unfit: every launch serves every chain)
-  m->grad_w = m->eopt.grad_waves > 0 ? m->eopt.grad_waves : 8;
   m->ncols_max = 0;
   for (auto &T : m->prog.targets) m->ncols_max = std::max<int>(m->ncols_max, (int)T.n_cols);
-  // wide models: stage row tiles through LDS and share them between the wavefronts of a workgroup
-  m->use_lds_grad = false;  // opt-in: measured slower than the register kernel on cfg 4 (VALU/occupancy-bound, not L2-bound)
-  if (const char *e = std::getenv("RH_GRAD_LDS")) m->use_lds_grad = std::atoi(e) != 0;
-  // <= 8 predictors: the plain VALU kernel wins (measured, profiles/r1_c: fp64 MFMA and fp64 VALU do not overlap and
-  // have the same peak, so moving eta to the matrix cores only adds AGPR traffic); the hybrid kernel stays opt-in.
-  const bool small_mfma = std::getenv("RH_GLM_SMALL_MFMA") && std::atoi(std::getenv("RH_GLM_SMALL_MFMA")) != 0;
-  if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && (!m->glm_small || small_mfma))
-    m->k_grad_glm = fit_kernel(m->code, m->module, m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel");   // (unfit: the plain VALU kernel)
+  // Dense linear predictors of more than 8 terms run both contractions on the fp64 matrix cores (rh_grad_glm_kernel).  Up to 8 the
+  // plain VALU kernel wins (measured, profiles/r1_c: fp64 MFMA and fp64 VALU do not overlap and have the same peak, so moving eta to
+  // the matrix cores only adds AGPR traffic) and no GLM kernel is built.  (Two more row-streaming kernels were measured and removed
+  // in round 6 because they lost to these two: a hybrid for <= 8 predictors -- eta on the matrix cores, the sums on the VALU -- and
+  // a VALU kernel whose workgroups share LDS-staged row tiles, VALU/occupancy-bound on cfg 4 like the register kernel; git history.)
+  if (m->has_glm && m->n_row_targets == 1 && !m->info.gather_mode && !m->glm_small)
+    m->k_grad_glm = fit_kernel(m->code, m->module, "rh_grad_glm_kernel");   // (unfit: the plain VALU kernel)
   if (m->has_glm) m->glm_ncols = (int)m->prog.targets[(size_t)m->info.glm_target].n_cols;
   // (Round 3 also measured the contractions OFF the matrix pipe -- one chain per lane, row values scalar-loaded as SGPR operands,
   //  162 VALU instructions per 64 evaluations: 33.9 vs 17.5 ms, bound by scalar-load latency; git 28d5e00, profiles/r3_cfg4.)
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
   {  // (column-major, stride 66)
     const size_t tile = (size_t)m->glm_ncols * 66u * sizeof(double);
-    if (!m->glm_small && tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
+    if (tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   }
-  if (const char *e = std::getenv("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
-  if (m->use_lds_grad && !m->k_grad_lds) m->use_lds_grad = false;
+  if (const char *e = rh::knob("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   if (m->n_row_targets > 0 && !m->info.gather_mode) {
     m->tick_ok = m->k_tick && m->k_density_fin && (m->k_grad || m->k_grad_glm);
     m->tick_why = !m->k_tick ? wt : (!m->k_density_fin ? wf : wg);
@@ -667,7 +659,7 @@ std::string variant_defines(int v) {
 // loops (only the variant's per-chain kernels are used, so the base module's choices are not affected).  The first build whose
 // sampler kernels are all fit is taken; otherwise the one with the most.
 std::vector<char> build_variant_code(rh_model *m, int v) {
-  const char *extra = std::getenv("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
+  const char *extra = rh::knob("RH_HIPRTC_EXTRA");  // the same flags as the base module (build_code)
   auto with = [&](int waves, int bigu) {
     std::string src = m->source;
     auto swap = [&](const std::string &name, int from, int to) {
@@ -688,7 +680,7 @@ std::vector<char> build_variant_code(rh_model *m, int v) {
   };
   const int want = (m->info.gather_mode ? 0 : 1) + (m->n_row_targets_hint > 0 ? 1 : 0);
   std::vector<std::pair<int, int>> shapes = {{m->eopt.chain_waves, m->eopt.big_unroll}};
-  if (!std::getenv("RH_CHAIN_WAVES") && m->eopt.chain_waves != 1 && !m->info.gather_mode) shapes.push_back({1, m->eopt.big_unroll});
+  if (!rh::knob("RH_CHAIN_WAVES") && m->eopt.chain_waves != 1 && !m->info.gather_mode) shapes.push_back({1, m->eopt.big_unroll});
   if (m->info.bign) for (int u = m->eopt.big_unroll / 2; u >= 2; u /= 2) shapes.push_back({1, u});
   std::vector<char> best;
   int best_n = -1;
@@ -773,7 +765,7 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   const uint32_t caller_cols = m->prog.n_cols_total;
   std::vector<uint32_t> old1, old2;
   bool lift = true;
-  if (const char *e = std::getenv("RH_LIFT_CONSTANTS")) lift = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_LIFT_CONSTANTS")) lift = std::atoi(e) != 0;
   if (lift) rh::lift_constants(m->prog, m->synth_cols, old1);
   else for (uint32_t t = 0; t < m->prog.targets.size(); t++) old1.push_back(t);
   // (rh_lower_only has no data: the preparation of parameter tables for gather mode synthesises columns NEXT TO the caller's, and
@@ -782,11 +774,11 @@ void load_program(rh_model *m, const void *rir, size_t rir_len, const double *co
   const bool have_data = columns != nullptr || caller_cols == 0 || tables_without_data;
   if (have_data) {  // a gather-shaped parameter table whose prior is data-free: the prior terms become a row target over the group index (lift.cpp)
     bool lp = true;
-    if (const char *e = std::getenv("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
+    if (const char *e = rh::knob("RH_LIFT_PRIORS")) lp = std::atoi(e) != 0;
     int gmin = m->eopt.gather_min;
-    if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
+    if (const char *e = rh::knob("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
     bool hoist = lp;
-    if (const char *e = std::getenv("RH_HOIST_TABLES")) hoist = std::atoi(e) != 0;
+    if (const char *e = rh::knob("RH_HOIST_TABLES")) hoist = std::atoi(e) != 0;
     if (hoist) rh::hoist_table_maps(m->prog, gmin);
     // (fast builds also lift a prior that ties the entries to shared parameters -- the centred parameterisation -- with both
     //  gradients derived again and verified: lift.cpp)
@@ -841,13 +833,13 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
     kept.push_back(c);
   }
   bool canon = m->prog.n_cols_total > 0, changed = false;
-  if (const char *e = std::getenv("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_CANON_COLUMNS")) canon = canon && std::atoi(e) != 0;
   // gather mode (a Lookup over a long run of trailing parameters indexed by a column: emit.cpp) keeps its targets as they are
   bool gather = false;
   {
     uint32_t first_table_param = m->prog.n_params;
     int gmin = m->eopt.gather_min;
-    if (const char *e = std::getenv("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
+    if (const char *e = rh::knob("RH_GATHER_MIN")) gmin = std::max(1, std::atoi(e));
     const rh::Program &P = m->prog;
     for (const rh::Node &nd : P.nodes) {
       if (nd.op != RH_RIR_LOOKUP || (int)nd.table.size() < gmin) continue;
@@ -869,7 +861,7 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
   if (canon) changed = rh::canonicalize_columns(m->prog, columns, nrows_t.data(), m->eopt.fp_contract, kept, err, allow_unroll && !gather);
   for (size_t t = 0; t < m->prog.targets.size(); t++) if (!m->prog.targets[t].n_cols) nrows_t[t] = 0;   // an unrolled initial chunk
   bool re = changed && m->eopt.fp_contract && m->eopt.simplify;
-  if (const char *e = std::getenv("RH_REFACTOR")) re = re && std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_REFACTOR")) re = re && std::atoi(e) != 0;
   m->col_src.clear(); m->col_len.clear();
   {
     size_t g = 0;
@@ -883,7 +875,7 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
     // fast builds: gradient re-derivation, re-association, and Model.observe's 8-way split rolled back into rows
     rh::Program Q = rh::simplify(m->prog, true);
     bool rederive = true;
-    if (const char *e = std::getenv("RH_REDERIVE")) rederive = std::atoi(e) != 0;
+    if (const char *e = rh::knob("RH_REDERIVE")) rederive = std::atoi(e) != 0;
     if (rederive) {  // the gradient in its natural form, from the value output (verified against the supplied one): rederive.cpp
       std::vector<const double *> cp;
       for (uint32_t c : kept) cp.push_back(columns[c]);
@@ -893,7 +885,7 @@ void canonicalize_once(rh_model *m, const double *const *columns, const int64_t 
   } else {
     // strict builds: the 8 slots rolled back without re-association (rollstrict.cpp), if the program is the reference's lowering
     bool rs = changed && !m->eopt.fp_contract && m->eopt.simplify;
-    if (const char *e = std::getenv("RH_ROLL_STRICT")) rs = rs && std::atoi(e) != 0;
+    if (const char *e = rh::knob("RH_ROLL_STRICT")) rs = rs && std::atoi(e) != 0;
     if (!rs) return;
     rh::Program Q = rh::simplify(m->prog, false);
     if (!rh::roll_strict(Q, parts)) return;
@@ -933,7 +925,7 @@ void launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t s, void 
 
 // ---- create-time self-checks (see selfcheck_engine) ----------------------------------------------------------------------------
 bool selfcheck_enabled() {
-  const char *e = std::getenv("RH_SELFCHECK");
+  const char *e = rh::unsafe_knob("RH_SELFCHECK");
   return !(e && std::atoi(e) == 0);
 }
 // |a - b| within summation-order noise of each other, judged against the size of the whole output vector (gradients cancel)
@@ -1137,7 +1129,7 @@ extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **ou
     if (dev >= ndev) throw Fail{RH_E_INVALID, "device ordinal out of range"};
     m->prog = src->prog; m->eopt = src->eopt; m->info = src->info; m->want_nuts = src->want_nuts;
     m->source = src->source; m->nacc_max = src->nacc_max; m->grad_k = src->grad_k; m->has_glm = src->has_glm;
-    m->glm_small = src->glm_small; m->glms_ct = src->glms_ct; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds; m->gather_waves = src->gather_waves;
+    m->glm_small = src->glm_small; m->glm_w = src->glm_w; m->lk_lds = src->lk_lds; m->gather_waves = src->gather_waves;
     m->goff_host = src->goff_host; m->gather_count = src->gather_count; m->col_len = src->col_len; m->col_src = src->col_src;
     m->rows_total = src->rows_total; m->data = src->data; m->data.cols = nullptr;
     // ... and the state of the lowering itself: build_code / build_variant_code decide from it which kernels the model needs and
@@ -1417,7 +1409,7 @@ struct GatherBufs {
       int gmin = 0x7fffffff;   // smallest non-empty group (the gather kernel's two-accumulator walk needs >= 64 rows per group)
       for (int gi = 0; gi < ng; gi++) { const int sz = off[(size_t)gi + 1] - off[(size_t)gi]; if (sz > 0) gmin = std::min(gmin, sz); }
       gd.gmin[rt] = gmin;
-      if (const char *e = std::getenv("RH_GATHER_SCAN")) if (std::atoi(e)) gd.gmin[rt] = 0;   // tests: the general (segmented scan) walk
+      if (const char *e = rh::knob("RH_GATHER_SCAN")) if (std::atoi(e)) gd.gmin[rt] = 0;   // tests: the general (segmented scan) walk
       if (m->gather_count[rt] == 0 || gd.gmin[rt] >= 64) any_big = true; else any_small = true;   // (the kernels' own test)
       if (m->gather_count[rt] > 0) {
         void *sb = nullptr;
@@ -1449,17 +1441,15 @@ int default_nsplit(const rh_model *m, int chains) {
   // (call B, another box: 16 / 24 / 32 / 48 splits 3.00 / 2.78 / 2.71 / 2.67 ms -- four rounds of 3072 wavefronts)
   // (call C: 32 / 48 / 64 / 96 splits 2.68 / 2.67 / 2.61 / 2.60 ms; 64 is also the most partial sums the tick's combine reads in one pass)
   if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (16384 + ngroups - 1) / ngroups);
-  if (const char *e = std::getenv("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
-  if (m->use_lds_grad) nsplit = (int)std::max<int64_t>(1, (2048 + ngroups - 1) / ngroups);
+  if (const char *e = rh::knob("RH_GATHER_WG")) if (m->info.gather_mode) nsplit = (int)std::max<int64_t>(1, (std::atoi(e) + ngroups - 1) / ngroups);
   if (m->k_grad_glm) { const int ctiles = (chains + 15) / 16; nsplit = (int)std::max<int64_t>(1, (2048 + ctiles - 1) / ctiles); }
-  if (m->k_grad_glm && m->glm_small) { const int cg = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct); nsplit = (int)std::max<int64_t>(1, (4096 + cg - 1) / cg); }
   nsplit = ((nsplit + 7) / 8) * 8;
   const int64_t cap = std::max<int64_t>(8, (max_rows / 2048) / 8 * 8);
   return (int)std::min<int64_t>(nsplit, cap);
 }
 
 // one batched gradient launch of the tick engine: whichever row-streaming kernel the model was lowered to
-// (rh_grad_gather_kernel | rh_grad_glm[s]_kernel | rh_grad_lds_kernel | rh_grad_kernel), per-split partial sums -> d_partial.
+// (rh_grad_gather_kernel [+ rh_grad_gather_scan_kernel] | rh_grad_glm_kernel | rh_grad_kernel), per-split partial sums -> d_partial.
 // The grid covers every chain; with a list (d_list / d_nlive; nullptr = all `chains`) slot s of the launch is chain list[s] and the
 // workgroups of the slots past the live count -- the last of the grid -- return at once.
 // d_vflag: the chains' request flags (rh_tick_kernel: 2 = gradient only, the log-density of that evaluation is never read) or nullptr.
@@ -1473,19 +1463,12 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_list, void *d_n
     return;
   }
   void *args[] = {&m->data, &d_q, &d_list, &d_nlive, &d_vflag, &d_partial, &d_graderr, &d_running, &chains, &nsplit, &xcd};
-  if (m->k_grad_glm && m->glm_small) {
-    const int cgroups = (chains + 16 * m->glms_ct - 1) / (16 * m->glms_ct);
-    launch(m->k_grad_glm, (unsigned)(cgroups * nsplit), 64, m->stream, args);
-  } else if (m->k_grad_glm) {
+  if (m->k_grad_glm) {
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
     const unsigned tile = (unsigned)m->glm_ncols * 66u * (unsigned)sizeof(double);  // the kernel's NBUF rule: two tiles while they fit
     const unsigned lds = (2u * tile + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
-  } else if (m->use_lds_grad) {
-    const unsigned blocks = (unsigned)(((ngroups + m->grad_w - 1) / m->grad_w) * nsplit);
-    const unsigned lds = 2u * (unsigned)m->ncols_max * 64u * sizeof(double);
-    HIPCHK(hipModuleLaunchKernel(m->k_grad_lds, blocks, 1, 1, 64u * m->grad_w, 1, 1, lds, m->stream, args, nullptr));
   } else
     launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);
 }
@@ -1535,7 +1518,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
         HIPCHK(hipStreamSynchronize(m->stream)); }
       HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
       int xcd = 1;
-      if (const char *e = std::getenv("RH_XCD_AWARE")) xcd = std::atoi(e);
+      if (const char *e = rh::knob("RH_XCD_AWARE")) xcd = std::atoi(e);
       launch_grad(m, &gb, dq, blist.p, nullptr, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
@@ -1717,6 +1700,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
         if (round >= 2 || selfcheck_engine(m, ks, v, tick)) break;   // (a failed check has cleared the kernel and left the reason: choose again)
       }
       s->k_chain = ks.k_chain; s->k_tick = ks.k_tick; s->state_words = ks.state_words; s->dense_off = ks.dense_off;
+      s->off_Pq = ks.off_Pq; s->off_Pg = ks.off_Pg; s->off_PU = ks.off_PU;
     }
     rh_cfg_dev &d = s->cfg;
     d.iterations = cfg->iterations; d.warmup = cfg->warmup; d.sampler = cfg->sampler; d.hmc_steps = cfg->hmc_steps;
@@ -1761,8 +1745,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       // A function of the sampler and the model only: a chain's sums do not depend on how many chains there are, are live, or
       // share the device (rh_sample_multi fixes grad_splits from the total chain count).
       int subf = cfg->sampler == RH_SAMPLER_HMC ? 1 : 8;
-      if (const char *e = std::getenv("RH_SUBF")) { subf = 1; while (subf * 2 <= std::atoi(e) && subf < 64) subf *= 2; }
-      if (const char *e = std::getenv("RH_COMPACT")) s->compact = std::atoi(e) != 0;
+      if (const char *e = rh::knob("RH_SUBF")) { subf = 1; while (subf * 2 <= std::atoi(e) && subf < 64) subf *= 2; }
+      if (const char *e = rh::knob("RH_COMPACT")) s->compact = std::atoi(e) != 0;
       { int64_t max_rows = 1;
         for (size_t t = 0; t < m->prog.targets.size(); t++) if (m->prog.targets[t].n_cols) max_rows = std::max<int64_t>(max_rows, m->data.nrows[t]);
         while (subf > 1 && max_rows / ((int64_t)nsplit * subf) < 1024) subf >>= 1; }
@@ -1778,7 +1762,7 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
         for (int c = 0; c < chains; c++) ident[(size_t)c] = c;
         HIPCHK(hipMemcpy(s->d_list, ident.data(), sizeof(int) * chains, hipMemcpyHostToDevice)); }
       HIPCHK(hipMemset(s->d_nlive, 0, sizeof(int)));
-      if (const char *e = std::getenv("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
+      if (const char *e = rh::knob("RH_XCD_AWARE")) s->xcd_aware = std::atoi(e);
       HIPCHK(hipMalloc(&s->d_qbuf, sizeof(double) * n * chains));
       HIPCHK(hipMalloc(&s->d_active, sizeof(int) * chains));
       HIPCHK(hipMalloc(&s->d_partial, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
@@ -1789,8 +1773,8 @@ extern "C" int rh_sampler_create(rh_model *m, const rh_config *cfg, const int64_
       {  // The fused launch (rh_grad_fused_kernel: static HMC's mid-trajectory update as the gradient launch's prologue) needs the
          // base sampler-kernel variant (its state layout is compiled into the gradient module), the plain VALU gradient kernel and
          // a lock-step sampler.  Chains are bit-identical with and without it (tests/test_gpu_fused.py); RH_FUSE=0 turns it off.
-        bool fuse = m->k_grad_fused && m->k_absorb && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm && !m->use_lds_grad;
-        if (const char *e = std::getenv("RH_FUSE")) fuse = fuse && std::atoi(e) != 0;
+        bool fuse = m->k_grad_fused && m->k_absorb && s->k_tick == m->k_tick && cfg->sampler == RH_SAMPLER_HMC && !m->k_grad_glm;
+        if (const char *e = rh::knob("RH_FUSE")) fuse = fuse && std::atoi(e) != 0;
         if (fuse) {
           const size_t rec_bytes = sizeof(uint64_t) * (size_t)(3 * n + 8) * chains;   // RH_REC_U64 (rh_engine.hip.h)
           HIPCHK(hipMalloc(&s->d_partial2, sizeof(double) * (size_t)m->n_row_targets * nsplit * chains * m->nacc_max));
@@ -1838,7 +1822,7 @@ void advance_to_ticks(rh_sampler *s, int it_stop) {
   void *no_list = nullptr;
   void *live_list = s->d_list, *live_n = s->compact ? s->d_nlive : nullptr;   // (without compaction d_list stays the identity)
   void *vflag = s->d_active;   // gradient-only requests (RH_VALUE_FREE=0: every launch computes the log-density too)
-  if (const char *e = std::getenv("RH_VALUE_FREE")) if (std::atoi(e) == 0) vflag = nullptr;
+  if (const char *e = rh::knob("RH_VALUE_FREE")) if (std::atoi(e) == 0) vflag = nullptr;
   auto tick = [&](int fresh, bool reset_counter, void *partial, bool listed, int log_slot) {
     if (reset_counter) HIPCHK(hipMemsetAsync(s->d_running, 0, sizeof(int), m->stream));
     void *lst = listed && s->compact ? live_list : no_list, *nl = listed && s->compact ? live_n : no_list;
@@ -1970,6 +1954,50 @@ void fetch_stats(rh_sampler *s) {
 }
 }  // namespace
 
+namespace {
+// Run-time spot check of the tick engine (VERDICT r5 next #6b): the create-time self-checks compare the kernels at three points once;
+// this one runs behind every rh_sampler_run.  The current point of three chains -- (q, gradient, log-density) as the sampler carries
+// them in its state, i.e. as the batched gradient launches of the run produced them (live-chain lists, gradient-only requests, fused
+// prologues and all) -- is evaluated again from scratch: on rh_density_kernel (another kernel around the same row code, one wavefront
+// per chain) when the model has one and the data are small enough for it, otherwise through a fresh, uncompacted launch of the
+// gradient path.  A disagreement beyond summation-order noise is RH_E_DEVICE naming the kernels.  Cost: three small copies and one
+// density evaluation per call.
+int spot_check(rh_sampler *s) {
+  rh_model *m = s->m;
+  if (!s->tick_engine || s->off_Pq < 0 || s->it_done <= 0 || !selfcheck_enabled()) return RH_OK;
+  if (const char *e = rh::knob("RH_SPOTCHECK")) if (std::atoi(e) == 0) return RH_OK;
+  const bool ref_density = m->density_ok && !m->info.gather_mode && m->rows_total <= ((int64_t)1 << 24);
+  const int n = (int)m->prog.n_params, nc = std::min(3, s->chains);
+  const int pick[3] = {0, s->chains / 2, s->chains - 1};
+  std::vector<double> q((size_t)nc * n), g((size_t)nc * n), lp(nc), gr((size_t)nc * n), lr(nc);
+  std::vector<uint64_t> img((size_t)s->state_words);
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (hipSetDevice(m->device) != hipSuccess) return RH_OK;
+    for (int c = 0; c < nc; c++) {
+      if (hipMemcpy(img.data(), (const uint64_t *)s->d_state + (size_t)pick[c] * s->state_words, img.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return RH_OK;
+      std::memcpy(&q[(size_t)c * n], img.data() + s->off_Pq, sizeof(double) * n);
+      std::memcpy(&g[(size_t)c * n], img.data() + s->off_Pg, sizeof(double) * n);
+      double pu; std::memcpy(&pu, img.data() + s->off_PU, sizeof pu);
+      lp[c] = -pu;
+    }
+  }
+  const int rc = rh_density_eval_ex(m, q.data(), nc, ref_density ? RH_ENGINE_CHAIN : RH_ENGINE_TICK, 0, lr.data(), gr.data());
+  if (rc != RH_OK) return RH_OK;   // (RH_E_LOOKUP: the sampler reports it itself; anything else: no reference, no verdict)
+  for (int c = 0; c < nc; c++) {
+    std::string what;
+    if (!outputs_agree(&lp[c], &g[(size_t)c * n], &lr[c], &gr[(size_t)c * n], n, what)) {
+      rh_timing t; std::memset(&t, 0, sizeof t);
+      (void)rh_sampler_timing(s, &t, 0);
+      m->err = g_err = std::string("run-time spot check: the point chain ") + std::to_string(pick[c]) + " carries (" + t.dominant_kernel + " + rh_tick_kernel) disagrees with " +
+                       (ref_density ? "rh_density_kernel" : "a fresh evaluation through the gradient path") + " at the same q (" + what + "): one of the two is wrong on this device";
+      return RH_E_DEVICE;
+    }
+  }
+  return RH_OK;
+}
+}  // namespace
+
 extern "C" int rh_sampler_warmup(rh_sampler *s) {
   if (!s) { g_err = "rh_sampler_warmup: NULL"; return RH_E_INVALID; }
   std::lock_guard<std::mutex> lk(s->m->mu);
@@ -1981,13 +2009,17 @@ extern "C" int rh_sampler_warmup(rh_sampler *s) {
 }
 extern "C" int rh_sampler_run(rh_sampler *s, int32_t n) {
   if (!s || n < 0) { g_err = "rh_sampler_run: bad arguments"; return RH_E_INVALID; }
-  std::lock_guard<std::mutex> lk(s->m->mu);
-  return guard(s->m, [&] {
-    if (!s->warmed) { advance_to(s, s->cfg.warmup); s->warmed = true; }
-    if (s->it_done + n > s->cfg.iterations) throw Fail{RH_E_INVALID, "rh_sampler_run: more iterations than configured"};
-    advance_to(s, s->cfg.warmup + s->it_done + n);
-    s->it_done += n;
-  });
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(s->m->mu);
+    rc = guard(s->m, [&] {
+      if (!s->warmed) { advance_to(s, s->cfg.warmup); s->warmed = true; }
+      if (s->it_done + n > s->cfg.iterations) throw Fail{RH_E_INVALID, "rh_sampler_run: more iterations than configured"};
+      advance_to(s, s->cfg.warmup + s->it_done + n);
+      s->it_done += n;
+    });
+  }
+  return rc == RH_OK && n > 0 ? spot_check(s) : rc;
 }
 extern "C" int rh_sampler_draws(rh_sampler *s, int32_t first, int32_t count, double *out) {
   if (!s || !out || first < 0 || count < 0 || first + count > s->it_done) { g_err = "rh_sampler_draws: bad range"; return RH_E_INVALID; }
@@ -2084,7 +2116,7 @@ extern "C" int rh_sampler_timing(rh_sampler *s, rh_timing *out, int reset) {
     out->kernel_ms = s->kernel_ms; out->total_ms = s->total_ms; out->launches = s->launches;
     out->density_evals = grads - s->grads_at_reset;
     out->row_chain_evals = out->density_evals * s->m->rows_total;
-    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? (s->m->glm_small ? "rh_grad_glms_kernel" : "rh_grad_glm_kernel") : s->m->use_lds_grad ? "rh_grad_lds_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
+    std::snprintf(out->dominant_kernel, sizeof out->dominant_kernel, s->tick_engine ? (s->m->info.gather_mode ? "rh_grad_gather_kernel" : s->m->k_grad_glm ? "rh_grad_glm_kernel" : (s->fuse && s->warmed && s->cfg.hmc_steps > 1) ? "rh_grad_fused_kernel" : "rh_grad_kernel") : "rh_chain_kernel");
     out->chain_slots = s->tick_engine ? s->chain_slots : out->density_evals;
     out->steady_kernel_ms = s->steady_ms; out->steady_launches = s->steady_launches; out->steady_density_evals = s->steady_evals;
     if (reset) { s->kernel_ms = 0; s->total_ms = 0; s->launches = 0; s->grads_at_reset = grads; s->chain_slots = 0; s->steady_ms = 0; s->steady_launches = 0; s->steady_evals = 0; }
@@ -2179,7 +2211,7 @@ extern "C" int rh_requirements_eval(const void *rir, size_t rir_len, const rh_co
     const std::string src = "// generated by rainier-hip: requirements program\n" + defines + kSharedSrc + "\n" + kPreludeSrc + "\n" + body + kReqKernel;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-      if (std::getenv("RH_LOWER_ONLY")) { (void)build_source("gfx950", src); return; }   // build()/CPU tests: cross-compile only
+      if (rh::knob("RH_LOWER_ONLY")) { (void)build_source("gfx950", src); return; }   // build()/CPU tests: cross-compile only
       throw Fail{RH_E_DEVICE, "no HIP device available: the engine has no CPU fallback"};
     }
     if (dev < 0) HIPCHK(hipGetDevice(&dev));

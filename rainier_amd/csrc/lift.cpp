@@ -228,7 +228,7 @@ bool lift_one(Program &P, std::vector<std::vector<double>> &synth, std::vector<u
     std::sort(cands.begin(), cands.end(), [](auto *a, auto *b) { return a->size() != b->size() ? a->size() > b->size() : (*a)[0] < (*b)[0]; });
     auto is_zero = [&](uint32_t id) { return P.nodes[id].op == RH_RIR_CONST && P.nodes[id].cval == 0.0; };
     const uint32_t np = P.n_params;
-    const bool why = std::getenv("RH_LIFT_WHY") != nullptr;
+    const bool why = rh::knob("RH_LIFT_WHY") != nullptr;
     if (why) std::fprintf(stderr, "lift: %zu parameter-blind candidate groups\n", cands.size());
     for (const std::vector<uint32_t> *cand : cands) {
       tmpl = (*cand)[0];
@@ -427,7 +427,7 @@ void flatten_sum(const Program &P, uint32_t id, std::vector<STerm> &out) {
 }  // namespace
 
 bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int gather_min, bool rederive_ok) {
-  auto no = [](int where) { if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table prior not lifted (check %d)\n", where); return false; };
+  auto no = [](int where) { if (rh::knob("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table prior not lifted (check %d)\n", where); return false; };
   if (P.kind != 0) return false;
   const uint32_t np = P.n_params;
   uint32_t t0 = np;
@@ -625,7 +625,7 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
       for (uint32_t o = 0; o <= t0 && ok; o++)
         if (differs(val_o[outs[o]], sum[o], mag[o])) {
           ok = false;
-          if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: output %u differs (%.6Lg vs %.6Lg; data-free part %.6Lg)\n", o, val_o[outs[o]], sum[o], val_d[T.outputs[o]]);
+          if (rh::knob("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: output %u differs (%.6Lg vs %.6Lg; data-free part %.6Lg)\n", o, val_o[outs[o]], sum[o], val_d[T.outputs[o]]);
         }
       const uint32_t nblk = (G + B - 1) / B, stride = std::max<uint32_t>(1, nblk / 8);
       for (uint32_t blk = 0; blk < nblk && ok; blk += stride) {
@@ -641,14 +641,14 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
           const long double a = val_o[outs[o]], b = val_d[T.outputs[o]] + val_r[(size_t)RT.outputs[o] * B + r];
           if (!rok[(size_t)r] || differs(a, b, std::fabs(b))) {
             ok = false;
-            if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: entry output %u differs (%.6Lg vs %.6Lg)\n", o, a, b);
+            if (rh::knob("RH_LIFT_WHY")) std::fprintf(stderr, "lift: centred table prior: entry output %u differs (%.6Lg vs %.6Lg)\n", o, a, b);
           }
         }
       }
     }
     // (the variable is a debugging aid.)  Nothing of the attempt is left behind: the row target's nodes were appended to P itself,
     // among them INPUT nodes beyond P.n_inputs that a later lift would hand the same indices to
-    if (!ok && !std::getenv("RH_LIFT_NOVERIFY")) { synth.resize(synth0); P.nodes.resize(n_old); return no(12); }
+    if (!ok && !rh::knob("RH_LIFT_NOVERIFY")) { synth.resize(synth0); P.nodes.resize(n_old); return no(12); }
   }
   P = std::move(Q);
   return true;
@@ -656,7 +656,7 @@ bool lift_table_priors(Program &P, std::vector<std::vector<double>> &synth, int 
 
 // ---- the affine map of a parameter table moved behind the lookup (see rir.hpp) ----------------------------------------------
 bool hoist_table_maps(Program &P, int gather_min) {
-  auto no = [](int where) { if (std::getenv("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table map not hoisted (check %d)\n", where); return false; };
+  auto no = [](int where) { if (rh::knob("RH_LIFT_WHY")) std::fprintf(stderr, "lift: table map not hoisted (check %d)\n", where); return false; };
   if (P.kind != 0) return false;
   const uint32_t np = P.n_params;
   std::vector<char> reaches_param(P.nodes.size(), 0);

@@ -307,7 +307,7 @@ Program rederive_gradients(const Program &P, const std::vector<const double *> &
         const xreal bound = 1e-11L * mag[p];
         if (worst[p] > bound || std::fabs(sa[p] - sb[p]) > bound) {
           ok = false;
-          if (std::getenv("RH_REDERIVE_WHY"))
+          if (rh::knob("RH_REDERIVE_WHY"))
             std::fprintf(stderr, "rederive: target %zu output %u trial %d: worst row difference %.3Lg, sum difference %.3Lg, bound %.3Lg\n", t, p, trial,
                          worst[p], std::fabs(sa[p] - sb[p]), bound);
         }

@@ -364,7 +364,7 @@ struct Refactor {
   };
   // RH_ROLL_WHY=1: say on stderr why a target with several column groups was not rolled
   static Rolled why(Rolled R, const char *reason) {
-    if (std::getenv("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: target not rolled back into rows: %s\n", reason);
+    if (rh::knob("RH_ROLL_WHY")) std::fprintf(stderr, "rainier-hip: target not rolled back into rows: %s\n", reason);
     return R;
   }
   Rolled try_roll(size_t t, const std::vector<char> &taken) {
@@ -418,7 +418,7 @@ struct Refactor {
       std::map<uint64_t, std::vector<size_t>> classes;
       for (size_t c = 0; c < comps.size(); c++) classes[ch[c]].push_back(c);
       size_t S0 = 0;
-      if (std::getenv("RH_ROLL_WHY"))
+      if (rh::knob("RH_ROLL_WHY"))
         for (auto &kv : classes)
           std::fprintf(stderr, "rainier-hip:   class of %zu component(s), %zu column(s) each, %s, first column input %u\n", kv.second.size(),
                        comps[kv.second[0]].size(), comp_param[kv.second[0]] ? "reached by parameters" : "data only", comps[kv.second[0]][0]);

@@ -1,12 +1,19 @@
 // rir.cpp -- RIR reader/validator (format: include/rainier_hip_rir.h).
 #include "rir.hpp"
 
+#include <cstdlib>
+
 #include <cstring>
 
 #include "../../include/rainier_hip_rir.h"
 #include "device/rh_shared.h"
 
 namespace rh {
+const char *knob(const char *name) {
+  static const bool diag = [] { const char *e = std::getenv("RH_DIAG"); return e && std::atoi(e) != 0; }();
+  return diag ? std::getenv(name) : nullptr;
+}
+
 namespace {
 struct Reader {
   const uint8_t *p;

@@ -5,6 +5,24 @@
 #include <vector>
 
 namespace rh {
+// ---- diagnostic knobs ------------------------------------------------------------------------------------------------------------
+// The engine reads its experiment / test switches (RH_FUSE, RH_COMPACT, RH_GATHER_*, RH_GLM_*, the *_WHY traces, ...: DESIGN appendix)
+// through knob(): they exist only in a process that has RH_DIAG=1 in its environment -- tests/conftest.py and the tools/ scripts set
+// it; nothing else does, so in normal use no environment variable changes which kernels run, how they are built or how results
+// round.  (What stays readable without it is operational: where the kernel cache lives, RH_NO_KERNEL_CACHE, RH_COMM_TIMEOUT_S.)
+// unsafe_knob(): the two switches that turn the correctness guards off (RH_ALLOW_UNHEALTHY: launch kernels kernel_health refused;
+// RH_SELFCHECK=0: skip the create-time self-checks) are compiled out of the library altogether unless it is built with
+// -DRH_DIAG_UNSAFE (`make unsafe-diag`: a separate file for reproducing compiler faults on a GPU, never the one that ships).
+const char *knob(const char *name);
+inline const char *unsafe_knob(const char *name) {
+#ifdef RH_DIAG_UNSAFE
+  return knob(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 
 struct Node {
   uint32_t op = 0, a = 0, b = 0;
@@ -121,7 +139,6 @@ struct EmitOptions {
   int gather_min = 65;   // Lookup tables of at least this many trailing parameters switch the model to gather mode
   bool glm_mfma = true;  // with factor_outputs: lower dense linear predictors to the fp64 MFMA kernel
   bool logit_link = true;  // fast mode: a VERIFIED Bernoulli-logit scalar part is emitted in closed form (RH_LOGIT_LINK=0 switches it off)
-  int grad_waves = 0;  // wavefronts (chain groups) per workgroup sharing LDS-staged row tiles; 0 = default (8)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
   int chunk = 0;          // > 0: memory-resident lowering (emit.cpp chunk_body): generated functions are cut into chunks of at most this many

@@ -440,7 +440,7 @@ bool roll_strict_impl(Program &P, std::vector<std::vector<uint32_t>> &parts, int
       comps.swap(cs); comp_param.swap(cp);
     }
     const bool loose_param = index_masks_on();
-    const bool say = std::getenv("RH_ROLL_WHY") != nullptr;   // RH_ROLL_WHY=1: why a target with several column groups keeps them
+    const bool say = rh::knob("RH_ROLL_WHY") != nullptr;   // RH_ROLL_WHY=1: why a target with several column groups keeps them
     if (comps.size() < 2) continue;
     not_rolled++;                                   // (taken back at the end of the loop body when the target does roll)
     std::map<uint32_t, size_t> comp_of;

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The engine's experiment / test switches (RH_FUSE, RH_COMPACT, RH_GATHER_MIN, ...) exist only in a process that asks for them
+# (csrc/rir.hpp: rh::knob): the tests compare the default path with what those switches select, so the test session does.
+os.environ.setdefault("RH_DIAG", "1")
 
 
 def pytest_configure(config):

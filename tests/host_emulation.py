@@ -11,6 +11,19 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _HARNESS = r'''
+// rh_host_gonly != 0: the rows are walked through row_g() / elem_g() -- the gradient-only row code of the tick engine's mid-trajectory
+// requests (csrc/emit.cpp: value_only) -- where the target has one; outputs 1.. must then equal the full evaluation's bit for bit
+static int rh_host_gonly = 0;
+template <class TG, class TH, class INV, class CP, class ACC>
+static void rh_host_row(const TH &th, const INV &inv, const CP &c, ACC &acc, int &err) {
+  if constexpr (TG::HAS_VALUE_ONLY) { if (rh_host_gonly) { TG::row_g(th, inv, c, acc, err); return; } }
+  TG::row(th, inv, c, acc, err);
+}
+template <class TG, class TH, class INV, class CP, class ACC>
+static void rh_host_row_gz(const TH &th, const INV &inv, const CP &c, const double gz, ACC &acc, double &sv, int &err) {
+  if constexpr (TG::HAS_VALUE_ONLY) { if (rh_host_gonly) { TG::row_g(th, inv, c, gz, acc, sv, err); return; } }
+  TG::row(th, inv, c, gz, acc, sv, err);
+}
 template <int T> static void rh_host_target(const double (&th)[RH_NTH], const double *const *cols, const long long *nrows,
                                             double (&tot)[RH_NOUT], int &err) {
   if constexpr (T < RH_NTARGETS) {
@@ -25,7 +38,7 @@ template <int T> static void rh_host_target(const double (&th)[RH_NTH], const do
       double c[TG::NCOLS > 0 ? TG::NCOLS : 1];
       for (long long r = 0; r < nrows[T]; r++) {
         for (int j = 0; j < TG::NCOLS; j++) c[j] = cols[TG::COL0 + j][r];
-        TG::row(th, inv, c, S, err);
+        rh_host_row<TG>(th, inv, c, S, err);
       }
       TG::finish(th, inv, S, (double)nrows[T], tot);
     }
@@ -56,7 +69,7 @@ template <int T> static void rh_host_gather_target(const double *q, const double
           if (g < 0 || g >= TG::G_COUNT) { err = 1; continue; }
           gz = q[TG::G_FIRST + g];
         }
-        TG::row(th, inv, c, gz, S, sv, err);
+        rh_host_row_gz<TG>(th, inv, c, gz, S, sv, err);
         if constexpr (TG::HAS_GATHER) tg[g] += sv;
       }
       TG::finish(th, inv, S, (double)nrows[T], tot);
@@ -95,7 +108,8 @@ extern "C" int rh_host_eval_glm(const double *q, const double *const *cols, cons
     double eta = 0.0;
     for (int k = 0; k < GL::P; k++) eta += GL::pred_scale[k] * th[GL::pred_param[k]] * (GL::pred_col[k] >= 0 ? c[GL::pred_col[k]] : 1.0);
     double w = 0.0, other[GL::NOTHER > 0 ? GL::NOTHER : 1];
-    GL::elem(thu, eta, [&](int j) { return c[j]; }, w, other, err);
+    if (rh_host_gonly) GL::elem_g(thu, eta, [&](int j) { return c[j]; }, w, other, err);
+    else GL::elem(thu, eta, [&](int j) { return c[j]; }, w, other, err);
     for (int k = 0; k < GL::P; k++) S[GL::pred_acc[k]] += w * (GL::pred_col[k] >= 0 ? c[GL::pred_col[k]] : 1.0);
     for (int k = 0; k < GL::NOTHER; k++) S[GL::other_acc[k]] += other[k];
   }
@@ -130,6 +144,7 @@ class HostTargets:
         harness = _HARNESS.replace('extern "C" int rh_host_eval_glm(', 'static int host_eval_glm_impl(').replace('extern "C" int rh_host_eval(', 'static int host_eval_impl(')
         text = (head + '#include "host_target_shim.hpp"\nnamespace {\n' + gen + harness + '}\n'
                 'extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_impl(q, cols, nrows, out); }\n'
+                'extern "C" void rh_host_set_gonly(int v) { rh_host_gonly = v; }\n'
                 '#ifdef RH_GLM_TARGET\nextern "C" int rh_host_eval_glm(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_glm_impl(q, cols, nrows, out); }\n#endif\n')
         key = hashlib.sha256(text.encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "rh_host_targets")
@@ -146,8 +161,20 @@ class HostTargets:
         """the GLM target alone, through rh_glm<t> (predictor tables + scalar part) instead of its row()"""
         return self._call(self.lib.rh_host_eval_glm, q, columns, nrows)
 
-    def eval(self, q, columns, nrows):
-        return self._call(self.lib.rh_host_eval, q, columns, nrows)
+    def eval_glm_gradient_only(self, q, columns, nrows):
+        self.lib.rh_host_set_gonly(1)
+        try:
+            return self._call(self.lib.rh_host_eval_glm, q, columns, nrows)
+        finally:
+            self.lib.rh_host_set_gonly(0)
+
+    def eval(self, q, columns, nrows, gradient_only=False):
+        """gradient_only: through row_g() / elem_g() where the targets have them (the log-density, output 0, is then not computed)"""
+        self.lib.rh_host_set_gonly(1 if gradient_only else 0)
+        try:
+            return self._call(self.lib.rh_host_eval, q, columns, nrows)
+        finally:
+            self.lib.rh_host_set_gonly(0)
 
     def _call(self, fn, q, columns, nrows):
         cols = [np.ascontiguousarray(c, dtype=np.float64) for c in columns]

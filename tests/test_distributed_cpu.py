@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: a world_size-2 gloo run of the HOST side of bench.py's multi-GPU protocol -- chain sharding by global
+"""N > 1 path on CPU: world_size-2 and world_size-8 gloo runs of the HOST side of bench.py's multi-GPU protocol -- chain sharding by global
 id, the broadcast that hands rank 0's RCCL unique id to the other ranks, the barrier and the host reductions.  The device
 side (rh_comm_*: RCCL all-gather of real engine draws) is covered on the GPU by tests/test_gpu_multi.py."""
 import os
@@ -36,17 +36,21 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
-def test_two_rank_gloo_sharding_and_bootstrap(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])     # 8: the node shape the driver's scaling runs use (one rank per MI355X)
+def test_gloo_sharding_and_bootstrap(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         env=env, capture_output=True, text=True, timeout=600)
+                         env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank0_ok" in out.stdout and "rank1_ok" in out.stdout
+    assert all("rank%d_ok" % r in out.stdout for r in range(world))
 
 
 def test_comm_entry_points_fail_cleanly_without_a_device():

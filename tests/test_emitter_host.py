@@ -54,6 +54,10 @@ def _check(spec, opts, qs, tol, with_data=True):
         assert err == 0
         both_nan = np.isnan(got) & np.isnan(ref)
         assert np.all((np.abs(got - ref) <= tol * ab + 1e-300) | both_nan), (spec.name, opts, np.max(np.abs(got - ref) / (tol * ab + 1e-300)))
+        # the gradient-only row code (row_g(): what the tick engine runs for a mid-trajectory request) leaves every gradient output
+        # exactly as the full row code computes it -- only output 0, the log-density, is not there
+        lean, err2 = h.eval(q, cols, nrows, gradient_only=True)
+        assert err2 == 0 and np.array_equal(lean[1:], got[1:], equal_nan=True), (spec.name, opts, "row_g() changes a gradient output")
     return src
 
 
@@ -174,6 +178,8 @@ def _glm_check(spec, qs, tol, with_data):
         assert err == 0
         assert np.all(np.abs(glm + others - ref) <= tol * ab + 1e-300), (spec.name, np.max(np.abs(glm + others - ref) / (tol * ab + 1e-300)))
         assert np.all(np.abs(full - ref) <= tol * ab + 1e-300)
+        lean, err2 = h.eval_glm_gradient_only(q, cols, only)               # elem_g(): the scalar part without the log-density's own terms
+        assert err2 == 0 and np.array_equal(lean[1:], glm[1:], equal_nan=True), (spec.name, "elem_g() changes a gradient output")
     return src
 
 

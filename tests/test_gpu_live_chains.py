@@ -124,3 +124,25 @@ def test_gradient_only_requests_leave_every_chain_bit_identical(case, sampler, m
     monkeypatch.delenv("RH_VALUE_FREE")
     assert np.array_equal(lean["draws"], full["draws"]) and np.array_equal(lean["mass"], full["mass"]) and lean["stats"] == full["stats"], name
     m.close()
+
+
+def test_big_mode_gather_tick_fast_path_is_bit_identical_to_the_general_path(monkeypatch):
+    """rh_tick_kernel's fast path for gather-mode models in big mode (one loop per element instead of six vector passes; it does not
+    store pend_g / Bg -- the invariant: whichever tick follows overwrites both before reading them, rh_engine.hip.h) against the
+    general path (RH_TICK_FAST=0, another build of the same model): adapted diagonal mass, 13 chains (a ragged last chain group),
+    704 parameters = 11 slots of 64 (not a multiple of the 8 slots the loop keeps in flight), piecewise runs."""
+    spec = models.hier_negbin(700, 100, seed=3)
+    build = dict(fp_contract=True, factor_outputs=True)
+    cfg = R.make_config(5, 14, R.HMCSampler(5), R.DualAvgTuner(0.8), R.DiagonalMassMatrixTuner(4, 1.5, 2, 2), engine=_capi.ENGINE_TICK)
+    seeds = [8400 + c for c in range(13)]
+    m = R.Model(spec, device=0, **build)
+    assert "#define RH_BIGN 1" in m.hip_source and "#define RH_SLOTS 11" in m.hip_source
+    fast = _run(m, cfg, seeds, pieces=[2, 3])
+    m.close()
+    monkeypatch.setenv("RH_TICK_FAST", "0")
+    m0 = R.Model(spec, device=0, **build)
+    assert "#define RH_TICK_FAST 0" in m0.hip_source
+    general = _run(m0, cfg, seeds, pieces=[2, 3])
+    m0.close()
+    monkeypatch.delenv("RH_TICK_FAST")
+    assert np.array_equal(fast["draws"], general["draws"]) and np.array_equal(fast["mass"], general["mass"]) and fast["stats"] == general["stats"]

@@ -1,5 +1,6 @@
 import sys, time, json
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import numpy as np
 import rainier_amd as R
 from rainier_amd import models, _capi

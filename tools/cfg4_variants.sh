@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # cfg-4-shaped probe (rh_grad_glm_kernel) under the knobs that shape the kernel; the code objects are precompiled on the
 # build host (tools/cfg4_variants.sh precompile) so that the GPU box only loads them.
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}

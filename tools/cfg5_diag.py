@@ -2,6 +2,7 @@
 (tests/test_gpu_baseline_sizes.py asserts it; this prints WHERE they differ when they do: which chains -- position in the K-group --,
 which outputs, how far.)  usage: [RH_* env] python tools/cfg5_diag.py [chains] [splits]"""
 import os, sys
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rainier_amd as R

@@ -7,6 +7,7 @@ GPU runs the SAME instance with the SAME seeds:   python tools/cfg5_oracle_nuts.
 Both print mean leapfrog steps per iteration (tree depth), acceptance, step size, and R-hat of the four shared parameters."""
 import json
 import os
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import sys
 import time
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # sample sclk / power while the cfg 2 bench (or the fp64 ubench) runs
 mkdir -p gpurun_out; out=gpurun_out/clock_probe.txt; : > $out
 probe() {

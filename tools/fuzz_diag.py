@@ -1,5 +1,6 @@
 """diagnostic: one eight-slot fuzz model through both engines, per build / row-loop variant / split count"""
 import os, sys
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rainier_amd as R

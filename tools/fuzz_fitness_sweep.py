@@ -7,6 +7,7 @@ import collections
 import json
 import multiprocessing as mp
 import os
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import sys
 import time
 

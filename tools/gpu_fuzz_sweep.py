@@ -2,6 +2,7 @@
   python tools/gpu_fuzz_sweep.py prebuild LO HI   -- cross-compile the cases' code objects into the in-tree cache (no GPU needed)
   python tools/gpu_fuzz_sweep.py run LO HI        -- on the GPU: every case, both math modes, both engines, vs the oracle at 1e-12"""
 import os, sys
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rainier_amd import _capi

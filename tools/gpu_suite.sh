@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # The GPU tier in one call: every -m gpu test (no -x: a failure must not hide the rest; the row representatives of tests/conftest.py
 # run first), smoke(), and the default bench line.  usage, from the repo root:
 #   gpurun --timeout 1500 -- "bash tools/gpu_suite.sh NAME [pytest args]"      -> gpurun_out/NAME/{tests.log,smoke.log,bench.json}

@@ -19,6 +19,7 @@ llvm-objdump's text, that the CPU suite compares the engine's verdicts with.
 usage: python tools/isa_check.py [--strict] file.hsaco ... | --cache DIR
 """
 import os
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import re
 import subprocess
 import sys

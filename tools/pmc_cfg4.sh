@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # PMC passes over the cfg-4-shaped probe (rh_grad_glm_kernel); results condensed into gpurun_out/pmc_glm.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_cfg4; mkdir -p $O

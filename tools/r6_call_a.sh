@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # GPU call A of round 6: the live-chain compaction (rh_compact_kernel, list-addressed gradient launches and ticks): its own tests, the
 # tests of everything it touched (fused launches, multi-shard, tick-engine parity, gather mode, GLM), then the side legs of the bench
 # that it is for (cfg 2 under DefaultConfig, cfg 4 / cfg 5 under NUTS) with and without compaction.  -> gpurun_out/r6_a/

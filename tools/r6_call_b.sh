@@ -1,4 +1,5 @@
 #!/bin/bash
+export RH_DIAG=1   # the engine reads its experiment switches only in a process that asks for them (csrc/rir.hpp: rh::knob)
 # GPU call B of round 6: the whole GPU tier at HEAD (live-chain lists, gradient-only requests, the fallback gather walks without a
 # divergent ragged tile), then the bench's side legs as the `configs` block runs them.  -> gpurun_out/r6_b/
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -23,6 +23,7 @@ engine launches, which is what the device-side checks (create-time self-check on
 usage: python tools/unproven_census.py [--jobs N] > profiles/r5_parity/unproven_blocks.md"""
 import collections
 import os
+os.environ.setdefault("RH_DIAG", "1")   # experiment switches are read only in a process that asks for them (csrc/rir.hpp: rh::knob)
 import re
 import sys
 from concurrent.futures import ProcessPoolExecutor
