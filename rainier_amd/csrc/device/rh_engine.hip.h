@@ -72,8 +72,9 @@ RH_DEV void rh_accumulate_target(const double (&th)[RH_NTH], const rh_model_data
   double inv[TG::NINV > 0 ? TG::NINV : 1];
   TG::invariants(th, inv, err);
   if constexpr (!TG::HAS_ROWS) {
-    // data-free target: evaluated once, outputs(o) += f_o(theta)   (DataFunction.scala:73-83)
-    TG::row(th, inv, nullptr, tot, err);
+    // data-free target: evaluated once, outputs(o) += f_o(theta)   (DataFunction.scala:73-83).  Its `c` is the constant pool: what of
+    // the folded observations is not spelled in the generated source (csrc/rir.hpp EmitInfo::kpool)
+    TG::row(th, inv, d.kpool, tot, err);
   } else {
     constexpr int NC = TG::NCOLS;
     constexpr int U = RH_ROWS_UNROLL;
@@ -1332,7 +1333,7 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
   constexpr int MYC = (NC + W - 1) / W;
   // row tiles are double-buffered in LDS while two of them fit the 160 KB of a CU (<= 155 columns); wider models (<= 310
   // columns) keep one tile and pay a second barrier per tile.  The host sizes the dynamic LDS with the same rule.
-  constexpr int NBUF = (2 * NC * RH_GLM_TRP * 8 + RH_LK_LDS * 4112 <= 160 * 1024) ? 2 : 1;   // (4112 B: the link table, when the model has one)
+  constexpr int NBUF = (2 * NC * RH_GLM_TRP * 8 + RH_LK_LDS * RH_LK_LDS_BYTES <= 160 * 1024) ? 2 : 1;   // (the link table, when the model has one)
   extern __shared__ __attribute__((aligned(16))) double rh_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -1973,14 +1974,15 @@ rh_grad_gather_scan_kernel(const rh_model_data d, const rh_gather_data gd, const
 
 // partial sums -> (logp, grad) of one chain, data-free targets evaluated here, everything in target order
 template <int T>
-RH_DEV void rh_combine_targets(const double (&th)[RH_NTH], const double *__restrict__ partial, const long long *nrows,
+RH_DEV void rh_combine_targets(const double (&th)[RH_NTH], const double *__restrict__ partial, const rh_model_data &d,
                                const int nsplit, const int chain, const int chains, const int lane,
                                double (&tot)[RH_NOUT], int &err) {
+  const long long *const nrows = d.nrows;
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (!TG::HAS_ROWS) {
       double inv[1];
-      TG::row(th, inv, nullptr, tot, err);
+      TG::row(th, inv, d.kpool, tot, err);
     } else {
       constexpr int NA = TG::NACC > 0 ? TG::NACC : 1;
       // lane l sums the splits l, l+64, ... (ascending), then the fixed-order butterfly: deterministic, and the
@@ -1998,7 +2000,7 @@ RH_UNROLL_ACC
       TG::invariants(th, inv, err);
       TG::finish(th, inv, S, (double)nrows[T], tot);
     }
-    rh_combine_targets<T + 1>(th, partial, nrows, nsplit, chain, chains, lane, tot, err);
+    rh_combine_targets<T + 1>(th, partial, d, nsplit, chain, chains, lane, tot, err);
   }
 }
 
@@ -2030,7 +2032,7 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
   const double (&th)[RH_NTH] = *reinterpret_cast<const double (*)[RH_NTH]>(q.s.p);
   double (&tot)[RH_NOUT] = *reinterpret_cast<double (*)[RH_NOUT]>(rh_tot_base);
   for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
-  rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+  rh_combine_targets<0>(th, partial, d, nsplit, chain, chains, lane, tot, err);
   logp = tot[0];
   for (int i = lane; i < RH_NVARS; i += 64) grad.s.p[i] = tot[1 + i];
   return;
@@ -2041,7 +2043,7 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
   double tot[RH_NOUT];
 #pragma unroll
   for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
-  rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+  rh_combine_targets<0>(th, partial, d, nsplit, chain, chains, lane, tot, err);
   logp = tot[0];
 #if RH_BIGN
   RH_UNROLL_SLOTS
@@ -2105,13 +2107,14 @@ RH_DEV void rh_combine_chain(const wvec &q, const rh_model_data &d,
 #if (RH_GRAD_K == 2 || RH_GRAD_K == 4 || RH_GRAD_K == 8 || RH_GRAD_K == 16) && (RH_NVARS * RH_GRAD_K <= 64) && !RH_BIGTH
 #define RH_HAVE_FUSED 1
 template <int T>
-RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *partial, const long long *nrows, const int nsplit,
+RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *partial, const rh_model_data &d, const int nsplit,
                                       const int chain, const int chains, const int j, double (&tot)[RH_NOUT], int &err) {
+  const long long *const nrows = d.nrows;
   if constexpr (T < RH_NTARGETS) {
     typedef rh_target<T> TG;
     if constexpr (!TG::HAS_ROWS) {
       double inv[1];
-      TG::row(th, inv, nullptr, tot, err);
+      TG::row(th, inv, d.kpool, tot, err);
     } else {
       constexpr int NA = TG::NACC > 0 ? TG::NACC : 1, M = RH_GRAD_K, LPC = 64 / RH_GRAD_K;
       double S[NA];
@@ -2165,7 +2168,7 @@ RH_DEV void rh_combine_targets_packed(const double (&th)[RH_NTH], const double *
       TG::invariants(th, inv, err);
       TG::finish(th, inv, S, (double)nrows[T], tot);
     }
-    rh_combine_targets_packed<T + 1>(th, partial, nrows, nsplit, chain, chains, j, tot, err);
+    rh_combine_targets_packed<T + 1>(th, partial, d, nsplit, chain, chains, j, tot, err);
   }
 }
 
@@ -2228,7 +2231,7 @@ RH_DEV void rh_fused_prologue(double (&thk)[RH_GRAD_K][RH_NTH], const rh_model_d
 #pragma unroll
     for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
     int err = 0;
-    rh_combine_targets_packed<0>(th, partial_in, d.nrows, nsplit, chain, chains, j, tot, err);
+    rh_combine_targets_packed<0>(th, partial_in, d, nsplit, chain, chains, j, tot, err);
     double g = 0.0;
 #pragma unroll
     for (int i = 0; i < RH_NVARS; i++) g = (j == i) ? tot[1 + i] : g;
@@ -2425,7 +2428,7 @@ RH_UNROLL_SLOTS
 #pragma unroll
       for (int o = 0; o < RH_NOUT; o++) tot[o] = 0.0;
       int err = grad_err[0];
-      rh_combine_targets<0>(th, partial, d.nrows, nsplit, chain, chains, lane, tot, err);
+      rh_combine_targets<0>(th, partial, d, nsplit, chain, chains, lane, tot, err);
       cerr |= err;
       const double pend_logp = tot[0];
       double gsh = 0.0;   // this lane's shared-parameter gradient (element `lane` of slot 0, lane < RH_NTH)

@@ -250,6 +250,53 @@ __device__ __attribute__((aligned(16))) const double rh_lk_tab[2 * 257] = {
   0x1.0204081020408p-1, 0x1.5ee02a9241676p-1, 0x1.0182436517a37p-1, 0x1.5fe1edad18919p-1, 0x1.0101010101010p-1, 0x1.60e32f44788d9p-1,
   0x1.0080402010080p-1, 0x1.61e3efda46467p-1, 0x1.0000000000000p-1, 0x1.62e42fefa39efp-1
 };
+// 2^(j/128), j = 0..127, as pairs (hi, lo): hi the correctly rounded value, lo = 2^(j/128) - hi (tools/gen_lk_table.py --exp).
+// rh_logit_link's e^{-|t|} = 2^k 2^(j/128) e^r with |r| <= ln2 / 256; the lo word keeps the table's own rounding out of the result.
+__device__ __attribute__((aligned(16))) const double rh_ex_tab[2 * 128] = {
+  0x1.0000000000000p+0, 0x0.0p+0, 0x1.0163da9fb3335p+0, 0x1.b61299ab8cdb7p-54, 0x1.02c9a3e778061p+0, -0x1.19083535b085dp-56,
+  0x1.04315e86e7f85p+0, -0x1.0a31c1977c96ep-54, 0x1.059b0d3158574p+0, 0x1.d73e2a475b465p-55, 0x1.0706b29ddf6dep+0, -0x1.c91dfe2b13c27p-55,
+  0x1.0874518759bc8p+0, 0x1.186be4bb284ffp-57, 0x1.09e3ecac6f383p+0, 0x1.1487818316136p-54, 0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54,
+  0x1.0cc922b7247f7p+0, 0x1.01edc16e24f71p-54, 0x1.0e3ec32d3d1a2p+0, 0x1.03a1727c57b53p-59, 0x1.0fb66affed31bp+0, -0x1.b9bedc44ebd7bp-57,
+  0x1.11301d0125b51p+0, -0x1.6c51039449b3ap-54, 0x1.12abdc06c31ccp+0, -0x1.1b514b36ca5c7p-58, 0x1.1429aaea92de0p+0, -0x1.32fbf9af1369ep-54,
+  0x1.15a98c8a58e51p+0, 0x1.2406ab9eeab0ap-55, 0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55, 0x1.18af9388c8deap+0, -0x1.11023d1970f6cp-54,
+  0x1.1a35beb6fcb75p+0, 0x1.e5b4c7b4968e4p-55, 0x1.1bbe084045cd4p+0, -0x1.95386352ef607p-54, 0x1.1d4873168b9aap+0, 0x1.e016e00a2643cp-54,
+  0x1.1ed5022fcd91dp+0, -0x1.1df98027bb78cp-54, 0x1.2063b88628cd6p+0, 0x1.dc775814a8495p-55, 0x1.21f49917ddc96p+0, 0x1.2a97e9494a5eep-55,
+  0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54, 0x1.251ce4fb2a63fp+0, 0x1.ac155bef4f4a4p-55, 0x1.26b4565e27cddp+0, 0x1.2bd339940e9d9p-55,
+  0x1.284dfe1f56381p+0, -0x1.a4c3a8c3f0d7ep-54, 0x1.29e9df51fdee1p+0, 0x1.612e8afad1255p-55, 0x1.2b87fd0dad990p+0, -0x1.10adcd6381aa4p-59,
+  0x1.2d285a6e4030bp+0, 0x1.0024754db41d5p-54, 0x1.2ecafa93e2f56p+0, 0x1.1ca0f45d52383p-56, 0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55,
+  0x1.32170fc4cd831p+0, 0x1.a9ce78e18047cp-55, 0x1.33c08b26416ffp+0, 0x1.32721843659a6p-54, 0x1.356c55f929ff1p+0, -0x1.b5cee5c4e4628p-55,
+  0x1.371a7373aa9cbp+0, -0x1.63aeabf42eae2p-54, 0x1.38cae6d05d866p+0, -0x1.e958d3c9904bdp-54, 0x1.3a7db34e59ff7p+0, -0x1.5e436d661f5e3p-56,
+  0x1.3c32dc313a8e5p+0, -0x1.efff8375d29c3p-54, 0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55, 0x1.3fa4504ac801cp+0, -0x1.7d023f956f9f3p-54,
+  0x1.4160a21f72e2ap+0, -0x1.ef3691c309278p-58, 0x1.431f5d950a897p+0, -0x1.1c7dde35f7999p-55, 0x1.44e086061892dp+0, 0x1.89b7a04ef80d0p-59,
+  0x1.46a41ed1d0057p+0, 0x1.c944bd1648a76p-54, 0x1.486a2b5c13cd0p+0, 0x1.3c1a3b69062f0p-56, 0x1.4a32af0d7d3dep+0, 0x1.9cb62f3d1be56p-54,
+  0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56, 0x1.4dcb299fddd0dp+0, 0x1.8ecdbbc6a7833p-54, 0x1.4f9b2769d2ca7p+0, -0x1.4b309d25957e3p-54,
+  0x1.516daa2cf6642p+0, -0x1.f768569bd93efp-55, 0x1.5342b569d4f82p+0, -0x1.07abe1db13cadp-55, 0x1.551a4ca5d920fp+0, -0x1.d689cefede59bp-55,
+  0x1.56f4736b527dap+0, 0x1.9bb2c011d93adp-54, 0x1.58d12d497c7fdp+0, 0x1.295e15b9a1de8p-55, 0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54,
+  0x1.5c9268a5946b7p+0, 0x1.c4b1b816986a2p-60, 0x1.5e76f15ad2148p+0, 0x1.ba6f93080e65ep-54, 0x1.605e1b976dc09p+0, -0x1.3e2429b56de47p-54,
+  0x1.6247eb03a5585p+0, -0x1.383c17e40b497p-54, 0x1.6434634ccc320p+0, -0x1.c483c759d8933p-55, 0x1.6623882552225p+0, -0x1.bb60987591c34p-54,
+  0x1.68155d44ca973p+0, 0x1.038ae44f73e65p-57, 0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54, 0x1.6c012750bdabfp+0, -0x1.2895667ff0b0dp-56,
+  0x1.6dfb23c651a2fp+0, -0x1.bbe3a683c88abp-57, 0x1.6ff7df9519484p+0, -0x1.83c0f25860ef6p-55, 0x1.71f75e8ec5f74p+0, -0x1.16e4786887a99p-55,
+  0x1.73f9a48a58174p+0, -0x1.0a8d96c65d53cp-54, 0x1.75feb564267c9p+0, -0x1.0245957316dd3p-54, 0x1.780694fde5d3fp+0, 0x1.866b80a02162dp-54,
+  0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55, 0x1.7c1ed0130c132p+0, 0x1.f124cd1164dd6p-54, 0x1.7e2f336cf4e62p+0, 0x1.05d02ba15797ep-56,
+  0x1.80427543e1a12p+0, -0x1.27c86626d972bp-54, 0x1.82589994cce13p+0, -0x1.d4c1dd41532d8p-54, 0x1.8471a4623c7adp+0, -0x1.8d684a341cdfbp-55,
+  0x1.868d99b4492edp+0, -0x1.fc6f89bd4f6bap-54, 0x1.88ac7d98a6699p+0, 0x1.994c2f37cb53ap-54, 0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54,
+  0x1.8cf3216b5448cp+0, -0x1.0d55e32e9e3aap-56, 0x1.8f1ae99157736p+0, 0x1.5cc13a2e3976cp-55, 0x1.9145b0b91ffc6p+0, -0x1.dd6792e582524p-54,
+  0x1.93737b0cdc5e5p+0, -0x1.75fc781b57ebcp-57, 0x1.95a44cbc8520fp+0, -0x1.64b7c96a5f039p-56, 0x1.97d829fde4e50p+0, -0x1.d185b7c1b85d1p-54,
+  0x1.9a0f170ca07bap+0, -0x1.173bd91cee632p-54, 0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56, 0x1.9e86319e32323p+0, 0x1.824ca78e64c6ep-56,
+  0x1.a0c667b5de565p+0, -0x1.359495d1cd533p-54, 0x1.a309bec4a2d33p+0, 0x1.6305c7ddc36abp-54, 0x1.a5503b23e255dp+0, -0x1.d2f6edb8d41e1p-54,
+  0x1.a799e1330b358p+0, 0x1.bcb7ecac563c7p-54, 0x1.a9e6b5579fdbfp+0, 0x1.0fac90ef7fd31p-54, 0x1.ac36bbfd3f37ap+0, -0x1.f9234cae76cd0p-55,
+  0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54, 0x1.b0e07298db666p+0, -0x1.bdef54c80e425p-54, 0x1.b33a2b84f15fbp+0, -0x1.2805e3084d708p-57,
+  0x1.b59728de5593ap+0, -0x1.c71dfbbba6de3p-54, 0x1.b7f76f2fb5e47p+0, -0x1.5584f7e54ac3bp-56, 0x1.ba5b030a1064ap+0, -0x1.efcd30e54292ep-54,
+  0x1.bcc1e904bc1d2p+0, 0x1.23dd07a2d9e84p-55, 0x1.bf2c25bd71e09p+0, -0x1.efdca3f6b9c73p-54, 0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55,
+  0x1.c40ab5fffd07ap+0, 0x1.b4537e083c60ap-54, 0x1.c67f12e57d14bp+0, 0x1.2884dff483cadp-54, 0x1.c8f6d9406e7b5p+0, 0x1.1acbc48805c44p-56,
+  0x1.cb720dcef9069p+0, 0x1.503cbd1e949dbp-56, 0x1.cdf0b555dc3fap+0, -0x1.dd83b53829d72p-55, 0x1.d072d4a07897cp+0, -0x1.cbc3743797a9cp-54,
+  0x1.d2f87080d89f2p+0, -0x1.d487b719d8578p-54, 0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55, 0x1.d80e316c98398p+0, -0x1.11ec18beddfe8p-54,
+  0x1.da9e603db3285p+0, 0x1.c2300696db532p-54, 0x1.dd321f301b460p+0, 0x1.2da5778f018c3p-54, 0x1.dfc97337b9b5fp+0, -0x1.1a5cd4f184b5cp-54,
+  0x1.e264614f5a129p+0, -0x1.7b627817a1496p-54, 0x1.e502ee78b3ff6p+0, 0x1.39e8980a9cc8fp-55, 0x1.e7a51fbc74c83p+0, 0x1.2d522ca0c8de2p-54,
+  0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54, 0x1.ecf482d8e67f1p+0, -0x1.c93f3b411ad8cp-54, 0x1.efa1bee615a27p+0, 0x1.dc7f486a4b6b0p-54,
+  0x1.f252b376bba97p+0, 0x1.3a1a5bf0d8e43p-54, 0x1.f50765b6e4540p+0, 0x1.9d3e12dd8a18bp-54, 0x1.f7bfdad9cbe14p+0, -0x1.dbb12d006350ap-54,
+  0x1.fa7c1819e90d8p+0, 0x1.74853f3a5931ep-55, 0x1.fd3c22b8f71f1p+0, 0x1.2eb74966579e7p-57
+};
 // Where the table is read from.  With RH_LK_LDS (set by the host for models whose row code calls rh_logit_link) every kernel copies
 // it into LDS first (rh_lk_init) and the per-lane 16-byte read is a ds_read_b128: reading it from global memory shares the
 // in-order vmcnt counter with the row-tile prefetches of the gradient kernels, so the first table read of a tile waits for the
@@ -257,46 +304,46 @@ __device__ __attribute__((aligned(16))) const double rh_lk_tab[2 * 257] = {
 #ifndef RH_LK_LDS
 #define RH_LK_LDS 0
 #endif
+#define RH_LK_LDS_BYTES ((2 * 257 + 2 * 128 + 2) * 8)   /* 6176: both tables in LDS */
 #if RH_LK_LDS
-__shared__ __attribute__((aligned(16))) double rh_lk_lds[2 * 257];
+__shared__ __attribute__((aligned(16))) double rh_lk_lds[2 * 257 + 2 * 128 + 2];   // (RH_LK_LDS_BYTES: the LDS budget of the GLM kernel's tiles knows)
 #define RH_LK_TAB rh_lk_lds
+#define RH_EX_TAB (rh_lk_lds + 2 * 257 + 2)   /* (16-byte aligned: one ds_read_b128 per pair) */
 RH_DEV void rh_lk_init() {   // at the top of a kernel, before any thread returns
   for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) rh_lk_lds[i] = rh_lk_tab[i];
+  for (int i = threadIdx.x; i < 2 * 128; i += blockDim.x) rh_lk_lds[2 * 257 + 2 + i] = rh_ex_tab[i];
   __syncthreads();
 }
 #else
 #define RH_LK_TAB rh_lk_tab
+#define RH_EX_TAB rh_ex_tab
 RH_DEV void rh_lk_init() {}
 #endif
 // low word of a double (the integer a 2^52-scale shift leaves in the mantissa)
 RH_DEV int rh_lo32(const double v) { long long b; __builtin_memcpy(&b, &v, 8); return (int)b; }
 RH_DEV void rh_logit_link(const double t, double &softplus, double &sigmoid) {
   const double at = __builtin_fabs(t);
-  // e^{-|t|}: k = round(x / ln 2), r = x - k ln 2 in [-0.347, 0.347], degree-13 Taylor polynomial, scale by 2^k.
-  // x = max(-|t|, -800): e^{-800} is exactly 0 in fp64 (v_ldexp_f64 underflows gradually and correctly down to it).
-  // Both roundings to an integer go through a shift (round 5: 3 vector instructions fewer per evaluation than rint + convert):
-  // x log2(e) + 1.5 * 2^52 has unit spacing, so the fused sum IS the nearest integer -- as a double after subtracting the shift,
-  // as a two's-complement int in its low word; u + 2^44 has spacing 2^-8, so its low word is round(256 u).
+  // e^{-|t|} = 2^k 2^(j/128) e^r  (round 6: table-driven; until then k = round(x / ln 2) and a degree-13 Taylor polynomial, 20 vector
+  // instructions for what is 15 now).  n = round(128 x log2 e) = 128 k + j with 0 <= j < 128, r = x - n ln2 / 128 in
+  // [-ln2 / 256, ln2 / 256] = +-2.7e-3: a degree-5 polynomial leaves r^6 / 720 < 6e-19; 2^(j/128) from a 128-entry (hi, lo) table
+  // that sits in LDS behind the log table.  x = max(-|t|, -800): e^{-800} is exactly 0 in fp64 (v_ldexp_f64 underflows gradually
+  // and correctly down to it).  Both roundings to an integer go through a shift: x 128 log2(e) + 1.5 * 2^52 has unit spacing, so the
+  // fused sum IS the nearest integer -- as a double after subtracting the shift, as a two's-complement int in its low word
+  // (|n| < 2^18; n ln2_hi / 128 is exact: 18 + 33 significant bits); u + 2^44 has spacing 2^-8, so its low word is round(256 u).
   const double x = __builtin_fmax(-at, -800.0);
-  const double ks = __builtin_fma(x, 0x1.71547652b82fep+0, 0x1.8p+52);
+  const double ks = __builtin_fma(x, 0x1.71547652b82fep+7, 0x1.8p+52);
   const double kf = ks - 0x1.8p+52;
-  double r = __builtin_fma(kf, -0x1.62e42fee00000p-1, x);
-  r = __builtin_fma(kf, -0x1.a39ef35793c76p-33, r);
-  double p = 0x1.6124613a86d09p-33;                       // 1/13!
-  p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);         // 1/12!
-  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);         // 1/11!
-  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);         // 1/10!
-  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);         // 1/9!
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);         // 1/8!
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);         // 1/7!
-  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);         // 1/6!
-  p = __builtin_fma(p, r, 0x1.1111111111111p-7);          // 1/5!
+  double r = __builtin_fma(kf, -0x1.62e42fee00000p-8, x);
+  r = __builtin_fma(kf, -0x1.a39ef35793c76p-40, r);
+  double p = 0x1.1111111111111p-7;                        // 1/5!
   p = __builtin_fma(p, r, 0x1.5555555555555p-5);          // 1/4!
   p = __builtin_fma(p, r, 0x1.5555555555555p-3);          // 1/3!
   p = __builtin_fma(p, r, 0x1p-1);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  const double u = __builtin_ldexp(p, rh_lo32(ks));        // v_ldexp_f64: correct gradual underflow
+  p = __builtin_fma(p, r, 1.0);                            // (e^r - 1) / r
+  const int n = rh_lo32(ks);
+  const double tj = RH_EX_TAB[2 * (n & 127)], tl = RH_EX_TAB[2 * (n & 127) + 1];   // one 16-byte load
+  // 2^(j/128) e^r as tj + (tj (e^r - 1) + tl): ONE rounding at full size (|e^r - 1| < 2.8e-3 carries the polynomial's own error)
+  const double u = __builtin_ldexp(tj + __builtin_fma(tj, p * r, tl), n >> 7);   // (arithmetic shift: n = 128 (n >> 7) + (n & 127) for negative n too)
   const int j = rh_lo32(u + 0x1p+44);                      // round(256 u): 0 .. 256
   const double rc = RH_LK_TAB[2 * j], L = RH_LK_TAB[2 * j + 1];   // one 16-byte load
   const double r2 = __builtin_fma(u, rc, rc - 1.0);

@@ -30,6 +30,7 @@ typedef struct rh_cfg_dev {
 typedef struct rh_model_data {
   const double *const *cols;
   long long nrows[RH_MAX_TARGETS];
+  const double *kpool;   /* the constants of the data-free targets that are not spelled in the generated source (csrc/rir.hpp EmitInfo::kpool) */
 } rh_model_data;
 
 /* gather mode (a parameter table indexed by a data column): rows are sorted by index, group g = rows whose index is

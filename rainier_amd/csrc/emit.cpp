@@ -208,6 +208,19 @@ struct TargetEmitter {
   std::map<uint32_t, int> inv_slot;       // non-trivial invariant node -> index in inv[]
   std::map<uint32_t, int> inv_table;      // row-level LOOKUP whose >= 8 entries are all non-trivial invariants -> first of their CONSECUTIVE inv[] slots
   std::vector<char> reach_row, reach_inv;
+  // the constant pool of data-free targets (EmitInfo::kpool): value bits -> index, shared by the targets of a program
+  std::vector<double> *kpool = nullptr;
+  std::map<uint64_t, int> *kpool_index = nullptr;
+  bool pooled() const { return kpool != nullptr && !has_rows(); }
+  static bool structural(double v) {   // small dyadic numbers (and +-inf) stay literals: they are what a model's TEXT contains, and the compiler folds them
+    return std::isinf(v) || (std::fabs(v) <= 4096.0 && v * 8.0 == std::nearbyint(v * 8.0));
+  }
+  std::string pool_ref(double v) const {
+    uint64_t bits; std::memcpy(&bits, &v, sizeof bits);
+    auto it = kpool_index->find(bits);
+    if (it == kpool_index->end()) { it = kpool_index->emplace(bits, (int)kpool->size()).first; kpool->push_back(v); }
+    return "c[" + std::to_string(it->second) + "]";
+  }
 
   TargetEmitter(const Program &p, uint32_t ti, bool f) : P(p), t(ti), factor(f), run_end(ti) {
     for (uint32_t i = 0; i < P.nodes.size(); i++)  // let synthesized nodes reuse identical existing ones
@@ -853,7 +866,7 @@ struct TargetEmitter {
     if (id == ZERO) return "0x0p+0";
     if (gather.ok && id == gather.node) return "gz";
     const Node &nd = P.nodes[id];
-    if (nd.op == RH_RIR_CONST) return lit(nd.cval);
+    if (nd.op == RH_RIR_CONST) return (pooled() && ctx == 1 && !structural(nd.cval)) ? pool_ref(nd.cval) : lit(nd.cval);
     if (nd.op == RH_RIR_INPUT) {
       if (nd.input < P.n_params) return "th[" + std::to_string(nd.input) + "]";
       return "c[" + std::to_string(nd.input - P.targets[t].input_start) + oz() + "]";   // (memory-resident lowering: the row's values stay in scratch too)
@@ -871,7 +884,7 @@ struct TargetEmitter {
     if (!fast_div || b >= P.nodes.size()) return false;
     const Node &nb = P.nodes[b];
     if (nb.op != RH_RIR_CONST || nb.cval == 0.0 || !std::isfinite(nb.cval) || !std::isfinite(1.0 / nb.cval)) return false;
-    out = lit(1.0 / nb.cval);
+    out = (pooled() && !structural(1.0 / nb.cval)) ? pool_ref(1.0 / nb.cval) : lit(1.0 / nb.cval);
     return true;
   }
   // LookupIR: D2I truncation, select table[k - low], out of range is an error (ExprMethodGenerator.scala:57-63).
@@ -908,7 +921,7 @@ struct TargetEmitter {
     } else {
       if (nd.table.size() > 65536) { err = "Lookup tables with more than 65536 entries are only supported in gather mode"; return false; }
       bool all_const = true;
-      for (uint32_t e : nd.table) all_const = all_const && P.nodes[e].op == RH_RIR_CONST;
+      for (uint32_t e : nd.table) all_const = all_const && P.nodes[e].op == RH_RIR_CONST && !(pooled() && !structural(P.nodes[e].cval));   // (a pooled entry is a load, not a literal)
       os << "    " << (all_const ? "static const double" : "const double") << " t" << id << "[" << nd.table.size() << "] = {";
       for (size_t e = 0; e < nd.table.size(); e++) os << (e ? ", " : "") << R(nd.table[e]);
       os << "};\n" << lhs << "((unsigned)" << k << " < " << nd.table.size() << "u) ? t" << id << "[" << k << "] : RH_NAN;\n";
@@ -1432,6 +1445,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
         t0.input + nd.table.size() == P.n_params) { gmode = true; n_shared = std::min(n_shared, t0.input); }
   }
   int ngather = 0;
+  std::map<uint64_t, int> kpool_index;
   for (uint32_t t = 0; t < P.targets.size(); t++) {
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
@@ -1442,6 +1456,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
       else { uint32_t e = t; while (e + 1 < P.targets.size() && P.targets[e + 1].n_cols == 0) e++; te.run_end = e; }
     }
     te.gmode = gmode; te.n_shared = n_shared;
+    if (o.const_pool) { te.kpool = &I.kpool; te.kpool_index = &kpool_index; }
     if (gmode) { if (!te.detect_gather(err)) return false; if (te.gather.ok) ngather++; }
     te.plan();
     if (o.logit_link) te.detect_link();
@@ -1480,6 +1495,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
   d << "#define RH_NROWTARGETS " << nrowt << "\n#define RH_NACC_MAX " << nacc_max << "\n#define RH_GRAD_K "
     << grad_k << "\n#define RH_GRAD_U " << (o.grad_unroll > 0 ? o.grad_unroll : 2)
     << "\n#define RH_GRAD_PIPELINE " << o.grad_pipeline << "\n";
+  d << "#define RH_KPOOL " << I.kpool.size() << "\n";   // doubles in the constant pool the data-free targets read (rh_model_data.kpool)
   if (glm_target >= 0) d << "#define RH_GLM_TARGET " << glm_target << "\n#define RH_GLM_SMALL " << (glm_small ? 1 : 0) << "\n";
   if (o.strict_math) d << "#define RH_EXP(x) rh_strict_exp(x)\n#define RH_LOG(x) rh_strict_log(x)\n";
   else d << "#define RH_EXP(x) exp(x)\n#define RH_LOG(x) " << (o.fast_log ? "rh_fast_log(x)" : "log(x)") << "\n";

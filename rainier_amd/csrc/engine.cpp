@@ -164,7 +164,7 @@ struct rh_model {
   int ncols_max = 0, glm_ncols = 0;
   hipFunction_t k_grad_glm = nullptr;
   bool glm_small = false;  // <= 8 predictors: the plain VALU kernel (the fp64 matrix pipe pays from ~9 predictors on, profiles/r1_c)
-  bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (4112 B of static LDS)
+  bool lk_lds = false;     // the kernels keep rh_logit_link's table in LDS (6176 B of static LDS: RH_LK_LDS_BYTES in rh_prelude.hip.h)
   bool has_glm = false;  // the emitter found a dense linear predictor: rh_grad_glm_kernel (fp64 MFMA) exists
   int n_row_targets_hint = 0; // row targets of the lowered program (known before the module is loaded)
   bool shape_guessed = false;    // assemble_source has made its first guesses from the size of the generated code
@@ -183,6 +183,7 @@ struct rh_model {
   rh_model_data data{};
   std::vector<void *> dev_cols;
   void *d_coltab = nullptr;                  // device table of the column pointers (rh_model_data.cols)
+  void *d_kpool = nullptr;                   // the constant pool of the data-free targets (rh_model_data.kpool; EmitInfo::kpool is the host copy)
   std::vector<std::vector<int64_t>> col_len; // ... and the length of every block (0xFFFFFFFF in col_src = a block of zeros)
   std::vector<std::vector<double>> synth_cols; // columns lifted out of many same-shaped data-free targets (lift.cpp)
   std::vector<std::vector<uint32_t>> col_src; // engine column -> the caller's columns concatenated into it (one, unless the
@@ -246,6 +247,7 @@ void assemble_source(rh_model *m) {
   if (const char *e = rh::knob("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_FORCE_BIGN")) m->eopt.force_bign = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_LOGIT_LINK")) m->eopt.logit_link = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_CONST_POOL")) m->eopt.const_pool = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_CHUNK")) if (m->eopt.chunk == 0) m->eopt.chunk = std::max(0, std::atoi(e));   // tests: the memory-resident lowering for any model
   if (m->eopt.chunk > 0) {   // the memory-resident lowering comes with the lightest kernel shapes and without the special-cased rows
     m->eopt.rows_unroll = 1; m->eopt.grad_unroll = 1; m->eopt.grad_pipeline = 0; m->unroll_auto = false;
@@ -625,7 +627,7 @@ void load_module(rh_model *m) {
   // one 64-row tile of all columns must fit the CU's LDS (310 columns); wider dense predictors stay on the plain VALU kernel
   {  // (column-major, stride 66)
     const size_t tile = (size_t)m->glm_ncols * 66u * sizeof(double);
-    if (tile + (m->lk_lds ? 4112u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
+    if (tile + (m->lk_lds ? 6176u : 0u) > 160u * 1024u) m->k_grad_glm = nullptr;
   }
   if (const char *e = rh::knob("RH_GLM_MFMA")) if (std::atoi(e) == 0) m->k_grad_glm = nullptr;
   if (m->n_row_targets > 0 && !m->info.gather_mode) {
@@ -991,6 +993,17 @@ void selfcheck_density(rh_model *m) {
 
 }  // namespace
 
+namespace {
+// the constants the data-free targets read instead of spelling them (EmitInfo::kpool) -> device
+void upload_kpool(rh_model *m) {
+  if (m->d_kpool) { (void)hipFree(m->d_kpool); m->d_kpool = nullptr; }
+  const std::vector<double> &k = m->info.kpool;
+  HIPCHK(hipMalloc(&m->d_kpool, std::max<size_t>(1, k.size()) * sizeof(double)));
+  if (!k.empty()) HIPCHK(hipMemcpy(m->d_kpool, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+  m->data.kpool = (const double *)m->d_kpool;
+}
+}  // namespace
+
 // ---- seam 1 -----------------------------------------------------------------------------------------
 extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *const *columns_in, const int64_t *nrows,
                                const rh_compile_opts *opts, rh_model **out) {
@@ -1024,6 +1037,7 @@ extern "C" int rh_model_create(const void *rir, size_t rir_len, const double *co
     if (colon != std::string::npos) m->arch = m->arch.substr(0, colon);
     build_code(m);
     load_module(m);
+    upload_kpool(m);
     if (m->want_nuts) (void)load_variant(m, 1);
     // observation columns -> HBM (the engine copies; the caller keeps ownership).  In gather mode the rows of a gather
     // target are first brought into index order (stable counting sort; only the summation order of the rows changes):
@@ -1167,6 +1181,7 @@ extern "C" int rh_model_clone(const rh_model *src, int32_t device, rh_model **ou
     HIPCHK(hipMalloc(&m->d_coltab, std::max<size_t>(1, m->dev_cols.size()) * sizeof(void *)));
     if (!m->dev_cols.empty()) HIPCHK(hipMemcpy(m->d_coltab, m->dev_cols.data(), m->dev_cols.size() * sizeof(void *), hipMemcpyHostToDevice));
     m->data.cols = (const double *const *)m->d_coltab;
+    m->d_kpool = nullptr; upload_kpool(m);
   });
   if (rc != RH_OK) { rh_model_destroy(m); return rc; }
   *out = m;
@@ -1179,6 +1194,7 @@ extern "C" void rh_model_destroy(rh_model *m) {
     hipSetDevice(m->device);
     for (void *d : m->dev_cols) hipFree(d);
     if (m->d_coltab) hipFree(m->d_coltab);
+    if (m->d_kpool) hipFree(m->d_kpool);
     for (void *d : m->goff_dev) hipFree(d);
     if (m->stream) hipStreamDestroy(m->stream);
     for (int v = 1; v < 8; v++)  // [0] aliases the base module
@@ -1292,7 +1308,18 @@ extern "C" int rh_lower_report_data(const void *rir, size_t rir_len, const doubl
       build_code(&m);         // may lower again with a smaller row-loop unroll: the source returned is the one that was compiled
       *code_size = m.code.size();
     }
-    if (src_out) { *src_out = (char *)std::malloc(m.source.size() + 1); std::memcpy(*src_out, m.source.c_str(), m.source.size() + 1); }
+    if (src_out) {
+      // (test hook: the constant pool's VALUES travel behind the source as a trailing comment, for the CPU tier's host emulation of the
+      //  generated code -- they are not part of the translation unit rh_model_create compiles and hashes)
+      std::string text = m.source;
+      if (!m.info.kpool.empty()) {
+        text += "\n// rh_kpool " + std::to_string(m.info.kpool.size()) + ":";
+        char buf[40];
+        for (double v : m.info.kpool) { std::snprintf(buf, sizeof buf, " %a", v); text += buf; }
+        text += "\n";
+      }
+      *src_out = (char *)std::malloc(text.size() + 1); std::memcpy(*src_out, text.c_str(), text.size() + 1);
+    }
     if (!code_size) return;
     std::vector<char> vcode;
     if (opts && opts->with_nuts) vcode = build_variant_code(&m, opts->with_nuts & 7);
@@ -1467,7 +1494,7 @@ void launch_grad(rh_model *m, GatherBufs *gb, void *d_q, void *d_list, void *d_n
     const int ctiles = (chains + 15) / 16;
     const unsigned blocks = (unsigned)(((ctiles + m->glm_w - 1) / m->glm_w) * nsplit);
     const unsigned tile = (unsigned)m->glm_ncols * 66u * (unsigned)sizeof(double);  // the kernel's NBUF rule: two tiles while they fit
-    const unsigned lds = (2u * tile + (m->lk_lds ? 4112u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
+    const unsigned lds = (2u * tile + (m->lk_lds ? 6176u : 0u) <= 160u * 1024u ? 2u : 1u) * tile;
     HIPCHK(hipModuleLaunchKernel(m->k_grad_glm, blocks, 1, 1, 64u * m->glm_w, 1, 1, lds, m->stream, args, nullptr));
   } else
     launch(m->k_grad, (unsigned)(ngroups * nsplit), 64, m->stream, args);

@@ -146,6 +146,7 @@ struct EmitOptions {
   int big_unroll = 16;    // big mode (chain vectors in HBM): slots in flight per lane in the vector loops (RH_BIGU); halved by the engine while a sampler kernel does not fit
   int chain_waves = 2;    // wavefronts per SIMD rh_chain_kernel asks for (2: 256 registers; the engine falls back to 1 when the kernel does not fit)
   int grad_pipeline = 2;  // row loop of the batched gradient kernel: 0 plain, 1 double-buffered, 2 rolling (a tile's registers are reloaded as soon as it is consumed)
+  bool const_pool = true; // the non-trivial constants of data-free targets are read from a per-model buffer, not spelled in the source (RH_CONST_POOL=0 switches it off)
 };
 
 // What the engine needs to know about the lowered program (besides the source text)
@@ -156,6 +157,12 @@ struct EmitInfo {
   bool glm_small = false;
   struct TargetInfo { bool has_rows = false, has_gather = false; int g_col = -1, g_count = 0, g_low = 0; };
   std::vector<TargetInfo> targets;
+  // The constant pool (round 6: compile once per model shape).  Model.observe's initial chunk (core/Model.scala:71-132) and every
+  // single observation arrive folded into data-free targets: their observations are CONSTANT nodes.  Spelled as literals they
+  // made the generated source -- the key of the code-object cache -- a function of the data; now a data-free target reads every
+  // constant that is not a small dyadic number from this buffer (`c[i]` in its row(): rh_model_data.kpool on the device), so two
+  // data sets of one model share a translation unit whenever their programs have the same structure.
+  std::vector<double> kpool;
 };
 
 // Lowers the program to the per-model part of the HIP translation unit (defines + rh_target<t> structs).

@@ -14,6 +14,7 @@ _HARNESS = r'''
 // rh_host_gonly != 0: the rows are walked through row_g() / elem_g() -- the gradient-only row code of the tick engine's mid-trajectory
 // requests (csrc/emit.cpp: value_only) -- where the target has one; outputs 1.. must then equal the full evaluation's bit for bit
 static int rh_host_gonly = 0;
+static const double *rh_host_kpool = nullptr;   // the constant pool the data-free targets read (EmitInfo::kpool; set from the test hook's trailing comment)
 template <class TG, class TH, class INV, class CP, class ACC>
 static void rh_host_row(const TH &th, const INV &inv, const CP &c, ACC &acc, int &err) {
   if constexpr (TG::HAS_VALUE_ONLY) { if (rh_host_gonly) { TG::row_g(th, inv, c, acc, err); return; } }
@@ -31,7 +32,7 @@ template <int T> static void rh_host_target(const double (&th)[RH_NTH], const do
     double inv[TG::NINV > 0 ? TG::NINV : 1];
     TG::invariants(th, inv, err);
     if constexpr (!TG::HAS_ROWS) {
-      TG::row(th, inv, nullptr, tot, err);
+      TG::row(th, inv, rh_host_kpool, tot, err);
     } else {
       double S[TG::NACC > 0 ? TG::NACC : 1];
       for (int j = 0; j < TG::NACC; j++) S[j] = 0.0;
@@ -55,7 +56,7 @@ template <int T> static void rh_host_gather_target(const double *q, const double
     double inv[TG::NINV > 0 ? TG::NINV : 1];
     TG::invariants(th, inv, err);
     if constexpr (!TG::HAS_ROWS) {
-      TG::row(th, inv, nullptr, tot, err);
+      TG::row(th, inv, rh_host_kpool, tot, err);
     } else {
       double S[TG::NACC > 0 ? TG::NACC : 1];
       for (int j = 0; j < TG::NACC; j++) S[j] = 0.0;
@@ -137,6 +138,11 @@ class HostTargets:
     """The generated rh_target<t> code of one lowered model, compiled for the host."""
 
     def __init__(self, hip_source: str):
+        # the constant pool's values: the lowering test hook appends them to the source as a comment ("// rh_kpool n: v0 v1 ...")
+        self.kpool = np.zeros(1)
+        if "\n// rh_kpool " in hip_source:
+            hip_source, tail = hip_source.rsplit("\n// rh_kpool ", 1)
+            self.kpool = np.array([float.fromhex(x) for x in tail.split(":", 1)[1].split()], dtype=np.float64)
         head = hip_source[:hip_source.index("// rh_shared.h")]
         i = hip_source.index("// ---- generated from RIR")
         gen = hip_source[i:hip_source.index("// rh_engine.hip.h", i)]
@@ -145,6 +151,7 @@ class HostTargets:
         text = (head + '#include "host_target_shim.hpp"\nnamespace {\n' + gen + harness + '}\n'
                 'extern "C" int rh_host_eval(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_impl(q, cols, nrows, out); }\n'
                 'extern "C" void rh_host_set_gonly(int v) { rh_host_gonly = v; }\n'
+                'extern "C" void rh_host_set_kpool(const double *p) { rh_host_kpool = p; }\n'
                 '#ifdef RH_GLM_TARGET\nextern "C" int rh_host_eval_glm(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_glm_impl(q, cols, nrows, out); }\n#endif\n')
         key = hashlib.sha256(text.encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "rh_host_targets")
@@ -155,6 +162,7 @@ class HostTargets:
             open(src, "w").write(text)
             subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-fno-gnu-unique", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
         self.lib = C.CDLL(so)
+        self.lib.rh_host_set_kpool(self.kpool.ctypes.data_as(C.POINTER(C.c_double)))
         self.n_out = 1 + int(head.split("#define RH_NVARS ")[1].split("\n")[0])    # (gather mode: RH_NOUT covers the shared outputs only)
 
     def eval_glm(self, q, columns, nrows):

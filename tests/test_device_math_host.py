@@ -62,6 +62,7 @@ def test_logit_link_text_on_the_host_is_within_three_ulp(tmp_path):
     # the table in the header is the generator's output
     tab = subprocess.check_output(["python", os.path.join(ROOT, "tools", "gen_lk_table.py")]).decode()
     assert tab in pre
+    assert subprocess.check_output(["python", os.path.join(ROOT, "tools", "gen_lk_table.py"), "--exp"]).decode() in pre     # rh_ex_tab: 2^(j/128) as (hi, lo)
 
 
 def test_split_wave_reduction_has_the_butterfly_s_bits():

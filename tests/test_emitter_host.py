@@ -68,6 +68,68 @@ def _split_logistic(n, k):
                                split=True).compile("logistic_split_%dx%d" % (k, n))
 
 
+def _observe_logistic(seed, n=5003, k=4):
+    """Model.observe (core/Model.scala:71-132: an initial chunk of n - 8 floor((n - 1) / 8) observations + the 8-way split) of a
+    Bernoulli-logit regression on a data set drawn from `seed`"""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, k)); beta = rng.normal(size=k)
+    y = (rng.random(n) < 1.0 / (1.0 + np.exp(-(0.3 + X @ beta)))).astype(float)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k)
+    return M.Model.observe_vec(list(y), [list(X[:, j]) for j in range(k)],
+                               lambda *u: M.Bernoulli((a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)])).logistic), split=True).compile("observe_logistic")
+
+
+def _observe_normal(seed, n=5003, k=5):
+    """Model.observe of a Normal regression with 5 covariates (more than the reference inlines) on a data set drawn from `seed`"""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, k)); beta = rng.normal(size=k)
+    y = 0.3 + X @ beta + 0.5 * rng.normal(size=n)
+    a = M.Normal(0, 1).latent; bs = M.Normal(0, 1).latentVec(k); sig = M.Normal(0, 1).latent.exp()
+    return M.Model.observe_vec(list(y), [list(X[:, j]) for j in range(k)],
+                               lambda *u: M.Normal(a + M.Real.sum([ui * bi for ui, bi in zip(u, bs)]), sig), split=True).compile("observe_normal")
+
+
+def test_one_source_per_model_shape_whatever_the_data():
+    """Compile once per model shape: the reference compiles a model in milliseconds (README.md:44), here a cold hiprtc
+    build is seconds, so the code-object cache must hit for a new data set of the same model.  Model.observe's initial chunk
+    (core/Model.scala:71-132) reaches the engine as up to 8 observations folded into a data-free target; the fast build appends those
+    rows to the rolled 8-slot target (csrc/refactor.cpp), so nothing of the data is left in the generated source: four data sets,
+    ONE translation unit -- what rh_model_create hashes for its kernel cache."""
+    import hashlib
+    shas = set()
+    for seed in (1, 2, 3, 4):
+        spec = _observe_logistic(seed)
+        assert spec.nrows[1] == 3                       # the initial chunk: 5003 - 8 * 625 observations
+        src, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**FAST), compile=False, columns=spec.columns, nrows=spec.nrows)
+        assert "rh_grad_glm_kernel" not in src or "RH_GLM_TARGET" in src
+        shas.add(hashlib.sha256(src.encode()).hexdigest())
+    assert len(shas) == 1, "the generated source of a fast build depends on the data"
+
+
+def test_folded_observations_travel_in_the_constant_pool_not_in_the_source():
+    """... and in the builds that keep the initial chunk where the front end folded it -- a data-free target, as the JVM-faithful build
+    must and the plain default build does -- the observations are read from the model's constant pool (csrc/rir.hpp EmitInfo::kpool;
+    `c[i]` in the data-free row()), not spelled as literals: a Normal regression through Model.observe (5 covariates, so the reference
+    does not inline it) on three data sets is ONE translation unit per build flavour, and the pool carries the data.
+    (A discrete response still shapes the folded chunk: the front end folds Bernoulli's Lookup(y, ...) and the x * 0 products with
+    the values in hand, so strict / plain builds of such a model have one source per PATTERN of the chunk, not per data set.)"""
+    import hashlib
+    normal_regression = _observe_normal
+    for opts in (STRICT, dict(), FAST):
+        shas, pools = set(), []
+        for seed in (1, 2, 3):
+            spec = normal_regression(seed)
+            text, _ = _capi.lower_only(spec.rir, _capi.compile_opts(**opts), compile=False, columns=spec.columns, nrows=spec.nrows)
+            src, _, tail = text.partition("\n// rh_kpool ")
+            shas.add(hashlib.sha256(src.encode()).hexdigest())
+            pools.append(tail)
+        assert len(shas) == 1, (opts, "the generated source depends on the data")
+        if not opts.get("fp_contract"):      # (the fast build rolls the chunk into the streamed rows: nothing of it is left to pool)
+            assert all(p for p in pools) and len(set(pools)) == 3, "the chunk's observations should be in the pool, and differ between data sets"
+    # the pooled programs still evaluate correctly (host emulation against the oracle, gradient-only code included)
+    _check(normal_regression(4), STRICT, np.random.default_rng(2).normal(size=(2, 7)) * 0.3, 1e-12)
+
+
 @pytest.mark.parametrize("opts", [STRICT, dict(factor_outputs=True), FAST], ids=["strict", "factored", "fast"])
 def test_natural_forms(opts):
     rng = np.random.default_rng(31)

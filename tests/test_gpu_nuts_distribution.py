@@ -43,7 +43,8 @@ def _moments(tr):
 CASES = {
     # name: (spec factory, warm-up, iterations, parameters held to the variance test)
     "eight_schools": (lambda: models.eight_schools_reference(), 400, 400, None),        # rainier-benchmark/.../bench/stan/EightSchools.scala
-    "kidiq": (lambda: models.kidiq_reference(_load("kidiq.json")), 400, 400, None),     # bench/stan/KidIQ.scala (400 rows)
+    # bench/stan/ARK.scala: an AR(5) series observed one value at a time (197 single-observation targets, lifted into one streamed target)
+    "ark": (lambda: models.ark_reference(_load("ark.json")), 400, 400, None),
     # Neal's funnel (the README's plumbing model, cfg 1): x_i | v ~ N(0, e^{v/2}) has a log-normal scale mixture for a marginal --
     # its sample variance has no useful standard error at any affordable length -- so the variance test is held on v alone and
     # the x_i are compared through their means (0 by symmetry) and the pooled R-hat

@@ -269,3 +269,42 @@ def test_hierarchical_models_as_the_front_end_hands_them_over_run_in_gather_mode
     _check(schools, mf, qs, 1e-12)
     _check(schools, mf, qs, 1e-12, engine=_capi.ENGINE_TICK)
     assert np.all(np.isfinite(mf.sample(R.make_config(20, 40), seeds=range(8)).chains))
+
+
+@pytest.mark.parametrize("case", ["bernoulli-logit, fast build", "normal regression, JVM-faithful build"])
+def test_a_second_data_set_of_the_same_model_does_not_compile_again(case, tmp_path, monkeypatch):
+    """Compile once per model shape, on the device: Model.observe of a regression on two data sets (different observations in the
+    initial chunk, core/Model.scala:71-132) -- the first create compiles into an EMPTY kernel cache, the second finds every code
+    object it needs there: rh_compile_count() does not move, and both models evaluate against the oracle.  The fast build rolls
+    the chunk into the streamed rows; the JVM-faithful build keeps it where the front end folded it and reads its observations from
+    the model's constant pool (rh_model_data.kpool)."""
+    from tests.test_emitter_host import _observe_logistic, _observe_normal
+    monkeypatch.setenv("RH_KERNEL_CACHE", str(tmp_path))     # cold: nothing of the in-tree cache is visible
+    L = _capi.lib()
+    mk, fast = (_observe_logistic, dict(fp_contract=True, factor_outputs=True)) if case.startswith("bernoulli") else (_observe_normal, dict(math_mode=_capi.MATH_STRICT))
+    c0 = L.rh_compile_count()
+    spec1 = mk(11)
+    m1 = R.Model(spec1, device=0, **fast)
+    c1 = L.rh_compile_count()
+    assert c1 > c0, "the first create must have compiled (the cache directory was empty)"
+    spec2 = mk(12)
+    assert not np.array_equal(spec1.columns[0][:3], spec2.columns[0][:3]) or not np.array_equal(spec1.columns[1][:3], spec2.columns[1][:3])
+    m2 = R.Model(spec2, device=0, **fast)
+    assert L.rh_compile_count() == c1, "a second data set of the same model compiled again: the generated source depends on the data"
+    assert m1.hip_source == m2.hip_source
+    for spec, m in ((spec1, m1), (spec2, m2)):
+        q = np.random.default_rng(5).normal(size=(2, spec.n_params)) * 0.3
+        lp, g = m.density_batch(q)
+        d = O.OracleDensity(spec)
+        for c in range(2):
+            ref, ab = d.update_both(q[c])
+            got = np.concatenate([[lp[c]], g[c]])
+            assert np.all(np.abs(got - ref) <= 1e-11 * ab + 1e-300)
+    # a few iterations of each (the sampler kernels read the pool too: their data-free targets are inlined copies)
+    cfg = R.make_config(3, 3, R.HMCSampler(3), R.StaticStepSize(1e-3), R.IdentityMassMatrixTuner())
+    for spec, m in ((spec1, m1), (spec2, m2)):
+        tr = m.sample(cfg, seeds=[71, 72])
+        want, _, _ = O.sample_model(spec, O.make_config(sampler=O.HMC, n_steps=3, iterations=3, warmup=3, step_tuner=O.STEP_STATIC, static_step=1e-3,
+                                                        mass_tuner=O.MASS_IDENTITY, math_mode=O.JM_DET), 71)
+        np.testing.assert_allclose(tr.chains[0], want, rtol=1e-9, atol=1e-11)
+    m1.close(); m2.close()
