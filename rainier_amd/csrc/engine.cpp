@@ -1546,7 +1546,24 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       HIPCHK(hipMemsetAsync(bpart.p, 0, pbytes, m->stream));
       int xcd = 1;
       if (const char *e = rh::knob("RH_XCD_AWARE")) xcd = std::atoi(e);
-      launch_grad(m, &gb, dq, blist.p, nullptr, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
+      // RH_DIAG only -- RH_EVAL_LIVE="3,7,8": the launch serves exactly these chains through a compacted list, as the sampler's launches
+      // do (rh_compact_kernel); the rows of the chains it leaves out come back as zeros (tools/r6_live_diag.py)
+      void *dnl = nullptr;
+      DevBuf bnl(sizeof(int));
+      if (const char *e = rh::knob("RH_EVAL_LIVE")) {
+        std::vector<int> live;
+        for (const char *p = e; *p;) { char *q2; long v = std::strtol(p, &q2, 10); if (q2 == p) break; if (v >= 0 && v < chains) live.push_back((int)v); p = *q2 ? q2 + 1 : q2; }
+        std::sort(live.begin(), live.end());
+        live.erase(std::unique(live.begin(), live.end()), live.end());
+        if (!live.empty()) {
+          const int nl = (int)live.size();
+          HIPCHK(hipMemcpyAsync(blist.p, live.data(), sizeof(int) * nl, hipMemcpyHostToDevice, m->stream));
+          HIPCHK(hipMemcpyAsync(bnl.p, &nl, sizeof(int), hipMemcpyHostToDevice, m->stream));
+          HIPCHK(hipStreamSynchronize(m->stream));
+          dnl = bnl.p;
+        }
+      }
+      launch_grad(m, &gb, dq, blist.p, dnl, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
       void *dpart = bpart.p;
       if (m->info.gather_mode) {
         void *fa[] = {&m->data, &gb.gd, &dq, &dpart, &dl, &dg, &de, &ch, &nsplit, &dtot};
