@@ -1308,6 +1308,7 @@ rh_grad_kernel(const rh_model_data d, const double *__restrict__ q, const int *_
 #endif
 #define RH_GLM_TRP 66
 typedef double rh_v4d __attribute__((ext_vector_type(4)));
+template <bool B> struct rh_bool { static constexpr bool v = B; };
 
 #if RH_FP_CONTRACT
 #pragma clang fp contract(fast)
@@ -1433,8 +1434,16 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
 #ifndef RH_GLM_ELEM_UNROLL
 #define RH_GLM_ELEM_UNROLL 4
 #endif
+#ifndef RH_GLM_ELEM_INLOOP
+#define RH_GLM_ELEM_INLOOP 0
+#endif
         // full tiles of a wavefront whose 16 chains all exist need no validity masks (the common case by far)
         const bool full = (r0 + t * 64 + 64 <= r1) && (slot0 + 16 <= nl);
+        // The four evaluations of a lane are ONE straight-line block per (gradient-only?, full?) combination, chosen by wave-uniform
+        // branches AROUND the unrolled loop: with the choice inside it (round 6, first form) every evaluation became a basic block of
+        // its own -- 8 blocks of ~65 instructions, each waiting for its own two table reads -- and the scheduler could no longer
+        // interleave the four dependent fp64 chains (cfg 4: 17.25 -> 18.9 ms per value launch; profiles/r6_cfg4).
+#if RH_GLM_ELEM_INLOOP   /* (RH_DIAG: RH_HIPRTC_EXTRA=-DRH_GLM_ELEM_INLOOP=1 -- the first form, kept for the A/B measurement) */
         if (full) {
 #pragma unroll RH_GLM_ELEM_UNROLL
           for (int r = 0; r < 4; r++) {
@@ -1459,6 +1468,34 @@ rh_grad_glm_kernel(const rh_model_data d, const double *__restrict__ q, const in
             for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
           }
         }
+#else
+        auto elems = [&](auto nv, auto fl) {
+#pragma unroll RH_GLM_ELEM_UNROLL
+          for (int r = 0; r < 4; r++) {
+            const int rrow = row0s + lg + 4 * r;
+            double w = 0.0, o[GL::NOTHER > 0 ? GL::NOTHER : 1];
+            if constexpr (decltype(nv)::v) GL::elem(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            else GL::elem_g(thu, D[r], [&](int j) { return tile[j * RH_GLM_TRP + rrow]; }, w, o, err);
+            if constexpr (decltype(fl)::v) {
+              Wv[r] = w;
+#pragma unroll
+              for (int k = 0; k < GL::NOTHER; k++) oth[k] += o[k];
+            } else {
+              const bool valid = (r0 + t * 64 + rrow < r1) && mine;
+              Wv[r] = valid ? w : 0.0;
+#pragma unroll
+              for (int k = 0; k < GL::NOTHER; k++) oth[k] += valid ? o[k] : 0.0;
+            }
+          }
+        };
+        if (full) {
+          if (vfree) elems(rh_bool<false>{}, rh_bool<true>{});
+          else elems(rh_bool<true>{}, rh_bool<true>{});
+        } else {
+          if (vfree) elems(rh_bool<false>{}, rh_bool<false>{});
+          else elems(rh_bool<true>{}, rh_bool<false>{});
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < RV; k++)
 #pragma unroll

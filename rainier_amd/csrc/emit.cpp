@@ -179,6 +179,13 @@ struct TargetEmitter {
   bool factor;
   bool fast_div = false;       // fast mode: x / const -> x * (1/const)
   bool fma_adds = false;       // per-row code: adds/subs as fma(x, +-1.0, y); with fast_div (= contraction allowed) mul+add is fused here
+  // Round 6: where contraction is allowed (fast builds) the row code of a streamed target fuses its mul+add pairs HERE, explicitly, and
+  // is compiled with contraction OFF.  The gradient kernels inline row() once per chain of the wavefront's group; left to the compiler
+  // (`#pragma clang fp contract(fast)`), the K copies were contracted differently (rh_grad_gather_kernel, centred cfg 5: 22 / 22 / 22 /
+  // 28 fused operations in the four copies of one tile), so a chain's sums depended by an ulp on the SLOT it was served in -- on which
+  // other chains were live (tests/test_gpu_live_chains.py, case 3; tools/r6_live_diag.py).  One spelling, one rounding sequence,
+  // whatever the slot, the kernel, or row() / row_g().  (Memory-resident lowerings run one chain per wavefront and keep the old form.)
+  bool xfuse = false;
   uint32_t run_end = 0;        // data-free targets t..run_end are emitted together (shared sub-expressions once)
   bool merged_away = false;    // this data-free target was emitted by an earlier one of its run
   int chunk = 0;               // > 0: memory-resident lowering, at most this many statement groups per chunk (chunk_body)
@@ -857,7 +864,7 @@ struct TargetEmitter {
     os << "    const double lk_t = " << lit(link.logm) << " - " << ref(link.L, 1) << ";\n"
        << "    double lk_sp, lk_sg;\n    rh_logit_link(lk_t, lk_sp, lk_sg);\n"
        << "    const double lk_a = " << link_sum(link.alpha) << ", lk_ab = lk_a + " << link_sum(link.beta) << ";\n"
-       << "    const double lk_g = lk_ab * lk_sg - lk_a;\n";
+       << (xfuse_row(1) ? "    const double lk_g = __builtin_fma(lk_ab, lk_sg, -lk_a);\n" : "    const double lk_g = lk_ab * lk_sg - lk_a;\n");
   }
 
   // how an operand is spelled: ctx 0 = invariants(), 1 = row(), 2 = finish()
@@ -936,7 +943,16 @@ struct TargetEmitter {
     return fast_div && fma_row(ctx) && id < P.nodes.size() && P.nodes[id].op == RH_RIR_MUL && P.nodes[id].dep != 0 &&
            !(gather.ok && id == gather.node);
   }
+  // explicit fusion without the fma-only spelling (xfuse): the row code of a streamed target in a register lowering
+  bool xfuse_row(int ctx) const { return xfuse && !fma_adds && ctx == 1 && has_rows() && chunk == 0; }
+  bool xfusable(uint32_t id, int ctx) const {
+    if (!(xfuse_row(ctx) && id < P.nodes.size() && P.nodes[id].op == RH_RIR_MUL && P.nodes[id].dep != 0 && !(gather.ok && id == gather.node) &&
+          !(link.ok && (id == link.V || link.cores.count(id))))) return false;   // (a closed-form node is not its literal product)
+    // x * +-1 is a sign, not a product: the compiler folds it into an operand modifier, and an fma would keep an instruction alive for it
+    return !(is_const(P.nodes[id].a, 1.0) || is_const(P.nodes[id].a, -1.0) || is_const(P.nodes[id].b, 1.0) || is_const(P.nodes[id].b, -1.0));
+  }
   std::string accumulate(const std::string &dst, uint32_t v, int ctx) const {
+    if (xfusable(v, ctx)) return "    " + dst + " = __builtin_fma(" + ref(P.nodes[v].a, ctx) + ", " + ref(P.nodes[v].b, ctx) + ", " + dst + ");\n";
     if (!fma_row(ctx)) return "    " + dst + " += " + ref(v, ctx) + ";\n";
     if (fusable(v, ctx)) return "    " + dst + " = __builtin_fma(" + ref(P.nodes[v].a, ctx) + ", " + ref(P.nodes[v].b, ctx) + ", " + dst + ");\n";
     return "    " + dst + " = __builtin_fma(" + ref(v, ctx) + ", rh1, " + dst + ");\n";
@@ -945,6 +961,14 @@ struct TargetEmitter {
     const Node &nd = P.nodes[id];
     auto R = [&](uint32_t x) { return ref(x, ctx); };
     const std::string lhs = "    const double n" + std::to_string(id) + " = ";
+    if (xfuse_row(ctx) && (nd.op == RH_RIR_ADD || nd.op == RH_RIR_SUB) && (xfusable(nd.a, ctx) || xfusable(nd.b, ctx))) {
+      // (a b) + y -> fma(a, b, y);  (a b) - y -> fma(a, b, -y);  x + (a b) -> fma(a, b, x);  x - (a b) -> fma(-a, b, x): the first operand
+      // that is a row-level product is the one that is fused (the rule the compiler's own combiner applies)
+      const bool sub = nd.op == RH_RIR_SUB;
+      if (xfusable(nd.a, ctx)) os << lhs << "__builtin_fma(" << R(P.nodes[nd.a].a) << ", " << R(P.nodes[nd.a].b) << ", " << (sub ? "-(" + R(nd.b) + ")" : R(nd.b)) << ");\n";
+      else os << lhs << "__builtin_fma(" << (sub ? "-(" + R(P.nodes[nd.b].a) + ")" : R(P.nodes[nd.b].a)) << ", " << R(P.nodes[nd.b].b) << ", " << R(nd.a) << ");\n";
+      return true;
+    }
     if (fma_row(ctx) && (nd.op == RH_RIR_ADD || nd.op == RH_RIR_SUB)) {
       // x + y == fma(x, 1.0, y) and x - y == fma(y, -1.0, x) exactly; where contraction is allowed a row-level product
       // feeding the sum is fused here, explicitly, instead of by the compiler
@@ -1335,12 +1359,14 @@ struct TargetEmitter {
     os << "  }\n";
     // ---- row
     if (rows) {
+      // (xfuse: what is not fused explicitly below stays unfused -- in every copy of the row code alike)
+      const std::string xpragma = xfuse_row(1) ? "#pragma clang fp contract(off)\n" : "";
       if (gmode)
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, const double gz, rh_acc_t *acc, double &sv, int &err) {\n"
-              "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+              << xpragma << "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       else
         os << "  static RH_DEV void row(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, rh_acc_t *acc, int &err) {\n"
-              "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+              << xpragma << "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
       // row() and, for the tick engine's mid-trajectory gradient requests, row_g(): the same statements without the value-only part
       const std::vector<char> vo = value_only();
       bool any_vo = false;
@@ -1351,10 +1377,10 @@ struct TargetEmitter {
         if (g_only) {
           if (gmode)
             os << "  static RH_DEV void row_g(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, const double gz, rh_acc_t *acc, double &sv, int &err) {\n"
-                  "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+                  << xpragma << "    (void)th; (void)inv; (void)c; (void)gz; (void)acc; (void)sv; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
           else
             os << "  static RH_DEV void row_g(const double (&th)[RH_NTH], const rh_acc_t *inv, const double *c, rh_acc_t *acc, int &err) {\n"
-                  "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
+                  << xpragma << "    (void)th; (void)inv; (void)c; (void)acc; (void)err;\n    const double rh1 = rh_one(); (void)rh1;\n";
         }
         bool link_open = false;
         std::ostringstream b;
@@ -1363,7 +1389,10 @@ struct TargetEmitter {
           if (gather.ok && n == gather.node) continue;  // the kernel supplies the gathered parameter
           if (link.ok && (n == link.V || link.cores.count((uint32_t)n))) {   // verified closed forms (detect_link)
             if (!link_open) { emit_link_prelude(b); link_open = true; }      // (row_g: the softplus half of rh_logit_link is dead code there)
-            if (n == link.V) b << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
+            if (n == link.V) {
+              if (xfuse_row(1)) b << "    const double n" << n << " = __builtin_fma(-lk_ab, lk_sp, __builtin_fma(lk_a, lk_t, " << link_sum(link.cterms) << "));\n";
+              else b << "    const double n" << n << " = " << link_sum(link.cterms) << " + (lk_a * lk_t - lk_ab * lk_sp);\n";
+            }
             else b << "    const double n" << n << " = " << lit(link.cores.at((uint32_t)n)) << " * lk_g;\n";
             continue;
           }
@@ -1450,6 +1479,7 @@ static bool emit_hip_impl(const Program &P, const EmitOptions &o, std::string &d
     TargetEmitter te(P, t, o.factor_outputs);
     te.fast_div = o.fp_contract;
     te.fma_adds = o.fma_adds;
+    te.xfuse = o.fp_contract && o.xfuse;
     te.chunk = o.chunk;
     if (P.targets[t].n_cols == 0) {  // runs of consecutive data-free targets share one evaluation
       if (t > 0 && P.targets[t - 1].n_cols == 0) te.merged_away = true;

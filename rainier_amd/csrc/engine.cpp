@@ -242,6 +242,7 @@ void assemble_source(rh_model *m) {
   std::string defines, targets, err;
   if (const char *e = rh::knob("RH_GRAD_PIPELINE")) m->eopt.grad_pipeline = std::atoi(e);
   if (const char *e = rh::knob("RH_FMA_ADDS")) m->eopt.fma_adds = std::atoi(e) != 0;
+  if (const char *e = rh::knob("RH_XFUSE")) m->eopt.xfuse = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_SIMPLIFY")) m->eopt.simplify = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_PACK")) m->eopt.pack = std::atoi(e) != 0;
   if (const char *e = rh::knob("RH_FAST_LOG")) m->eopt.fast_log = std::atoi(e) != 0;

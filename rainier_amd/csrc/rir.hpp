@@ -141,6 +141,8 @@ struct EmitOptions {
   bool logit_link = true;  // fast mode: a VERIFIED Bernoulli-logit scalar part is emitted in closed form (RH_LOGIT_LINK=0 switches it off)
   bool fma_adds = false; // opt-in (RH_FMA_ADDS=1), per-row code: every fp64 add/sub as v_fma_f64(x, +-1.0, y) (same rounding).  Measured: no gain on
                          // cfg 2 -- the kernel already sits at ~88 % of the fp64 issue ceiling (profiles/r1_d_fp64_ceiling)
+  bool xfuse = true;     // with fp_contract: the row code of streamed targets fuses mul+add explicitly and is compiled with contraction off, so that every
+                         // inlined copy of it rounds alike (emit.cpp: TargetEmitter::xfuse; RH_XFUSE=0 gives the compiler's own contraction back)
   int chunk = 0;          // > 0: memory-resident lowering (emit.cpp chunk_body): generated functions are cut into chunks of at most this many
                           // statement groups and values travel between chunks through a per-lane scratch array; the engine's last resort for heavy models
   int big_unroll = 16;    // big mode (chain vectors in HBM): slots in flight per lane in the vector loops (RH_BIGU); halved by the engine while a sampler kernel does not fit

@@ -153,14 +153,17 @@ class HostTargets:
                 'extern "C" void rh_host_set_gonly(int v) { rh_host_gonly = v; }\n'
                 'extern "C" void rh_host_set_kpool(const double *p) { rh_host_kpool = p; }\n'
                 '#ifdef RH_GLM_TARGET\nextern "C" int rh_host_eval_glm(const double *q, const double *const *cols, const long long *nrows, double *out) { return host_eval_glm_impl(q, cols, nrows, out); }\n#endif\n')
-        key = hashlib.sha256(text.encode()).hexdigest()[:16]
+        # (-fno-builtin-sin/cos: g++ would merge sin(x) and cos(x) of a row() into one sincos() call, whose sine may differ by an ulp from the
+        #  lone sin(x) of row_g() -- an artefact of the host compiler, not of the generated code)
+        flags = ["-std=c++17", "-O1", "-w", "-ffp-contract=off", "-fno-builtin-sin", "-fno-builtin-cos", "-fno-gnu-unique", "-shared", "-fPIC"]
+        key = hashlib.sha256((" ".join(flags) + text).encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "rh_host_targets")
         os.makedirs(d, exist_ok=True)
         so = os.path.join(d, key + ".so")
         if not os.path.exists(so):
             src = os.path.join(d, key + ".cpp")
             open(src, "w").write(text)
-            subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-ffp-contract=off", "-fno-gnu-unique", "-shared", "-fPIC", "-I", os.path.join(HERE, "stubs"), src, "-o", so])
+            subprocess.check_call(["g++"] + flags + ["-I", os.path.join(HERE, "stubs"), src, "-o", so])
         self.lib = C.CDLL(so)
         self.lib.rh_host_set_kpool(self.kpool.ctypes.data_as(C.POINTER(C.c_double)))
         self.n_out = 1 + int(head.split("#define RH_NVARS ")[1].split("\n")[0])    # (gather mode: RH_NOUT covers the shared outputs only)
