@@ -351,7 +351,7 @@ def all_configs(budget_s=1000.0):
         ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default", 120),
         ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default", 120),
         ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts", 120),
-        ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 64, 200, 1024, "default", 240),
+        ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 256, 200, 1024, "default", 240),   # (256 iterations: the run's tail -- chains finishing at different launches -- is ~1/sqrt(n) of it)
         ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8", 240),
         ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 100, 60, 256, "default", 420),
         ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8", 240),
