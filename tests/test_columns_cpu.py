@@ -267,7 +267,8 @@ def test_realtest_expressions_survive_rederivation_and_rolling(name, fn):
     target (one expression, 8 x 3 columns, the third column of every slot a derived one: -x_s), gradient by the authoring DSL.
     Fast-mode passes must fold the derived columns, re-derive the gradient, roll the slots (24 -> 2 columns, 8 x the rows) and
     keep value and gradient to rounding wherever the original is finite."""
-    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)   # (a stable seed: hash() of a string changes from process to process)
     n, S = 40, 8
     xs = [rng.uniform(-0.45, 0.45, n) for _ in range(S)]
     zs = [rng.normal(size=n) for _ in range(S)]

@@ -6,7 +6,7 @@ both written in this repository.  What IS pinned to the reference is the EHMC pa
 EHMCSampler(1024), DualAvgTuner(0.8), windowed diagonal mass) on the device is bit-identical to oracle/sampler.c, and that oracle
 reproduces the reference's own SBC goldsets (tests/test_reference_goldset.py, TM/SBCModel.scala:46-267 at 1e-10).  This test ties the
 two together from the outside: on models of the reference's own test / benchmark suites, in STRICT (JVM-faithful) builds of 1024
-chains each (GLMMPoisson2: the fast build, 256 chains -- see CASES),
+chains each,
 
     every parameter's posterior mean under NUTS(10) lies within 4 Monte-Carlo standard errors of its mean under DefaultConfig EHMC,
     the posterior variances agree within 10 %,
@@ -51,9 +51,10 @@ CASES = {
     # its sample variance has no useful standard error at any affordable length -- so the variance test is held on v alone and
     # the x_i are compared through their means (0 by symmetry) and the pooled R-hat
     "funnel10": (lambda: models.funnel_reference(10), 600, 600, [0], [], "strict", 1024),
-    # bench/stan/GLMMPoisson2.scala (146 parameters, two crossed tables): the fast build -- the strict build of this model is the
-    # memory-resident lowering, one chain per wavefront through scratch, minutes per run at this size
-    "glmm_poisson2": (lambda: models.glmm_poisson2_reference(100, 40, _load("glmm_poisson2.json")), 150, 150, None, [], "fast", 256),
+    # (bench/stan/GLMMPoisson2.scala, 146 parameters, was tried as a fourth case and is not one: at any length the GPU tier can afford
+    #  NEITHER sampler converges on it -- 256 chains x (150 + 150) iterations, fast build: R-hat 45 for each sampler alone, NUTS at
+    #  790 of its 1023 leapfrog steps per iteration, 6.5 minutes of device time -- so there are no two posteriors to compare
+    #  (profiles/r6_side/glmm_timing.txt, profiles/r6_parity/nuts_distribution.txt))
 }
 BUILDS = {"strict": dict(math_mode=_capi.MATH_STRICT), "fast": dict(fp_contract=True, factor_outputs=True)}
 
