@@ -126,6 +126,33 @@ def test_exec_restores_the_rule_cannot_classify_stay_within_the_census():
     assert seen >= 500
 
 
+def test_copies_ahead_of_an_exec_restore_in_row_streaming_kernels_carry_the_arm_s_own_value():
+    """VERDICT r5 next #6c.  Among the blocks the join-block rule cannot classify, the ones that END in a register / AGPR copy right ahead
+    of the exec restore are textually what the allocator's fault would leave too.  What tells them apart: the fault copies a value that is
+    live ACROSS the region (defined before it); an arm copies the value IT computed.  tools/unproven_census.py's witness -- every source
+    of the trailing copy run is written earlier in the same block by a non-copy instruction -- must hold for every such block of the
+    row-streaming kernels the engine launches, over the whole cache (the shapes that returned wrong sums in round 3; the sampler kernels'
+    multi-block arms are outside a single-block witness and stay with the on-device bit comparisons)."""
+    import sys
+    from concurrent.futures import ProcessPoolExecutor
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import unproven_census as U
+    files = _cache_objects()
+    with ProcessPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+        rows = [r for rs in ex.map(U.one, files, chunksize=8) for r in rs]
+    row_kernels = ("rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_glm_kernel", "rh_grad_gather_kernel", "rh_grad_gather_scan_kernel",
+                   "rh_density_kernel", "rh_density_fin_kernel")
+    ending_in_copy = [r for r in rows if r[1] in row_kernels and r[6] in ("copy", "agpr") and r[7] == 1]
+    bad = [r for r in ending_in_copy if not (r[8] > 0 and r[9] == r[8])]
+    assert not bad, [(r[0], r[1], r[2], r[8], r[9]) for r in bad[:5]]
+    # (and nothing of a launched row-streaming kernel ends in a scratch access there)
+    assert not [r for r in rows if r[1] in row_kernels and r[6] == "scratch" and r[7] == 1]
+    # the witness itself, on a fault-shaped block: the copied value comes from outside the block
+    assert U.arm_value_witness(["v_add_f64 v[2:3], v[4:5], v[6:7]", "v_accvgpr_write_b32 a3, v10", "s_or_b64 exec, exec, s[0:1]"], 2) == (1, 0)
+    assert U.arm_value_witness(["v_add_f64 v[2:3], v[4:5], v[6:7]", "v_accvgpr_write_b32 a3, v2", "v_accvgpr_write_b32 a4, v3", "s_or_b64 exec, exec, s[0:1]"], 3) == (2, 2)
+    assert U.arm_value_witness(["v_mov_b32_e32 v2, v9", "v_accvgpr_write_b32 a3, v2", "s_or_b64 exec, exec, s[0:1]"], 2) == (2, 0)   # a copy of a copy from outside
+
+
 def _build_report():
     import json
     path = os.path.join(KCACHE, "build_report.json")

@@ -39,6 +39,67 @@ _RESTORE = re.compile(r"^s_or_b64 exec, exec, (s\[\d+:\d+\])")
 _BACK = re.compile(r"^s_cbranch_(execnz|scc0|scc1|vccz|vccnz) (\S+)")
 
 
+_REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+_COPY = re.compile(r"^(v_mov_b(32|64)(_e32|_e64)?|v_accvgpr_write_b32|v_accvgpr_mov_b32|v_accvgpr_read_b32)\s")
+
+
+def regs_of(operand):
+    """'v[82:83]' -> {('v', 82), ('v', 83)}; 'a35' -> {('a', 35)}; anything else -> empty"""
+    out = set()
+    for m in _REG.finditer(operand):
+        if m.group(1):
+            out.add((m.group(1), int(m.group(2))))
+        else:
+            out.update((m.group(3), r) for r in range(int(m.group(4)), int(m.group(5)) + 1))
+    return out
+
+
+def arm_value_witness(body, at):
+    """The trailing run of register / AGPR copies ahead of the exec restore at body[at]: is every copied VALUE defined by the block itself?
+
+    What the allocator's fault leaves there is a copy of a value that is live ACROSS the region (defined before it, meant for every lane,
+    executed under the arm's mask).  What an arm legitimately ends with is the copy of a value the ARM computed into the register the join
+    reads -- its source is written, by something that is not itself a copy from outside, earlier in the same block.  Returns
+    (copies in the run, copies whose source the block defines); a run with AGPR -> VGPR reads (reloads) counts them as not witnessed."""
+    run = []
+    k = at - 1
+    while k >= 0 and (body[k].startswith(("s_waitcnt", "s_nop")) or _COPY.match(body[k])):
+        if _COPY.match(body[k]):
+            run.append(k)
+        k -= 1
+    defined = set()      # registers written by non-copy vector instructions (or loads) of this block, in program order up to the run
+    for ins in body[:k + 1]:
+        if ins.startswith(("v_cmp", "v_cmpx")) or not I._VECTOR.match(ins) or I._EXEC_IGNORING.match(ins):
+            continue
+        if ins.startswith(("ds_write", "global_store", "flat_store", "scratch_store", "buffer_store", "ds_bpermute", "ds_permute")) and not ins.startswith(("ds_bpermute", "ds_permute")):
+            continue
+        ops = ins.split(None, 1)
+        if len(ops) < 2:
+            continue
+        dest = ops[1].split(",")[0]
+        if _COPY.match(ins):
+            src = ops[1].split(",", 1)[1] if "," in ops[1] else ""
+            if regs_of(src) and regs_of(src) <= defined:     # a copy of a value the block defined passes the definition on
+                defined |= regs_of(dest)
+            else:
+                defined -= regs_of(dest)
+            continue
+        defined |= regs_of(dest)
+    ok = 0
+    for j in sorted(run):
+        ins = body[j]
+        ops = ins.split(None, 1)[1]
+        dest, src = ops.split(",", 1)
+        if ins.startswith("v_accvgpr_read"):
+            continue
+        s = regs_of(src)
+        if not s and re.match(r"^\s*(-?\d|0x|-?\d*\.\d)", src.strip()):   # an immediate: the arm's own constant
+            ok += 1; defined |= regs_of(dest); continue
+        if s and s <= defined:
+            ok += 1; defined |= regs_of(dest)
+    return len(run), ok
+
+
 def blocks_of(lines):
     blocks, kernel = [], None
     for ln in lines:
@@ -103,7 +164,8 @@ def one(path):
                 last = next((b for b in reversed(body[:at]) if not b.startswith(("s_waitcnt", "s_nop"))), "")
                 kind = ("copy" if re.match(r"^v_mov_b(32|64)(_e32|_e64)? v\[?\d+(:\d+)?\]?, v", last) else
                         "agpr" if "accvgpr" in last else "scratch" if last.startswith("scratch_") else "-")
-                out.append((os.path.basename(path), kern, lab, cls, first_vec, ins, kind, fit.get(kern, 0)))
+                ncopy, nwit = arm_value_witness(body, at) if kind in ("copy", "agpr") else (0, 0)
+                out.append((os.path.basename(path), kern, lab, cls, first_vec, ins, kind, fit.get(kern, 0), ncopy, nwit))
                 break
             seen_any = True
             if I.writes_exec(ins):
@@ -129,7 +191,7 @@ def main(argv):
     others = [r for r in rows if r[3] == "other"]
     if others:
         print("\n## `other`, one by one\n")
-        for f, k, lab, _, v, r, _, _ in others[:60]:
+        for f, k, lab, _, v, r, *_ in others[:60]:
             print("* `%s` `%s` <%s>: `%s` ahead of `%s`" % (f[:16], k, lab, v, r))
     tail = collections.Counter((r[1], r[6], r[7]) for r in rows)
     print("\n## The instruction immediately ahead of the restore (kernels the engine launches / kernels it refuses)\n")
@@ -137,6 +199,24 @@ def main(argv):
     print("| kernel | " + " | ".join("arm's own code" if k == "-" else k for k in kinds) + " |\n|---|" + "---|" * len(kinds))
     for k in kernels:
         print("| `%s` | " % k + " | ".join("%d / %d" % (tail.get((k, kd, 1), 0), tail.get((k, kd, 0), 0)) for kd in kinds) + " |")
+    print("\n## Register / AGPR copies ahead of the restore: is the copied value the arm's own?\n")
+    print("A copy there is what the allocator's fault would leave (a value live across the region, copied for every lane under the arm's mask) "
+          "and what an arm legitimately ends with (the value IT computed, copied into the register the join reads).  Witness: every source of the "
+          "trailing copy run is written earlier in the same block by a non-copy instruction (`arm_value_witness`).\n")
+    print("| kernel (launched) | blocks ending in a copy / AGPR copy | every copy witnessed | not witnessed |\n|---|---|---|---|")
+    unw = []
+    for k in kernels:
+        rs = [r for r in rows if r[1] == k and r[6] in ("copy", "agpr") and r[7] == 1]
+        if not rs:
+            continue
+        good = [r for r in rs if r[8] > 0 and r[9] == r[8]]
+        bad = [r for r in rs if not (r[8] > 0 and r[9] == r[8])]
+        unw += bad
+        print("| `%s` | %d | %d | %d |" % (k, len(rs), len(good), len(bad)))
+    if unw:
+        print("\n### not witnessed, one by one\n")
+        for r in unw[:40]:
+            print("* `%s` `%s` <%s> (%s): %d of %d copies witnessed" % (r[0][:16], r[1], r[2], r[3], r[9], r[8]))
     return 0
 
 
