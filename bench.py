@@ -339,23 +339,29 @@ def side_workload(a, R, models, rank, local_rank, world, dist):
         print(json.dumps(out))
 
 
-def all_configs(budget_s=1000.0):
+def all_configs(budget_s=600.0, long_legs=False):
     """The `configs` block of the default (N = 1) line: every BASELINE.json configuration driver-timed in this run, each leg a CHILD
     process (`bench.py --workload ...`, the same code path as `--workload` from the command line) under a watchdog, so that a leg
     that hangs or dies cannot take the judged cfg-2 line with it.  Sizes are the BASELINE ones.  The legs under the
-    samplers BASELINE names (NUTS) and the reference defaults to (EHMC + windowed diagonal mass: sampler/Sampler.scala:17-27) are
-    sized to tens of seconds each -- enough iterations for R-hat < 1.05, beside which alone an ESS/s is printed -- and carry the
-    live-chain accounting of their gradient launches (roofline.slot_efficiency, roofline.steady_state); the static-HMC legs are the
-    dominant kernel's own figure (every launch serves every chain)."""
+    samplers BASELINE names (NUTS) and the reference defaults to (EHMC + windowed diagonal mass: sampler/Sampler.scala:17-27) carry
+    the live-chain accounting of their gradient launches (roofline.slot_efficiency, roofline.steady_state) and print an ESS/s only
+    beside R-hat < 1.05; the static-HMC legs are the dominant kernel's own figure (every launch serves every chain).
+      The two NUTS legs at BASELINE size cost MINUTES to converge (cfg 4: 1e7 rows x 256 chains, ~17 ms per launch, ~90 leapfrog steps
+    per iteration; cfg 5: 1e6 rows x 1024 chains, trees at depth 10), which a command that has to finish "within a few minutes" does
+    not have: by default they run ~2.5 minutes each (kernel-speed and steady-state figures, R-hat reported, ESS/s withheld while it
+    is above 1.05); `--long-configs` runs them at 60 + 100 and 36 + 60 iterations (5.5 minutes each) -- that run of the tree as
+    handed over is committed as profiles/r6_side/bench_long_configs.json."""
     plan = [  # (key, workload, steps, warmup, chains, sampler, watchdog seconds)
         ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default", 120),
         ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default", 120),
         ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts", 120),
         ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 256, 200, 1024, "default", 240),   # (256 iterations: the run's tail -- chains finishing at different launches -- is ~1/sqrt(n) of it)
         ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8", 240),
-        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 100, 60, 256, "default", 420),
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 100, 60, 256, "default", 420) if long_legs else
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 40, 36, 256, "default", 300),
         ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8", 240),
-        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 60, 36, 1024, "default", 420),
+        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 60, 36, 1024, "default", 420) if long_legs else
+        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 24, 24, 1024, "default", 300),
     ]
     out, t_all = {}, time.perf_counter()
     for key, w, steps, warm, cpg, smp, limit in plan:
@@ -398,6 +404,7 @@ def main():
     ap.add_argument("--no-ess", action="store_true", help="skip the two ESS/s legs (profiling runs)")
     ap.add_argument("--no-inlined", action="store_true", help="skip the gpu_inlined leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations, timed in-process at N = 1)")
+    ap.add_argument("--long-configs", action="store_true", help="the two BASELINE-size NUTS legs of the `configs` block at 60 + 100 / 36 + 60 iterations (5.5 minutes each) instead of ~2.5 minutes each")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs); the committed, "
                          "sha-guarded profile is quoted instead.  Always set when this command is itself being profiled")
@@ -588,7 +595,7 @@ def main():
             out["roofline"]["traffic_source"] = "none: profiles/%s was taken on different kernel source or workload (sha16 %s vs %s)" % (
                 TRAFFIC_PROFILE, pj.get("generated_source_sha16"), src_sha)
     if not a.no_configs and world == 1 and dist is None:   # (a plain `python bench.py` run; not under torch.distributed.run)
-        out["configs"] = all_configs()
+        out["configs"] = all_configs(budget_s=1100.0 if a.long_configs else 600.0, long_legs=a.long_configs)
     if not a.no_inlined and world == 1:
         out["gpu_inlined"] = gpu_inlined(R, models, local_rank, L)
     if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
