@@ -346,21 +346,25 @@ def all_configs(budget_s=600.0, long_legs=False):
     samplers BASELINE names (NUTS) and the reference defaults to (EHMC + windowed diagonal mass: sampler/Sampler.scala:17-27) carry
     the live-chain accounting of their gradient launches (roofline.slot_efficiency, roofline.steady_state) and print an ESS/s only
     beside R-hat < 1.05; the static-HMC legs are the dominant kernel's own figure (every launch serves every chain).
-      The two NUTS legs at BASELINE size cost MINUTES to converge (cfg 4: 1e7 rows x 256 chains, ~17 ms per launch, ~90 leapfrog steps
-    per iteration; cfg 5: 1e6 rows x 1024 chains, trees at depth 10), which a command that has to finish "within a few minutes" does
-    not have: by default they run ~2.5 minutes each (kernel-speed and steady-state figures, R-hat reported, ESS/s withheld while it
-    is above 1.05); `--long-configs` runs them at 60 + 100 and 36 + 60 iterations (5.5 minutes each) -- that run of the tree as
-    handed over is committed as profiles/r6_side/bench_long_configs.json."""
+      The NUTS legs at BASELINE size converge once the mass windows are DefaultConfig's own (warm-up 150; round 6, GPU calls G / H): cfg 4
+    then needs ~9 leapfrog steps per iteration instead of ~90 and runs 150 + 300 iterations in under three minutes -- the default.  cfg 5
+    (centred form) spends ~6 minutes in the first 100 warm-up iterations (trees at depth 10, ~3 s each) before its trees drop from 1014
+    to 31 steps: by default it runs 24 + 24 iterations (kernel-speed and steady-state figures; R-hat reported, ESS/s withheld while it
+    is above 1.05), and `--long-configs` runs the converging 150 + 400 (profiles/r6_side/cfg5c_nuts_warmup150.json: R-hat 0.995)."""
     plan = [  # (key, workload, steps, warmup, chains, sampler, watchdog seconds)
         ("cfg1_funnel_hmc5_1024", "cfg1", 2000, 300, 1024, "default", 120),
         ("cfg3_eight_schools_ehmc_1024", "cfg3", 500, 300, 1024, "default", 120),
         ("cfg3_eight_schools_nuts10_1024", "cfg3", 200, 300, 1024, "nuts", 120),
         ("cfg2_default_config_ehmc_diag_mass_1024", "cfg2d", 256, 200, 1024, "default", 240),   # (256 iterations: the run's tail -- chains finishing at different launches -- is ~1/sqrt(n) of it)
         ("cfg4_logistic_1e7x50_hmc8_256", "cfg4", 2, 2, 256, "hmc8", 240),
-        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 100, 60, 256, "default", 420) if long_legs else
-        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 40, 36, 256, "default", 300),
+        # (warm-up 150 = DefaultConfig's own mass windows 50 / x1.5 / 50 / 50: the adapted mass brings the mean tree from ~90 leapfrog steps --
+        #  what a 60-iteration warm-up with windows of 10-22 draws leaves -- to ~9, and the 150 iterations cost what those 60 did;
+        #  profiles/r6_side/cfg4_nuts_warmup{100,150}.json)
+        ("cfg4_logistic_1e7x50_nuts10_diag_mass_256", "cfg4", 300, 150, 256, "default", 420),
         ("cfg5_hier_negbin_10000x100_hmc8_1024", "cfg5", 4, 2, 1024, "hmc8", 240),
-        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 60, 36, 1024, "default", 420) if long_legs else
+        # (cfg 5 converges the same way -- warm-up 150: mean tree 1014 -> 31 leapfrog steps, R-hat 0.995 -- but ITS first 100 warm-up iterations
+        #  run at depth 10, ~3 s each: 6 minutes of warm-up, which only --long-configs spends; profiles/r6_side/cfg5c_nuts_warmup150.json)
+        ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 400, 150, 1024, "default", 640) if long_legs else
         ("cfg5_hier_negbin_centred_10000x100_nuts10_1024", "cfg5c", 24, 24, 1024, "default", 300),
     ]
     out, t_all = {}, time.perf_counter()
