@@ -143,8 +143,13 @@ def test_copies_ahead_of_an_exec_restore_in_row_streaming_kernels_carry_the_arm_
     row_kernels = ("rh_grad_kernel", "rh_grad_fused_kernel", "rh_grad_glm_kernel", "rh_grad_gather_kernel", "rh_grad_gather_scan_kernel",
                    "rh_density_kernel", "rh_density_fin_kernel")
     ending_in_copy = [r for r in rows if r[1] in row_kernels and r[6] in ("copy", "agpr") and r[7] == 1]
-    bad = [r for r in ending_in_copy if not (r[8] > 0 and r[9] == r[8])]
-    assert not bad, [(r[0], r[1], r[2], r[8], r[9]) for r in bad[:5]]
+    # single-block arms (`arm-ool`, `arm`: the whole arm is in the block, so a value it copies out must have been computed in it).  A
+    # `nested` block -- it opens with an INNER region's restore and ends with the outer one's -- may legitimately copy the inner region's
+    # result, which other blocks define: outside this witness (strict builds of the fuzz models show a few; they run against the oracle
+    # on the device, tools/gpu_fuzz_sweep.py), counted by the census, not asserted here
+    bad = [r for r in ending_in_copy if r[3] in ("arm-ool", "arm") and not (r[8] > 0 and r[9] == r[8])]
+    assert not bad, [(r[0], r[1], r[2], r[3], r[8], r[9]) for r in bad[:5]]
+    assert all(r[3] in ("arm-ool", "arm", "nested") for r in ending_in_copy), sorted({r[3] for r in ending_in_copy})
     # (and nothing of a launched row-streaming kernel ends in a scratch access there)
     assert not [r for r in rows if r[1] in row_kernels and r[6] == "scratch" and r[7] == 1]
     # the witness itself, on a fault-shaped block: the copied value comes from outside the block

@@ -203,7 +203,7 @@ def main(argv):
     print("A copy there is what the allocator's fault would leave (a value live across the region, copied for every lane under the arm's mask) "
           "and what an arm legitimately ends with (the value IT computed, copied into the register the join reads).  Witness: every source of the "
           "trailing copy run is written earlier in the same block by a non-copy instruction (`arm_value_witness`).\n")
-    print("| kernel (launched) | blocks ending in a copy / AGPR copy | every copy witnessed | not witnessed |\n|---|---|---|---|")
+    print("| kernel (launched) | blocks ending in a copy / AGPR copy | every copy witnessed | not witnessed: single-block arm | not witnessed: nested (may copy an inner region's result) |\n|---|---|---|---|---|")
     unw = []
     for k in kernels:
         rs = [r for r in rows if r[1] == k and r[6] in ("copy", "agpr") and r[7] == 1]
@@ -212,7 +212,7 @@ def main(argv):
         good = [r for r in rs if r[8] > 0 and r[9] == r[8]]
         bad = [r for r in rs if not (r[8] > 0 and r[9] == r[8])]
         unw += bad
-        print("| `%s` | %d | %d | %d |" % (k, len(rs), len(good), len(bad)))
+        print("| `%s` | %d | %d | %d | %d |" % (k, len(rs), len(good), len([r for r in bad if r[3] != "nested"]), len([r for r in bad if r[3] == "nested"])))
     if unw:
         print("\n### not witnessed, one by one\n")
         for r in unw[:40]:
