@@ -87,6 +87,32 @@ def test_a_chain_does_not_depend_on_its_neighbours(case):
     m.close()
 
 
+@pytest.mark.parametrize("case", [2, 3])
+def test_gradient_through_a_compacted_list_does_not_depend_on_the_slot(case, monkeypatch):
+    """The sharpest form of the statement above, at the gradient level: (logp, gradient) of a chain served through a compacted list
+    (RH_EVAL_LIVE: another slot of its chain group, other company, padded groups) equals the identity-list launch bit for bit -- at
+    |q| ~ 4 too, where single rows dominate the sums and one row's ulp survives them.  Until round 6's explicit-fusion row code the
+    compiler fused the K inlined copies of row() differently and this failed by one ulp for a chain whose slot changed
+    (profiles/r6_parity/live_diag.txt)."""
+    name, mk, build, _ = _cases()[case]
+    spec = mk()
+    m = R.Model(spec, device=0, **build)
+    rng = np.random.default_rng(11)
+    nc = 23
+    for scale in (0.3, 4.0):
+        qs = rng.normal(size=(nc, spec.n_params)) * scale
+        lp, g = m.density_batch(qs, engine=_capi.ENGINE_TICK, grad_splits=64)
+        ref = np.concatenate([lp[:, None], g], axis=1)
+        for sub in ([7], [7, 8], [3, 7, 8], [1, 7, 8, 9, 10], list(range(0, 23, 2)), list(range(1, 23, 2)), list(range(5, 23))):
+            monkeypatch.setenv("RH_EVAL_LIVE", ",".join(str(c) for c in sub))
+            lp2, g2 = m.density_batch(qs, engine=_capi.ENGINE_TICK, grad_splits=64)
+            monkeypatch.delenv("RH_EVAL_LIVE")
+            got = np.concatenate([lp2[:, None], g2], axis=1)
+            for c in sub:
+                assert np.array_equal(got[c], ref[c], equal_nan=True), (name, scale, sub, c, np.flatnonzero(got[c] != ref[c])[:4])
+    m.close()
+
+
 def test_compacted_nuts_and_ehmc_against_the_oracle():
     """oracle first: the compacted tick engine's chains against oracle/sampler.c (tame dynamics: a static step, identity mass, short
     trees, so that the rounding of the row sums does not grow)"""
