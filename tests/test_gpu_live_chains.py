@@ -97,10 +97,9 @@ def test_gradient_through_a_compacted_list_does_not_depend_on_the_slot(case, mon
     name, mk, build, _ = _cases()[case]
     spec = mk()
     m = R.Model(spec, device=0, **build)
-    rng = np.random.default_rng(11)
     nc = 23
     for scale in (0.3, 4.0):
-        qs = rng.normal(size=(nc, spec.n_params)) * scale
+        qs = np.random.default_rng(11).normal(size=(nc, spec.n_params)) * scale      # (the points of tools/r6_live_diag.py)
         lp, g = m.density_batch(qs, engine=_capi.ENGINE_TICK, grad_splits=64)
         ref = np.concatenate([lp[:, None], g], axis=1)
         for sub in ([7], [7, 8], [3, 7, 8], [1, 7, 8, 9, 10], list(range(0, 23, 2)), list(range(1, 23, 2)), list(range(5, 23))):
