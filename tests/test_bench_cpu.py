@@ -65,3 +65,41 @@ def test_live_traffic_reports_failure_instead_of_a_number(fake_profiler, monkeyp
     monkeypatch.setenv("FAKE_FAIL", "1")
     traffic, how = bench.live_traffic(_args(), "rh_grad_fused_kernel")
     assert traffic is None and "failed" in how
+
+
+def test_configs_block_runs_each_leg_as_a_watchdogged_child_and_survives_a_leg_that_dies(monkeypatch):
+    """The `configs` block: every BASELINE configuration is a child `bench.py --workload ...` under a watchdog (a leg that hangs or dies
+    must not take the judged line with it); the default plan keeps cfg 5's NUTS leg short and cfg 4's at DefaultConfig's own mass
+    windows (warm-up 150), `--long-configs` swaps in cfg 5's converging 150 + 400."""
+    import json
+    import subprocess
+    import bench
+    seen = []
+
+    def fake_run(cmd, capture_output, text, timeout):
+        w = cmd[cmd.index("--workload") + 1]
+        seen.append(dict(workload=w, sampler=cmd[cmd.index("--sampler") + 1], steps=int(cmd[cmd.index("--steps") + 1]),
+                         warmup=int(cmd[cmd.index("--warmup") + 1]), chains=int(cmd[cmd.index("--chains-per-gpu") + 1]), timeout=timeout))
+        if w == "cfg3":
+            raise subprocess.TimeoutExpired(cmd, timeout)
+        if w == "cfg1":
+            return types.SimpleNamespace(returncode=1, stdout="", stderr="boom")
+        line = json.dumps({"value": 1.0, "unit": "leapfrog steps/s", "steps": 1, "warmup": 1, "ms_per_step": 1.0, "config": {"workload": w}, "roofline": {"frac": 0.5}})
+        return types.SimpleNamespace(returncode=0, stdout="noise\n" + line + "\n", stderr="")
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    out = bench.all_configs()
+    assert len(out) == 8 and len(seen) == 8
+    assert "error" in out["cfg1_funnel_hmc5_1024"] and "watchdog" in out["cfg3_eight_schools_ehmc_1024"]["error"]
+    assert out["cfg2_default_config_ehmc_diag_mass_1024"]["roofline"]["frac"] == 0.5
+    by = {(s["workload"], s["sampler"]): s for s in seen}
+    assert by[("cfg4", "default")]["warmup"] == 150 and by[("cfg4", "default")]["chains"] == 256      # DefaultConfig's own mass windows
+    assert by[("cfg5c", "default")]["warmup"] < 150 and by[("cfg5c", "default")]["chains"] == 1024     # the converging leg is --long-configs'
+    assert all(0 < s["timeout"] <= 640 for s in seen)
+    seen.clear()
+    bench.all_configs(budget_s=1100.0, long_legs=True)
+    by = {(s["workload"], s["sampler"]): s for s in seen}
+    assert by[("cfg5c", "default")]["warmup"] == 150 and by[("cfg5c", "default")]["steps"] >= 100
+    # a spent budget skips the remaining legs instead of starting them
+    seen.clear()
+    out = bench.all_configs(budget_s=0.0)
+    assert not seen and all("skipped" in v for v in out.values())
