@@ -232,7 +232,12 @@ def side_run(w, R, models, rank, local_rank, world, dist, steps, warmup, cpg, ro
         # (tests/test_gpu_baseline_samplers.py: R-hat < 1.05; the non-centred one above keeps R-hat at 3-6 for any affordable length)
         mk = models.hier_negbin_centred if w == "cfg5c" else models.hier_negbin
         spec = spec or mk(10_000 if not rows else max(100, rows // 100), 100); cfg = R.make_config(steps, warmup, R.NUTSSampler(10))
-    if w in ("cfg4", "cfg5", "cfg5c") and 24 <= warmup < 150:
+    if w in ("cfg4", "cfg5", "cfg5c") and 90 <= warmup < 150:
+        # ONE mass window early enough to leave DefaultConfig's 50 iterations of step-size adaptation behind it (skipLast = 50): what makes
+        # the difference between trees of ~90 and ~9 leapfrog steps is less the number of draws in the window than whether the step size
+        # has time to settle on the adapted mass (cfg 4, warm-up 100 with three windows ending at 84: tree 97; warm-up 150: 9)
+        cfg.massMatrixTuner = lambda: R.DiagonalMassMatrixTuner(warmup - 70, 1.5, 20, 50)
+    elif w in ("cfg4", "cfg5", "cfg5c") and 24 <= warmup < 90:
         # DefaultConfig's mass windows (50, x1.5, skip 50 / 50: sampler/Sampler.scala:24-25) never open in a warm-up this short:
         # the same tuner scaled to the leg's warm-up, so that "NUTS + diag mass-matrix adapt" (BASELINE cfg 4) really adapts
         k = warmup // 6
