@@ -17,6 +17,7 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1550,7 +1551,7 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
       // RH_DIAG only -- RH_EVAL_LIVE="3,7,8": the launch serves exactly these chains through a compacted list, as the sampler's launches
       // do (rh_compact_kernel); the rows of the chains it leaves out come back as zeros (tools/r6_live_diag.py)
       void *dnl = nullptr;
-      DevBuf bnl(sizeof(int));
+      std::unique_ptr<DevBuf> bnl;
       if (const char *e = rh::knob("RH_EVAL_LIVE")) {
         std::vector<int> live;
         for (const char *p = e; *p;) { char *q2; long v = std::strtol(p, &q2, 10); if (q2 == p) break; if (v >= 0 && v < chains) live.push_back((int)v); p = *q2 ? q2 + 1 : q2; }
@@ -1559,9 +1560,10 @@ extern "C" int rh_density_eval_ex(rh_model *m, const double *q, int32_t chains, 
         if (!live.empty()) {
           const int nl = (int)live.size();
           HIPCHK(hipMemcpyAsync(blist.p, live.data(), sizeof(int) * nl, hipMemcpyHostToDevice, m->stream));
-          HIPCHK(hipMemcpyAsync(bnl.p, &nl, sizeof(int), hipMemcpyHostToDevice, m->stream));
+          bnl.reset(new DevBuf(sizeof(int)));
+          HIPCHK(hipMemcpyAsync(bnl->p, &nl, sizeof(int), hipMemcpyHostToDevice, m->stream));
           HIPCHK(hipStreamSynchronize(m->stream));
-          dnl = bnl.p;
+          dnl = bnl->p;
         }
       }
       launch_grad(m, &gb, dq, blist.p, dnl, nullptr, bpart.p, de, brun.p, chains, nsplit, xcd);
